@@ -1,0 +1,239 @@
+"""CPU oracle for the CAGGC + MAGGC hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a CPU restatement (plain PyTorch fp32 ops on the host, op-for-op in the
+reference's order: un-folded einsum+mean, three [N,N,D] GAT linears, per-head /
+per-layer loops, one document per call) of
+
+    /root/reference/models/GCGCN_glove.py:18-168   (the five graph blocks)
+    /root/reference/models/GCGCN_glove.py:329-341  (the hop-loop glue)
+
+It is NOT part of the product.  Only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import it, and only as the checker / the timed
+CPU baseline.  ``gcgcn_amd`` never imports it and has no CPU fallback.
+
+Parity pin: ``oracle/make_golden.py`` imports the reference's own classes (by file
+path, in the build container only), runs them on seeded inputs and commits
+inputs/outputs/gradients as ``tests/golden/*.npz``; ``tests/test_oracle_golden.py``
+checks every function below against those vectors (<= 1e-5).  The reference has no
+tests or golden vectors of its own.
+
+State dicts use the reference's parameter names, so a reference checkpoint's
+sub-dict feeds these functions directly.  Dropout is expressed through explicit
+keep-masks (already scaled or not, see ``_drop``) so that train-mode results can be
+compared with the HIP path bit-for-bit in the mask.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+Tensor = torch.Tensor
+Params = Dict[str, Tensor]
+
+
+def _drop(t: Tensor, keep: Optional[Tensor], p: float) -> Tensor:
+    """nn.Dropout(p) in train mode with an explicit boolean keep-mask.
+
+    keep is None  -> eval mode (identity), as nn.Dropout under .eval().
+    """
+    if keep is None:
+        return t
+    return t * keep.to(t.dtype) / (1.0 - p)
+
+
+# --------------------------------------------------------------------------------------
+# GraphConv.forward                                          GCGCN_glove.py:36-50
+# --------------------------------------------------------------------------------------
+def graph_conv(x: Tensor, e: Tensor, adj: Tensor, w_edge: Tensor, w_node: Tensor) -> Tensor:
+    """x [N,Din], e [N,N,D], adj [N,N], w_edge [D,gh], w_node [Din,gh] -> [N,gh]."""
+    edge = torch.einsum("ijk,kp->ijp", e, w_edge)            # :40
+    edge = edge.mean(dim=1)                                  # :41
+    # :42 chain_matmul(adj, x, w_node): multi_dot's cost model always picks adj·(x·w_node)
+    # here because gh <= Din (N·N·gh <= N·N·Din).
+    node = adj @ (x @ w_node)
+    out = edge + node                                        # :43
+    r = adj.sum(1)                                           # :47
+    r = r + (r == 0).to(r.dtype)                             # :48-49
+    return out / r.unsqueeze(1)                              # :50
+
+
+# --------------------------------------------------------------------------------------
+# GraphConvolution.forward  (CAGGC conv)                     GCGCN_glove.py:63-80
+# --------------------------------------------------------------------------------------
+def graph_convolution(x: Tensor, e: Tensor, adj: Tensor, sd: Params, layer_num: int,
+                      keep: Optional[Sequence[Tensor]] = None, p: float = 0.2) -> Tensor:
+    """sd keys: graphconv.{l}.weights_edge / weights_node, linear_layer.weight / bias."""
+    cache = [x]
+    outs = []
+    cur = x
+    for l in range(layer_num):
+        y = torch.relu(graph_conv(cur, e, adj, sd[f"graphconv.{l}.weights_edge"],
+                                  sd[f"graphconv.{l}.weights_node"]))          # :71
+        cache.append(y)
+        cur = torch.cat(cache, dim=-1)                                         # :73
+        outs.append(_drop(y, None if keep is None else keep[l], p))            # :74
+    h = torch.cat(outs, dim=-1) + x                                            # :75-76
+    return h @ sd["linear_layer.weight"].t() + sd["linear_layer.bias"]         # :78
+
+
+# --------------------------------------------------------------------------------------
+# MultiGraphConvolution.forward  (MAGGC conv)                GCGCN_glove.py:97-120
+# --------------------------------------------------------------------------------------
+def multi_graph_convolution(x: Tensor, e: Tensor, adj_list: Sequence[Tensor], sd: Params,
+                            layer_num: int, head_num: int,
+                            keep: Optional[Sequence[Sequence[Tensor]]] = None,
+                            p: float = 0.2) -> Tensor:
+    heads = []
+    for h in range(head_num):
+        cache = [x]
+        outs = []
+        cur = x
+        for l in range(layer_num):
+            k = h * layer_num + l                                              # :107
+            y = torch.relu(graph_conv(cur, e, adj_list[h], sd[f"graphconv.{k}.weights_edge"],
+                                      sd[f"graphconv.{k}.weights_node"]))      # :108
+            cache.append(y)
+            cur = torch.cat(cache, dim=-1)
+            outs.append(_drop(y, None if keep is None else keep[h][l], p))     # :111
+        heads.append(torch.cat(outs, dim=-1) + x)                              # :112-113
+    cat = torch.cat(heads, dim=-1)                                             # :117
+    return cat @ sd["linear_layer.weight"].t() + sd["linear_layer.bias"]       # :118
+
+
+# --------------------------------------------------------------------------------------
+# MultiHeadAttention.forward  (MAGGC adjacency)              GCGCN_glove.py:133-142
+# --------------------------------------------------------------------------------------
+def multi_head_attention(x: Tensor, sd: Params, head_num: int,
+                         keep: Optional[Sequence[Tensor]] = None, p: float = 0.1) -> List[Tensor]:
+    """Keys use the *query* projection (reference quirk, :136-137); linears_k unused."""
+    d = x.shape[1]
+    dh = d // head_num
+    out = []
+    for h in range(head_num):
+        w, b = sd[f"linears_q.{h}.weight"], sd[f"linears_q.{h}.bias"]
+        q = x @ w.t() + b                                                      # :136
+        k = (x @ w.t() + b).t()                                                # :137
+        att = torch.softmax((q @ k) / math.sqrt(dh), dim=-1)                   # :138
+        out.append(_drop(att, None if keep is None else keep[h], p))           # :139-140
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# GATAttention.forward  (CAGGC adjacency)                    GCGCN_glove.py:154-168
+# --------------------------------------------------------------------------------------
+def gat_attention(x: Tensor, e: Tensor, sd: Params, mask: Optional[Tensor] = None,
+                  keep: Optional[Tensor] = None, p: float = 0.1,
+                  apply_mask: bool = False) -> Tensor:
+    """mask is ignored by default exactly as in the reference (:163-164 drops the
+    out-of-place masked_fill result).  apply_mask=True is the paper-faithful opt-in."""
+    n = x.shape[0]
+    xh = x.unsqueeze(0).expand(n, n, -1)                                       # :156
+    xt = x.unsqueeze(0).expand(n, n, -1)                                       # :157 (same view)
+    ah = xh @ sd["linear_node_h.weight"].t() + sd["linear_node_h.bias"]        # :159
+    at = xt @ sd["linear_node_t.weight"].t() + sd["linear_node_t.bias"]        # :160
+    ar = e @ sd["linear_edge_r.weight"].t() + sd["linear_edge_r.bias"]         # :161
+    energy = (torch.cat([ah, at, ar], -1) @ sd["wt.weight"].t() + sd["wt.bias"]).squeeze(-1)  # :162
+    if apply_mask and mask is not None:
+        energy = energy.masked_fill(mask, -100000.0)
+    att = torch.softmax(energy, dim=-1)                                        # :165
+    return _drop(att, keep, p)                                                 # :166-167
+
+
+# --------------------------------------------------------------------------------------
+# hop-loop glue                                              GCGCN_glove.py:329-341
+# --------------------------------------------------------------------------------------
+def sub(sd: Params, prefix: str) -> Params:
+    """Sub-dict of a state dict: keys under ``prefix.`` with the prefix removed."""
+    pre = prefix + "."
+    return {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+
+
+def hop_stack(x: Tensor, e_list: Sequence[Tensor], adj: Optional[Tensor], sd: Params,
+              layer_num: int, head_num: int, alpha: float = 1.0,
+              keeps: Optional[dict] = None, p_glue: float = 0.2) -> List[Tensor]:
+    """The model's hop loop restricted to the graph blocks: hop 0 = GAT + CAGGC conv,
+    hop i>=1 = MHA + MAGGC conv.  Returns [x0, x1, ..., x_hops] where x_{i+1} is the node
+    feature after hop i (post alpha-mix and glue dropout); the model itself records the
+    pre-update features (:338), i.e. the first ``hops`` entries of this list.
+
+    sd uses the model's key names: get_weighted_adj_matrix.*, get_adj_matrix.{i-1}.*,
+    graphcnn.{i}.*.  keeps (train mode): dict with optional entries 'gat', 'cag' (list L),
+    'mha.{i}' (list H), 'mag.{i}' (list H of list L), 'glue.{i}'.
+    """
+    keeps = keeps or {}
+    feats = [x]
+    for i, e in enumerate(e_list):
+        if i < 1:
+            mask = None if adj is None else torch.eq(adj, 0)                   # :330
+            a = gat_attention(x, e, sub(sd, "get_weighted_adj_matrix"), mask,
+                              keep=keeps.get("gat"))                           # :332
+            new = graph_convolution(x, e, a, sub(sd, f"graphcnn.{i}"), layer_num,
+                                    keep=keeps.get("cag"))                     # :333
+        else:
+            al = multi_head_attention(x, sub(sd, f"get_adj_matrix.{i - 1}"), head_num,
+                                      keep=keeps.get(f"mha.{i}"))              # :336
+            new = multi_graph_convolution(x, e, al, sub(sd, f"graphcnn.{i}"), layer_num,
+                                          head_num, keep=keeps.get(f"mag.{i}"))  # :337
+        x = alpha * new + (1 - alpha) * x                                      # :339
+        x = _drop(x, keeps.get(f"glue.{i}"), p_glue)                           # :341
+        feats.append(x)
+    return feats
+
+
+# --------------------------------------------------------------------------------------
+# parameter construction with the reference's initialisers (for synthetic benchmarks)
+# --------------------------------------------------------------------------------------
+def init_stack_params(d: int, layer_num: int, head_num: int, hops: int = 2,
+                      seed: int = 1337) -> Params:
+    """Random parameters in the model's key layout, reference initialisers:
+    xavier-uniform for weights_edge / weights_node (GCGCN_glove.py:32-34), nn.Linear
+    default (kaiming-uniform a=sqrt(5) + uniform bias) elsewhere."""
+    g = torch.Generator().manual_seed(seed)
+    gh = d // layer_num
+    dh = d // head_num
+    sd: Params = {}
+
+    def xavier(fi, fo):
+        a = math.sqrt(6.0 / (fi + fo))
+        return (torch.rand(fi, fo, generator=g) * 2 - 1) * a
+
+    def linear(name, fo, fi):
+        bound = 1.0 / math.sqrt(fi)
+        sd[name + ".weight"] = (torch.rand(fo, fi, generator=g) * 2 - 1) * bound
+        sd[name + ".bias"] = (torch.rand(fo, generator=g) * 2 - 1) * bound
+
+    for nm in ("linear_node_h", "linear_node_t", "linear_edge_r"):
+        linear("get_weighted_adj_matrix." + nm, d, d)
+    linear("get_weighted_adj_matrix.wt", 1, 3 * d)
+    for i in range(hops):
+        if i == 0:
+            for l in range(layer_num):
+                sd[f"graphcnn.0.graphconv.{l}.weights_edge"] = xavier(d, gh)
+                sd[f"graphcnn.0.graphconv.{l}.weights_node"] = xavier(d + gh * l, gh)
+            linear("graphcnn.0.linear_layer", d, d)
+        else:
+            for h in range(head_num):
+                linear(f"get_adj_matrix.{i - 1}.linears_q.{h}", dh, d)
+            for h in range(head_num):
+                linear(f"get_adj_matrix.{i - 1}.linears_k.{h}", dh, d)
+            for h in range(head_num):
+                for l in range(layer_num):
+                    k = h * layer_num + l
+                    sd[f"graphcnn.{i}.graphconv.{k}.weights_edge"] = xavier(d, gh)
+                    sd[f"graphcnn.{i}.graphconv.{k}.weights_node"] = xavier(d + gh * l, gh)
+            linear(f"graphcnn.{i}.linear_layer", d, d * head_num)
+    return sd
+
+
+def synth_docs(b: int, n: int, d: int, seed: int = 1337, sparsity: float = 0.3):
+    """Synthetic DocRED-shaped documents: X ~ U(-1,1) [B,N,D];
+    E1,E2 ~ N(0,0.5^2) [B,N,N,D], E1 zeroed where adj==0; adj ~ Bernoulli(0.3), zero diag."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(b, n, d, generator=g) * 2 - 1
+    adj = (torch.rand(b, n, n, generator=g) < sparsity).float()
+    adj = adj * (1 - torch.eye(n)).unsqueeze(0)
+    e1 = torch.randn(b, n, n, d, generator=g) * 0.5 * adj.unsqueeze(-1)
+    e2 = torch.randn(b, n, n, d, generator=g) * 0.5
+    return x, e1, e2, adj

@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own classes on CPU.
+
+Build-container only: imports /root/reference/models/GCGCN_glove.py by file path (the
+package import is broken upstream) behind a stub for the absent
+``pytorch_pretrained_bert`` module.  Nothing from the reference is copied: the output
+files hold only numeric inputs, parameters, outputs and gradients.  The reference does
+not exist on the GPU box; tests read the committed .npz files instead.
+
+Usage:  python oracle/make_golden.py            (writes tests/golden/)
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF_FILE = "/root/reference/models/GCGCN_glove.py"
+OUT_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def load_reference():
+    sys.dont_write_bytecode = True          # the reference tree is read-only
+    stub = types.ModuleType("pytorch_pretrained_bert")
+    stub.BertModel = object                 # only needed for the import line (glove:13)
+    sys.modules["pytorch_pretrained_bert"] = stub
+    spec = importlib.util.spec_from_file_location("ref_glove", REF_FILE)
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    return ref
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _pack(inputs, module, out, cot, grads_in, extra=None):
+    d = {}
+    for k, v in inputs.items():
+        d["in." + k] = _np(v)
+    for k, v in module.state_dict().items():
+        d["sd." + k] = _np(v)
+    d["out"] = _np(out)
+    d["cot"] = _np(cot)
+    for k, v in grads_in.items():
+        d["grad.in." + k] = _np(v)
+    for k, p in module.named_parameters():
+        if p.grad is not None:
+            d["grad.sd." + k] = _np(p.grad)
+    for k, v in (extra or {}).items():
+        d[k] = np.asarray(v)
+    return d
+
+
+def _inputs(n, d, seed, zero_rows=()):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.rand(n, d, generator=g) * 2 - 1).requires_grad_()
+    adj01 = (torch.rand(n, n, generator=g) < 0.3).float() * (1 - torch.eye(n))
+    e = (torch.randn(n, n, d, generator=g) * 0.5 * adj01.unsqueeze(-1)).requires_grad_()
+    e2 = (torch.randn(n, n, d, generator=g) * 0.5).requires_grad_()
+    a = torch.rand(n, n, generator=g)
+    for r in zero_rows:
+        a[r] = 0
+    a = a.requires_grad_()
+    return g, x, e, e2, adj01, a
+
+
+def block_cases(ref):
+    shapes = [(5, 8, 2, 2), (16, 128, 2, 8), (7, 12, 4, 4), (16, 64, 4, 4), (1, 8, 2, 2), (2, 8, 2, 2)]
+    for (n, d, L, H) in shapes:
+        for seed in (1337, 0):
+            if (n <= 2 or d >= 64) and seed == 0:
+                continue      # big / degenerate shapes: one seed keeps the fixtures small
+            tag = f"n{n}_d{d}_l{L}_h{H}_s{seed}"
+            torch.manual_seed(seed)
+            meta = {"meta.n": n, "meta.d": d, "meta.l": L, "meta.h": H}
+
+            # GraphConv with an all-zero adjacency row (exercises glove:47-49)
+            g, x, e, e2, adj01, a = _inputs(n, d, seed, zero_rows=(0,) if n > 1 else ())
+            m = ref.GraphConv(d, d, d // L).eval()
+            out = m(x, e, a)
+            cot = torch.randn(out.shape, generator=g)
+            out.backward(cot)
+            yield f"graphconv_{tag}", _pack({"x": x, "e": e, "adj": a}, m, out, cot,
+                                             {"x": x.grad, "e": e.grad, "adj": a.grad}, meta)
+
+            # GATAttention: mask given (must be a no-op) — glove:154-168
+            g, x, e, e2, adj01, a = _inputs(n, d, seed)
+            m = ref.GATAttention(d, d).eval()
+            mask = torch.eq(adj01, 0)
+            out = m(x, e, mask)
+            out_nomask = m(x, e, None)
+            out_allmask = m(x, e, torch.ones(n, n, dtype=torch.bool))
+            assert torch.equal(out, out_nomask) and torch.equal(out, out_allmask)
+            cot = torch.randn(out.shape, generator=g)
+            out.backward(cot)
+            yield f"gat_{tag}", _pack({"x": x, "e": e, "mask": mask}, m, out, cot,
+                                       {"x": x.grad, "e": e.grad}, meta)
+
+            # GraphConvolution (CAGGC conv) — glove:52-80
+            g, x, e, e2, adj01, a = _inputs(n, d, seed, zero_rows=(n - 1,) if n > 2 else ())
+            m = ref.GraphConvolution(L, d, d).eval()
+            out = m(x, e, a)
+            cot = torch.randn(out.shape, generator=g)
+            out.backward(cot)
+            yield f"caggc_{tag}", _pack({"x": x, "e": e, "adj": a}, m, out, cot,
+                                         {"x": x.grad, "e": e.grad, "adj": a.grad}, meta)
+
+            # MultiHeadAttention (E passed in the ignored slot, as glove:336 does)
+            g, x, e, e2, adj01, a = _inputs(n, d, seed)
+            m = ref.MultiHeadAttention(H, d).eval()
+            outs = m(x, e2)
+            cots = [torch.randn(o.shape, generator=g) for o in outs]
+            torch.autograd.backward(outs, cots)
+            assert e2.grad is None
+            yield f"mha_{tag}", _pack({"x": x}, m, torch.stack(outs), torch.stack(cots),
+                                       {"x": x.grad}, meta)
+
+            # MultiGraphConvolution (MAGGC conv) — glove:82-120
+            g, x, e, e2, adj01, a = _inputs(n, d, seed)
+            al = [torch.rand(n, n, generator=g).requires_grad_() for _ in range(H)]
+            m = ref.MultiGraphConvolution(L, H, d, d).eval()
+            out = m(x, e2, al)
+            cot = torch.randn(out.shape, generator=g)
+            out.backward(cot)
+            yield f"maggc_{tag}", _pack({"x": x, "e": e2, "adj": torch.stack(al)}, m, out, cot,
+                                         {"x": x.grad, "e": e2.grad,
+                                          "adj": torch.stack([t.grad for t in al])}, meta)
+
+            # chained GAT -> CAGGC conv -> MHA -> MAGGC conv (glue of glove:329-341, alpha=1)
+            g, x, e, e2, adj01, a = _inputs(n, d, seed)
+            gat = ref.GATAttention(d, d).eval()
+            cag = ref.GraphConvolution(L, d, d).eval()
+            mha = ref.MultiHeadAttention(H, d).eval()
+            mag = ref.MultiGraphConvolution(L, H, d, d).eval()
+            a0 = gat(x, e, torch.eq(adj01, 0))
+            x1 = cag(x, e, a0)
+            al = mha(x1, e2)
+            x2 = mag(x1, e2, al)
+            cot = torch.randn(x2.shape, generator=g)
+            x2.backward(cot)
+            holder = torch.nn.Module()
+            holder.get_weighted_adj_matrix = gat
+            holder.get_adj_matrix = torch.nn.ModuleList([mha])
+            holder.graphcnn = torch.nn.ModuleList([cag, mag])
+            pk = _pack({"x": x, "e1": e, "e2": e2, "adj": adj01}, holder, x2, cot,
+                       {"x": x.grad, "e1": e.grad, "e2": e2.grad}, meta)
+            pk["mid.a0"] = _np(a0)
+            pk["mid.x1"] = _np(x1)
+            pk["mid.al"] = _np(torch.stack(al))
+            yield f"stack_{tag}", pk
+
+
+class _Cfg:
+    """Duck-typed config for GCGCN_glove(config) (attributes read at glove:222-279,306-339)."""
+    entity_type_size = 20
+    coref_size = 20
+    max_length = 512
+    keep_prob = 1.0
+    graph_hop = 2
+    dis_size = 20
+    dis_num = 21
+    dis_plus = 10
+    relation_num = 97
+    alpha = 1.0
+
+    def __init__(self, vocab):
+        rs = np.random.RandomState(1337)
+        self.data_word_vec = rs.randn(vocab, 100).astype(np.float32) * 0.1
+
+
+def full_model_case(ref, docs=8, n=16, t=40, s=3, vocab=200):
+    """cfg 1: the full GCGCN_glove forward on 8 synthetic docs; hooks record what the four
+    hot-path modules saw and returned inside the real model."""
+    torch.manual_seed(1337)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = ref.GCGCN_glove(_Cfg(vocab)).eval()
+    rec = {}
+
+    def hook(name):
+        def f(mod, inp, out):
+            rec[name + ".in"] = [i for i in inp]
+            rec[name + ".out"] = out
+        return f
+    model.get_weighted_adj_matrix.register_forward_hook(hook("gat"))
+    model.graphcnn[0].register_forward_hook(hook("cag"))
+    model.get_adj_matrix[0].register_forward_hook(hook("mha"))
+    model.graphcnn[1].register_forward_hook(hook("mag"))
+
+    g = torch.Generator().manual_seed(1337)
+    pk = {"meta.n": n, "meta.d": 128, "meta.l": 2, "meta.h": 8, "meta.docs": docs}
+    hot = ("get_weighted_adj_matrix.", "get_adj_matrix.", "graphcnn.")
+    for k, v in model.state_dict().items():
+        if k.startswith(hot):
+            pk["sd." + k] = _np(v)
+    for di in range(docs):
+        document = torch.randint(1, vocab, (t,), generator=g)
+        ner = torch.randint(0, 7, (t,), generator=g)
+        pos = torch.randint(0, n + 1, (t,), generator=g)
+        adj = (torch.rand(n, n, generator=g) < 0.3).float() * (1 - torch.eye(n))
+        sen = torch.zeros(n, n, s, t, dtype=torch.bool)
+        for i in range(n):
+            for j in range(n):
+                if adj[i, j] > 0:
+                    for k in range(int(torch.randint(1, s + 1, (1,), generator=g))):
+                        a0 = int(torch.randint(0, t - 8, (1,), generator=g))
+                        sen[i, j, k, a0:a0 + 8] = True
+        ph = torch.randint(0, 21, (n, n, s, t), generator=g)
+        pt = torch.randint(0, 21, (n, n, s, t), generator=g)
+        node_pos = torch.zeros(n, t)
+        for i in range(n):
+            a0 = int(torch.randint(0, t - 3, (1,), generator=g))
+            node_pos[i, a0:a0 + 3] = 1.0 / 3
+        node_type = torch.randint(0, 7, (n,), generator=g)
+        rel = torch.randint(-10, 11, (n, n), generator=g)
+        with torch.no_grad():
+            logits = model(document, ner, pos, adj, sen, ph, pt, node_pos, node_type, rel)
+        p = f"doc{di}."
+        pk[p + "adj"] = _np(adj)
+        pk[p + "x0"] = _np(rec["gat.in"][0])
+        pk[p + "e1"] = _np(rec["gat.in"][1])
+        pk[p + "a0"] = _np(rec["gat.out"])
+        pk[p + "x1_new"] = _np(rec["cag.out"])
+        pk[p + "x1"] = _np(rec["mha.in"][0])          # eval: dropout identity, alpha=1 -> == x1_new
+        pk[p + "e2"] = _np(rec["mag.in"][1])
+        pk[p + "al"] = _np(torch.stack(rec["mha.out"]))
+        pk[p + "x2_new"] = _np(rec["mag.out"])
+        pk[p + "logits_sum"] = np.float64(logits.double().sum().item())
+    return "model_c1", pk
+
+
+def main():
+    ref = load_reference()
+    os.makedirs(OUT_DIR, exist_ok=True)
+    total = 0
+    for name, pk in list(block_cases(ref)) + [full_model_case(ref)]:
+        path = os.path.join(OUT_DIR, name + ".npz")
+        np.savez_compressed(path, **pk)
+        total += os.path.getsize(path)
+        print(f"{name:40s} {os.path.getsize(path) / 1024:9.1f} KiB")
+    print(f"total {total / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,126 @@
+"""The CPU oracle (oracle/gcgcn_oracle.py) against golden vectors produced by the reference's
+own classes (oracle/make_golden.py).  This is what pins the oracle; tolerance 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_files, ids, load_golden
+from oracle import gcgcn_oracle as O
+
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+def _leaf(t):
+    return t.clone().requires_grad_()
+
+
+def _sd_leaf(sd):
+    return {k: _leaf(v) for k, v in sd.items()}
+
+
+def _check_grads(g, ins, sd):
+    for k, ref in g["grad_in"].items():
+        assert ins[k].grad is not None, k
+        torch.testing.assert_close(ins[k].grad, ref, **TOL, msg=lambda m: f"grad in.{k}: {m}")
+    for k, ref in g["grad_sd"].items():
+        assert sd[k].grad is not None, k
+        torch.testing.assert_close(sd[k].grad, ref, **TOL, msg=lambda m: f"grad sd.{k}: {m}")
+    # parameters the reference leaves without a gradient must stay untouched here too
+    for k, v in sd.items():
+        if k not in g["grad_sd"]:
+            assert v.grad is None, f"{k} has a gradient but the reference's has none"
+
+
+@pytest.mark.parametrize("path", golden_files("graphconv"), ids=ids(golden_files("graphconv")))
+def test_graphconv(path):
+    g = load_golden(path)
+    ins = {k: _leaf(v) for k, v in g["in"].items()}
+    sd = _sd_leaf(g["sd"])
+    out = O.graph_conv(ins["x"], ins["e"], ins["adj"], sd["weights_edge"], sd["weights_node"])
+    torch.testing.assert_close(out, g["out"], **TOL)
+    out.backward(g["cot"])
+    _check_grads(g, ins, sd)
+
+
+@pytest.mark.parametrize("path", golden_files("gat"), ids=ids(golden_files("gat")))
+def test_gat(path):
+    g = load_golden(path)
+    ins = {k: _leaf(v) for k, v in g["in"].items() if k != "mask"}
+    sd = _sd_leaf(g["sd"])
+    out = O.gat_attention(ins["x"], ins["e"], sd, mask=g["in"]["mask"])
+    torch.testing.assert_close(out, g["out"], **TOL)
+    out.backward(g["cot"])
+    _check_grads(g, ins, sd)
+
+
+@pytest.mark.parametrize("path", golden_files("caggc"), ids=ids(golden_files("caggc")))
+def test_caggc_conv(path):
+    g = load_golden(path)
+    ins = {k: _leaf(v) for k, v in g["in"].items()}
+    sd = _sd_leaf(g["sd"])
+    out = O.graph_convolution(ins["x"], ins["e"], ins["adj"], sd, g["meta"]["l"])
+    torch.testing.assert_close(out, g["out"], **TOL)
+    out.backward(g["cot"])
+    _check_grads(g, ins, sd)
+
+
+@pytest.mark.parametrize("path", golden_files("mha"), ids=ids(golden_files("mha")))
+def test_mha(path):
+    g = load_golden(path)
+    ins = {k: _leaf(v) for k, v in g["in"].items()}
+    sd = _sd_leaf(g["sd"])
+    outs = torch.stack(O.multi_head_attention(ins["x"], sd, g["meta"]["h"]))
+    torch.testing.assert_close(outs, g["out"], **TOL)
+    outs.backward(g["cot"])
+    _check_grads(g, ins, sd)          # also asserts linears_k.* got no gradient
+
+
+@pytest.mark.parametrize("path", golden_files("maggc"), ids=ids(golden_files("maggc")))
+def test_maggc_conv(path):
+    g = load_golden(path)
+    ins = {k: _leaf(v) for k, v in g["in"].items()}
+    sd = _sd_leaf(g["sd"])
+    out = O.multi_graph_convolution(ins["x"], ins["e"], list(ins["adj"].unbind(0)), sd,
+                                    g["meta"]["l"], g["meta"]["h"])
+    torch.testing.assert_close(out, g["out"], **TOL)
+    out.backward(g["cot"])
+    _check_grads(g, ins, sd)
+
+
+@pytest.mark.parametrize("path", golden_files("stack"), ids=ids(golden_files("stack")))
+def test_stack(path):
+    g = load_golden(path)
+    ins = {k: _leaf(v) for k, v in g["in"].items() if k != "adj"}
+    sd = _sd_leaf(g["sd"])
+    feats = O.hop_stack(ins["x"], [ins["e1"], ins["e2"]], g["in"]["adj"], sd,
+                        g["meta"]["l"], g["meta"]["h"])
+    torch.testing.assert_close(feats[1], g["mid"]["x1"], **TOL)
+    torch.testing.assert_close(feats[2], g["out"], **TOL)
+    feats[2].backward(g["cot"])
+    _check_grads(g, ins, sd)
+
+
+def test_model_c1_hooks():
+    """cfg 1: what the four hot-path modules saw/returned inside the real GCGCN_glove forward."""
+    g = load_golden(golden_files("model")[0])
+    raw, sd = g["raw"], g["sd"]
+    L, H = g["meta"]["l"], g["meta"]["h"]
+    for di in range(g["meta"]["docs"]):
+        p = f"doc{di}."
+        t = lambda k: torch.from_numpy(raw[p + k])
+        feats = O.hop_stack(t("x0"), [t("e1"), t("e2")], t("adj"), sd, L, H)
+        a0 = O.gat_attention(t("x0"), t("e1"), O.sub(sd, "get_weighted_adj_matrix"))
+        torch.testing.assert_close(a0, t("a0"), **TOL)
+        torch.testing.assert_close(feats[1], t("x1_new"), **TOL)
+        torch.testing.assert_close(feats[1], t("x1"), **TOL)
+        al = torch.stack(O.multi_head_attention(t("x1"), O.sub(sd, "get_adj_matrix.0"), H))
+        torch.testing.assert_close(al, t("al"), **TOL)
+        torch.testing.assert_close(feats[2], t("x2_new"), **TOL)
+
+
+def test_dropout_mask_convention():
+    x = torch.ones(4, 4)
+    keep = torch.tensor([[1, 0, 1, 0]] * 4, dtype=torch.bool)
+    y = O._drop(x, keep, 0.2)
+    assert torch.allclose(y[:, 0], torch.full((4,), 1.25)) and (y[:, 1] == 0).all()
+    assert O._drop(x, None, 0.2) is x
