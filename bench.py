@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py -- docs/sec forward+backward through the CAGGC+MAGGC stack on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5|c1] [--mode eager|graph]
+
+One step = one forward + backward of GATAttention -> GraphConvolution -> MultiHeadAttention ->
+MultiGraphConvolution (the hop loop of GCGCN_glove.py:329-341) over one batch of B synthetic
+DocRED-shaped documents per GPU, train mode (all four dropout sites on), X / E1 / E2 and every
+parameter requiring grad, loss = sum of the MAGGC output.  For N > 1 the driver
+launches one rank per GPU (torch.distributed.run); documents are sharded along the batch axis (weak
+scaling: B per GPU fixed) and the step ends with ONE RCCL all-reduce of the flat gradient bucket.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with two extra objects:
+  roofline     -- the dominant kernel's algorithmic HBM bytes / its HIP-event-timed duration
+  cpu_baseline -- the CPU oracle (a port of the reference's op sequence) timed on this host's cores
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {  # BASELINE.json configs; per-GPU batch
+    "c1": dict(B=8, N=16, D=128, L=2, H=8),
+    "c2": dict(B=32, N=64, D=256, L=2, H=8),
+    "c3": dict(B=32, N=64, D=768, L=4, H=4),
+    "c5": dict(B=32, N=256, D=512, L=2, H=8),
+}
+HBM_PEAK = 8.0e12        # B/s, MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+MFMA_F32_PEAK = 157.3e12  # flop/s, exact-f32 MFMA (spec)
+
+
+def algorithmic_flops_per_doc(N, D, L, H):
+    """F = 3 * F_fwd."""
+    gh, dh = D // L, D // H
+    S = sum(2 * N * (D + l * gh) * gh + 2 * N * N * gh + 2 * N * D * gh for l in range(L))
+    f = (2 * N * N * D + 2 * N * D) + 2 * N * N * D + S + 2 * N * D * D
+    f += H * (2 * N * D * dh + 2 * N * N * dh) + H * S + 2 * N * H * D * D
+    return 3 * f
+
+
+def synth(cfg, seed, dev):
+    """Same generator as oracle.synth_docs, restated here so that the product path
+    never imports the oracle: X~U(-1,1), E~N(0,0.25), adj~Bernoulli(0.3) zero-diag, E1 masked by adj."""
+    B, N, D = cfg["B"], cfg["N"], cfg["D"]
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, N, D, generator=g) * 2 - 1
+    adj = (torch.rand(B, N, N, generator=g) < 0.3).float() * (1 - torch.eye(N)).unsqueeze(0)
+    e1 = torch.randn(B, N, N, D, generator=g) * 0.5 * adj.unsqueeze(-1)
+    e2 = torch.randn(B, N, N, D, generator=g) * 0.5
+    return [t.to(dev) for t in (x, e1, e2, adj)]
+
+
+def cpu_baseline(cfg, budget_s=20.0):
+    """The CPU oracle (reference op sequence, one document per call, PyTorch CPU kernels) on this host."""
+    from oracle import gcgcn_oracle as O
+    N, D, L, H = cfg["N"], cfg["D"], cfg["L"], cfg["H"]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.requires_grad_() for k, v in O.init_stack_params(D, L, H, seed=1337).items()}
+    nd = 8
+    x, e1, e2, adj = O.synth_docs(nd, N, D, seed=1337)
+    g = torch.Generator().manual_seed(0)
+
+    def one(b):
+        xb, a, c = x[b].clone().requires_grad_(), e1[b].clone().requires_grad_(), e2[b].clone().requires_grad_()
+        keeps = {"gat": torch.rand(N, N, generator=g) > 0.1, "cag": [torch.rand(N, D // L, generator=g) > 0.2] * L,
+                 "glue.0": torch.rand(N, D, generator=g) > 0.2, "mha.1": [torch.rand(N, N, generator=g) > 0.1] * H,
+                 "mag.1": [[torch.rand(N, D // L, generator=g) > 0.2] * L] * H, "glue.1": torch.rand(N, D, generator=g) > 0.2}
+        out = O.hop_stack(xb, [a, c], adj[b], sd, L, H, keeps=keeps)[-1]
+        for v in sd.values():
+            v.grad = None
+        out.sum().backward()
+
+    t0 = time.perf_counter()
+    one(0)
+    first = time.perf_counter() - t0
+    warm = 2 if first < budget_s / 8 else 0
+    for b in range(warm):
+        one(1 + b)
+    n, t0 = 0, time.perf_counter()
+    while n < 20 and (time.perf_counter() - t0) < budget_s:
+        one(n % nd)
+        n += 1
+    dt = time.perf_counter() - t0
+    if n == 0:
+        n, dt = 1, first
+    return {"value": round(n / dt, 4), "unit": "docs/s", "cores": cores, "kind": "port",
+            "sample": f"{n} documents (N={N}, D={D}, L={L}, H={H}) forward+backward, one per call, train mode, "
+                      f"after {1 + warm} warm-up; PyTorch CPU kernels with {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--mode", default=os.environ.get("GCGCN_BENCH_MODE", "eager"), choices=["eager", "graph"])
+    ap.add_argument("--prof-kernel", default="edge_bwd", help="kernel-name prefix timed with HIP events")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="extra untimed passes: per-kernel-group times to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import gcgcn_amd
+    from gcgcn_amd import _lib
+    from gcgcn_amd.dist import FlatGradBucket
+
+    cfg = CONFIGS[args.config]
+    B, N, D, L, H = (cfg[k] for k in "BNDLH")
+    torch.manual_seed(1337)                       # identical parameters on every rank
+    hops = gcgcn_amd.GraphHops(D, L, H).to(dev).train()
+    gcgcn_amd.manual_seed(1337 + rank, dev)
+    bucket = FlatGradBucket(hops)
+    x, e1, e2, adj = synth(cfg, 1337 + rank, dev)
+    for t in (x, e1, e2):
+        t.requires_grad_()
+    cot = torch.ones(B, N, D, device=dev)         # d(sum(out))/d(out)
+
+    def fwd_bwd():
+        x.grad = e1.grad = e2.grad = None
+        bucket.zero_grad()
+        out = hops(x, [e1, e2], adj)[-1]
+        torch.autograd.backward(out, cot)
+
+    graph = None
+    if args.mode == "graph":                      # capture the launch-bound step in one hipGraph
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                fwd_bwd()
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            fwd_bwd()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+        else:
+            fwd_bwd()
+        if world > 1:
+            bucket.all_reduce()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    lib = _lib.lib()
+    use_prof = graph is None
+    if use_prof:
+        _lib.call("gcgcn_prof_start", args.prof_kernel.encode(), args.steps * 4 + 8)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    kms, kn = ctypes.c_double(0), ctypes.c_int(0)
+    if use_prof:
+        _lib.call("gcgcn_prof_stop", ctypes.byref(kms), ctypes.byref(kn))
+
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+
+    breakdown = {}
+    if args.breakdown and graph is None:
+        for grp in ("edge_fwd_att", "edge_fwd_mean", "edge_bwd", "edge_bcast", "gemm", "softmax", "relu_norm_bwd",
+                    "head_sum", "rowsum", "dropout", "gat_fold", "node_score", "mask_rows"):
+            _lib.call("gcgcn_prof_start", grp.encode(), 4096)
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            ms, n = ctypes.c_double(0), ctypes.c_int(0)
+            _lib.call("gcgcn_prof_stop", ctypes.byref(ms), ctypes.byref(n))
+            breakdown[grp] = {"ms_per_step": round(ms.value / 5, 4), "launches_per_step": n.value / 5}
+
+    if rank == 0:
+        docs = B * world * args.steps
+        value = docs / dt
+        bytes_per_doc = {"edge_bwd": 8, "edge_fwd_att": 4, "edge_fwd_mean": 4, "edge_bcast": 4}
+        roof = None
+        if use_prof and kn.value > 0 and args.prof_kernel in bytes_per_doc:
+            per_launch = bytes_per_doc[args.prof_kernel] * N * N * D * B        # algorithmic bytes of one launch
+            avg_s = kms.value / kn.value * 1e-3
+            ach = per_launch / avg_s
+            roof = {"bound": "hbm", "kernel": args.prof_kernel, "achieved": round(ach / 1e9, 2), "peak": HBM_PEAK / 1e9,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4), "traffic": None,
+                    "avg_launch_us": round(avg_s * 1e6, 2), "launches": kn.value, "bytes_per_launch": per_launch}
+        flops = algorithmic_flops_per_doc(N, D, L, H)
+        line = {
+            "metric": "docs/sec fwd+bwd through CAGGC+MAGGC", "value": round(value, 2), "unit": "docs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: GraphHops fwd+bwd, B={B}/GPU N={N} D={D} L={L} H={H}, train mode, "
+                                   f"E1/E2/X/params require grad", "global_batch": B * world, "mode": args.mode,
+                       "parallelism": f"dp{world}"},
+            "roofline": roof,
+            "whole_step": {"hbm_frac": round(value / world * 20 * N * N * D / HBM_PEAK, 4),
+                           "mfma_frac": round(value / world * flops / MFMA_F32_PEAK, 4),
+                           "algorithmic_bytes_per_doc": 20 * N * N * D, "algorithmic_flops_per_doc": flops},
+        }
+        if breakdown:
+            line["breakdown"] = breakdown
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

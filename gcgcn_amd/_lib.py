@@ -1,0 +1,86 @@
+"""ctypes binding of libgcgcn_hip.so (the C ABI declared in include/gcgcn.h).
+
+There is no CPU or eager-PyTorch fallback: if the shared library is missing this module
+raises, and every op raises when handed a non-GPU tensor.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgcgcn_hip.so")
+
+SALT_GAT = 0x47415431
+SALT_MHA = 0x4D484131
+SALT_GCN = 0x47434E31
+SALT_GLUE = 0x474C5531
+
+P = c_void_p  # every device pointer crosses the ABI as void*
+I = c_int
+F = c_float
+L = c_int64
+
+# name -> (restype, argtypes); kept in the order of include/gcgcn.h
+SIGNATURES = {
+    "gcgcn_version": (I, []),
+    "gcgcn_last_error": (c_char_p, []),
+    "gcgcn_prof_start": (I, [c_char_p, I]),
+    "gcgcn_prof_stop": (I, [P, P]),
+    "gcgcn_rng_next": (I, [P, P, P]),
+    "gcgcn_dropout_keep": (I, [P, L, P, c_uint64, F, P]),
+    "gcgcn_dropout": (I, [P, P, L, P, c_uint64, F, P]),
+    "gcgcn_gat_layout": (I, [I, P]),
+    "gcgcn_gat_fwd": (I, [I, I, I, P, P, P, P, P, F, P, P, P, P, P, P]),
+    "gcgcn_gat_bwd_scratch": (L, [I, I, I]),
+    "gcgcn_gat_bwd": (I, [I, I, I, P, P, P, P, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_edge_mean_fwd": (I, [I, I, I, P, P, P, P]),
+    "gcgcn_edge_mean_bwd": (I, [I, I, I, P, P, P, P]),
+    "gcgcn_mha_layout": (I, [I, P]),
+    "gcgcn_mha_fwd": (I, [I, I, I, I, P, P, P, P, F, P, P, P, P]),
+    "gcgcn_mha_bwd_scratch": (L, [I, I, I]),
+    "gcgcn_mha_bwd": (I, [I, I, I, I, P, P, P, F, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_gcn_layout": (I, [I, I, I, P]),
+    "gcgcn_gcn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, P, P, P, P, P, P]),
+    "gcgcn_gcn_bwd_scratch": (L, [I, I, I]),
+    "gcgcn_gcn_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_gemm": (I, [I, I, I, P, L, I, P, L, I, P, L, I, L, L, L, F, P, I, I, I, P]),
+}
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load the HIP library once.  Raises RuntimeError (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"gcgcn_amd: {LIB_PATH} not found. Build it with `make -C gcgcn_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if handle.gcgcn_version() != 1:
+            raise RuntimeError(f"gcgcn_amd: ABI version {handle.gcgcn_version()} != 1")
+        _lib = handle
+    return _lib
+
+
+def call(name: str, *args):
+    """Invoke an int-status entry point; raise RuntimeError with the library's message on failure."""
+    h = lib()
+    rc = getattr(h, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {h.gcgcn_last_error().decode()}")
+
+
+def layout(kind: str, *dims) -> list:
+    """Offsets (in floats) of a block's flat parameter buffer, straight from the library."""
+    n = {"gat": 9, "mha": 3, "gcn": 7}[kind]
+    out = (c_int64 * n)()
+    call(f"gcgcn_{kind}_layout", *dims, ctypes.cast(out, c_void_p))
+    return list(out)

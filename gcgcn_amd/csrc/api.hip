@@ -1,0 +1,515 @@
+// C ABI of libgcgcn_hip.so (include/gcgcn.h): host-side orchestration of the HIP kernels for
+// each block of the CAGGC/MAGGC path.  Every function only enqueues work on the caller's stream.
+#include "../../include/gcgcn.h"
+
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "gemm.hpp"
+#include "rowops.hpp"
+
+namespace gc {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return 2;
+  }
+  return 0;
+}
+
+// ---- per-kernel timing ---------------------------------------------------------------------------
+static struct {
+  bool on = false;
+  char filter[48] = "";
+  std::vector<hipEvent_t> ev;  // pairs: start, stop
+  int used = 0;                // pairs recorded
+} g_prof;
+
+ProfScope::ProfScope(const char* tag, hipStream_t s) : slot(-1), st(s) {
+  if (!g_prof.on || strncmp(tag, g_prof.filter, strlen(g_prof.filter)) != 0) return;
+  if (2 * (g_prof.used + 1) > (int)g_prof.ev.size()) return;  // ring full: stop recording
+  slot = g_prof.used++;
+  (void)hipEventRecord(g_prof.ev[2 * slot], st);
+}
+ProfScope::~ProfScope() {
+  if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
+}
+
+#define GC_TRY(expr)            \
+  do {                          \
+    if (int _e = (expr)) return _e; \
+  } while (0)
+
+struct GcnLayout {
+  long oWnX, oWe, oWd, oWlin, oblin, total, wd_head;
+  int gh;
+  long wd_off(int h, int l) const { return oWd + h * wd_head + (long)gh * gh * l * (l - 1) / 2; }
+};
+static GcnLayout gcn_layout(int D, int L, int H) {
+  GcnLayout y;
+  y.gh = D / L;
+  const long DHD = (long)D * H * D;
+  y.wd_head = (long)y.gh * y.gh * L * (L - 1) / 2;
+  y.oWnX = 0;
+  y.oWe = DHD;
+  y.oWd = 2 * DHD;
+  y.oWlin = y.oWd + H * y.wd_head;
+  y.oblin = y.oWlin + DHD;
+  y.total = y.oblin + D;
+  return y;
+}
+
+static int check_dims(const char* who, int B, int N, int D, int L, int H) {
+  GC_REQUIRE(B > 0 && N > 0 && D > 0, "%s: bad shape B=%d N=%d D=%d", who, B, N, D);
+  GC_REQUIRE(L > 0 && D % L == 0, "%s: D=%d not divisible by layer_num=%d", who, D, L);
+  GC_REQUIRE(H > 0 && D % H == 0, "%s: D=%d not divisible by head_num=%d", who, D, H);
+  return 0;
+}
+
+}  // namespace gc
+
+using namespace gc;
+
+extern "C" {
+
+int gcgcn_version(void) { return 1; }
+const char* gcgcn_last_error(void) { return g_err; }
+
+int gcgcn_prof_start(const char* kernel_prefix, int capacity) {
+  GC_REQUIRE(kernel_prefix && capacity > 0, "prof_start: bad arguments");
+  for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+  g_prof.ev.assign(2 * (size_t)capacity, nullptr);
+  for (auto& e : g_prof.ev) {
+    if (hipEventCreate(&e) != hipSuccess) {
+      set_error("prof_start: hipEventCreate failed");
+      return 2;
+    }
+  }
+  strncpy(g_prof.filter, kernel_prefix, sizeof(g_prof.filter) - 1);
+  g_prof.used = 0;
+  g_prof.on = true;
+  return 0;
+}
+int gcgcn_prof_stop(double* total_ms, int* launches) {
+  GC_REQUIRE(total_ms && launches, "prof_stop: null pointer");
+  g_prof.on = false;
+  double tot = 0;
+  for (int i = 0; i < g_prof.used; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess ||
+        hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) {
+      set_error("prof_stop: event query failed");
+      return 2;
+    }
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = g_prof.used;
+  for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+  g_prof.ev.clear();
+  g_prof.used = 0;
+  return 0;
+}
+
+int gcgcn_rng_next(void* state, void* snap, void* stream) {
+  GC_REQUIRE(state && snap, "rng_next: null pointer");
+  return rng_next(state, snap, (hipStream_t)stream);
+}
+int gcgcn_dropout_keep(uint8_t* keep, int64_t n, const void* rng_snap, uint64_t salt, float p, void* stream) {
+  GC_REQUIRE(keep && rng_snap, "dropout_keep: null pointer");
+  Drop d = make_drop(rng_snap, salt, p);
+  d.snap = (const uint64_t*)rng_snap;
+  return dropout_keep(keep, n, d, (hipStream_t)stream);
+}
+int gcgcn_dropout(const float* x, float* y, int64_t n, const void* rng_snap, uint64_t salt, float p, void* stream) {
+  GC_REQUIRE(x && y && rng_snap, "dropout: null pointer");
+  GC_REQUIRE(p >= 0.f && p < 1.f, "dropout: p=%f out of [0,1)", p);
+  Drop d = make_drop(rng_snap, salt, p);
+  d.snap = (const uint64_t*)rng_snap;
+  return dropout(x, y, n, d, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// GATAttention
+// ---------------------------------------------------------------------------------------------
+int gcgcn_gat_layout(int D, int64_t* o) {
+  GC_REQUIRE(D > 0 && o, "gat_layout: bad arguments");
+  const long DD = (long)D * D;
+  o[0] = 0;             // W_h
+  o[1] = DD;            // b_h
+  o[2] = o[1] + D;      // W_t
+  o[3] = o[2] + DD;     // b_t
+  o[4] = o[3] + D;      // W_r
+  o[5] = o[4] + DD;     // b_r
+  o[6] = o[5] + D;      // wt
+  o[7] = o[6] + 3 * D;  // wt bias
+  o[8] = o[7] + 1;
+  return 0;
+}
+
+int gcgcn_gat_fwd(int B, int N, int D, const float* X, const float* E, const int32_t* n_valid, const float* flat,
+                  const void* rng_snap, float p, float* uvc, float* s, float* P, float* A, float* Ebar, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  GC_TRY(check_dims("gat_fwd", B, N, D, 1, 1));
+  GC_REQUIRE(X && E && flat && uvc && s && P && Ebar, "gat_fwd: null pointer");
+  const Drop drop = make_drop(rng_snap, GCGCN_SALT_GAT, p);
+  GC_REQUIRE(!drop.snap || A, "gat_fwd: dropout on but A is NULL");
+  const long M = (long)B * N;
+  GC_TRY(gat_fold_fwd(flat, uvc, D, st));
+  GC_TRY(node_score_fwd(X, uvc, s, M, D, st));
+  GC_TRY(edge_fwd(E, uvc + D, n_valid, Ebar, P, B, N, D, st));
+  GC_TRY(softmax_fwd(P, s, n_valid, P, A, M, N, 1, drop, st));
+  return 0;
+}
+
+int64_t gcgcn_gat_bwd_scratch(int B, int N, int D) { return colsum_scratch_elems((long)B * N, D, 1); }
+
+int gcgcn_gat_bwd(int B, int N, int D, const float* X, const float* E, const int32_t* n_valid, const float* flat,
+                  const void* rng_snap, float p, const float* uvc, const float* P, const float* dA, const float* dEbar,
+                  float* dX, float* dE, float* dflat, float* dlogit, float* ds, float* dvpart, float* duvc,
+                  float* scratch, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  GC_TRY(check_dims("gat_bwd", B, N, D, 1, 1));
+  GC_REQUIRE(X && E && flat && uvc && P && dA && dX && dflat && dlogit && ds && dvpart && duvc,
+             "gat_bwd: null pointer");
+  const Drop drop = make_drop(rng_snap, GCGCN_SALT_GAT, p);
+  const long M = (long)B * N;
+  GC_TRY(softmax_bwd(P, dA, dlogit, M, N, drop, st));
+  // ds[b, j] = sum_i dlogit[b, i, j]
+  GC_TRY(colsum(dlogit, nullptr, ds, N, N, N, B, (long)N * N, 0, N, 0, nullptr, st));
+  GC_TRY(edge_bwd(E, uvc + D, n_valid, dlogit, dEbar, dE, dvpart, B, N, D, st));
+  GC_TRY(colsum(dvpart, nullptr, duvc + D, M, D, D, 1, 0, 0, 0, 0, scratch, st));  // dv
+  GC_TRY(colsum(X, ds, duvc, M, D, D, 1, 0, 0, 0, 0, scratch, st));               // du = sum ds[m] X[m,:]
+  GC_TRY(colsum(ds, nullptr, duvc + 2 * D, M, 1, 1, 1, 0, 0, 0, 0, scratch, st));  // dc
+  GC_TRY(node_score_bwd(ds, uvc, dX, M, D, st));
+  GC_TRY(gat_fold_bwd(flat, duvc, dflat, D, st));
+  return 0;
+}
+
+int gcgcn_edge_mean_fwd(int B, int N, int D, const float* E, const int32_t* n_valid, float* Ebar, void* stream) {
+  return edge_fwd(E, nullptr, n_valid, Ebar, nullptr, B, N, D, (hipStream_t)stream);
+}
+int gcgcn_edge_mean_bwd(int B, int N, int D, const float* dEbar, const int32_t* n_valid, float* dE, void* stream) {
+  GC_REQUIRE(B > 0 && N > 0 && D > 0, "edge_mean_bwd: bad shape");
+  return edge_bcast(dEbar, n_valid, dE, B, N, D, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// MultiHeadAttention
+// ---------------------------------------------------------------------------------------------
+int gcgcn_mha_layout(int D, int64_t* o) {
+  GC_REQUIRE(D > 0 && o, "mha_layout: bad arguments");
+  o[0] = 0;
+  o[1] = (long)D * D;
+  o[2] = o[1] + D;
+  return 0;
+}
+
+int gcgcn_mha_fwd(int B, int N, int D, int H, const float* X, const int32_t* n_valid, const float* flat,
+                  const void* rng_snap, float p, float* Q, float* P, float* A, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  GC_TRY(check_dims("mha_fwd", B, N, D, 1, H));
+  GC_REQUIRE(X && flat && Q && P, "mha_fwd: null pointer");
+  const Drop drop = make_drop(rng_snap, GCGCN_SALT_MHA, p);
+  GC_REQUIRE(!drop.snap || A, "mha_fwd: dropout on but A is NULL");
+  const long M = (long)B * N;
+  const int dh = D / H;
+  {  // Q = X Wq^T + bq      (glove:136, all heads at once)
+    GemmArgs g;
+    g.A = X, g.lda = D, g.a_kc = 1;
+    g.B = flat, g.ldb = D, g.b_kc = 1;
+    g.C = Q, g.ldc = D;
+    g.M = (int)M, g.N = D, g.K = D;
+    g.bias = flat + (long)D * D;
+    GC_TRY(gemm(g, st));
+  }
+  {  // S[b,h] = Q_h Q_h^T / sqrt(dh)   (glove:137-138: keys use the query projection)
+    GemmArgs g;
+    g.A = Q, g.lda = D, g.a_kc = 1, g.sA1 = (long)N * D, g.sA2 = dh;
+    g.B = Q, g.ldb = D, g.b_kc = 1, g.sB1 = (long)N * D, g.sB2 = dh;
+    g.C = P, g.ldc = N, g.sC1 = (long)H * N * N, g.sC2 = (long)N * N;
+    g.M = N, g.N = N, g.K = dh;
+    g.batch1 = B, g.batch2 = H;
+    g.alpha = 1.f / sqrtf((float)dh);
+    GC_TRY(gemm(g, st));
+  }
+  GC_TRY(softmax_fwd(P, nullptr, n_valid, P, A, M * H, N, H, drop, st));
+  return 0;
+}
+
+int64_t gcgcn_mha_bwd_scratch(int B, int N, int D) { return colsum_scratch_elems((long)B * N, D, 1); }
+
+int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat, const void* rng_snap, float p,
+                  const float* Q, const float* P, const float* dA, float* dX, float* dflat, float* dS, float* dQ,
+                  float* scratch, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  GC_TRY(check_dims("mha_bwd", B, N, D, 1, H));
+  GC_REQUIRE(X && flat && Q && P && dA && dX && dflat && dS && dQ, "mha_bwd: null pointer");
+  const Drop drop = make_drop(rng_snap, GCGCN_SALT_MHA, p);
+  const long M = (long)B * N;
+  const int dh = D / H;
+  const float alpha = 1.f / sqrtf((float)dh);
+  GC_TRY(softmax_bwd(P, dA, dS, M * H, N, drop, st));
+  for (int pass = 0; pass < 2; ++pass) {  // dQ_h = alpha (dS + dS^T) Q_h
+    GemmArgs g;
+    g.A = dS, g.lda = N, g.a_kc = (pass == 0), g.sA1 = (long)H * N * N, g.sA2 = (long)N * N;
+    g.B = Q, g.ldb = D, g.b_kc = 0, g.sB1 = (long)N * D, g.sB2 = dh;
+    g.C = dQ, g.ldc = D, g.sC1 = (long)N * D, g.sC2 = dh;
+    g.M = N, g.N = dh, g.K = N;
+    g.batch1 = B, g.batch2 = H;
+    g.alpha = alpha;
+    g.accumulate = pass;
+    GC_TRY(gemm(g, st));
+  }
+  {  // dX = dQ Wq
+    GemmArgs g;
+    g.A = dQ, g.lda = D, g.a_kc = 1;
+    g.B = flat, g.ldb = D, g.b_kc = 0;
+    g.C = dX, g.ldc = D;
+    g.M = (int)M, g.N = D, g.K = D;
+    GC_TRY(gemm(g, st));
+  }
+  {  // dWq = dQ^T X
+    GemmArgs g;
+    g.A = dQ, g.lda = D, g.a_kc = 0;
+    g.B = X, g.ldb = D, g.b_kc = 0;
+    g.C = dflat, g.ldc = D;
+    g.M = D, g.N = D, g.K = (int)M;
+    GC_TRY(gemm(g, st));
+  }
+  GC_TRY(colsum(dQ, nullptr, dflat + (long)D * D, M, D, D, 1, 0, 0, 0, 0, scratch, st));  // dbq
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GraphConvolution / MultiGraphConvolution
+// ---------------------------------------------------------------------------------------------
+int gcgcn_gcn_layout(int D, int L, int H, int64_t* o) {
+  GC_TRY(check_dims("gcn_layout", 1, 1, D, L, H));
+  GC_REQUIRE(o, "gcn_layout: null pointer");
+  const GcnLayout y = gcn_layout(D, L, H);
+  o[0] = y.oWnX, o[1] = y.oWe, o[2] = y.oWd, o[3] = y.oWlin, o[4] = y.oblin, o[5] = y.total, o[6] = y.wd_head;
+  return 0;
+}
+
+int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float* Ebar, const float* A,
+                  const int32_t* n_valid, const float* flat, const void* rng_snap, float p, float* out, float* Pn,
+                  float* Y, float* HO, float* rinv, float* G, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  GC_TRY(check_dims("gcn_fwd", B, N, D, L, H));
+  GC_REQUIRE(X && Ebar && A && flat && out && Pn && Y && HO && rinv && G, "gcn_fwd: null pointer");
+  const GcnLayout y = gcn_layout(D, L, H);
+  const Drop drop = make_drop(rng_snap, GCGCN_SALT_GCN, p);
+  const long M = (long)B * N;
+  const int gh = y.gh;
+  const long HD = (long)H * D;
+  GC_REQUIRE(M <= 0x7fffffffL, "gcn_fwd: B*N too large");
+
+  GC_TRY(rowsum_inv(A, rinv, (long)B * H * N, N, st));  // glove:47-49
+  {  // Pn = X WnX : node term of every (head, sub-layer) for the X part of the dense input
+    GemmArgs g;
+    g.A = X, g.lda = D, g.a_kc = 1;
+    g.B = flat + y.oWnX, g.ldb = HD, g.b_kc = 0;
+    g.C = Pn, g.ldc = HD;
+    g.M = (int)M, g.N = (int)HD, g.K = D;
+    GC_TRY(gemm(g, st));
+  }
+  {  // G = Ebar We : edge term, mean commuted with the projection (glove:40-41)
+    GemmArgs g;
+    g.A = Ebar, g.lda = D, g.a_kc = 1;
+    g.B = flat + y.oWe, g.ldb = HD, g.b_kc = 0;
+    g.C = G, g.ldc = HD;
+    g.M = (int)M, g.N = (int)HD, g.K = D;
+    GC_TRY(gemm(g, st));
+  }
+  for (int l = 0; l < L; ++l) {
+    if (l > 0) {  // Pn_l += [Y_0 .. Y_{l-1}] Wd_l : dense connection (glove:73 / 110)
+      GemmArgs g;
+      g.A = Y, g.lda = HD, g.a_kc = 1, g.sA2 = (long)L * gh;
+      g.B = flat + y.wd_off(0, l), g.ldb = gh, g.b_kc = 0, g.sB2 = y.wd_head;
+      g.C = Pn + (long)l * gh, g.ldc = HD, g.sC2 = (long)L * gh;
+      g.M = (int)M, g.N = gh, g.K = l * gh;
+      g.batch2 = H;
+      g.accumulate = 1;
+      GC_TRY(gemm(g, st));
+    }
+    {  // Y_l = relu((G_l + A_h Pn_l) * rinv);  HO_l = dropout(Y_l) + X_l   (glove:42-50, 71-76)
+      GemmArgs g;
+      g.A = A, g.lda = N, g.a_kc = 1, g.sA1 = (long)H * N * N, g.sA2 = (long)N * N;
+      g.B = Pn + (long)l * gh, g.ldb = HD, g.b_kc = 0, g.sB1 = (long)N * HD, g.sB2 = (long)L * gh;
+      g.C = Y + (long)l * gh, g.ldc = HD, g.sC1 = (long)N * HD, g.sC2 = (long)L * gh;
+      g.M = N, g.N = gh, g.K = N;
+      g.batch1 = B, g.batch2 = H;
+      g.add = G + (long)l * gh, g.ldadd = HD, g.sAdd1 = (long)N * HD, g.sAdd2 = (long)L * gh;
+      g.rowscale = rinv, g.sRs1 = (long)H * N, g.sRs2 = N;
+      g.relu = 1;
+      g.C2 = HO + (long)l * gh, g.ldc2 = HD, g.sC21 = (long)N * HD, g.sC22 = (long)L * gh;
+      g.add2 = X + (long)l * gh, g.ldadd2 = D, g.sAdd21 = (long)N * D, g.sAdd22 = 0;
+      g.drop = drop, g.drop_base = (long)l * gh;  // dropout index = offset inside HO
+      GC_TRY(gemm(g, st));
+    }
+  }
+  {  // out = HO Wlin^T + blin   (glove:78 / 118)
+    GemmArgs g;
+    g.A = HO, g.lda = HD, g.a_kc = 1;
+    g.B = flat + y.oWlin, g.ldb = HD, g.b_kc = 1;
+    g.C = out, g.ldc = D;
+    g.M = (int)M, g.N = D, g.K = (int)HD;
+    g.bias = flat + y.oblin;
+    g.n_valid = n_valid, g.nv_rows = N, g.nv_zdoc = 0;
+    GC_TRY(gemm(g, st));
+  }
+  return 0;
+}
+
+int64_t gcgcn_gcn_bwd_scratch(int B, int N, int D) { return colsum_scratch_elems((long)B * N, D, 1); }
+
+int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float* Ebar, const float* A,
+                  const int32_t* n_valid, const float* flat, const void* rng_snap, float p, const float* Pn,
+                  const float* Y, const float* HO, const float* rinv, const float* dout, float* dX, float* dEbar,
+                  float* dA, float* dflat, float* W1, float* W2, float* W3, float* drow, float* dXres, float* dout_m,
+                  float* scratch, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  GC_TRY(check_dims("gcn_bwd", B, N, D, L, H));
+  GC_REQUIRE(X && Ebar && A && flat && Pn && Y && HO && rinv && dout && dX && dEbar && dA && dflat && W1 && W2 && W3 &&
+                 drow && dXres,
+             "gcn_bwd: null pointer");
+  GC_REQUIRE(!n_valid || dout_m, "gcn_bwd: n_valid given without dout_m workspace");
+  const GcnLayout y = gcn_layout(D, L, H);
+  const Drop drop = make_drop(rng_snap, GCGCN_SALT_GCN, p);
+  const long M = (long)B * N;
+  const int gh = y.gh;
+  const long HD = (long)H * D;
+  float* dYa = W1;  // dHO, then the running gradient of the relu outputs Y (same layout)
+  float* dM = W2;   // gradient of M_l = G_l + A_h Pn_l  (== dG)
+  float* dP = W3;   // gradient of Pn_l
+
+  if (n_valid) {  // gradients arriving on padding rows are ignored
+    GC_TRY(mask_rows(dout, dout_m, M, D, N, n_valid, st));
+    dout = dout_m;
+  }
+  {  // dHO = dout Wlin
+    GemmArgs g;
+    g.A = dout, g.lda = D, g.a_kc = 1;
+    g.B = flat + y.oWlin, g.ldb = HD, g.b_kc = 0;
+    g.C = dYa, g.ldc = HD;
+    g.M = (int)M, g.N = (int)HD, g.K = D;
+    GC_TRY(gemm(g, st));
+  }
+  {  // dWlin = dout^T HO
+    GemmArgs g;
+    g.A = dout, g.lda = D, g.a_kc = 0;
+    g.B = HO, g.ldb = HD, g.b_kc = 0;
+    g.C = dflat + y.oWlin, g.ldc = HD;
+    g.M = D, g.N = (int)HD, g.K = (int)M;
+    GC_TRY(gemm(g, st));
+  }
+  GC_TRY(colsum(dout, nullptr, dflat + y.oblin, M, D, D, 1, 0, 0, 0, 0, scratch, st));  // dblin
+  GC_TRY(head_sum_drop_bwd(dYa, dYa, dXres, M, H, D, drop, st));  // residual + dropout backward
+
+  for (int l = L - 1; l >= 0; --l) {
+    GC_TRY(relu_norm_bwd(dYa, Y, rinv, dM, drow, M, N, H, L, gh, l, l == L - 1, st));
+    {  // dPn_l = A_h^T dM_l
+      GemmArgs g;
+      g.A = A, g.lda = N, g.a_kc = 0, g.sA1 = (long)H * N * N, g.sA2 = (long)N * N;
+      g.B = dM + (long)l * gh, g.ldb = HD, g.b_kc = 0, g.sB1 = (long)N * HD, g.sB2 = (long)L * gh;
+      g.C = dP + (long)l * gh, g.ldc = HD, g.sC1 = (long)N * HD, g.sC2 = (long)L * gh;
+      g.M = N, g.N = gh, g.K = N;
+      g.batch1 = B, g.batch2 = H;
+      GC_TRY(gemm(g, st));
+    }
+    {  // dA_h (+)= dM_l Pn_l^T ; the normaliser's gradient drow is added on the last pass
+      GemmArgs g;
+      g.A = dM + (long)l * gh, g.lda = HD, g.a_kc = 1, g.sA1 = (long)N * HD, g.sA2 = (long)L * gh;
+      g.B = Pn + (long)l * gh, g.ldb = HD, g.b_kc = 1, g.sB1 = (long)N * HD, g.sB2 = (long)L * gh;
+      g.C = dA, g.ldc = N, g.sC1 = (long)H * N * N, g.sC2 = (long)N * N;
+      g.M = N, g.N = N, g.K = gh;
+      g.batch1 = B, g.batch2 = H;
+      g.accumulate = (l != L - 1);
+      if (l == 0) g.rowadd = drow, g.sRa1 = (long)H * N, g.sRa2 = N;
+      GC_TRY(gemm(g, st));
+    }
+    if (l > 0) {  // dY_{0..l-1} += dPn_l Wd_l^T
+      GemmArgs g;
+      g.A = dP + (long)l * gh, g.lda = HD, g.a_kc = 1, g.sA2 = (long)L * gh;
+      g.B = flat + y.wd_off(0, l), g.ldb = gh, g.b_kc = 1, g.sB2 = y.wd_head;
+      g.C = dYa, g.ldc = HD, g.sC2 = (long)L * gh;
+      g.M = (int)M, g.N = l * gh, g.K = gh;
+      g.batch2 = H;
+      g.accumulate = 1;
+      GC_TRY(gemm(g, st));
+    }
+  }
+  for (int l = 1; l < L; ++l) {  // dWd_{h,l} = [Y_0 .. Y_{l-1}]_h^T dPn_{h,l}
+    GemmArgs g;
+    g.A = Y, g.lda = HD, g.a_kc = 0, g.sA2 = (long)L * gh;
+    g.B = dP + (long)l * gh, g.ldb = HD, g.b_kc = 0, g.sB2 = (long)L * gh;
+    g.C = dflat + y.wd_off(0, l), g.ldc = gh, g.sC2 = y.wd_head;
+    g.M = l * gh, g.N = gh, g.K = (int)M;
+    g.batch2 = H;
+    GC_TRY(gemm(g, st));
+  }
+  {  // dWnX = X^T dPn
+    GemmArgs g;
+    g.A = X, g.lda = D, g.a_kc = 0;
+    g.B = dP, g.ldb = HD, g.b_kc = 0;
+    g.C = dflat + y.oWnX, g.ldc = HD;
+    g.M = D, g.N = (int)HD, g.K = (int)M;
+    GC_TRY(gemm(g, st));
+  }
+  {  // dWe = Ebar^T dM
+    GemmArgs g;
+    g.A = Ebar, g.lda = D, g.a_kc = 0;
+    g.B = dM, g.ldb = HD, g.b_kc = 0;
+    g.C = dflat + y.oWe, g.ldc = HD;
+    g.M = D, g.N = (int)HD, g.K = (int)M;
+    GC_TRY(gemm(g, st));
+  }
+  {  // dX = dPn WnX^T + sum_h dHO_h
+    GemmArgs g;
+    g.A = dP, g.lda = HD, g.a_kc = 1;
+    g.B = flat + y.oWnX, g.ldb = HD, g.b_kc = 1;
+    g.C = dX, g.ldc = D;
+    g.M = (int)M, g.N = D, g.K = (int)HD;
+    g.add = dXres, g.ldadd = D;
+    GC_TRY(gemm(g, st));
+  }
+  {  // dEbar = dM We^T
+    GemmArgs g;
+    g.A = dM, g.lda = HD, g.a_kc = 1;
+    g.B = flat + y.oWe, g.ldb = HD, g.b_kc = 1;
+    g.C = dEbar, g.ldc = D;
+    g.M = (int)M, g.N = D, g.K = (int)HD;
+    GC_TRY(gemm(g, st));
+  }
+  return 0;
+}
+
+int gcgcn_gemm(int M, int N, int K, const float* A, int64_t lda, int a_kc, const float* B, int64_t ldb, int b_kc,
+               float* C, int64_t ldc, int batch, int64_t sA, int64_t sB, int64_t sC, float alpha, const float* bias,
+               int relu, int accumulate, int tile, void* stream) {
+  GemmArgs g;
+  g.A = A, g.lda = lda, g.a_kc = a_kc;
+  g.B = B, g.ldb = ldb, g.b_kc = b_kc;
+  g.C = C, g.ldc = ldc;
+  g.M = M, g.N = N, g.K = K;
+  g.batch1 = 1, g.batch2 = batch;
+  g.sA2 = sA, g.sB2 = sB, g.sC2 = sC;
+  g.alpha = alpha, g.bias = bias, g.relu = relu, g.accumulate = accumulate;
+  return gemm(g, (hipStream_t)stream, tile);
+}
+
+}  // extern "C"

@@ -1,0 +1,92 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the CAGGC/MAGGC path.
+// wave = 64 lanes everywhere; no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define GC_WAVE 64
+
+namespace gc {
+
+// ---- error plumbing -------------------------------------------------------------------
+// The C ABI returns an int status (0 = ok) and keeps the message in a thread-local buffer
+// readable through gcgcn_last_error(); no exceptions cross the boundary.
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define GC_REQUIRE(cond, ...)                      \
+  do {                                             \
+    if (!(cond)) {                                 \
+      gc::set_error(__VA_ARGS__);                  \
+      return 1;                                    \
+    }                                              \
+  } while (0)
+
+// ---- wave-level reductions (64 lanes, shuffle based) --------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, GC_WAVE);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, GC_WAVE));
+  return v;
+}
+
+// ---- counter-based dropout RNG ------------------------------------------------------------
+// A dropout site is identified by (seed, counter) -- snapshotted on the device at forward time
+// by gcgcn_rng_next, so a hipGraph replay draws fresh masks -- plus a per-site salt.  Element
+// `idx` of the site keeps iff u32(key, idx) >= thresh, thresh = p * 2^32.  The backward
+// kernels regenerate the same bits from the same snapshot; no mask is ever stored.
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__host__ __device__ __forceinline__ uint64_t rng_key(uint64_t seed, uint64_t ctr, uint64_t salt) {
+  return mix64(mix64(seed + 0x9E3779B97F4A7C15ull) ^ mix64(ctr * 0xD1342543DE82EF95ull + salt));
+}
+__host__ __device__ __forceinline__ uint32_t rng_u32(uint64_t key, uint64_t idx) {
+  return (uint32_t)(mix64(key + idx * 0x9E3779B97F4A7C15ull) >> 32);
+}
+__host__ __device__ __forceinline__ uint32_t drop_thresh(float p) {
+  double t = (double)p * 4294967296.0;
+  if (t < 0) t = 0;
+  if (t > 4294967295.0) t = 4294967295.0;
+  return (uint32_t)t;
+}
+
+struct Drop {            // by-value kernel argument describing one dropout site
+  const uint64_t* snap;  // device int64[2] {seed, counter}; nullptr = dropout off (eval)
+  uint64_t salt;
+  uint32_t thresh;       // keep iff rng >= thresh
+  float scale;           // 1 / (1 - p)
+};
+__device__ __forceinline__ uint64_t drop_key(const Drop& d) {
+  return rng_key(d.snap[0], d.snap[1], d.salt);
+}
+inline Drop make_drop(const void* snap, uint64_t salt, float p) {
+  Drop d;
+  d.snap = (p > 0.f) ? (const uint64_t*)snap : nullptr;
+  d.salt = salt;
+  d.thresh = drop_thresh(p);
+  d.scale = (p < 1.f) ? 1.f / (1.f - p) : 0.f;
+  return d;
+}
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- optional per-kernel timing (gcgcn_prof_start / gcgcn_prof_stop) ------------------------------
+// While a filter is active, every launcher whose tag starts with the filter brackets its launch
+// with two hipEvents on the launch stream; bench.py reads the summed duration.  Off by default
+// (one predictable branch per launch); must stay off while a hipGraph is being captured.
+struct ProfScope {
+  ProfScope(const char* tag, hipStream_t st);
+  ~ProfScope();
+  int slot;
+  hipStream_t st;
+};
+
+}  // namespace gc

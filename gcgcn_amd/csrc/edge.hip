@@ -1,0 +1,309 @@
+// Edge-feature streaming kernels: the HBM-bound half of the CAGGC/MAGGC path.
+//
+// E is the per-pair edge tensor [B, N, N, D] (fp32, row-major): 4*N*N*D bytes per document,
+// far larger than everything else on the path.  Each byte of E is read exactly once in the
+// forward pass and once in the backward pass; dE is written exactly once.
+//
+//   edge_fwd  : one workgroup per entity row (b, i) streams E[b, i, :, :] (N*D contiguous
+//               floats, 16 B per lane, a 1-KiB row segment per wave instruction) and produces
+//                 Ebar[b, i, :]  = mean_j E[b, i, j, :]          (GraphConv edge term, glove:40-41
+//                                                                 after commuting mean and W_e)
+//                 logit[b, i, j] = v . E[b, i, j, :]             (GATAttention edge term, glove:161-162
+//                                                                 folded: v = W_r^T wt_r)
+//   edge_bwd  : re-reads E for dv = sum dlogit * E and writes
+//                 dE[b, i, j, :] = dlogit[b, i, j] * v + dEbar[b, i, :] / n
+//   edge_bcast: dE[b, i, j, :] = dEbar[b, i, :] / n   (MAGGC hop: E only feeds the mean)
+//
+// Ragged batches: n_valid[b] <= N entities are real; padding rows/columns are neither read nor
+// averaged, and their outputs are zero.
+#include "common.hpp"
+
+namespace gc {
+
+template <int VEC>
+__device__ __forceinline__ void vload(float (&r)[VEC], const float* p) {
+  if constexpr (VEC == 4) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    r[0] = v.x, r[1] = v.y, r[2] = v.z, r[3] = v.w;
+  } else {
+    r[0] = p[0];
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void vstore(float* p, const float (&r)[VEC]) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
+  } else {
+    p[0] = r[0];
+  }
+}
+
+constexpr int EW = 4;    // waves per workgroup
+constexpr int EUNR = 4;  // rows in flight per wave
+
+// ---------------------------------------------------------------------------------------------
+// forward: Ebar (always) and raw logits v.e_ij (ATT only).  dynamic LDS: EW * D floats.
+// ---------------------------------------------------------------------------------------------
+template <int VEC, bool ATT>
+__global__ __launch_bounds__(64 * EW) void edge_fwd_kernel(const float* __restrict__ E, const float* __restrict__ v,
+                                                           const int* __restrict__ n_valid, float* __restrict__ Ebar,
+                                                           float* __restrict__ logit, int N, int D) {
+  extern __shared__ __attribute__((aligned(16))) float cs[];  // [EW][D] per-wave column sums
+  const int bi = blockIdx.x;
+  const int b = bi / N, i = bi - b * N;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int nv = n_valid ? n_valid[b] : N;
+  float* eb = Ebar + (long)bi * D;
+  float* lg = ATT ? logit + (long)bi * N : nullptr;
+  if (i >= nv) {  // padding entity: outputs are zero, nothing is read
+    for (int c = t; c < D; c += 64 * EW) eb[c] = 0.f;
+    if (ATT)
+      for (int j = t; j < N; j += 64 * EW) lg[j] = 0.f;
+    return;
+  }
+  const float* __restrict__ Er = E + (long)bi * N * D;
+  const int nchunk = (D + 64 * VEC - 1) / (64 * VEC);
+  for (int q = 0; q < nchunk; ++q) {
+    const int c = (q * 64 + lane) * VEC;
+    const bool act = c < D;
+    float vr[VEC], acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) vr[e] = 0.f, acc[e] = 0.f;
+    if (ATT && act) vload<VEC>(vr, v + c);
+    int j = wave;
+    for (; j + (EUNR - 1) * EW < nv; j += EUNR * EW) {
+      float x[EUNR][VEC];
+#pragma unroll
+      for (int u = 0; u < EUNR; ++u) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) x[u][e] = 0.f;
+        if (act) vload<VEC>(x[u], Er + (long)(j + u * EW) * D + c);
+      }
+#pragma unroll
+      for (int u = 0; u < EUNR; ++u) {
+        float dot = 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          acc[e] += x[u][e];
+          dot = fmaf(x[u][e], vr[e], dot);
+        }
+        if (ATT) {
+          dot = wave_sum(dot);
+          if (lane == 0) {  // row j is owned by this wave: no race on lg[j]
+            if (q == 0) lg[j + u * EW] = dot;
+            else lg[j + u * EW] += dot;
+          }
+        }
+      }
+    }
+    for (; j < nv; j += EW) {
+      float x[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) x[e] = 0.f;
+      if (act) vload<VEC>(x, Er + (long)j * D + c);
+      float dot = 0.f;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        acc[e] += x[e];
+        dot = fmaf(x[e], vr[e], dot);
+      }
+      if (ATT) {
+        dot = wave_sum(dot);
+        if (lane == 0) {
+          if (q == 0) lg[j] = dot;
+          else lg[j] += dot;
+        }
+      }
+    }
+    if (act) vstore<VEC>(cs + wave * D + c, acc);
+  }
+  __syncthreads();
+  const float inv = 1.f / (float)nv;
+  for (int c = t; c < D; c += 64 * EW) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < EW; ++w) s += cs[w * D + c];
+    eb[c] = s * inv;
+  }
+  if (ATT)
+    for (int j = nv + t; j < N; j += 64 * EW) lg[j] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward of the CAGGC hop: dE = dlogit (x) v + dEbar / n ;  dv partial per workgroup.
+// dynamic LDS: N + EW * D floats.
+// ---------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(64 * EW) void edge_bwd_kernel(const float* __restrict__ E, const float* __restrict__ v,
+                                                           const int* __restrict__ n_valid,
+                                                           const float* __restrict__ dlogit,
+                                                           const float* __restrict__ dEbar, float* __restrict__ dE,
+                                                           float* __restrict__ dvpart, int N, int D) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* dl = sm;                    // [N]
+  float* cs = sm + ((N + 3) & ~3);   // [EW][D]
+  const int bi = blockIdx.x;
+  const int b = bi / N, i = bi - b * N;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int nv = n_valid ? n_valid[b] : N;
+  float* dEr = dE ? dE + (long)bi * N * D : nullptr;
+  float* dvp = dvpart + (long)bi * D;
+  if (i >= nv) {
+    for (int c = t; c < D; c += 64 * EW) dvp[c] = 0.f;
+    if (dEr) {
+      const long tot = (long)N * D;
+      for (long o = t; o < tot; o += 64 * EW) dEr[o] = 0.f;
+    }
+    return;
+  }
+  for (int j = t; j < N; j += 64 * EW) dl[j] = dlogit[(long)bi * N + j];
+  __syncthreads();
+  const float* __restrict__ Er = E + (long)bi * N * D;
+  const float inv = 1.f / (float)nv;
+  const int nchunk = (D + 64 * VEC - 1) / (64 * VEC);
+  for (int q = 0; q < nchunk; ++q) {
+    const int c = (q * 64 + lane) * VEC;
+    const bool act = c < D;
+    float vr[VEC], g[VEC], acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) vr[e] = 0.f, g[e] = 0.f, acc[e] = 0.f;
+    if (act) {
+      vload<VEC>(vr, v + c);
+      if (dEbar) {
+        vload<VEC>(g, dEbar + (long)bi * D + c);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) g[e] *= inv;
+      }
+    }
+    int j = wave;
+    for (; j + (EUNR - 1) * EW < nv; j += EUNR * EW) {
+      float x[EUNR][VEC];
+#pragma unroll
+      for (int u = 0; u < EUNR; ++u) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) x[u][e] = 0.f;
+        if (act) vload<VEC>(x[u], Er + (long)(j + u * EW) * D + c);
+      }
+#pragma unroll
+      for (int u = 0; u < EUNR; ++u) {
+        const float d = dl[j + u * EW];
+        float o[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          acc[e] = fmaf(d, x[u][e], acc[e]);
+          o[e] = fmaf(d, vr[e], g[e]);
+        }
+        if (dEr && act) vstore<VEC>(dEr + (long)(j + u * EW) * D + c, o);
+      }
+    }
+    for (; j < nv; j += EW) {
+      float x[VEC], o[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) x[e] = 0.f;
+      if (act) vload<VEC>(x, Er + (long)j * D + c);
+      const float d = dl[j];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        acc[e] = fmaf(d, x[e], acc[e]);
+        o[e] = fmaf(d, vr[e], g[e]);
+      }
+      if (dEr && act) vstore<VEC>(dEr + (long)j * D + c, o);
+    }
+    if (dEr && act) {  // padding columns of a real row
+      float z[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) z[e] = 0.f;
+      for (int jj = nv + wave; jj < N; jj += EW) vstore<VEC>(dEr + (long)jj * D + c, z);
+    }
+    if (act) vstore<VEC>(cs + wave * D + c, acc);
+  }
+  __syncthreads();
+  for (int c = t; c < D; c += 64 * EW) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < EW; ++w) s += cs[w * D + c];
+    dvp[c] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward of the mean alone: dE[b,i,j,:] = dEbar[b,i,:] / n   (pure streaming store)
+// ---------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(64 * EW) void edge_bcast_kernel(const float* __restrict__ dEbar,
+                                                             const int* __restrict__ n_valid, float* __restrict__ dE,
+                                                             int N, int D) {
+  const int bi = blockIdx.x;
+  const int b = bi / N, i = bi - b * N;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int nv = n_valid ? n_valid[b] : N;
+  float* dEr = dE + (long)bi * N * D;
+  const bool rowpad = i >= nv;
+  const float inv = rowpad ? 0.f : 1.f / (float)nv;
+  const int nchunk = (D + 64 * VEC - 1) / (64 * VEC);
+  for (int q = 0; q < nchunk; ++q) {
+    const int c = (q * 64 + lane) * VEC;
+    if (c >= D) continue;
+    float g[VEC], z[VEC];
+    vload<VEC>(g, dEbar + (long)bi * D + c);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) g[e] *= inv, z[e] = 0.f;
+    for (int j = wave; j < N; j += EW) {
+      if (!rowpad && j < nv) vstore<VEC>(dEr + (long)j * D + c, g);
+      else vstore<VEC>(dEr + (long)j * D + c, z);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------
+static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+int edge_fwd(const float* E, const float* v, const int* n_valid, float* Ebar, float* logit, int B, int N, int D,
+             hipStream_t st) {
+  GC_REQUIRE(E && Ebar, "edge_fwd: null pointer");
+  GC_REQUIRE(B > 0 && N > 0 && D > 0, "edge_fwd: bad shape B=%d N=%d D=%d", B, N, D);
+  const bool att = logit != nullptr;
+  GC_REQUIRE(!att || v, "edge_fwd: logits requested without v");
+  const bool vec = (D % 4 == 0) && al16(E) && al16(Ebar) && (!att || al16(v));
+  const size_t lds = (size_t)EW * D * sizeof(float);
+  GC_REQUIRE(lds <= 160 * 1024, "edge_fwd: D=%d needs %zu B of LDS", D, lds);
+  dim3 grid((unsigned)((long)B * N)), block(64 * EW);
+  ProfScope ps(att ? "edge_fwd_att" : "edge_fwd_mean", st);
+  if (vec) {
+    if (att) hipLaunchKernelGGL((edge_fwd_kernel<4, true>), grid, block, lds, st, E, v, n_valid, Ebar, logit, N, D);
+    else hipLaunchKernelGGL((edge_fwd_kernel<4, false>), grid, block, lds, st, E, v, n_valid, Ebar, logit, N, D);
+  } else {
+    if (att) hipLaunchKernelGGL((edge_fwd_kernel<1, true>), grid, block, lds, st, E, v, n_valid, Ebar, logit, N, D);
+    else hipLaunchKernelGGL((edge_fwd_kernel<1, false>), grid, block, lds, st, E, v, n_valid, Ebar, logit, N, D);
+  }
+  return check_launch("edge_fwd");
+}
+
+int edge_bwd(const float* E, const float* v, const int* n_valid, const float* dlogit, const float* dEbar, float* dE,
+             float* dvpart, int B, int N, int D, hipStream_t st) {
+  GC_REQUIRE(E && v && dlogit && dvpart, "edge_bwd: null pointer");
+  const bool vec = (D % 4 == 0) && al16(E) && al16(v) && (!dE || al16(dE)) && (!dEbar || al16(dEbar));
+  const size_t lds = ((size_t)((N + 3) & ~3) + (size_t)EW * D) * sizeof(float);
+  GC_REQUIRE(lds <= 160 * 1024, "edge_bwd: N=%d D=%d needs %zu B of LDS", N, D, lds);
+  dim3 grid((unsigned)((long)B * N)), block(64 * EW);
+  ProfScope ps("edge_bwd", st);
+  if (vec)
+    hipLaunchKernelGGL((edge_bwd_kernel<4>), grid, block, lds, st, E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D);
+  else
+    hipLaunchKernelGGL((edge_bwd_kernel<1>), grid, block, lds, st, E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D);
+  return check_launch("edge_bwd");
+}
+
+int edge_bcast(const float* dEbar, const int* n_valid, float* dE, int B, int N, int D, hipStream_t st) {
+  GC_REQUIRE(dEbar && dE, "edge_bcast: null pointer");
+  const bool vec = (D % 4 == 0) && al16(dE) && al16(dEbar);
+  dim3 grid((unsigned)((long)B * N)), block(64 * EW);
+  ProfScope ps("edge_bcast", st);
+  if (vec) hipLaunchKernelGGL((edge_bcast_kernel<4>), grid, block, 0, st, dEbar, n_valid, dE, N, D);
+  else hipLaunchKernelGGL((edge_bcast_kernel<1>), grid, block, 0, st, dEbar, n_valid, dE, N, D);
+  return check_launch("edge_bcast");
+}
+
+}  // namespace gc

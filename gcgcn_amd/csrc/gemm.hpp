@@ -1,0 +1,60 @@
+// Batched fp32 GEMM on the exact-f32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32) with the
+// fused epilogues the graph-convolution stack needs.  Internal header (host launcher + args).
+#pragma once
+#include "common.hpp"
+
+namespace gc {
+
+// C[z] = epilogue( alpha * opA(A[z]) * opB(B[z]) )          z = z1 * batch2 + z2
+//   a_kc : A is stored [M][K] (k contiguous, "N" form);  else A is stored [K][M] ("T" form)
+//   b_kc : B is stored [N][K] (k contiguous, "T" form);  else B is stored [K][N] ("N" form)
+// epilogue, in this order (every pointer optional):
+//   v  = alpha * acc
+//   v += add[row * ldadd + col]            (batch strided)
+//   v += bias[col]
+//   v += rowadd[row]                       (batch strided)
+//   v *= rowscale[row]                     (batch strided)
+//   v  = max(v, 0)           if relu
+//   v += C[row, col]         if accumulate
+//   v  = 0                   if the row is a padding row (n_valid given)
+//   C[row, col] = v
+//   C2[row, col] = dropout(v) + add2[row * ldadd2 + col]     if C2 (dropout index = element
+//                                                             offset inside the C2 buffer)
+struct GemmArgs {
+  const float* A = nullptr;
+  const float* B = nullptr;
+  float* C = nullptr;
+  int M = 0, N = 0, K = 0;
+  long lda = 0, ldb = 0, ldc = 0;
+  int a_kc = 1, b_kc = 0;
+  int batch1 = 1, batch2 = 1;
+  long sA1 = 0, sA2 = 0, sB1 = 0, sB2 = 0, sC1 = 0, sC2 = 0;
+  float alpha = 1.f;
+  const float* add = nullptr;
+  long ldadd = 0, sAdd1 = 0, sAdd2 = 0;
+  const float* bias = nullptr;
+  const float* rowadd = nullptr;
+  long sRa1 = 0, sRa2 = 0;
+  const float* rowscale = nullptr;
+  long sRs1 = 0, sRs2 = 0;
+  int relu = 0;
+  int accumulate = 0;
+  float* C2 = nullptr;
+  long ldc2 = 0, sC21 = 0, sC22 = 0;
+  const float* add2 = nullptr;
+  long ldadd2 = 0, sAdd21 = 0, sAdd22 = 0;
+  Drop drop = {nullptr, 0, 0, 1.f};
+  long drop_base = 0;  // added to the C2 element offset to form the dropout index (C2 may be a shifted view)
+  // ragged documents: output row r of batch (z1, z2) belongs to document
+  // z1 * nv_zdoc + r / nv_rows and is a padding row iff r % nv_rows >= n_valid[doc].
+  const int* n_valid = nullptr;
+  int nv_rows = 1, nv_zdoc = 0;
+  const char* tag = "gemm";  // name seen by the per-kernel timer
+  // filled by the launcher
+  int vecA = 0, vecB = 0;
+};
+
+// Enqueue on `stream`.  tile: 0 = pick by grid fill, 1 = 64x64 block, 2 = 128x128 block.
+int gemm(const GemmArgs& g, hipStream_t stream, int tile = 0);
+
+}  // namespace gc

@@ -1,0 +1,435 @@
+// Small row-wise kernels of the CAGGC/MAGGC path: softmax (+dropout) over attention rows,
+// adjacency row normaliser, relu/normaliser backward, dropout, column reductions, the folded
+// GAT projection, and the device-side dropout RNG state.  All are launch-latency sized; the
+// big terms live in edge.hip (HBM) and gemm.hip (MFMA).
+#include "rowops.hpp"
+
+namespace gc {
+
+constexpr int RW = 4;  // waves (= rows) per workgroup for the wave-per-row kernels
+
+// ---------------------------------------------------------------------------------------------
+// attention rows: P = softmax_j(scale * S[r, j] + coladd[doc, j]),  A = dropout(P)
+//   rows r = ((doc * heads) + h) * N + i ; valid columns j < n_valid[doc]; padding rows -> 0
+//   GATAttention glove:165-167 (coladd = u.x_j + c) and MultiHeadAttention glove:138-140.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * RW) void softmax_fwd_kernel(const float* __restrict__ S, const float* __restrict__ coladd,
+                                                              const int* __restrict__ n_valid, float* __restrict__ P,
+                                                              float* __restrict__ A, long rows, int N, int heads,
+                                                              Drop drop) {
+  const long r = (long)blockIdx.x * RW + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const long doc = r / ((long)heads * N);
+  const int i = (int)(r % N);
+  const int nv = n_valid ? n_valid[doc] : N;
+  const float* s = S + r * N;
+  float* p = P + r * N;
+  float* a = A ? A + r * N : nullptr;
+  if (i >= nv) {
+    for (int j = lane; j < N; j += 64) {
+      p[j] = 0.f;
+      if (a) a[j] = 0.f;
+    }
+    return;
+  }
+  const float* ca = coladd ? coladd + doc * N : nullptr;
+  float m = -INFINITY;
+  for (int j = lane; j < nv; j += 64) m = fmaxf(m, s[j] + (ca ? ca[j] : 0.f));
+  m = wave_max(m);
+  float sum = 0.f;
+  for (int j = lane; j < nv; j += 64) sum += expf(s[j] + (ca ? ca[j] : 0.f) - m);
+  sum = wave_sum(sum);
+  const float inv = 1.f / sum;
+  const bool dd = a && drop.snap;
+  const uint64_t key = dd ? drop_key(drop) : 0;
+  for (int j = lane; j < N; j += 64) {
+    float v = 0.f;
+    if (j < nv) v = expf(s[j] + (ca ? ca[j] : 0.f) - m) * inv;
+    p[j] = v;
+    if (a) {
+      if (dd) v = (rng_u32(key, (uint64_t)(r * N + j)) >= drop.thresh) ? v * drop.scale : 0.f;
+      a[j] = v;
+    }
+  }
+}
+
+// dS = P * (dP - sum_j dP * P),  dP = dropout_bwd(dA)
+__global__ __launch_bounds__(64 * RW) void softmax_bwd_kernel(const float* __restrict__ P, const float* __restrict__ dA,
+                                                              float* __restrict__ dS, long rows, int N, Drop drop) {
+  const long r = (long)blockIdx.x * RW + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* p = P + r * N;
+  const float* da = dA + r * N;
+  float* ds = dS + r * N;
+  const bool dd = drop.snap != nullptr;
+  const uint64_t key = dd ? drop_key(drop) : 0;
+  float dot = 0.f;
+  for (int j = lane; j < N; j += 64) {
+    float g = da[j];
+    if (dd) g = (rng_u32(key, (uint64_t)(r * N + j)) >= drop.thresh) ? g * drop.scale : 0.f;
+    dot = fmaf(g, p[j], dot);
+  }
+  dot = wave_sum(dot);
+  for (int j = lane; j < N; j += 64) {
+    float g = da[j];
+    if (dd) g = (rng_u32(key, (uint64_t)(r * N + j)) >= drop.thresh) ? g * drop.scale : 0.f;
+    ds[j] = p[j] * (g - dot);  // padding entries have p == 0
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GraphConv row normaliser (glove:47-50): rinv[r] = 1 / (sum_j A[r,j] + [sum == 0])
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * RW) void rowsum_inv_kernel(const float* __restrict__ A, float* __restrict__ rinv,
+                                                             long rows, int N) {
+  const long r = (long)blockIdx.x * RW + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float s = 0.f;
+  for (int j = lane; j < N; j += 64) s += A[r * N + j];
+  s = wave_sum(s);
+  if (lane == 0) rinv[r] = 1.f / (s + (s == 0.f ? 1.f : 0.f));
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward through  Y = relu(S),  S = M * rinv  for one sub-layer l of the stack:
+//   dS = dY * [Y > 0];  dM = dS * rinv;  drow (grad of the row sum r) -= rinv * sum_c dS * Y
+// Tensors are [rows_m, H, L, gh]; one wave per (m, h).  rinv / drow are [B, H, N].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * RW) void relu_norm_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
+                                                                const float* __restrict__ rinv, float* __restrict__ dM,
+                                                                float* __restrict__ drow, long rows_m, int N, int H,
+                                                                int L, int gh, int l, int first) {
+  const long w = (long)blockIdx.x * RW + (threadIdx.x >> 6);
+  if (w >= rows_m * H) return;
+  const int lane = threadIdx.x & 63;
+  const long m = w / H;
+  const int h = (int)(w - m * H);
+  const long b = m / N;
+  const int i = (int)(m - b * N);
+  const long off = (w * L + l) * gh;
+  const long ri = (b * H + h) * N + i;
+  const float rv = rinv[ri];
+  float acc = 0.f;
+  for (int c = lane; c < gh; c += 64) {
+    const float y = Y[off + c];
+    const float g = y > 0.f ? dY[off + c] : 0.f;
+    dM[off + c] = g * rv;
+    acc = fmaf(g, y, acc);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    const float d = -rv * acc;
+    drow[ri] = first ? d : drow[ri] + d;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward of  HO[m, h, :] = dropout(Y[m, h, :]) + X[m, :]  (glove:74-76 / 111-113):
+//   dY[m, h, c] = dropout_bwd(dHO[m, h, c])   (may alias dHO)
+//   dXres[m, c] = sum_h dHO[m, h, c]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_sum_drop_bwd_kernel(const float* dHO, float* dY, float* __restrict__ dXres,
+                                                                long M, int H, int D, Drop drop) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= M * D) return;
+  const long m = e / D;
+  const int c = (int)(e - m * D);
+  const bool dd = drop.snap != nullptr;
+  const uint64_t key = dd ? drop_key(drop) : 0;
+  float s = 0.f;
+  for (int h = 0; h < H; ++h) {
+    const long o = (m * H + h) * D + c;
+    const float g = dHO[o];
+    s += g;
+    if (dd) dY[o] = (rng_u32(key, (uint64_t)o) >= drop.thresh) ? g * drop.scale : 0.f;
+    else if (dY != dHO) dY[o] = g;
+  }
+  dXres[e] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// elementwise dropout (hop glue, glove:341); the same kernel is its own backward.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, Drop drop) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const uint64_t key = drop_key(drop);
+  y[e] = (rng_u32(key, (uint64_t)e) >= drop.thresh) ? x[e] * drop.scale : 0.f;
+}
+
+__global__ void dropout_keep_kernel(unsigned char* keep, long n, Drop drop) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  keep[e] = rng_u32(drop_key(drop), (uint64_t)e) >= drop.thresh;
+}
+
+__global__ void rng_next_kernel(uint64_t* state, uint64_t* snap) {
+  snap[0] = state[0];
+  snap[1] = state[1];
+  state[1] = state[1] + 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weighted column sums:  out[z, c] (+)= sum_r w[z, r] * X[z, r, c]      (w optional)
+// grid (ceil(C/64), nsplit, batch); each block covers a row range, 4 waves stride the rows, lanes
+// own columns.  nsplit > 1 writes partials [batch, nsplit, C] that a second call reduces.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, const float* __restrict__ w,
+                                                     float* __restrict__ out, long R, int C, long ld, long sXz, long sWz,
+                                                     long sOz, long rows_per_split, int accumulate) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int sp = blockIdx.y, z = blockIdx.z;
+  const long r0 = sp * rows_per_split;
+  long r1 = r0 + rows_per_split;
+  if (r1 > R) r1 = R;
+  const float* x = X + z * sXz;
+  const float* ww = w ? w + z * sWz : nullptr;
+  float acc = 0.f;
+  if (c < C)
+    for (long r = r0 + wave; r < r1; r += 4) acc = fmaf(ww ? ww[r] : 1.f, x[r * ld + c], acc);
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && c < C) {
+    const float s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    float* o = out + z * sOz + (long)sp * C + c;
+    *o = accumulate ? *o + s : s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GATAttention folded (glove:156-162 has no non-linearity between the three
+// Linear(D,D) and wt):  energy[i,j] = u.x_j + v.e_ij + c
+//   u = W_h^T wt_h + W_t^T wt_t,  v = W_r^T wt_r,  c = wt_h.b_h + wt_t.b_t + wt_r.b_r + b
+// flat parameter layout: [W_h D*D | b_h D | W_t D*D | b_t D | W_r D*D | b_r D | wt 3D | wtb 1]
+// uvc output: [u D | v D | c 1]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gat_fold_fwd_kernel(const float* __restrict__ flat, float* __restrict__ uvc, int D) {
+  __shared__ float red[4][64];
+  __shared__ float redc[4];
+  const long DD = (long)D * D;
+  const float* Wh = flat;
+  const float* bh = Wh + DD;
+  const float* Wt = bh + D;
+  const float* bt = Wt + DD;
+  const float* Wr = bt + D;
+  const float* br = Wr + DD;
+  const float* wt = br + D;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  float au = 0.f, av = 0.f;
+  if (k < D)
+    for (int d = wave; d < D; d += 4) {
+      au = fmaf(Wh[(long)d * D + k], wt[d], au);
+      au = fmaf(Wt[(long)d * D + k], wt[D + d], au);
+      av = fmaf(Wr[(long)d * D + k], wt[2 * D + d], av);
+    }
+  red[wave][lane] = au;
+  __syncthreads();
+  if (wave == 0 && k < D) uvc[k] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+  __syncthreads();
+  red[wave][lane] = av;
+  __syncthreads();
+  if (wave == 0 && k < D) uvc[D + k] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+  if (blockIdx.x == 0) {
+    float c = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256)
+      c += wt[d] * bh[d] + wt[D + d] * bt[d] + wt[2 * D + d] * br[d];
+    c = wave_sum(c);
+    if (lane == 0) redc[wave] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) uvc[2 * D] = redc[0] + redc[1] + redc[2] + redc[3] + wt[3 * D];
+  }
+}
+
+// backward of the fold; one wave per parameter row d.  duvc = [du D | dv D | dc 1]
+__global__ __launch_bounds__(64 * RW) void gat_fold_bwd_kernel(const float* __restrict__ flat, const float* __restrict__ duvc,
+                                                               float* __restrict__ dflat, int D) {
+  const int d = blockIdx.x * RW + (threadIdx.x >> 6);
+  if (d >= D) return;
+  const int lane = threadIdx.x & 63;
+  const long DD = (long)D * D;
+  const long oWh = 0, obh = DD, oWt = obh + D, obt = oWt + DD, oWr = obt + D, obr = oWr + DD, owt = obr + D;
+  const float* du = duvc;
+  const float* dv = duvc + D;
+  const float dc = duvc[2 * D];
+  const float wh = flat[owt + d], wtt = flat[owt + D + d], wr = flat[owt + 2 * D + d];
+  float ah = 0.f, at = 0.f, ar = 0.f;
+  for (int k = lane; k < D; k += 64) {
+    const float u = du[k], v = dv[k];
+    dflat[oWh + (long)d * D + k] = wh * u;
+    dflat[oWt + (long)d * D + k] = wtt * u;
+    dflat[oWr + (long)d * D + k] = wr * v;
+    ah = fmaf(flat[oWh + (long)d * D + k], u, ah);
+    at = fmaf(flat[oWt + (long)d * D + k], u, at);
+    ar = fmaf(flat[oWr + (long)d * D + k], v, ar);
+  }
+  ah = wave_sum(ah), at = wave_sum(at), ar = wave_sum(ar);
+  if (lane == 0) {
+    dflat[obh + d] = wh * dc;
+    dflat[obt + d] = wtt * dc;
+    dflat[obr + d] = wr * dc;
+    dflat[owt + d] = ah + flat[obh + d] * dc;
+    dflat[owt + D + d] = at + flat[obt + d] * dc;
+    dflat[owt + 2 * D + d] = ar + flat[obr + d] * dc;
+    if (d == 0) dflat[owt + 3 * D] = dc;
+  }
+}
+
+// s[m] = u . X[m, :] + c      (one wave per node row)
+__global__ __launch_bounds__(64 * RW) void node_score_fwd_kernel(const float* __restrict__ X, const float* __restrict__ uvc,
+                                                                 float* __restrict__ s, long M, int D) {
+  const long m = (long)blockIdx.x * RW + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int lane = threadIdx.x & 63;
+  float a = 0.f;
+  for (int k = lane; k < D; k += 64) a = fmaf(X[m * D + k], uvc[k], a);
+  a = wave_sum(a);
+  if (lane == 0) s[m] = a + uvc[2 * D];
+}
+
+// dX[m, :] = ds[m] * u
+__global__ __launch_bounds__(256) void node_score_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ uvc,
+                                                             float* __restrict__ dX, long M, int D) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= M * D) return;
+  const long m = e / D;
+  dX[e] = ds[m] * uvc[e - m * D];
+}
+
+// y (+)= a   elementwise
+__global__ __launch_bounds__(256) void add_kernel(float* __restrict__ y, const float* __restrict__ a, long n) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e < n) y[e] += a[e];
+}
+
+// y[m, :] = x[m, :] for real entities, 0 for padding rows (m = b * N + i, i >= n_valid[b])
+__global__ __launch_bounds__(256) void mask_rows_kernel(const float* __restrict__ x, float* __restrict__ y, long M, int D,
+                                                        int N, const int* __restrict__ n_valid) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= M * D) return;
+  const long m = e / D;
+  const long b = m / N;
+  y[e] = ((int)(m - b * N) < n_valid[b]) ? x[e] : 0.f;
+}
+
+// =============================================================================================
+// launchers
+// =============================================================================================
+int softmax_fwd(const float* S, const float* coladd, const int* n_valid, float* P, float* A, long rows, int N, int heads,
+                Drop drop, hipStream_t st) {
+  if (rows == 0) return 0;
+  ProfScope ps("softmax_fwd", st);
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3(cdiv(rows, RW)), dim3(64 * RW), 0, st, S, coladd, n_valid, P, A, rows, N,
+                     heads, drop);
+  return check_launch("softmax_fwd");
+}
+int softmax_bwd(const float* P, const float* dA, float* dS, long rows, int N, Drop drop, hipStream_t st) {
+  if (rows == 0) return 0;
+  ProfScope ps("softmax_bwd", st);
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3(cdiv(rows, RW)), dim3(64 * RW), 0, st, P, dA, dS, rows, N, drop);
+  return check_launch("softmax_bwd");
+}
+int rowsum_inv(const float* A, float* rinv, long rows, int N, hipStream_t st) {
+  if (rows == 0) return 0;
+  ProfScope ps("rowsum_inv", st);
+  hipLaunchKernelGGL(rowsum_inv_kernel, dim3(cdiv(rows, RW)), dim3(64 * RW), 0, st, A, rinv, rows, N);
+  return check_launch("rowsum_inv");
+}
+int relu_norm_bwd(const float* dY, const float* Y, const float* rinv, float* dM, float* drow, long rows_m, int N, int H,
+                  int L, int gh, int l, int first, hipStream_t st) {
+  ProfScope ps("relu_norm_bwd", st);
+  hipLaunchKernelGGL(relu_norm_bwd_kernel, dim3(cdiv(rows_m * H, RW)), dim3(64 * RW), 0, st, dY, Y, rinv, dM, drow,
+                     rows_m, N, H, L, gh, l, first);
+  return check_launch("relu_norm_bwd");
+}
+int head_sum_drop_bwd(const float* dHO, float* dY, float* dXres, long M, int H, int D, Drop drop, hipStream_t st) {
+  ProfScope ps("head_sum_drop_bwd", st);
+  hipLaunchKernelGGL(head_sum_drop_bwd_kernel, dim3(cdiv(M * D, 256)), dim3(256), 0, st, dHO, dY, dXres, M, H, D, drop);
+  return check_launch("head_sum_drop_bwd");
+}
+int dropout(const float* x, float* y, long n, Drop drop, hipStream_t st) {
+  GC_REQUIRE(drop.snap, "dropout: no rng snapshot");
+  if (n == 0) return 0;
+  ProfScope ps("dropout", st);
+  hipLaunchKernelGGL(dropout_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, x, y, n, drop);
+  return check_launch("dropout");
+}
+int dropout_keep(unsigned char* keep, long n, Drop drop, hipStream_t st) {
+  GC_REQUIRE(drop.snap, "dropout_keep: no rng snapshot");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(dropout_keep_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, keep, n, drop);
+  return check_launch("dropout_keep");
+}
+int rng_next(void* state, void* snap, hipStream_t st) {
+  hipLaunchKernelGGL(rng_next_kernel, dim3(1), dim3(1), 0, st, (uint64_t*)state, (uint64_t*)snap);
+  return check_launch("rng_next");
+}
+
+// out[z, :] (+)= sum_r w[z,r] X[z, r, :].  `scratch` must hold batch * COLSUM_SPLITS * C floats when
+// R is large enough to be split (see colsum_scratch_elems).
+constexpr int COLSUM_MIN_ROWS = 256;
+long colsum_scratch_elems(long R, int C, int batch) {
+  if (R < 2 * COLSUM_MIN_ROWS) return 0;
+  long ns = R / COLSUM_MIN_ROWS;
+  if (ns > 64) ns = 64;
+  return ns * C * batch;
+}
+int colsum(const float* X, const float* w, float* out, long R, int C, long ld, int batch, long sXz, long sWz, long sOz,
+           int accumulate, float* scratch, hipStream_t st) {
+  if (C == 0 || batch == 0) return 0;
+  long ns = 1;
+  if (R >= 2 * COLSUM_MIN_ROWS && scratch) {
+    ns = R / COLSUM_MIN_ROWS;
+    if (ns > 64) ns = 64;
+  }
+  if (ns == 1) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64), 1, batch), dim3(256), 0, st, X, w, out, R, C, ld, sXz, sWz, sOz,
+                       R > 0 ? R : 1, accumulate);
+    return check_launch("colsum");
+  }
+  const long rps = (R + ns - 1) / ns;
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64), (unsigned)ns, batch), dim3(256), 0, st, X, w, scratch, R, C, ld, sXz,
+                     sWz, ns * C, rps, 0);
+  if (int e = check_launch("colsum/1")) return e;
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64), 1, batch), dim3(256), 0, st, scratch, (const float*)nullptr, out, ns, C,
+                     (long)C, ns * C, 0L, sOz, ns, accumulate);
+  return check_launch("colsum/2");
+}
+
+int gat_fold_fwd(const float* flat, float* uvc, int D, hipStream_t st) {
+  ProfScope ps("gat_fold_fwd", st);
+  hipLaunchKernelGGL(gat_fold_fwd_kernel, dim3(cdiv(D, 64)), dim3(256), 0, st, flat, uvc, D);
+  return check_launch("gat_fold_fwd");
+}
+int gat_fold_bwd(const float* flat, const float* duvc, float* dflat, int D, hipStream_t st) {
+  ProfScope ps("gat_fold_bwd", st);
+  hipLaunchKernelGGL(gat_fold_bwd_kernel, dim3(cdiv(D, RW)), dim3(64 * RW), 0, st, flat, duvc, dflat, D);
+  return check_launch("gat_fold_bwd");
+}
+int node_score_fwd(const float* X, const float* uvc, float* s, long M, int D, hipStream_t st) {
+  ProfScope ps("node_score_fwd", st);
+  hipLaunchKernelGGL(node_score_fwd_kernel, dim3(cdiv(M, RW)), dim3(64 * RW), 0, st, X, uvc, s, M, D);
+  return check_launch("node_score_fwd");
+}
+int node_score_bwd(const float* ds, const float* uvc, float* dX, long M, int D, hipStream_t st) {
+  ProfScope ps("node_score_bwd", st);
+  hipLaunchKernelGGL(node_score_bwd_kernel, dim3(cdiv(M * D, 256)), dim3(256), 0, st, ds, uvc, dX, M, D);
+  return check_launch("node_score_bwd");
+}
+int mask_rows(const float* x, float* y, long M, int D, int N, const int* n_valid, hipStream_t st) {
+  ProfScope ps("mask_rows", st);
+  hipLaunchKernelGGL(mask_rows_kernel, dim3(cdiv(M * D, 256)), dim3(256), 0, st, x, y, M, D, N, n_valid);
+  return check_launch("mask_rows");
+}
+int add_inplace(float* y, const float* a, long n, hipStream_t st) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(add_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, y, a, n);
+  return check_launch("add");
+}
+
+}  // namespace gc

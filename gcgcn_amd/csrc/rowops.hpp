@@ -1,0 +1,33 @@
+// Internal launchers of the small row-wise kernels (rowops.hip) and edge kernels (edge.hip).
+#pragma once
+#include "common.hpp"
+
+namespace gc {
+
+int softmax_fwd(const float* S, const float* coladd, const int* n_valid, float* P, float* A, long rows, int N, int heads,
+                Drop drop, hipStream_t st);
+int softmax_bwd(const float* P, const float* dA, float* dS, long rows, int N, Drop drop, hipStream_t st);
+int rowsum_inv(const float* A, float* rinv, long rows, int N, hipStream_t st);
+int relu_norm_bwd(const float* dY, const float* Y, const float* rinv, float* dM, float* drow, long rows_m, int N, int H,
+                  int L, int gh, int l, int first, hipStream_t st);
+int head_sum_drop_bwd(const float* dHO, float* dY, float* dXres, long M, int H, int D, Drop drop, hipStream_t st);
+int dropout(const float* x, float* y, long n, Drop drop, hipStream_t st);
+int dropout_keep(unsigned char* keep, long n, Drop drop, hipStream_t st);
+int rng_next(void* state, void* snap, hipStream_t st);
+long colsum_scratch_elems(long R, int C, int batch);
+int colsum(const float* X, const float* w, float* out, long R, int C, long ld, int batch, long sXz, long sWz, long sOz,
+           int accumulate, float* scratch, hipStream_t st);
+int gat_fold_fwd(const float* flat, float* uvc, int D, hipStream_t st);
+int gat_fold_bwd(const float* flat, const float* duvc, float* dflat, int D, hipStream_t st);
+int node_score_fwd(const float* X, const float* uvc, float* s, long M, int D, hipStream_t st);
+int node_score_bwd(const float* ds, const float* uvc, float* dX, long M, int D, hipStream_t st);
+int mask_rows(const float* x, float* y, long M, int D, int N, const int* n_valid, hipStream_t st);
+int add_inplace(float* y, const float* a, long n, hipStream_t st);
+
+int edge_fwd(const float* E, const float* v, const int* n_valid, float* Ebar, float* logit, int B, int N, int D,
+             hipStream_t st);
+int edge_bwd(const float* E, const float* v, const int* n_valid, const float* dlogit, const float* dEbar, float* dE,
+             float* dvpart, int B, int N, int D, hipStream_t st);
+int edge_bcast(const float* dEbar, const int* n_valid, float* dE, int B, int N, int D, hipStream_t st);
+
+}  // namespace gc

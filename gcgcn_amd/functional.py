@@ -1,0 +1,296 @@
+"""torch.autograd bindings of the HIP blocks (C ABI in include/gcgcn.h).
+
+PyTorch is used for device memory (caching allocator), the current HIP stream and autograd
+bookkeeping only; all arithmetic happens in libgcgcn_hip.so.  Inputs must be fp32 tensors on a
+GPU -- anything else raises (no CPU path).
+"""
+from __future__ import annotations
+
+import ctypes
+import weakref
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import SALT_GAT, SALT_GCN, SALT_GLUE, SALT_MHA, call
+
+Tensor = torch.Tensor
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t: Tensor, name: str, ndim: Optional[int] = None) -> Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: gcgcn_amd runs on MI355X only; got a {t.device} tensor (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError(f"{name}: expected {ndim} dims, got shape {tuple(t.shape)}")
+    return t.contiguous()
+
+
+def _nv(n_valid: Optional[Tensor], B: int, N: int, dev) -> Optional[Tensor]:
+    if n_valid is None:
+        return None
+    nv = n_valid.to(device=dev, dtype=torch.int32).contiguous()
+    if nv.shape != (B,):
+        raise ValueError(f"n_valid: expected shape ({B},), got {tuple(nv.shape)}")
+    return nv
+
+
+# ---- dropout RNG state -----------------------------------------------------------------------------
+_rng_state = {}
+
+
+def manual_seed(seed: int, device=None):
+    """Seed the dropout generator of this library (per device): state = {seed, counter = 0}."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    _rng_state[dev.index or 0] = torch.tensor([seed, 0], dtype=torch.int64, device=dev)
+
+
+def rng_snapshot(dev: torch.device) -> Tensor:
+    """Device-side {seed, counter} for one dropout-using forward; advances the counter on the GPU,
+    so a captured hipGraph draws a fresh mask at every replay."""
+    idx = dev.index or 0
+    if idx not in _rng_state:
+        manual_seed(torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, dev)
+    snap = torch.empty(2, dtype=torch.int64, device=dev)
+    call("gcgcn_rng_next", _p(_rng_state[idx]), _p(snap), _stream())
+    return snap
+
+
+def dropout_keep_mask(snap: Tensor, salt: int, p: float, numel: int) -> Tensor:
+    """Boolean keep-mask of a dropout site (test aid: lets the CPU oracle replay the same mask)."""
+    keep = torch.empty(numel, dtype=torch.uint8, device=snap.device)
+    call("gcgcn_dropout_keep", _p(keep), numel, _p(snap), salt, float(p), _stream())
+    return keep.bool()
+
+
+# ---- GATAttention + single pass over E -------------------------------------------------------------
+class GatFn(torch.autograd.Function):
+    """(X[B,N,D], E[B,N,N,D], flat) -> (A[B,N,N], Ebar[B,N,D]).  GCGCN_glove.py:154-168 (+ :40-41)."""
+
+    @staticmethod
+    def forward(ctx, x, e, flat, n_valid, p, snap):
+        B, N, D = x.shape
+        dev = x.device
+        uvc = torch.empty(2 * D + 1, device=dev)
+        s = torch.empty(B, N, device=dev)
+        P = torch.empty(B, N, N, device=dev)
+        A = torch.empty(B, N, N, device=dev) if snap is not None else None
+        ebar = torch.empty(B, N, D, device=dev)
+        call("gcgcn_gat_fwd", B, N, D, _p(x), _p(e), _p(n_valid), _p(flat), _p(snap), float(p), _p(uvc), _p(s),
+             _p(P), _p(A), _p(ebar), _stream())
+        ctx.save_for_backward(x, e, flat, uvc, P)
+        ctx.n_valid, ctx.p, ctx.snap = n_valid, float(p), snap
+        return (P if A is None else A), ebar
+
+    @staticmethod
+    def backward(ctx, dA, dEbar):
+        x, e, flat, uvc, P = ctx.saved_tensors
+        B, N, D = x.shape
+        dev = x.device
+        dA = torch.zeros(B, N, N, device=dev) if dA is None else dA.contiguous()
+        dEbar = None if dEbar is None else dEbar.contiguous()
+        dX = torch.empty_like(x)
+        dE = torch.empty_like(e) if ctx.needs_input_grad[1] else None
+        dflat = torch.empty_like(flat)
+        dlogit = torch.empty(B, N, N, device=dev)
+        ds = torch.empty(B, N, device=dev)
+        dvpart = torch.empty(B * N, D, device=dev)
+        duvc = torch.empty(2 * D + 1, device=dev)
+        nscr = _lib.lib().gcgcn_gat_bwd_scratch(B, N, D)
+        scratch = torch.empty(max(nscr, 1), device=dev)
+        call("gcgcn_gat_bwd", B, N, D, _p(x), _p(e), _p(ctx.n_valid), _p(flat), _p(ctx.snap), ctx.p, _p(uvc), _p(P),
+             _p(dA), _p(dEbar), _p(dX), _p(dE), _p(dflat), _p(dlogit), _p(ds), _p(dvpart), _p(duvc), _p(scratch),
+             _stream())
+        return dX, dE, dflat, None, None, None
+
+
+class EdgeMeanFn(torch.autograd.Function):
+    """E[B,N,N,D] -> Ebar[B,N,D] = mean_j E  (GraphConv edge term, GCGCN_glove.py:40-41 commuted)."""
+
+    @staticmethod
+    def forward(ctx, e, n_valid):
+        B, N, _, D = e.shape
+        ebar = torch.empty(B, N, D, device=e.device)
+        call("gcgcn_edge_mean_fwd", B, N, D, _p(e), _p(n_valid), _p(ebar), _stream())
+        ctx.n_valid, ctx.shape = n_valid, (B, N, D)
+        return ebar
+
+    @staticmethod
+    def backward(ctx, dEbar):
+        B, N, D = ctx.shape
+        dEbar = dEbar.contiguous()
+        dE = torch.empty(B, N, N, D, device=dEbar.device)
+        call("gcgcn_edge_mean_bwd", B, N, D, _p(dEbar), _p(ctx.n_valid), _p(dE), _stream())
+        return dE, None
+
+
+class MhaFn(torch.autograd.Function):
+    """(X[B,N,D], flat) -> A[B,H,N,N].  MultiHeadAttention.forward, GCGCN_glove.py:133-142."""
+
+    @staticmethod
+    def forward(ctx, x, flat, n_valid, H, p, snap):
+        B, N, D = x.shape
+        dev = x.device
+        Q = torch.empty(B, N, D, device=dev)
+        P = torch.empty(B, H, N, N, device=dev)
+        A = torch.empty(B, H, N, N, device=dev) if snap is not None else None
+        call("gcgcn_mha_fwd", B, N, D, H, _p(x), _p(n_valid), _p(flat), _p(snap), float(p), _p(Q), _p(P), _p(A),
+             _stream())
+        ctx.save_for_backward(x, flat, Q, P)
+        ctx.H, ctx.p, ctx.snap = H, float(p), snap
+        return P if A is None else A
+
+    @staticmethod
+    def backward(ctx, dA):
+        x, flat, Q, P = ctx.saved_tensors
+        B, N, D = x.shape
+        H, dev = ctx.H, x.device
+        dA = dA.contiguous()
+        dX = torch.empty_like(x)
+        dflat = torch.empty_like(flat)
+        dS = torch.empty(B, H, N, N, device=dev)
+        dQ = torch.empty(B, N, D, device=dev)
+        scratch = torch.empty(max(_lib.lib().gcgcn_mha_bwd_scratch(B, N, D), 1), device=dev)
+        call("gcgcn_mha_bwd", B, N, D, H, _p(x), _p(flat), _p(ctx.snap), ctx.p, _p(Q), _p(P), _p(dA), _p(dX),
+             _p(dflat), _p(dS), _p(dQ), _p(scratch), _stream())
+        return dX, dflat, None, None, None, None
+
+
+class GcnFn(torch.autograd.Function):
+    """(X[B,N,D], Ebar[B,N,D], A[B,H,N,N], flat) -> out[B,N,D].
+    GraphConvolution.forward (H = 1) / MultiGraphConvolution.forward, GCGCN_glove.py:63-80 / 97-120."""
+
+    @staticmethod
+    def forward(ctx, x, ebar, adj, flat, n_valid, L, H, p, snap):
+        B, N, D = x.shape
+        dev = x.device
+        HD = H * D
+        out = torch.empty(B, N, D, device=dev)
+        Pn = torch.empty(B, N, HD, device=dev)
+        Y = torch.empty(B, N, HD, device=dev)
+        HO = torch.empty(B, N, HD, device=dev)
+        rinv = torch.empty(B, H, N, device=dev)
+        G = torch.empty(B, N, HD, device=dev)
+        call("gcgcn_gcn_fwd", B, N, D, L, H, _p(x), _p(ebar), _p(adj), _p(n_valid), _p(flat), _p(snap), float(p),
+             _p(out), _p(Pn), _p(Y), _p(HO), _p(rinv), _p(G), _stream())
+        ctx.save_for_backward(x, ebar, adj, flat, Pn, Y, HO, rinv)
+        ctx.n_valid, ctx.L, ctx.H, ctx.p, ctx.snap = n_valid, L, H, float(p), snap
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, ebar, adj, flat, Pn, Y, HO, rinv = ctx.saved_tensors
+        B, N, D = x.shape
+        L, H, dev = ctx.L, ctx.H, x.device
+        HD = H * D
+        dout = dout.contiguous()
+        dX = torch.empty_like(x)
+        dEbar = torch.empty_like(ebar)
+        dA = torch.empty_like(adj)
+        dflat = torch.empty_like(flat)
+        W1 = torch.empty(B, N, HD, device=dev)
+        W2 = torch.empty(B, N, HD, device=dev)
+        W3 = torch.empty(B, N, HD, device=dev)
+        drow = torch.empty(B, H, N, device=dev)
+        dXres = torch.empty(B, N, D, device=dev)
+        dout_m = torch.empty(B, N, D, device=dev) if ctx.n_valid is not None else None
+        scratch = torch.empty(max(_lib.lib().gcgcn_gcn_bwd_scratch(B, N, D), 1), device=dev)
+        call("gcgcn_gcn_bwd", B, N, D, L, H, _p(x), _p(ebar), _p(adj), _p(ctx.n_valid), _p(flat), _p(ctx.snap),
+             ctx.p, _p(Pn), _p(Y), _p(HO), _p(rinv), _p(dout), _p(dX), _p(dEbar), _p(dA), _p(dflat), _p(W1), _p(W2),
+             _p(W3), _p(drow), _p(dXres), _p(dout_m), _p(scratch), _stream())
+        return dX, dEbar, dA, dflat, None, None, None, None, None
+
+
+class DropoutFn(torch.autograd.Function):
+    """Elementwise dropout of the hop glue (GCGCN_glove.py:341); backward replays the same mask."""
+
+    @staticmethod
+    def forward(ctx, x, p, snap, salt):
+        y = torch.empty_like(x)
+        call("gcgcn_dropout", _p(x), _p(y), x.numel(), _p(snap), salt, float(p), _stream())
+        ctx.p, ctx.snap, ctx.salt = float(p), snap, salt
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        call("gcgcn_dropout", _p(dy), _p(dx), dy.numel(), _p(ctx.snap), ctx.salt, ctx.p, _stream())
+        return dx, None, None, None
+
+
+# ---- functional entry points -------------------------------------------------------------------------
+def _snap_for(training: bool, p: float, dev) -> Optional[Tensor]:
+    return rng_snapshot(dev) if (training and p > 0.0) else None
+
+
+def gat_attention(x, e, flat, n_valid=None, p=0.1, training=False):
+    x, e = _chk(x, "node_feat", 3), _chk(e, "edge_feat", 4)
+    B, N, D = x.shape
+    if e.shape != (B, N, N, D):
+        raise ValueError(f"edge_feat: expected {(B, N, N, D)}, got {tuple(e.shape)}")
+    nv = _nv(n_valid, B, N, x.device)
+    return GatFn.apply(x, e, _chk(flat, "flat"), nv, p, _snap_for(training, p, x.device))
+
+
+def edge_mean(e, n_valid=None):
+    e = _chk(e, "edge_feat", 4)
+    B, N = e.shape[0], e.shape[1]
+    return EdgeMeanFn.apply(e, _nv(n_valid, B, N, e.device))
+
+
+def multi_head_adjacency(x, flat, H, n_valid=None, p=0.1, training=False):
+    x = _chk(x, "node_feat", 3)
+    B, N, D = x.shape
+    return MhaFn.apply(x, _chk(flat, "flat"), _nv(n_valid, B, N, x.device), H, p, _snap_for(training, p, x.device))
+
+
+def gcn_stack(x, ebar, adj, flat, L, H, n_valid=None, p=0.2, training=False):
+    x, ebar, adj = _chk(x, "node_feat", 3), _chk(ebar, "edge_mean", 3), _chk(adj, "adjacency", 4)
+    B, N, D = x.shape
+    if ebar.shape != (B, N, D) or adj.shape != (B, H, N, N):
+        raise ValueError(f"gcn_stack: shapes x{tuple(x.shape)} ebar{tuple(ebar.shape)} adj{tuple(adj.shape)} H={H}")
+    return GcnFn.apply(x, ebar, adj, _chk(flat, "flat"), _nv(n_valid, B, N, x.device), L, H, p,
+                       _snap_for(training, p, x.device))
+
+
+def dropout(x, p=0.2, training=False, salt=SALT_GLUE):
+    x = _chk(x, "x")
+    if not training or p <= 0.0:
+        return x
+    return DropoutFn.apply(x, p, rng_snapshot(x.device), salt)
+
+
+# ---- one-slot hand-off of the edge mean from GATAttention to the GraphConvolution that follows ------
+# The reference calls gat(X, E, mask) and then graphcnn[0](X, E, A) with the SAME E (glove:332-333).
+# GATAttention's single pass over E also yields mean_j E; it is parked here so the convolution does
+# not stream E from HBM a second time.  One slot, consumed on use, replaced by the next GAT call.
+_handoff = None
+
+
+def park_edge_mean(e: Tensor, n_valid, ebar: Tensor):
+    global _handoff
+    _handoff = (weakref.ref(e), e._version, n_valid, ebar)
+
+
+def take_edge_mean(e: Tensor, n_valid) -> Optional[Tensor]:
+    global _handoff
+    h, _handoff = _handoff, None
+    if h is None:
+        return None
+    ref, ver, nvp, ebar = h
+    if ref() is e and e._version == ver and nvp is n_valid:
+        return ebar
+    return None

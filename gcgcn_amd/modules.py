@@ -1,0 +1,315 @@
+"""Drop-in nn.Modules for GCGCN's graph blocks, running on hand-written HIP kernels (gfx950).
+
+Same class names, constructor arguments, ``forward`` signatures and ``state_dict`` keys/shapes as
+``/root/reference/models/GCGCN_glove.py:18-168`` (identical copies in
+``GraphCNN_multihead_bert_gate_cls.py:18-172``), so the blocks slot into the reference's hop loop
+(glove:329-341) and load/save its checkpoints.  Extensions: every ``forward`` also accepts a
+leading batch axis (``[B,N,D]``, ``[B,N,N,D]``, ``[B,N,N]`` / ``[B,H,N,N]``) and an optional
+``n_valid[B]`` for ragged batches; without a batch axis behaviour is the reference's.
+
+Each module owns ONE flat fp32 ``nn.Parameter`` (``.flat``) in kernel layout (params.py); the
+reference-named tensors exist in ``state_dict()`` / ``load_state_dict()`` / ``named_tensors()``.
+Element-wise optimisers (Adam, SGD) on ``.flat`` are equivalent to the reference's per-tensor
+optimiser state.  Reference quirks reproduced on purpose: the GAT ``mask`` is a
+no-op, GAT head/tail are both column-indexed, MHA keys use the query projection and
+``linears_k.*`` never receive a gradient.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Union
+
+import torch
+from torch import nn
+
+from . import functional as F_
+from . import params as P_
+
+Tensor = torch.Tensor
+
+
+class _FlatBlock(nn.Module):
+    """Common state_dict plumbing: reference keys <-> flat kernel-layout parameters."""
+
+    def _ref_tensors(self) -> Dict[str, Tensor]:  # reference-named (detached) tensors
+        raise NotImplementedError
+
+    def _load_ref(self, sd: Dict[str, Tensor]):
+        raise NotImplementedError
+
+    def _ref_shapes(self) -> Dict[str, tuple]:
+        raise NotImplementedError
+
+    def named_tensors(self) -> Dict[str, Tensor]:
+        """Parameters under the reference's names (copies/views of ``.flat``, detached)."""
+        with torch.no_grad():
+            return self._ref_tensors()
+
+    def named_grads(self) -> Dict[str, Optional[Tensor]]:
+        """Gradients under the reference's names (None where the reference leaves grad=None)."""
+        raise NotImplementedError
+
+    # nn.Module hooks -------------------------------------------------------------------------------
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        for k, v in self.named_tensors().items():
+            destination[prefix + k] = v.detach().clone()
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        shapes = self._ref_shapes()
+        got = {}
+        for k, shp in shapes.items():
+            key = prefix + k
+            if key not in state_dict:
+                missing_keys.append(key)
+                continue
+            v = state_dict[key]
+            if tuple(v.shape) != tuple(shp):
+                error_msgs.append(f"size mismatch for {key}: copying a param with shape {tuple(v.shape)} from "
+                                  f"checkpoint, the shape in current model is {tuple(shp)}.")
+                continue
+            got[k] = v
+        if strict:
+            for key in state_dict.keys():
+                if key.startswith(prefix) and key[len(prefix):] not in shapes:
+                    unexpected_keys.append(key)
+        if len(got) == len(shapes):
+            with torch.no_grad():
+                dev = self.flat.device
+                self._load_ref({k: v.to(device=dev, dtype=torch.float32) for k, v in got.items()})
+
+
+def _batched(x: Tensor, nd: int):
+    """-> (tensor with a leading batch axis, had_batch)."""
+    if x.dim() == nd:
+        return x.unsqueeze(0), False
+    if x.dim() == nd + 1:
+        return x, True
+    raise ValueError(f"expected {nd} or {nd + 1} dims, got shape {tuple(x.shape)}")
+
+
+# ======================================================================================================
+class GATAttention(_FlatBlock):
+    """CAGGC adjacency (GCGCN_glove.py:144-168): A = dropout(softmax_j(wt.[W_h x_j; W_t x_j; W_r e_ij])).
+
+    ``mask`` is accepted and ignored exactly like the reference (its masked_fill result is discarded,
+    glove:163-164).  The one pass over ``edge_feat`` also produces ``mean_j edge_feat`` which is parked
+    for the ``GraphConvolution`` call that follows with the same tensor (functional.park_edge_mean).
+    """
+
+    def __init__(self, att_input_dim: int, hidden_dim: int, dropout: float = 0.1):
+        super().__init__()
+        if att_input_dim != hidden_dim:
+            # the reference only ever builds GATAttention(hidden, hidden) (glove:254); the fold of the three
+            # Linear layers into (u, v, c) holds for any hidden_dim, the flat layout assumes a square W.
+            raise ValueError("GATAttention: att_input_dim must equal hidden_dim")
+        self.dim = att_input_dim
+        self.p = float(dropout) if dropout is not None else 0.0
+        self.flat = nn.Parameter(torch.empty(P_.gat_layout(self.dim)[-1]))
+        with torch.no_grad():
+            P_.pack_gat(P_.init_gat(self.dim), self.dim, self.flat)
+
+    def _ref_shapes(self):
+        return P_.gat_shapes(self.dim)
+
+    def _ref_tensors(self):
+        return P_.unpack_gat(self.flat.detach(), self.dim)
+
+    def _load_ref(self, sd):
+        P_.pack_gat(sd, self.dim, self.flat)
+
+    def named_grads(self):
+        return P_.unpack_gat(self.flat.grad, self.dim) if self.flat.grad is not None else {}
+
+    def forward(self, node_feat: Tensor, edge_feat: Tensor, mask: Optional[Tensor] = None,
+                n_valid: Optional[Tensor] = None) -> Tensor:
+        x, batched = _batched(node_feat, 2)
+        e, _ = _batched(edge_feat, 3)
+        a, ebar = F_.gat_attention(x, e, self.flat, n_valid, self.p, self.training)
+        F_.park_edge_mean(edge_feat, n_valid, ebar)
+        return a if batched else a.squeeze(0)
+
+
+# ======================================================================================================
+class MultiHeadAttention(_FlatBlock):
+    """MAGGC adjacency (GCGCN_glove.py:122-142): per head softmax(Q_h Q_h^T / sqrt(dh)), keys projected
+    with the QUERY weights (glove:136-137).  Returns a list of ``head_num`` matrices like the reference
+    (views of one ``[B,H,N,N]`` tensor).  ``linears_k.*`` are kept for checkpoint compatibility and never
+    receive a gradient, as in the reference.  The second positional argument (``mask`` in the reference,
+    which the model feeds with the edge tensor, glove:336) is ignored.
+    """
+
+    def __init__(self, head_num: int, att_size: int, dropout: float = 0.1):
+        super().__init__()
+        assert att_size % head_num == 0          # glove:125
+        self.hidden_size = att_size // head_num
+        self.head_num = head_num
+        self.dim = att_size
+        self.p = float(dropout) if dropout is not None else 0.0
+        n = P_.mha_layout(att_size)[-1]
+        self.flat = nn.Parameter(torch.empty(n))
+        self.flat_k = nn.Parameter(torch.empty(n))   # linears_k.*: allocated, saved, never used (glove:130)
+        with torch.no_grad():
+            P_.pack_mha(P_.init_mha(att_size, head_num, "q"), att_size, head_num, self.flat, "q")
+            P_.pack_mha(P_.init_mha(att_size, head_num, "k"), att_size, head_num, self.flat_k, "k")
+
+    def _ref_shapes(self):
+        dh, D = self.hidden_size, self.dim
+        s = {}
+        for w in ("q", "k"):
+            for h in range(self.head_num):
+                s[f"linears_{w}.{h}.weight"] = (dh, D)
+                s[f"linears_{w}.{h}.bias"] = (dh,)
+        return s
+
+    def _ref_tensors(self):
+        d = P_.unpack_mha(self.flat.detach(), self.dim, self.head_num, "q")
+        d.update(P_.unpack_mha(self.flat_k.detach(), self.dim, self.head_num, "k"))
+        return d
+
+    def _load_ref(self, sd):
+        P_.pack_mha(sd, self.dim, self.head_num, self.flat, "q")
+        P_.pack_mha(sd, self.dim, self.head_num, self.flat_k, "k")
+
+    def named_grads(self):
+        if self.flat.grad is None:
+            return {}
+        return P_.unpack_mha(self.flat.grad, self.dim, self.head_num, "q")
+
+    def forward(self, node_feat: Tensor, mask: Optional[Tensor] = None, n_valid: Optional[Tensor] = None) -> List[Tensor]:
+        x, batched = _batched(node_feat, 2)
+        a = F_.multi_head_adjacency(x, self.flat, self.head_num, n_valid, self.p, self.training)  # [B,H,N,N]
+        return list(a.unbind(1)) if batched else list(a.squeeze(0).unbind(0))
+
+
+# ======================================================================================================
+class _GcnBase(_FlatBlock):
+    def _setup(self, layer_num: int, head_num: int, input_dim: int, output_dim: int, bias: bool):
+        if bias:
+            raise NotImplementedError("GraphConv bias=True is never used by the reference (glove:60,94)")
+        if input_dim != output_dim:
+            raise ValueError("residual connection needs input_dim == output_dim (glove:76)")
+        if output_dim % layer_num != 0:
+            raise ValueError("output_dim must be divisible by layer_num (glove:58,76)")
+        self.input_dim = input_dim
+        self.layer_num = layer_num
+        self.head_num = head_num
+        self.dim = output_dim
+        self.p = 0.2                                  # self.gcn_dropout = nn.Dropout(0.2), glove:59/90
+        self.flat = nn.Parameter(torch.empty(P_.gcn_layout(self.dim, layer_num, head_num)[5]))
+        with torch.no_grad():
+            P_.pack_gcn(P_.init_gcn(self.dim, layer_num, head_num), self.dim, layer_num, head_num, self.flat)
+
+    def _ref_shapes(self):
+        return P_.gcn_shapes(self.dim, self.layer_num, self.head_num)
+
+    def _ref_tensors(self):
+        return P_.unpack_gcn(self.flat.detach(), self.dim, self.layer_num, self.head_num)
+
+    def _load_ref(self, sd):
+        P_.pack_gcn(sd, self.dim, self.layer_num, self.head_num, self.flat)
+
+    def named_grads(self):
+        if self.flat.grad is None:
+            return {}
+        return P_.unpack_gcn(self.flat.grad, self.dim, self.layer_num, self.head_num)
+
+    def _edge_mean(self, edge_feat: Tensor, n_valid) -> Tensor:
+        """mean_j E: taken from the GATAttention call that just streamed this tensor, else computed."""
+        ebar = F_.take_edge_mean(edge_feat, n_valid)
+        if ebar is None:
+            e, _ = _batched(edge_feat, 3)
+            ebar = F_.edge_mean(e, n_valid)
+        return ebar
+
+
+class GraphConvolution(_GcnBase):
+    """CAGGC convolution (GCGCN_glove.py:52-80): ``layer_num`` densely connected GraphConv layers over one
+    adjacency, dropout 0.2 on the emitted copies, residual, Linear(D, D)."""
+
+    def __init__(self, layer_num: int, input_dim: int, output_dim: int, bias: bool = False):
+        super().__init__()
+        self._setup(layer_num, 1, input_dim, output_dim, bias)
+
+    def forward(self, node_feat: Tensor, edge_feat: Tensor, adj_matrix: Tensor,
+                n_valid: Optional[Tensor] = None) -> Tensor:
+        x, batched = _batched(node_feat, 2)
+        adj, _ = _batched(adj_matrix, 2)
+        ebar = self._edge_mean(edge_feat, n_valid)
+        out = F_.gcn_stack(x, ebar, adj.unsqueeze(1), self.flat, self.layer_num, 1, n_valid, self.p, self.training)
+        return out if batched else out.squeeze(0)
+
+
+class MultiGraphConvolution(_GcnBase):
+    """MAGGC convolution (GCGCN_glove.py:82-120): ``head_num`` independent dense stacks, one adjacency per
+    head, concatenated heads -> Linear(H*D, D)."""
+
+    def __init__(self, layer_num: int, head_num: int, input_dim: int, output_dim: int, bias: bool = False):
+        super().__init__()
+        self._setup(layer_num, head_num, input_dim, output_dim, bias)
+
+    @staticmethod
+    def _stack_heads(adj_list: Union[Tensor, Sequence[Tensor]], batched: bool) -> Tensor:
+        if isinstance(adj_list, torch.Tensor):
+            return adj_list if adj_list.dim() == 4 else adj_list.unsqueeze(0)
+        H, a0 = len(adj_list), adj_list[0]
+        base, step = a0._base, a0.shape[-1] * a0.shape[-2] * a0.element_size()
+        # the list MultiHeadAttention returns is H views of one [B,H,N,N] buffer: use it without a copy
+        if (base is not None and base.dim() == 4 and base.shape[1] == H and base.is_contiguous()
+                and all(a._base is base and a.data_ptr() == base.data_ptr() + h * step
+                        for h, a in enumerate(adj_list))):
+            return base
+        stacked = torch.stack(list(adj_list), dim=1 if batched else 0)
+        return stacked if batched else stacked.unsqueeze(0)
+
+    def forward(self, node_feat: Tensor, edge_feat: Tensor, adj_matrix_list: Union[Tensor, Sequence[Tensor]],
+                n_valid: Optional[Tensor] = None) -> Tensor:
+        x, batched = _batched(node_feat, 2)
+        adj = self._stack_heads(adj_matrix_list, batched)
+        ebar = self._edge_mean(edge_feat, n_valid)
+        out = F_.gcn_stack(x, ebar, adj, self.flat, self.layer_num, self.head_num, n_valid, self.p, self.training)
+        return out if batched else out.squeeze(0)
+
+
+# ======================================================================================================
+class GraphHops(nn.Module):
+    """The model's hop loop restricted to the graph blocks (GCGCN_glove.py:254-262 construction,
+    :329-341 forward): hop 0 = GATAttention + GraphConvolution (CAGGC), hop i >= 1 = MultiHeadAttention +
+    MultiGraphConvolution (MAGGC), ``x <- dropout(alpha * new + (1 - alpha) * x)``.
+
+    Sub-module names equal the model's attribute names, so ``GraphHops.state_dict()`` is exactly the
+    hot-path slice of a ``GCGCN_glove`` checkpoint (keys ``get_weighted_adj_matrix.*``,
+    ``get_adj_matrix.{i}.*``, ``graphcnn.{i}.*``).
+    """
+
+    def __init__(self, hidden_size: int = 128, layer_num: int = 2, head_num: int = 8, graph_hop: int = 2,
+                 alpha: float = 1.0, dropout: float = 0.2):
+        super().__init__()
+        self.graph_hop, self.alpha, self.p = graph_hop, float(alpha), float(dropout)
+        self.get_weighted_adj_matrix = GATAttention(hidden_size, hidden_size)
+        self.get_adj_matrix = nn.ModuleList([MultiHeadAttention(head_num, hidden_size) for _ in range(graph_hop - 1)])
+        self.graphcnn = nn.ModuleList()
+        for i in range(graph_hop):
+            if i == 0:
+                self.graphcnn.append(GraphConvolution(layer_num, hidden_size, hidden_size))
+            else:
+                self.graphcnn.append(MultiGraphConvolution(layer_num, head_num, hidden_size, hidden_size))
+
+    def forward(self, node_feat: Tensor, edge_feats: Sequence[Tensor], adj_matrix: Optional[Tensor] = None,
+                n_valid: Optional[Tensor] = None) -> List[Tensor]:
+        """edge_feats[i] is the edge tensor of hop i (``context_sent_att``).  Returns
+        ``[x_0, x_1, ..., x_hops]``; the model's ``node_feats`` list (glove:338) is the first ``hops``."""
+        feats = [node_feat]
+        x = node_feat
+        for i in range(self.graph_hop):
+            e = edge_feats[i]
+            if i < 1:
+                mask = None if adj_matrix is None else torch.eq(adj_matrix, 0)               # glove:330
+                a = self.get_weighted_adj_matrix(x, e, mask, n_valid=n_valid)                # glove:332
+                new = self.graphcnn[i](x, e, a, n_valid=n_valid)                             # glove:333
+            else:
+                al = self.get_adj_matrix[i - 1](x, e, n_valid=n_valid)                       # glove:336
+                new = self.graphcnn[i](x, e, al, n_valid=n_valid)                            # glove:337
+            x = new if self.alpha == 1.0 else self.alpha * new + (1 - self.alpha) * x        # glove:339
+            x = F_.dropout(x, self.p, self.training)                                         # glove:341
+            feats.append(x)
+        return feats

@@ -1,0 +1,196 @@
+"""Flat parameter buffers of the graph blocks and their mapping to the reference's state_dict.
+
+Each block keeps ONE contiguous fp32 parameter tensor laid out the way the HIP kernels read it
+(column-concatenated so that all heads / sub-layers are one GEMM operand); its gradient has the
+same layout, so a block's gradient is a single contiguous RCCL all-reduce bucket.  The
+reference's parameter names and shapes (GCGCN_glove.py:24-25, 60-61, 94-95, 129-130, 148-151)
+are recovered by ``unpack_*`` for ``state_dict()`` and consumed by ``pack_*`` for
+``load_state_dict()``, so checkpoints are interchangeable in both directions.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+
+Tensor = torch.Tensor
+
+
+# ---- layouts (mirrors of gcgcn_*_layout in csrc/api.hip; checked against the library in tests)
+def gat_layout(D: int):
+    DD = D * D
+    o = [0, DD, DD + D, 2 * DD + D, 2 * DD + 2 * D, 3 * DD + 2 * D, 3 * DD + 3 * D, 3 * DD + 6 * D]
+    return o + [o[-1] + 1]
+
+
+def mha_layout(D: int):
+    return [0, D * D, D * D + D]
+
+
+def gcn_layout(D: int, L: int, H: int):
+    gh = D // L
+    dhd = D * H * D
+    wd_head = gh * gh * L * (L - 1) // 2
+    o_wd = 2 * dhd
+    o_wlin = o_wd + H * wd_head
+    o_blin = o_wlin + dhd
+    return [0, dhd, o_wd, o_wlin, o_blin, o_blin + D, wd_head]
+
+
+def wd_offset(D: int, L: int, H: int, h: int, l: int) -> int:
+    gh = D // L
+    lay = gcn_layout(D, L, H)
+    return lay[2] + h * lay[6] + gh * gh * l * (l - 1) // 2
+
+
+# ---- GATAttention ------------------------------------------------------------------------------
+GAT_KEYS = ("linear_node_h.weight", "linear_node_h.bias", "linear_node_t.weight", "linear_node_t.bias",
+            "linear_edge_r.weight", "linear_edge_r.bias", "wt.weight", "wt.bias")
+
+
+def gat_shapes(D: int) -> Dict[str, tuple]:
+    return {"linear_node_h.weight": (D, D), "linear_node_h.bias": (D,),
+            "linear_node_t.weight": (D, D), "linear_node_t.bias": (D,),
+            "linear_edge_r.weight": (D, D), "linear_edge_r.bias": (D,),
+            "wt.weight": (1, 3 * D), "wt.bias": (1,)}
+
+
+def unpack_gat(flat: Tensor, D: int) -> Dict[str, Tensor]:
+    o = gat_layout(D)
+    shp = gat_shapes(D)
+    return {k: flat[o[i]:o[i + 1]].view(shp[k]) for i, k in enumerate(GAT_KEYS)}
+
+
+def pack_gat(sd: Dict[str, Tensor], D: int, out: Tensor) -> Tensor:
+    o = gat_layout(D)
+    for i, k in enumerate(GAT_KEYS):
+        out[o[i]:o[i + 1]].copy_(sd[k].reshape(-1))
+    return out
+
+
+# ---- MultiHeadAttention ------------------------------------------------------------------------
+def mha_keys(H: int, which: str = "q"):
+    ks = []
+    for h in range(H):
+        ks += [f"linears_{which}.{h}.weight", f"linears_{which}.{h}.bias"]
+    return ks
+
+
+def unpack_mha(flat: Tensor, D: int, H: int, which: str = "q") -> Dict[str, Tensor]:
+    dh = D // H
+    W = flat[:D * D].view(D, D)
+    b = flat[D * D:D * D + D]
+    out = {}
+    for h in range(H):
+        out[f"linears_{which}.{h}.weight"] = W[h * dh:(h + 1) * dh]
+        out[f"linears_{which}.{h}.bias"] = b[h * dh:(h + 1) * dh]
+    return out
+
+
+def pack_mha(sd: Dict[str, Tensor], D: int, H: int, out: Tensor, which: str = "q") -> Tensor:
+    dh = D // H
+    W = out[:D * D].view(D, D)
+    b = out[D * D:D * D + D]
+    for h in range(H):
+        W[h * dh:(h + 1) * dh].copy_(sd[f"linears_{which}.{h}.weight"])
+        b[h * dh:(h + 1) * dh].copy_(sd[f"linears_{which}.{h}.bias"])
+    return out
+
+
+# ---- GraphConvolution (H = 1) / MultiGraphConvolution --------------------------------------------
+def gcn_keys(L: int, H: int):
+    ks = []
+    for k in range(H * L):
+        ks += [f"graphconv.{k}.weights_edge", f"graphconv.{k}.weights_node"]
+    return ks + ["linear_layer.weight", "linear_layer.bias"]
+
+
+def gcn_shapes(D: int, L: int, H: int) -> Dict[str, tuple]:
+    gh = D // L
+    s = {}
+    for h in range(H):
+        for l in range(L):
+            k = h * L + l
+            s[f"graphconv.{k}.weights_edge"] = (D, gh)
+            s[f"graphconv.{k}.weights_node"] = (D + gh * l, gh)
+    s["linear_layer.weight"] = (D, H * D)
+    s["linear_layer.bias"] = (D,)
+    return s
+
+
+def unpack_gcn(flat: Tensor, D: int, L: int, H: int) -> Dict[str, Tensor]:
+    """Reference-named tensors (weights_node needs a cat, so these are copies, not views)."""
+    gh = D // L
+    lay = gcn_layout(D, L, H)
+    HD = H * D
+    WnX = flat[lay[0]:lay[1]].view(D, HD)
+    We = flat[lay[1]:lay[2]].view(D, HD)
+    out = {}
+    for h in range(H):
+        for l in range(L):
+            k = h * L + l
+            out[f"graphconv.{k}.weights_edge"] = We[:, k * gh:(k + 1) * gh].clone()
+            top = WnX[:, k * gh:(k + 1) * gh]
+            if l > 0:
+                o = wd_offset(D, L, H, h, l)
+                top = torch.cat([top, flat[o:o + l * gh * gh].view(l * gh, gh)], dim=0)
+            out[f"graphconv.{k}.weights_node"] = top.clone()
+    out["linear_layer.weight"] = flat[lay[3]:lay[4]].view(D, HD).clone()
+    out["linear_layer.bias"] = flat[lay[4]:lay[5]].clone()
+    return out
+
+
+def pack_gcn(sd: Dict[str, Tensor], D: int, L: int, H: int, out: Tensor) -> Tensor:
+    gh = D // L
+    lay = gcn_layout(D, L, H)
+    HD = H * D
+    WnX = out[lay[0]:lay[1]].view(D, HD)
+    We = out[lay[1]:lay[2]].view(D, HD)
+    for h in range(H):
+        for l in range(L):
+            k = h * L + l
+            We[:, k * gh:(k + 1) * gh].copy_(sd[f"graphconv.{k}.weights_edge"])
+            wn = sd[f"graphconv.{k}.weights_node"]
+            WnX[:, k * gh:(k + 1) * gh].copy_(wn[:D])
+            if l > 0:
+                o = wd_offset(D, L, H, h, l)
+                out[o:o + l * gh * gh].view(l * gh, gh).copy_(wn[D:])
+    out[lay[3]:lay[4]].view(D, HD).copy_(sd["linear_layer.weight"])
+    out[lay[4]:lay[5]].copy_(sd["linear_layer.bias"])
+    return out
+
+
+# ---- reference initialisers ------------------------------------------------------------------------
+def _linear_init(weight: Tensor, bias: Tensor):
+    """nn.Linear.reset_parameters(): kaiming_uniform(a=sqrt(5)) + U(-1/sqrt(fan_in), 1/sqrt(fan_in))."""
+    torch.nn.init.kaiming_uniform_(weight, a=math.sqrt(5))
+    bound = 1.0 / math.sqrt(weight.shape[1])
+    torch.nn.init.uniform_(bias, -bound, bound)
+
+
+def init_gat(D: int) -> Dict[str, Tensor]:
+    sd = {k: torch.empty(s) for k, s in gat_shapes(D).items()}
+    for nm in ("linear_node_h", "linear_node_t", "linear_edge_r", "wt"):
+        _linear_init(sd[nm + ".weight"], sd[nm + ".bias"])
+    return sd
+
+
+def init_mha(D: int, H: int, which: str = "q") -> Dict[str, Tensor]:
+    dh = D // H
+    sd = {}
+    for h in range(H):
+        w, b = torch.empty(dh, D), torch.empty(dh)
+        _linear_init(w, b)
+        sd[f"linears_{which}.{h}.weight"], sd[f"linears_{which}.{h}.bias"] = w, b
+    return sd
+
+
+def init_gcn(D: int, L: int, H: int) -> Dict[str, Tensor]:
+    """xavier_uniform for weights_edge / weights_node (GCGCN_glove.py:32-34), Linear default."""
+    sd = {k: torch.empty(s) for k, s in gcn_shapes(D, L, H).items()}
+    for k, v in sd.items():
+        if k.startswith("graphconv."):
+            torch.nn.init.xavier_uniform_(v)
+    _linear_init(sd["linear_layer.weight"], sd["linear_layer.bias"])
+    return sd

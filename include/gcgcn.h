@@ -1,0 +1,136 @@
+/* gcgcn.h -- C ABI of libgcgcn_hip.so: the CAGGC + MAGGC graph-convolution hot path of GCGCN
+ * as hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * The reference (Huiweizhou/GCGCN) has no FFI: its boundary for this path is the nn.Module
+ * protocol of five Python classes in models/GCGCN_glove.py:18-168 (code-identical copies in
+ * models/GraphCNN_multihead_bert_gate_cls.py:18-172).  Each entry point below replaces the
+ * forward (or autograd backward) of one of those classes and cites it.  gcgcn_amd/functional.py
+ * binds these with ctypes; INTEGRATION.md shows the binding a maintainer of the reference adds.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 (unless typed otherwise), row-major, dense;
+ *   - B documents, N entity slots per document, D feature width, L sub-layers, H heads,
+ *     gh = D / L, dh = D / H, M = B * N;
+ *   - n_valid: optional int32[B]; entities >= n_valid[b] are padding (their rows of X must be
+ *     zero; their outputs and gradients are zero).  NULL = every document has N entities;
+ *   - the caller owns all memory (inputs, outputs, saved-for-backward, workspace); the library
+ *     keeps no device memory and never synchronises: work is enqueued on `stream`
+ *     (a hipStream_t) and is hipGraph-capturable;
+ *   - return value 0 = ok, otherwise gcgcn_last_error() describes the failure (thread-local);
+ *   - dropout: rng_snap is a device int64[2] {seed, counter} written by gcgcn_rng_next at
+ *     forward time; NULL (or p == 0) = eval mode.  Backward takes the same snapshot.
+ *
+ * Parameter buffers ("flat") hold one block's parameters contiguously in the layout the
+ * kernels want; gcgcn_*_layout report offsets (in floats).  Gradient buffers use the same
+ * layout, so a block's gradient is one contiguous all-reduce bucket.
+ */
+#ifndef GCGCN_H
+#define GCGCN_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int gcgcn_version(void);            /* ABI version, currently 1 */
+const char* gcgcn_last_error(void); /* message of the last failing call on this thread */
+
+/* ---- per-kernel timing for roofline reports (bench.py) ------------------------------------------- */
+/* While active, every kernel launch whose name starts with kernel_prefix ("edge_bwd", "edge_fwd",
+ * "edge_bcast", "gemm", "softmax", ...) is bracketed by hipEvents on its launch stream (at most
+ * `capacity` launches).  prof_stop synchronises those events and returns their summed duration and
+ * count.  Not thread-safe; keep it off while capturing a hipGraph. */
+int gcgcn_prof_start(const char* kernel_prefix, int capacity);
+int gcgcn_prof_stop(double* total_ms, int* launches);
+
+/* ---- dropout RNG state (replaces torch's global CUDA generator used by nn.Dropout) ------- */
+/* snap <- state; state.counter += 1.   state, snap: device int64[2] {seed, counter}. */
+int gcgcn_rng_next(void* state, void* snap, void* stream);
+/* keep[i] = 1 iff element i of dropout site (snap, salt, p) is kept.  Test/debug aid. */
+int gcgcn_dropout_keep(uint8_t* keep, int64_t n, const void* rng_snap, uint64_t salt, float p, void* stream);
+/* y = dropout(x); calling it on a gradient with the same snapshot is the backward.
+ * Replaces self.dropout in the hop glue, GCGCN_glove.py:341. */
+int gcgcn_dropout(const float* x, float* y, int64_t n, const void* rng_snap, uint64_t salt, float p, void* stream);
+
+/* salts of the dropout sites inside the blocks */
+#define GCGCN_SALT_GAT 0x47415431ull
+#define GCGCN_SALT_MHA 0x4d484131ull
+#define GCGCN_SALT_GCN 0x47434e31ull
+#define GCGCN_SALT_GLUE 0x474c5531ull
+
+/* ---- GATAttention (CAGGC adjacency)  GCGCN_glove.py:144-168 -------------------------------- */
+/* flat = [W_h D*D | b_h D | W_t D*D | b_t D | W_r D*D | b_r D | wt 3D | wt_bias 1]
+ * out[0..7] = offsets of those eight pieces, out[8] = total floats. */
+int gcgcn_gat_layout(int D, int64_t* out9);
+
+/* forward(node_feat X[B,N,D], edge_feat E[B,N,N,D], mask ignored as in the reference):
+ *   P[B,N,N]    softmax_j(u.x_j + v.e_ij + c)            (saved for backward)
+ *   A[B,N,N]    dropout(P); may be NULL when rng_snap is NULL (then A == P)
+ *   Ebar[B,N,D] mean_j E[b,i,j,:]  -- by-product of the single pass over E, consumed by the
+ *               GraphConvolution that follows (GCGCN_glove.py:40-41 commuted)
+ *   uvc[2D+1], s[B,N]  folded projection and node scores (saved for backward) */
+int gcgcn_gat_fwd(int B, int N, int D, const float* X, const float* E, const int32_t* n_valid, const float* flat,
+                  const void* rng_snap, float p, float* uvc, float* s, float* P, float* A, float* Ebar, void* stream);
+
+/* backward.  dA[B,N,N], dEbar[B,N,D] (NULL = zero) -> dX[B,N,D], dE[B,N,N,D] (NULL = not
+ * wanted), dflat.  Workspace: dlogit[B,N,N], ds[B,N], dvpart[B*N*D], duvc[2D+1],
+ * scratch[gcgcn_gat_bwd_scratch(B,N,D)]. */
+int64_t gcgcn_gat_bwd_scratch(int B, int N, int D);
+int gcgcn_gat_bwd(int B, int N, int D, const float* X, const float* E, const int32_t* n_valid, const float* flat,
+                  const void* rng_snap, float p, const float* uvc, const float* P, const float* dA, const float* dEbar,
+                  float* dX, float* dE, float* dflat, float* dlogit, float* ds, float* dvpart, float* duvc,
+                  float* scratch, void* stream);
+
+/* ---- edge mean alone (MAGGC hop: E enters only through GraphConv's mean, glove:40-41) ------ */
+int gcgcn_edge_mean_fwd(int B, int N, int D, const float* E, const int32_t* n_valid, float* Ebar, void* stream);
+int gcgcn_edge_mean_bwd(int B, int N, int D, const float* dEbar, const int32_t* n_valid, float* dE, void* stream);
+
+/* ---- MultiHeadAttention (MAGGC adjacency)  GCGCN_glove.py:122-142 -------------------------- */
+/* flat = [Wq D*D (rows h*dh.. = linears_q.h.weight) | bq D]; linears_k.* never enter (the
+ * reference projects keys with linears_q, glove:136-137).  out = {oWq, obq, total}. */
+int gcgcn_mha_layout(int D, int64_t* out3);
+/* forward(node_feat X[B,N,D]) -> A[B,H,N,N] = dropout(P), P = softmax(Q_h Q_h^T / sqrt(dh));
+ * saved: Q[B,N,D], P[B,H,N,N].  A may be NULL when rng_snap is NULL. */
+int gcgcn_mha_fwd(int B, int N, int D, int H, const float* X, const int32_t* n_valid, const float* flat,
+                  const void* rng_snap, float p, float* Q, float* P, float* A, void* stream);
+/* backward.  Workspace: dS[B,H,N,N], dQ[B,N,D], scratch[gcgcn_mha_bwd_scratch]. */
+int64_t gcgcn_mha_bwd_scratch(int B, int N, int D);
+int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat, const void* rng_snap, float p,
+                  const float* Q, const float* P, const float* dA, float* dX, float* dflat, float* dS, float* dQ,
+                  float* scratch, void* stream);
+
+/* ---- GraphConvolution (H = 1) / MultiGraphConvolution  GCGCN_glove.py:52-120 --------------- */
+/* flat = [WnX D x H*D | We D x H*D | Wd | Wlin D x H*D | blin D]
+ *   WnX[:, (h*L+l)*gh ..] = graphconv.{h*L+l}.weights_node[:D]     (X part of the dense connection)
+ *   We [:, (h*L+l)*gh ..] = graphconv.{h*L+l}.weights_edge
+ *   Wd: for h, for l = 1..L-1: graphconv.{h*L+l}.weights_node[D:]  ([l*gh, gh], the Y_0..Y_{l-1} part)
+ *   Wlin, blin = linear_layer.weight / .bias
+ * out = {oWnX, oWe, oWd, oWlin, oblin, total, wd_floats_per_head}. */
+int gcgcn_gcn_layout(int D, int L, int H, int64_t* out7);
+/* forward(node_feat X[B,N,D], mean edge feature Ebar[B,N,D], adjacency A[B,H,N,N]) -> out[B,N,D].
+ * saved for backward: Pn, Y, HO (each [B,N,H*D]) and rinv[B,H,N].  Workspace: G[B,N,H*D]. */
+int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float* Ebar, const float* A,
+                  const int32_t* n_valid, const float* flat, const void* rng_snap, float p, float* out, float* Pn,
+                  float* Y, float* HO, float* rinv, float* G, void* stream);
+/* backward.  dout[B,N,D] -> dX, dEbar [B,N,D], dA[B,H,N,N], dflat.
+ * Workspace: W1, W2, W3 (each [B,N,H*D]), drow[B,H,N], dXres[B,N,D], dout_m[B,N,D] (only read
+ * when n_valid != NULL), scratch[gcgcn_gcn_bwd_scratch]. */
+int64_t gcgcn_gcn_bwd_scratch(int B, int N, int D);
+int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float* Ebar, const float* A,
+                  const int32_t* n_valid, const float* flat, const void* rng_snap, float p, const float* Pn,
+                  const float* Y, const float* HO, const float* rinv, const float* dout, float* dX, float* dEbar,
+                  float* dA, float* dflat, float* W1, float* W2, float* W3, float* drow, float* dXres, float* dout_m,
+                  float* scratch, void* stream);
+
+/* ---- raw batched GEMM (exposed for unit tests and benchmarks of the MFMA kernel) ----------- */
+/* C[z] = alpha * opA(A[z]) opB(B[z]);  a_kc: A stored [M][K] else [K][M];  b_kc: B stored [N][K]
+ * else [K][N];  z < batch with element strides sA, sB, sC;  tile: 0 auto, 1 = 64x64, 2 = 128x128;
+ * bias[N] optional, relu/accumulate flags. */
+int gcgcn_gemm(int M, int N, int K, const float* A, int64_t lda, int a_kc, const float* B, int64_t ldb, int b_kc,
+               float* C, int64_t ldc, int batch, int64_t sA, int64_t sB, int64_t sC, float alpha, const float* bias,
+               int relu, int accumulate, int tile, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCGCN_H */

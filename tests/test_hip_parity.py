@@ -1,0 +1,368 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the drop-in nn.Modules) against
+(1) golden vectors produced by the reference's own classes and (2) the CPU oracle on seeded inputs.
+Bar: 1e-4 absolute on fp32 outputs and gradients (BASELINE.json north_star)."""
+import ctypes
+import math
+
+import pytest
+import torch
+
+from conftest import golden_files, ids, load_golden
+import gcgcn_amd
+from gcgcn_amd import _lib, functional as F_
+from oracle import gcgcn_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-4, atol=1e-4)
+
+
+def dev_leaf(t, dev):
+    return t.to(dev).clone().requires_grad_()
+
+
+def close(a, b, what=""):
+    torch.testing.assert_close(a.detach().cpu(), b.detach().cpu(), **TOL, msg=lambda m: f"{what}: {m}")
+
+
+def check_param_grads(module, golden_grad_sd, prefix=""):
+    grads = module.named_grads()
+    for k, ref in golden_grad_sd.items():
+        if not k.startswith(prefix):
+            continue
+        kk = k[len(prefix):]
+        assert kk in grads, f"missing gradient {kk}"
+        close(grads[kk], ref, f"grad {k}")
+
+
+# ------------------------------------------------------------------------------------------------------
+# raw MFMA GEMM
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tile", [1, 2])
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 0), (1, 1), (0, 0), (0, 1)])
+@pytest.mark.parametrize("M,N,K,batch", [(64, 64, 16, 1), (100, 37, 53, 3), (256, 192, 256, 2), (5, 4, 8, 4),
+                                          (130, 257, 18, 1)])
+def test_gemm(gpu_device, M, N, K, batch, a_kc, b_kc, tile):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(batch, M, K, generator=g)
+    B = torch.randn(batch, K, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = torch.relu(0.5 * (A.double() @ B.double()) + bias.double()).float()
+    # asymmetric operands + non-square shapes catch row/col swaps in the MFMA C/D map
+    Ad = (A if a_kc else A.transpose(1, 2)).contiguous().to(gpu_device)
+    Bd = (B.transpose(1, 2) if b_kc else B).contiguous().to(gpu_device)
+    C = torch.full((batch, M, N), float("nan"), device=gpu_device)
+    lda = K if a_kc else M
+    ldb = K if b_kc else N
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.call("gcgcn_gemm", M, N, K, p(Ad), lda, a_kc, p(Bd), ldb, b_kc, p(C), N, batch, M * K, K * N, M * N,
+              0.5, p(bias.to(gpu_device)), 1, 0, tile, None)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(C.cpu(), ref, rtol=1e-4, atol=1e-4)
+    # accumulate: C += A B (no bias/relu)
+    C2 = C.clone()
+    _lib.call("gcgcn_gemm", M, N, K, p(Ad), lda, a_kc, p(Bd), ldb, b_kc, p(C2), N, batch, M * K, K * N, M * N,
+              1.0, None, 0, 1, tile, None)
+    torch.testing.assert_close(C2.cpu(), ref + (A.double() @ B.double()).float(), rtol=1e-4, atol=2e-4)
+
+
+def test_gemm_a_identity_asymmetric_b(gpu_device):
+    """A = I with an asymmetric B: output must equal B exactly (bitwise) -- catches transposed C writes."""
+    n = 96
+    B = torch.arange(n * 40, dtype=torch.float32).view(n, 40)
+    A = torch.eye(n)
+    C = torch.empty(n, 40, device=gpu_device)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    for tile in (1, 2):
+        _lib.call("gcgcn_gemm", n, 40, n, p(A.to(gpu_device)), n, 1, p(B.to(gpu_device)), 40, 0, p(C), 40, 1, 0, 0, 0,
+                  1.0, None, 0, 0, tile, None)
+        assert torch.equal(C.cpu(), B)
+
+
+# ------------------------------------------------------------------------------------------------------
+# blocks against the reference's golden vectors
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", golden_files("gat"), ids=ids(golden_files("gat")))
+def test_gat_golden(gpu_device, path):
+    g = load_golden(path)
+    D = g["meta"]["d"]
+    m = gcgcn_amd.GATAttention(D, D).to(gpu_device).eval()
+    m.load_state_dict(g["sd"])
+    x, e = dev_leaf(g["in"]["x"], gpu_device), dev_leaf(g["in"]["e"], gpu_device)
+    out = m(x, e, g["in"]["mask"].to(gpu_device))
+    close(out, g["out"], "gat out")
+    out.backward(g["cot"].to(gpu_device))
+    close(x.grad, g["grad_in"]["x"], "dX")
+    close(e.grad, g["grad_in"]["e"], "dE")
+    check_param_grads(m, g["grad_sd"])
+
+
+@pytest.mark.parametrize("path", golden_files("caggc"), ids=ids(golden_files("caggc")))
+def test_caggc_conv_golden(gpu_device, path):
+    g = load_golden(path)
+    D, L = g["meta"]["d"], g["meta"]["l"]
+    m = gcgcn_amd.GraphConvolution(L, D, D).to(gpu_device).eval()
+    m.load_state_dict(g["sd"])
+    ins = {k: dev_leaf(v, gpu_device) for k, v in g["in"].items()}
+    out = m(ins["x"], ins["e"], ins["adj"])
+    close(out, g["out"], "caggc out")
+    out.backward(g["cot"].to(gpu_device))
+    for k in ("x", "e", "adj"):
+        close(ins[k].grad, g["grad_in"][k], f"d{k}")
+    check_param_grads(m, g["grad_sd"])
+
+
+@pytest.mark.parametrize("path", golden_files("mha"), ids=ids(golden_files("mha")))
+def test_mha_golden(gpu_device, path):
+    g = load_golden(path)
+    D, H = g["meta"]["d"], g["meta"]["h"]
+    m = gcgcn_amd.MultiHeadAttention(H, D).to(gpu_device).eval()
+    m.load_state_dict(g["sd"])
+    x = dev_leaf(g["in"]["x"], gpu_device)
+    outs = m(x, torch.zeros(1, device=gpu_device))          # 2nd arg ignored, as glove:336 relies on
+    assert isinstance(outs, list) and len(outs) == H
+    st = torch.stack(outs)
+    close(st, g["out"], "mha out")
+    st.backward(g["cot"].to(gpu_device))
+    close(x.grad, g["grad_in"]["x"], "dX")
+    check_param_grads(m, g["grad_sd"])
+    assert m.flat_k.grad is None                           # linears_k never get a gradient
+
+
+@pytest.mark.parametrize("path", golden_files("maggc"), ids=ids(golden_files("maggc")))
+def test_maggc_conv_golden(gpu_device, path):
+    g = load_golden(path)
+    D, L, H = g["meta"]["d"], g["meta"]["l"], g["meta"]["h"]
+    m = gcgcn_amd.MultiGraphConvolution(L, H, D, D).to(gpu_device).eval()
+    m.load_state_dict(g["sd"])
+    ins = {k: dev_leaf(v, gpu_device) for k, v in g["in"].items()}
+    out = m(ins["x"], ins["e"], list(ins["adj"].unbind(0)))
+    close(out, g["out"], "maggc out")
+    out.backward(g["cot"].to(gpu_device))
+    for k in ("x", "e", "adj"):
+        close(ins[k].grad, g["grad_in"][k], f"d{k}")
+    check_param_grads(m, g["grad_sd"])
+
+
+@pytest.mark.parametrize("path", golden_files("stack"), ids=ids(golden_files("stack")))
+def test_stack_golden(gpu_device, path):
+    """GAT -> CAGGC conv -> MHA -> MAGGC conv through the hop glue, reference call pattern."""
+    g = load_golden(path)
+    D, L, H = g["meta"]["d"], g["meta"]["l"], g["meta"]["h"]
+    hops = gcgcn_amd.GraphHops(D, L, H).to(gpu_device).eval()
+    hops.load_state_dict(g["sd"], strict=True)
+    x = dev_leaf(g["in"]["x"], gpu_device)
+    e1, e2 = dev_leaf(g["in"]["e1"], gpu_device), dev_leaf(g["in"]["e2"], gpu_device)
+    feats = hops(x, [e1, e2], g["in"]["adj"].to(gpu_device))
+    close(feats[1], g["mid"]["x1"], "x1")
+    close(feats[2], g["out"], "x2")
+    feats[2].backward(g["cot"].to(gpu_device))
+    close(x.grad, g["grad_in"]["x"], "dX")
+    close(e1.grad, g["grad_in"]["e1"], "dE1")
+    close(e2.grad, g["grad_in"]["e2"], "dE2")
+    check_param_grads(hops.get_weighted_adj_matrix, g["grad_sd"], "get_weighted_adj_matrix.")
+    check_param_grads(hops.graphcnn[0], g["grad_sd"], "graphcnn.0.")
+    check_param_grads(hops.get_adj_matrix[0], g["grad_sd"], "get_adj_matrix.0.")
+    check_param_grads(hops.graphcnn[1], g["grad_sd"], "graphcnn.1.")
+
+
+def test_model_c1_hooks(gpu_device):
+    """cfg 1: 8 synthetic docs through the real GCGCN_glove; our blocks fed what the reference's
+    blocks saw must return what they returned (batched: all 8 docs in one call)."""
+    g = load_golden(golden_files("model")[0])
+    raw, L, H, docs = g["raw"], g["meta"]["l"], g["meta"]["h"], g["meta"]["docs"]
+    hops = gcgcn_amd.GraphHops(g["meta"]["d"], L, H).to(gpu_device).eval()
+    hops.load_state_dict(g["sd"], strict=True)
+    st = lambda k: torch.stack([torch.from_numpy(raw[f"doc{i}.{k}"]) for i in range(docs)]).to(gpu_device)
+    with torch.no_grad():
+        feats = hops(st("x0"), [st("e1"), st("e2")], st("adj"))
+        a0 = hops.get_weighted_adj_matrix(st("x0"), st("e1"))
+        al = torch.stack(hops.get_adj_matrix[0](st("x1")), dim=1)
+    close(a0, st("a0"), "gat A")
+    close(feats[1], st("x1_new"), "caggc out")
+    close(al, st("al"), "mha A")
+    close(feats[2], st("x2_new"), "maggc out")
+
+
+# ------------------------------------------------------------------------------------------------------
+# batched / ragged / train-mode against the CPU oracle
+# ------------------------------------------------------------------------------------------------------
+def _oracle_stack(x, e1, e2, adj, sd, L, H, nv=None, keeps=None):
+    """Per-document loop of the CPU oracle; returns outputs and grads (loss = sum(out * cot))."""
+    B = x.shape[0]
+    outs, gx, ge1, ge2 = [], [], [], []
+    sdl = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    for b in range(B):
+        n = x.shape[1] if nv is None else int(nv[b])
+        xb = x[b, :n].clone().requires_grad_()
+        e1b = e1[b, :n, :n].clone().requires_grad_()
+        e2b = e2[b, :n, :n].clone().requires_grad_()
+        kb = None if keeps is None else keeps[b]
+        f = O.hop_stack(xb, [e1b, e2b], adj[b, :n, :n], sdl, L, H, keeps=kb)
+        outs.append(f)
+        gx.append(xb), ge1.append(e1b), ge2.append(e2b)
+    return outs, gx, ge1, ge2, sdl
+
+
+@pytest.mark.parametrize("B,N,D,L,H", [(3, 64, 256, 2, 8), (2, 24, 96, 4, 4), (2, 70, 64, 2, 2)])
+def test_batched_matches_per_doc_oracle(gpu_device, B, N, D, L, H):
+    sd = O.init_stack_params(D, L, H, seed=1337)
+    x, e1, e2, adj = O.synth_docs(B, N, D, seed=5)
+    cot = torch.randn(B, N, D, generator=torch.Generator().manual_seed(3))
+    hops = gcgcn_amd.GraphHops(D, L, H).to(gpu_device).eval()
+    hops.load_state_dict(sd, strict=True)
+    xg, e1g, e2g = dev_leaf(x, gpu_device), dev_leaf(e1, gpu_device), dev_leaf(e2, gpu_device)
+    feats = hops(xg, [e1g, e2g], adj.to(gpu_device))
+    (feats[2] * cot.to(gpu_device)).sum().backward()
+    outs, gx, ge1, ge2, sdl = _oracle_stack(x, e1, e2, adj, sd, L, H)
+    loss = sum((outs[b][2] * cot[b]).sum() for b in range(B))
+    loss.backward()
+    for b in range(B):
+        close(feats[1][b], outs[b][1], f"x1[{b}]")
+        close(feats[2][b], outs[b][2], f"x2[{b}]")
+        close(xg.grad[b], gx[b].grad, f"dX[{b}]")
+        close(e1g.grad[b], ge1[b].grad, f"dE1[{b}]")
+        close(e2g.grad[b], ge2[b].grad, f"dE2[{b}]")
+    ref_grads = {k: v.grad for k, v in sdl.items() if v.grad is not None}
+    # parameter gradients are sums over B*N rows: allow the fp32 summation-order slack
+    for mod, pre in ((hops.get_weighted_adj_matrix, "get_weighted_adj_matrix."), (hops.graphcnn[0], "graphcnn.0."),
+                     (hops.get_adj_matrix[0], "get_adj_matrix.0."), (hops.graphcnn[1], "graphcnn.1.")):
+        for k, gk in mod.named_grads().items():
+            torch.testing.assert_close(gk.cpu(), ref_grads[pre + k], rtol=1e-3, atol=2e-4,
+                                       msg=lambda m: f"grad {pre + k}: {m}")
+
+
+def test_ragged_batch_matches_truncated_docs(gpu_device):
+    B, N, D, L, H = 4, 32, 64, 2, 4
+    nv = torch.tensor([32, 7, 19, 2])
+    sd = O.init_stack_params(D, L, H, seed=11)
+    x, e1, e2, adj = O.synth_docs(B, N, D, seed=9)
+    for b in range(B):                                     # padding rows of X must be zero (gcgcn.h)
+        x[b, nv[b]:] = 0
+    cot = torch.randn(B, N, D, generator=torch.Generator().manual_seed(4))
+    hops = gcgcn_amd.GraphHops(D, L, H).to(gpu_device).eval()
+    hops.load_state_dict(sd, strict=True)
+    xg, e1g, e2g = dev_leaf(x, gpu_device), dev_leaf(e1, gpu_device), dev_leaf(e2, gpu_device)
+    nvg = nv.to(gpu_device)
+    feats = hops(xg, [e1g, e2g], adj.to(gpu_device), n_valid=nvg)
+    (feats[2] * cot.to(gpu_device)).sum().backward()
+    outs, gx, ge1, ge2, sdl = _oracle_stack(x, e1, e2, adj, sd, L, H, nv=nv)
+    sum((outs[b][2] * cot[b, :nv[b]]).sum() for b in range(B)).backward()
+    for b in range(B):
+        n = int(nv[b])
+        close(feats[2][b, :n], outs[b][2], f"x2[{b}]")
+        assert feats[2][b, n:].abs().max().item() == 0 if n < N else True
+        close(xg.grad[b, :n], gx[b].grad, f"dX[{b}]")
+        close(e1g.grad[b, :n, :n], ge1[b].grad, f"dE1[{b}]")
+        close(e2g.grad[b, :n, :n], ge2[b].grad, f"dE2[{b}]")
+        if n < N:
+            assert e1g.grad[b, n:].abs().max().item() == 0 and e1g.grad[b, :, n:].abs().max().item() == 0
+            assert e2g.grad[b, n:].abs().max().item() == 0 and e2g.grad[b, :, n:].abs().max().item() == 0
+    ref_grads = {k: v.grad for k, v in sdl.items() if v.grad is not None}
+    for k, gk in hops.graphcnn[1].named_grads().items():
+        torch.testing.assert_close(gk.cpu(), ref_grads["graphcnn.1." + k], rtol=1e-3, atol=2e-4)
+
+
+def test_train_mode_matches_oracle_with_replayed_masks(gpu_device):
+    """Dropout on (4 sites): replay the kernel's keep-masks in the CPU oracle; results must agree."""
+    B, N, D, L, H = 2, 16, 32, 2, 4
+    sd = O.init_stack_params(D, L, H, seed=21)
+    x, e1, e2, adj = O.synth_docs(B, N, D, seed=22)
+    hops = gcgcn_amd.GraphHops(D, L, H).to(gpu_device).train()
+    hops.load_state_dict(sd, strict=True)
+    gcgcn_amd.manual_seed(1234)
+    snaps = []
+    orig = F_.rng_snapshot
+
+    def spy(dev):
+        s = orig(dev)
+        snaps.append(s)
+        return s
+    F_.rng_snapshot = spy
+    try:
+        xg, e1g, e2g = dev_leaf(x, gpu_device), dev_leaf(e1, gpu_device), dev_leaf(e2, gpu_device)
+        feats = hops(xg, [e1g, e2g], adj.to(gpu_device))
+        feats[2].sum().backward()
+    finally:
+        F_.rng_snapshot = orig
+    # call order: gat, caggc conv, glue0, mha, maggc conv, glue1
+    assert len(snaps) == 6
+    HD = H * D
+    k_gat = F_.dropout_keep_mask(snaps[0], _lib.SALT_GAT, 0.1, B * N * N).view(B, N, N).cpu()
+    k_cag = F_.dropout_keep_mask(snaps[1], _lib.SALT_GCN, 0.2, B * N * D).view(B, N, 1, L, D // L).cpu()
+    k_gl0 = F_.dropout_keep_mask(snaps[2], _lib.SALT_GLUE, 0.2, B * N * D).view(B, N, D).cpu()
+    k_mha = F_.dropout_keep_mask(snaps[3], _lib.SALT_MHA, 0.1, B * H * N * N).view(B, H, N, N).cpu()
+    k_mag = F_.dropout_keep_mask(snaps[4], _lib.SALT_GCN, 0.2, B * N * HD).view(B, N, H, L, D // L).cpu()
+    k_gl1 = F_.dropout_keep_mask(snaps[5], _lib.SALT_GLUE, 0.2, B * N * D).view(B, N, D).cpu()
+    for k, p in ((k_mag, 0.2), (k_mha, 0.1)):
+        assert abs(k.float().mean().item() - (1 - p)) < 0.03, "keep rate off"
+    keeps = []
+    for b in range(B):
+        keeps.append({"gat": k_gat[b], "cag": [k_cag[b, :, 0, l] for l in range(L)], "glue.0": k_gl0[b],
+                      "mha.1": [k_mha[b, h] for h in range(H)],
+                      "mag.1": [[k_mag[b, :, h, l] for l in range(L)] for h in range(H)], "glue.1": k_gl1[b]})
+    outs, gx, ge1, ge2, sdl = _oracle_stack(x, e1, e2, adj, sd, L, H, keeps=keeps)
+    sum(outs[b][2].sum() for b in range(B)).backward()
+    for b in range(B):
+        close(feats[2][b], outs[b][2], f"x2[{b}]")
+        close(xg.grad[b], gx[b].grad, f"dX[{b}]")
+        close(e1g.grad[b], ge1[b].grad, f"dE1[{b}]")
+    # a second forward draws different masks
+    f2 = hops(xg.detach(), [e1g.detach(), e2g.detach()], adj.to(gpu_device))
+    assert not torch.equal(f2[2], feats[2])
+
+
+# ------------------------------------------------------------------------------------------------------
+# full-size properties (cfg 2: B=32, N=64, D=256, L=2, H=8)
+# ------------------------------------------------------------------------------------------------------
+def test_full_size_properties(gpu_device):
+    B, N, D, L, H = 32, 64, 256, 2, 8
+    sd = O.init_stack_params(D, L, H, seed=1337)
+    x, e1, e2, adj = O.synth_docs(B, N, D, seed=1337)
+    hops = gcgcn_amd.GraphHops(D, L, H).to(gpu_device).eval()
+    hops.load_state_dict(sd, strict=True)
+
+    def run(xs, e1s, e2s):
+        xg, a, b = dev_leaf(xs, gpu_device), dev_leaf(e1s, gpu_device), dev_leaf(e2s, gpu_device)
+        f = hops(xg, [a, b])
+        f[2].sum().backward()
+        return f, xg.grad, a.grad, b.grad
+
+    f, dx, de1, de2 = run(x, e1, e2)
+    f_again, dx2, de1_2, _ = run(x, e1, e2)
+    assert torch.equal(f[2], f_again[2]) and torch.equal(dx, dx2) and torch.equal(de1, de1_2)   # deterministic
+    # batch independence: a document alone (B=1, the reference's call shape) == the same document in the batch
+    f1, dx1, de1_1, de2_1 = run(x[5:6], e1[5:6], e2[5:6])
+    assert torch.equal(f1[2][0], f[2][5]) and torch.equal(dx1[0], dx[5]) and torch.equal(de2_1[0], de2[5])
+    # attention rows are distributions; dE2 is constant along j
+    a0 = hops.get_weighted_adj_matrix(x.to(gpu_device), e1.to(gpu_device))
+    torch.testing.assert_close(a0.sum(-1), torch.ones(B, N, device=gpu_device), rtol=1e-5, atol=1e-5)
+    assert torch.equal(de2[:, :, 0, :], de2[:, :, N - 1, :])
+    # one document of the full batch against the CPU oracle
+    xr = x[31].clone().requires_grad_()
+    ref = O.hop_stack(xr, [e1[31], e2[31]], None, sd, L, H)
+    ref[2].sum().backward()
+    close(f[2][31], ref[2], "x2[31]")
+    close(dx[31], xr.grad, "dX[31]")
+
+
+def test_edge_mean_handoff_is_used_and_safe(gpu_device):
+    """GraphConvolution reuses GATAttention's edge mean only for the very same, unmodified tensor."""
+    D = 32
+    gat = gcgcn_amd.GATAttention(D, D).to(gpu_device).eval()
+    conv = gcgcn_amd.GraphConvolution(2, D, D).to(gpu_device).eval()
+    x = torch.randn(6, D, device=gpu_device)
+    e = torch.randn(6, 6, D, device=gpu_device)
+    with torch.no_grad():
+        a = gat(x, e)
+        assert F_._handoff is not None
+        y1 = conv(x, e, a)
+        assert F_._handoff is None                      # consumed
+        y2 = conv(x, e, a)                              # recomputed from E
+        a = gat(x, e)
+        e2 = e.clone()
+        y3 = conv(x, e2, a)                             # different tensor object: hand-off ignored
+        a = gat(x, e)
+        e.mul_(2.0)                                     # in-place change bumps the version: ignored
+        y4 = conv(x, e, a)
+    assert torch.equal(y1, y2) and torch.equal(y1, y3)
+    assert not torch.allclose(y1, y4)
