@@ -52,7 +52,7 @@ __global__ __launch_bounds__(64 * EW) void edge_fwd_kernel(const float* __restri
   const int bi = blockIdx.x;
   const int b = bi / N, i = bi - b * N;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int nv = n_valid ? n_valid[b] : N;
+  const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
   float* eb = Ebar + (long)bi * D;
   float* lg = ATT ? logit + (long)bi * N : nullptr;
   if (i >= nv) {  // padding entity: outputs are zero, nothing is read
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64 * EW) void edge_bwd_kernel(const float* __restri
   const int bi = blockIdx.x;
   const int b = bi / N, i = bi - b * N;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int nv = n_valid ? n_valid[b] : N;
+  const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
   float* dEr = dE ? dE + (long)bi * N * D : nullptr;
   float* dvp = dvpart + (long)bi * D;
   if (i >= nv) {
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(64 * EW) void edge_bcast_kernel(const float* __rest
   const int bi = blockIdx.x;
   const int b = bi / N, i = bi - b * N;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int nv = n_valid ? n_valid[b] : N;
+  const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
   float* dEr = dE + (long)bi * N * D;
   const bool rowpad = i >= nv;
   const float inv = rowpad ? 0.f : 1.f / (float)nv;

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(64 * RW) void softmax_fwd_kernel(const float* __res
   const int lane = threadIdx.x & 63;
   const long doc = r / ((long)heads * N);
   const int i = (int)(r % N);
-  const int nv = n_valid ? n_valid[doc] : N;
+  const int nv = n_valid ? min(max(n_valid[doc], 0), N) : N;
   const float* s = S + r * N;
   float* p = P + r * N;
   float* a = A ? A + r * N : nullptr;
