@@ -54,8 +54,9 @@ def test_gemm(gpu_device, M, N, K, batch, a_kc, b_kc, tile):
     lda = K if a_kc else M
     ldb = K if b_kc else N
     p = lambda t: ctypes.c_void_p(t.data_ptr())
+    biasd = bias.to(gpu_device)
     _lib.call("gcgcn_gemm", M, N, K, p(Ad), lda, a_kc, p(Bd), ldb, b_kc, p(C), N, batch, M * K, K * N, M * N,
-              0.5, p(bias.to(gpu_device)), 1, 0, tile, None)
+              0.5, p(biasd), 1, 0, tile, None)
     torch.cuda.synchronize()
     torch.testing.assert_close(C.cpu(), ref, rtol=1e-4, atol=1e-4)
     # accumulate: C += A B (no bias/relu)
@@ -71,9 +72,10 @@ def test_gemm_a_identity_asymmetric_b(gpu_device):
     B = torch.arange(n * 40, dtype=torch.float32).view(n, 40)
     A = torch.eye(n)
     C = torch.empty(n, 40, device=gpu_device)
+    Ad, Bd = A.to(gpu_device), B.to(gpu_device)      # keep the device copies alive across the call
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     for tile in (1, 2):
-        _lib.call("gcgcn_gemm", n, 40, n, p(A.to(gpu_device)), n, 1, p(B.to(gpu_device)), 40, 0, p(C), 40, 1, 0, 0, 0,
+        _lib.call("gcgcn_gemm", n, 40, n, p(Ad), n, 1, p(Bd), 40, 0, p(C), 40, 1, 0, 0, 0,
                   1.0, None, 0, 0, tile, None)
         assert torch.equal(C.cpu(), B)
 
