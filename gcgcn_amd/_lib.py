@@ -38,14 +38,14 @@ SIGNATURES = {
     "gcgcn_edge_mean_fwd": (I, [I, I, I, P, P, P, P]),
     "gcgcn_edge_mean_bwd": (I, [I, I, I, P, P, P, P]),
     "gcgcn_mha_layout": (I, [I, P]),
-    "gcgcn_mha_fwd": (I, [I, I, I, I, P, P, P, P, F, P, P, P, P]),
-    "gcgcn_mha_bwd_scratch": (L, [I, I, I]),
+    "gcgcn_mha_scratch": (L, [I, I, I]),
+    "gcgcn_mha_fwd": (I, [I, I, I, I, P, P, P, P, F, P, P, P, P, P]),
     "gcgcn_mha_bwd": (I, [I, I, I, I, P, P, P, F, P, P, P, P, P, P, P, P, P]),
     "gcgcn_gcn_layout": (I, [I, I, I, P]),
-    "gcgcn_gcn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, P, P, P, P, P, P]),
-    "gcgcn_gcn_bwd_scratch": (L, [I, I, I]),
+    "gcgcn_gcn_scratch": (L, [I, I, I, I]),
+    "gcgcn_gcn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, P, P, P, P, P, P, P]),
     "gcgcn_gcn_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
-    "gcgcn_gemm": (I, [I, I, I, P, L, I, P, L, I, P, L, I, L, L, L, F, P, I, I, I, P]),
+    "gcgcn_gemm": (I, [I, I, I, P, L, I, P, L, I, P, L, I, L, L, L, F, P, I, I, I, I, P, L, P]),
 }
 
 _lib = None

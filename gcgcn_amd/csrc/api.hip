@@ -79,6 +79,13 @@ static int check_dims(const char* who, int B, int N, int D, int L, int H) {
   return 0;
 }
 
+static long scratch_elems(int B, int N, int D, int H) {
+  const long a = colsum_scratch_elems((long)B * N, D, 1);
+  const long rows = (long)B * N > D ? (long)B * N : D;
+  const long b = gemm_ws_elems(rows, (long)H * D);
+  return a > b ? a : b;
+}
+
 }  // namespace gc
 
 using namespace gc;
@@ -219,9 +226,10 @@ int gcgcn_mha_layout(int D, int64_t* o) {
 }
 
 int gcgcn_mha_fwd(int B, int N, int D, int H, const float* X, const int32_t* n_valid, const float* flat,
-                  const void* rng_snap, float p, float* Q, float* P, float* A, void* stream) {
+                  const void* rng_snap, float p, float* Q, float* P, float* A, float* scratch, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("mha_fwd", B, N, D, 1, H));
+  const long wse = scratch ? scratch_elems(B, N, D, 1) : 0;
   GC_REQUIRE(X && flat && Q && P, "mha_fwd: null pointer");
   const Drop drop = make_drop(rng_snap, GCGCN_SALT_MHA, p);
   GC_REQUIRE(!drop.snap || A, "mha_fwd: dropout on but A is NULL");
@@ -229,6 +237,7 @@ int gcgcn_mha_fwd(int B, int N, int D, int H, const float* X, const int32_t* n_v
   const int dh = D / H;
   {  // Q = X Wq^T + bq      (glove:136, all heads at once)
     GemmArgs g;
+    g.ws = scratch, g.ws_elems = wse;
     g.A = X, g.lda = D, g.a_kc = 1;
     g.B = flat, g.ldb = D, g.b_kc = 1;
     g.C = Q, g.ldc = D;
@@ -238,6 +247,7 @@ int gcgcn_mha_fwd(int B, int N, int D, int H, const float* X, const int32_t* n_v
   }
   {  // S[b,h] = Q_h Q_h^T / sqrt(dh)   (glove:137-138: keys use the query projection)
     GemmArgs g;
+    g.ws = scratch, g.ws_elems = wse;
     g.A = Q, g.lda = D, g.a_kc = 1, g.sA1 = (long)N * D, g.sA2 = dh;
     g.B = Q, g.ldb = D, g.b_kc = 1, g.sB1 = (long)N * D, g.sB2 = dh;
     g.C = P, g.ldc = N, g.sC1 = (long)H * N * N, g.sC2 = (long)N * N;
@@ -250,13 +260,14 @@ int gcgcn_mha_fwd(int B, int N, int D, int H, const float* X, const int32_t* n_v
   return 0;
 }
 
-int64_t gcgcn_mha_bwd_scratch(int B, int N, int D) { return colsum_scratch_elems((long)B * N, D, 1); }
+int64_t gcgcn_mha_scratch(int B, int N, int D) { return scratch_elems(B, N, D, 1); }
 
 int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat, const void* rng_snap, float p,
                   const float* Q, const float* P, const float* dA, float* dX, float* dflat, float* dS, float* dQ,
                   float* scratch, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("mha_bwd", B, N, D, 1, H));
+  const long wse = scratch ? scratch_elems(B, N, D, 1) : 0;
   GC_REQUIRE(X && flat && Q && P && dA && dX && dflat && dS && dQ, "mha_bwd: null pointer");
   const Drop drop = make_drop(rng_snap, GCGCN_SALT_MHA, p);
   const long M = (long)B * N;
@@ -265,6 +276,7 @@ int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat,
   GC_TRY(softmax_bwd(P, dA, dS, M * H, N, drop, st));
   for (int pass = 0; pass < 2; ++pass) {  // dQ_h = alpha (dS + dS^T) Q_h
     GemmArgs g;
+    g.ws = scratch, g.ws_elems = wse;
     g.A = dS, g.lda = N, g.a_kc = (pass == 0), g.sA1 = (long)H * N * N, g.sA2 = (long)N * N;
     g.B = Q, g.ldb = D, g.b_kc = 0, g.sB1 = (long)N * D, g.sB2 = dh;
     g.C = dQ, g.ldc = D, g.sC1 = (long)N * D, g.sC2 = dh;
@@ -276,6 +288,7 @@ int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat,
   }
   {  // dX = dQ Wq
     GemmArgs g;
+    g.ws = scratch, g.ws_elems = wse;
     g.A = dQ, g.lda = D, g.a_kc = 1;
     g.B = flat, g.ldb = D, g.b_kc = 0;
     g.C = dX, g.ldc = D;
@@ -284,6 +297,7 @@ int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat,
   }
   {  // dWq = dQ^T X
     GemmArgs g;
+    g.ws = scratch, g.ws_elems = wse;
     g.A = dQ, g.lda = D, g.a_kc = 0;
     g.B = X, g.ldb = D, g.b_kc = 0;
     g.C = dflat, g.ldc = D;
@@ -307,9 +321,10 @@ int gcgcn_gcn_layout(int D, int L, int H, int64_t* o) {
 
 int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float* Ebar, const float* A,
                   const int32_t* n_valid, const float* flat, const void* rng_snap, float p, float* out, float* Pn,
-                  float* Y, float* HO, float* rinv, float* G, void* stream) {
+                  float* Y, float* HO, float* rinv, float* G, float* scratch, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("gcn_fwd", B, N, D, L, H));
+  const long wse = scratch ? scratch_elems(B, N, D, H) : 0;
   GC_REQUIRE(X && Ebar && A && flat && out && Pn && Y && HO && rinv && G, "gcn_fwd: null pointer");
   const GcnLayout y = gcn_layout(D, L, H);
   const Drop drop = make_drop(rng_snap, GCGCN_SALT_GCN, p);
@@ -321,6 +336,7 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
   GC_TRY(rowsum_inv(A, rinv, (long)B * H * N, N, st));  // glove:47-49
   {  // Pn = X WnX : node term of every (head, sub-layer) for the X part of the dense input
     GemmArgs g;
+    g.ws = scratch, g.ws_elems = wse;
     g.A = X, g.lda = D, g.a_kc = 1;
     g.B = flat + y.oWnX, g.ldb = HD, g.b_kc = 0;
     g.C = Pn, g.ldc = HD;
@@ -329,6 +345,7 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
   }
   {  // G = Ebar We : edge term, mean commuted with the projection (glove:40-41)
     GemmArgs g;
+    g.ws = scratch, g.ws_elems = wse;
     g.A = Ebar, g.lda = D, g.a_kc = 1;
     g.B = flat + y.oWe, g.ldb = HD, g.b_kc = 0;
     g.C = G, g.ldc = HD;
@@ -338,6 +355,7 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
   for (int l = 0; l < L; ++l) {
     if (l > 0) {  // Pn_l += [Y_0 .. Y_{l-1}] Wd_l : dense connection (glove:73 / 110)
       GemmArgs g;
+    g.ws = scratch, g.ws_elems = wse;
       g.A = Y, g.lda = HD, g.a_kc = 1, g.sA2 = (long)L * gh;
       g.B = flat + y.wd_off(0, l), g.ldb = gh, g.b_kc = 0, g.sB2 = y.wd_head;
       g.C = Pn + (long)l * gh, g.ldc = HD, g.sC2 = (long)L * gh;
@@ -348,6 +366,7 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
     }
     {  // Y_l = relu((G_l + A_h Pn_l) * rinv);  HO_l = dropout(Y_l) + X_l   (glove:42-50, 71-76)
       GemmArgs g;
+    g.ws = scratch, g.ws_elems = wse;
       g.A = A, g.lda = N, g.a_kc = 1, g.sA1 = (long)H * N * N, g.sA2 = (long)N * N;
       g.B = Pn + (long)l * gh, g.ldb = HD, g.b_kc = 0, g.sB1 = (long)N * HD, g.sB2 = (long)L * gh;
       g.C = Y + (long)l * gh, g.ldc = HD, g.sC1 = (long)N * HD, g.sC2 = (long)L * gh;
@@ -364,6 +383,7 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
   }
   {  // out = HO Wlin^T + blin   (glove:78 / 118)
     GemmArgs g;
+    g.ws = scratch, g.ws_elems = wse;
     g.A = HO, g.lda = HD, g.a_kc = 1;
     g.B = flat + y.oWlin, g.ldb = HD, g.b_kc = 1;
     g.C = out, g.ldc = D;
@@ -375,7 +395,7 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
   return 0;
 }
 
-int64_t gcgcn_gcn_bwd_scratch(int B, int N, int D) { return colsum_scratch_elems((long)B * N, D, 1); }
+int64_t gcgcn_gcn_scratch(int B, int N, int D, int H) { return scratch_elems(B, N, D, H); }
 
 int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float* Ebar, const float* A,
                   const int32_t* n_valid, const float* flat, const void* rng_snap, float p, const float* Pn,
@@ -384,6 +404,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
                   float* scratch, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("gcn_bwd", B, N, D, L, H));
+  const long wse = scratch ? scratch_elems(B, N, D, H) : 0;
   GC_REQUIRE(X && Ebar && A && flat && Pn && Y && HO && rinv && dout && dX && dEbar && dA && dflat && W1 && W2 && W3 &&
                  drow && dXres,
              "gcn_bwd: null pointer");
@@ -403,6 +424,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
   }
   {  // dHO = dout Wlin
     GemmArgs g;
+    g.ws = scratch, g.ws_elems = wse;
     g.A = dout, g.lda = D, g.a_kc = 1;
     g.B = flat + y.oWlin, g.ldb = HD, g.b_kc = 0;
     g.C = dYa, g.ldc = HD;
@@ -411,6 +433,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
   }
   {  // dWlin = dout^T HO
     GemmArgs g;
+    g.ws = scratch, g.ws_elems = wse;
     g.A = dout, g.lda = D, g.a_kc = 0;
     g.B = HO, g.ldb = HD, g.b_kc = 0;
     g.C = dflat + y.oWlin, g.ldc = HD;
@@ -424,6 +447,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
     GC_TRY(relu_norm_bwd(dYa, Y, rinv, dM, drow, M, N, H, L, gh, l, l == L - 1, st));
     {  // dPn_l = A_h^T dM_l
       GemmArgs g;
+    g.ws = scratch, g.ws_elems = wse;
       g.A = A, g.lda = N, g.a_kc = 0, g.sA1 = (long)H * N * N, g.sA2 = (long)N * N;
       g.B = dM + (long)l * gh, g.ldb = HD, g.b_kc = 0, g.sB1 = (long)N * HD, g.sB2 = (long)L * gh;
       g.C = dP + (long)l * gh, g.ldc = HD, g.sC1 = (long)N * HD, g.sC2 = (long)L * gh;
@@ -433,6 +457,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
     }
     {  // dA_h (+)= dM_l Pn_l^T ; the normaliser's gradient drow is added on the last pass
       GemmArgs g;
+    g.ws = scratch, g.ws_elems = wse;
       g.A = dM + (long)l * gh, g.lda = HD, g.a_kc = 1, g.sA1 = (long)N * HD, g.sA2 = (long)L * gh;
       g.B = Pn + (long)l * gh, g.ldb = HD, g.b_kc = 1, g.sB1 = (long)N * HD, g.sB2 = (long)L * gh;
       g.C = dA, g.ldc = N, g.sC1 = (long)H * N * N, g.sC2 = (long)N * N;
@@ -444,6 +469,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
     }
     if (l > 0) {  // dY_{0..l-1} += dPn_l Wd_l^T
       GemmArgs g;
+    g.ws = scratch, g.ws_elems = wse;
       g.A = dP + (long)l * gh, g.lda = HD, g.a_kc = 1, g.sA2 = (long)L * gh;
       g.B = flat + y.wd_off(0, l), g.ldb = gh, g.b_kc = 1, g.sB2 = y.wd_head;
       g.C = dYa, g.ldc = HD, g.sC2 = (long)L * gh;
@@ -455,6 +481,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
   }
   for (int l = 1; l < L; ++l) {  // dWd_{h,l} = [Y_0 .. Y_{l-1}]_h^T dPn_{h,l}
     GemmArgs g;
+    g.ws = scratch, g.ws_elems = wse;
     g.A = Y, g.lda = HD, g.a_kc = 0, g.sA2 = (long)L * gh;
     g.B = dP + (long)l * gh, g.ldb = HD, g.b_kc = 0, g.sB2 = (long)L * gh;
     g.C = dflat + y.wd_off(0, l), g.ldc = gh, g.sC2 = y.wd_head;
@@ -464,6 +491,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
   }
   {  // dWnX = X^T dPn
     GemmArgs g;
+    g.ws = scratch, g.ws_elems = wse;
     g.A = X, g.lda = D, g.a_kc = 0;
     g.B = dP, g.ldb = HD, g.b_kc = 0;
     g.C = dflat + y.oWnX, g.ldc = HD;
@@ -472,6 +500,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
   }
   {  // dWe = Ebar^T dM
     GemmArgs g;
+    g.ws = scratch, g.ws_elems = wse;
     g.A = Ebar, g.lda = D, g.a_kc = 0;
     g.B = dM, g.ldb = HD, g.b_kc = 0;
     g.C = dflat + y.oWe, g.ldc = HD;
@@ -480,6 +509,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
   }
   {  // dX = dPn WnX^T + sum_h dHO_h
     GemmArgs g;
+    g.ws = scratch, g.ws_elems = wse;
     g.A = dP, g.lda = HD, g.a_kc = 1;
     g.B = flat + y.oWnX, g.ldb = HD, g.b_kc = 1;
     g.C = dX, g.ldc = D;
@@ -489,6 +519,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
   }
   {  // dEbar = dM We^T
     GemmArgs g;
+    g.ws = scratch, g.ws_elems = wse;
     g.A = dM, g.lda = HD, g.a_kc = 1;
     g.B = flat + y.oWe, g.ldb = HD, g.b_kc = 1;
     g.C = dEbar, g.ldc = D;
@@ -500,7 +531,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
 
 int gcgcn_gemm(int M, int N, int K, const float* A, int64_t lda, int a_kc, const float* B, int64_t ldb, int b_kc,
                float* C, int64_t ldc, int batch, int64_t sA, int64_t sB, int64_t sC, float alpha, const float* bias,
-               int relu, int accumulate, int tile, void* stream) {
+               int relu, int accumulate, int tile, int splits, float* ws, int64_t ws_elems, void* stream) {
   GemmArgs g;
   g.A = A, g.lda = lda, g.a_kc = a_kc;
   g.B = B, g.ldb = ldb, g.b_kc = b_kc;
@@ -509,7 +540,8 @@ int gcgcn_gemm(int M, int N, int K, const float* A, int64_t lda, int a_kc, const
   g.batch1 = 1, g.batch2 = batch;
   g.sA2 = sA, g.sB2 = sB, g.sC2 = sC;
   g.alpha = alpha, g.bias = bias, g.relu = relu, g.accumulate = accumulate;
-  return gemm(g, (hipStream_t)stream, tile);
+  g.ws = ws, g.ws_elems = ws_elems;
+  return gemm(g, (hipStream_t)stream, tile, splits);
 }
 
 }  // extern "C"

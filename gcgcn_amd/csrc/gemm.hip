@@ -1,69 +1,79 @@
 // Batched exact-fp32 GEMM for gfx950: v_mfma_f32_32x32x2_f32 tiles, k-major LDS images,
-// register-prefetch double buffering, fused epilogue (gemm.hpp).
+// register-prefetch double buffering, split-K with a deterministic reduce, fused epilogue (gemm.hpp).
 //
 // Block = 256 threads = 4 waves in a 2x2 arrangement; a wave owns (32*TM) x (32*TN) outputs,
-// i.e. TM*TN accumulator tiles of 32x32 (16 VGPRs each).  BK = 16.
+// i.e. TM*TN accumulator tiles of 32x32 (16 VGPRs each).  BK = 32.
 //
 // LDS images are k-major: As[k][m], Bs[k][n].  The MFMA operand of lane l is
 //   a = A[i = l & 31][k = l >> 5],  b = B[k = l >> 5][j = l & 31]
-// so each half-wave reads 32 consecutive floats of one k-row: conflict free ds_read_b32.
-// A k-contiguous source (A as [M][K], B as [N][K]) is transposed on the LDS write; its row
-// stride is BMN + 2 so that the four 4-byte stores of the 8 rows x 4 k-quads handled by a
-// 32-lane group fall on 32 different banks.  f32 MFMA runs at the f32 vector rate (1/16 of
-// bf16), so operand traffic is far from binding: one ds_read_b32 per operand per 64-cycle MFMA.
+// so each half-wave reads 32 consecutive floats of one k-row: conflict-free ds_read_b32.
+// A k-contiguous source (A as [M][K], B as [N][K]) is read 128 B per row (8 lanes x 16 B) and
+// transposed on the LDS write; its row stride is BMN + 1 so that the 4-byte stores of the
+// 4 rows x 8 k-quads handled by a 32-lane group fall on 32 different banks.
+//
+// The problems on this path are small (M = B*N ~ 2048, N, K in {64..2048}); an f32 MFMA tile
+// takes 64 cycles, so a 64x64x32 step is only ~0.4 us of matrix work against ~1 us of load
+// latency.  Throughput therefore comes from residency, not from big tiles: 64x64 blocks at
+// 3-5 blocks per CU, and split-K (partials to a workspace + one reduce/epilogue kernel,
+// bitwise reproducible) when M*N alone gives fewer than ~3 blocks per CU.
+//
+// Codegen note (ROCm 7.2): per-lane guarded float4 loads get if-converted into predicated
+// scalar loads with a vmcnt(0) at the loop head.  The interior path (ALIGNED) is therefore a
+// separate instantiation with unconditional 16-byte loads; ragged shapes take the guarded one.
 #include "gemm.hpp"
 
 namespace gc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;
+constexpr int BK = 32;
 
-// Load the [BMN x BK] tile of an operand into registers.
-//   KC = true : memory is [mn][k], k contiguous     -> float4 along k, NV = BMN/64 per thread
-//   KC = false: memory is [k][mn], mn contiguous    -> float4 along mn
-template <int BMN, bool KC>
-__device__ __forceinline__ void load_tile(float4 (&r)[BMN / 64], const float* __restrict__ src, long ld,
-                                          int mn0, int k0, int MN, int K, int vec, int t) {
+template <int BMN, bool KC, bool ALIGNED>
+__device__ __forceinline__ void load_tile(float4 (&r)[BMN / 32], const float* __restrict__ src, long ld, int mn0, int k0,
+                                          int MN, int Kend, int vec, int t) {
 #pragma unroll
-  for (int q = 0; q < BMN / 64; ++q) {
+  for (int q = 0; q < BMN / 32; ++q) {
     const int f = t + 256 * q;
     int row, col, rlim, clim;  // row indexes the strided dim, col the contiguous one
     if (KC) {
-      row = mn0 + (f >> 2);
-      col = k0 + ((f & 3) << 2);
+      row = mn0 + (f >> 3);
+      col = k0 + ((f & 7) << 2);
       rlim = MN;
-      clim = K;
+      clim = Kend;
     } else {
       row = k0 + f / (BMN / 4);
       col = mn0 + ((f % (BMN / 4)) << 2);
-      rlim = K;
+      rlim = Kend;
       clim = MN;
     }
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < rlim) {
-      const float* p = src + (long)row * ld + col;
-      if (vec && col + 3 < clim) {
-        v = *reinterpret_cast<const float4*>(p);
-      } else {
-        if (col < clim) v.x = p[0];
-        if (col + 1 < clim) v.y = p[1];
-        if (col + 2 < clim) v.z = p[2];
-        if (col + 3 < clim) v.w = p[3];
+    const float* p = src + (long)row * ld + col;
+    if (ALIGNED) {
+      r[q] = *reinterpret_cast<const float4*>(p);
+    } else {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < rlim) {
+        if (vec && col + 3 < clim) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (col < clim) v.x = p[0];
+          if (col + 1 < clim) v.y = p[1];
+          if (col + 2 < clim) v.z = p[2];
+          if (col + 3 < clim) v.w = p[3];
+        }
       }
+      r[q] = v;
     }
-    r[q] = v;
   }
 }
 
 template <int BMN, bool KC>
-__device__ __forceinline__ void store_tile(const float4 (&r)[BMN / 64], float* __restrict__ lds, int t) {
-  constexpr int LD = KC ? BMN + 2 : BMN;
+__device__ __forceinline__ void store_tile(const float4 (&r)[BMN / 32], float* __restrict__ lds, int t) {
+  constexpr int LD = KC ? BMN + 1 : BMN;
 #pragma unroll
-  for (int q = 0; q < BMN / 64; ++q) {
+  for (int q = 0; q < BMN / 32; ++q) {
     const int f = t + 256 * q;
     if (KC) {
-      const int m = f >> 2, k = (f & 3) << 2;
+      const int m = f >> 3, k = (f & 7) << 2;
       lds[(k + 0) * LD + m] = r[q].x;
       lds[(k + 1) * LD + m] = r[q].y;
       lds[(k + 2) * LD + m] = r[q].z;
@@ -75,23 +85,81 @@ __device__ __forceinline__ void store_tile(const float4 (&r)[BMN / 64], float* _
   }
 }
 
-template <int TM, int TN, bool AKC, bool BKC>
+// One output element through the fused epilogue (order documented in gemm.hpp).
+struct Epi {
+  float* C;
+  const float* add;
+  const float* rowadd;
+  const float* rowscale;
+  float* C2;
+  const float* add2;
+  long offC2;
+  uint64_t key;
+  bool dodrop;
+  int z1;
+};
+__device__ __forceinline__ Epi make_epi(const GemmArgs& g, int z1, int z2) {
+  Epi e;
+  e.z1 = z1;
+  e.C = g.C + z1 * g.sC1 + z2 * g.sC2;
+  e.add = g.add ? g.add + z1 * g.sAdd1 + z2 * g.sAdd2 : nullptr;
+  e.rowadd = g.rowadd ? g.rowadd + z1 * g.sRa1 + z2 * g.sRa2 : nullptr;
+  e.rowscale = g.rowscale ? g.rowscale + z1 * g.sRs1 + z2 * g.sRs2 : nullptr;
+  e.offC2 = z1 * g.sC21 + z2 * g.sC22;
+  e.C2 = g.C2 ? g.C2 + e.offC2 : nullptr;
+  e.add2 = g.add2 ? g.add2 + z1 * g.sAdd21 + z2 * g.sAdd22 : nullptr;
+  e.dodrop = e.C2 && g.drop.snap;
+  e.key = e.dodrop ? drop_key(g.drop) : 0;
+  return e;
+}
+__device__ __forceinline__ void epi_store(const GemmArgs& g, const Epi& e, int row, int col, float acc) {
+  float v = g.alpha * acc;
+  if (e.add) v += e.add[(long)row * g.ldadd + col];
+  if (g.bias) v += g.bias[col];
+  if (e.rowadd) v += e.rowadd[row];
+  if (e.rowscale) v *= e.rowscale[row];
+  if (g.relu) v = fmaxf(v, 0.f);
+  const long oc = (long)row * g.ldc + col;
+  if (g.accumulate) v += e.C[oc];
+  bool pad = false;
+  if (g.n_valid) {
+    const int doc = e.z1 * g.nv_zdoc + row / g.nv_rows;
+    pad = (row % g.nv_rows) >= g.n_valid[doc];
+  }
+  if (pad) v = 0.f;
+  e.C[oc] = v;
+  if (e.C2) {
+    const long o2 = (long)row * g.ldc2 + col;
+    float w = v;
+    if (e.dodrop)
+      w = (rng_u32(e.key, (uint64_t)(g.drop_base + e.offC2 + o2)) >= g.drop.thresh) ? w * g.drop.scale : 0.f;
+    if (e.add2) w += e.add2[(long)row * g.ldadd2 + col];
+    if (pad) w = 0.f;
+    e.C2[o2] = w;
+  }
+}
+
+template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
-  constexpr int LDA = AKC ? BM + 2 : BM;
-  constexpr int LDB = BKC ? BN + 2 : BN;
-  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (LDA + LDB)];
-  auto As = [&](int b) -> float* { return lds + b * (BK * LDA); };
-  auto Bs = [&](int b) -> float* { return lds + 2 * BK * LDA + b * (BK * LDB); };
+  constexpr int LDA = AKC ? BM + 1 : BM;
+  constexpr int LDB = BKC ? BN + 1 : BN;
+  constexpr int SA = BK * LDA, SB = BK * LDB;  // floats per stage
+  // the B image starts 16-byte aligned whatever LDA's parity
+  constexpr int OFFB = (2 * SA + 3) & ~3;
+  __shared__ __attribute__((aligned(16))) float lds[OFFB + 2 * SB];
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  const int z = blockIdx.z;
+  const int zs = blockIdx.z;
+  const int z = zs / g.splits, sp = zs - z * g.splits;
   const int z1 = z / g.batch2, z2 = z - z1 * g.batch2;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = sp * g.ksplit;
+  const int kend = min(g.K, kbeg + g.ksplit);
 
   const float* __restrict__ A = g.A + z1 * g.sA1 + z2 * g.sA2;
   const float* __restrict__ B = g.B + z1 * g.sB1 + z2 * g.sB2;
@@ -104,22 +172,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[TM], rb[TN];
-  const int nk = (g.K + BK - 1) / BK;
-  load_tile<BM, AKC>(ra, A, g.lda, m0, 0, g.M, g.K, g.vecA, t);
-  load_tile<BN, BKC>(rb, B, g.ldb, n0, 0, g.N, g.K, g.vecB, t);
-  store_tile<BM, AKC>(ra, As(0), t);
-  store_tile<BN, BKC>(rb, Bs(0), t);
+  float4 ra[BM / 32], rb[BN / 32];
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (nk > 0) {
+    load_tile<BM, AKC, ALIGNED>(ra, A, g.lda, m0, kbeg, g.M, kend, g.vecA, t);
+    load_tile<BN, BKC, ALIGNED>(rb, B, g.ldb, n0, kbeg, g.N, kend, g.vecB, t);
+    store_tile<BM, AKC>(ra, lds, t);
+    store_tile<BN, BKC>(rb, lds + OFFB, t);
+  }
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      load_tile<BM, AKC>(ra, A, g.lda, m0, (kt + 1) * BK, g.M, g.K, g.vecA, t);
-      load_tile<BN, BKC>(rb, B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, g.vecB, t);
+      load_tile<BM, AKC, ALIGNED>(ra, A, g.lda, m0, kbeg + (kt + 1) * BK, g.M, kend, g.vecA, t);
+      load_tile<BN, BKC, ALIGNED>(rb, B, g.ldb, n0, kbeg + (kt + 1) * BK, g.N, kend, g.vecB, t);
     }
-    const float* as = As(cur) + wr * 32 * TM + l31;
-    const float* bs = Bs(cur) + wc * 32 * TN + l31;
+    const float* as = lds + cur * SA + wr * 32 * TM + l31;
+    const float* bs = lds + OFFB + cur * SB + wc * 32 * TN + l31;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       float a[TM], b[TN];
@@ -134,95 +204,113 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) {
-      store_tile<BM, AKC>(ra, As(cur ^ 1), t);
-      store_tile<BN, BKC>(rb, Bs(cur ^ 1), t);
+      store_tile<BM, AKC>(ra, lds + (cur ^ 1) * SA, t);
+      store_tile<BN, BKC>(rb, lds + OFFB + (cur ^ 1) * SB, t);
     }
     __syncthreads();
   }
 
-  // ---- epilogue -----------------------------------------------------------------------
-  float* __restrict__ C = g.C + z1 * g.sC1 + z2 * g.sC2;
-  const float* add = g.add ? g.add + z1 * g.sAdd1 + z2 * g.sAdd2 : nullptr;
-  const float* rowadd = g.rowadd ? g.rowadd + z1 * g.sRa1 + z2 * g.sRa2 : nullptr;
-  const float* rowscale = g.rowscale ? g.rowscale + z1 * g.sRs1 + z2 * g.sRs2 : nullptr;
-  const long offC2 = z1 * g.sC21 + z2 * g.sC22;
-  float* C2 = g.C2 ? g.C2 + offC2 : nullptr;
-  const float* add2 = g.add2 ? g.add2 + z1 * g.sAdd21 + z2 * g.sAdd22 : nullptr;
-  const bool dodrop = C2 && g.drop.snap;
-  const uint64_t key = dodrop ? drop_key(g.drop) : 0;
-
+  // ---- store ------------------------------------------------------------------------------
+  if (g.splits > 1) {  // raw partial sums -> workspace [split][batch][M][N]
+    float* __restrict__ W = g.ws + ((long)sp * g.batch1 * g.batch2 + z) * g.M * g.N;
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (!ALIGNED && row >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = n0 + (wc * TN + j) * 32 + l31;
+          if (!ALIGNED && col >= g.N) continue;
+          W[(long)row * g.N + col] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+  const Epi e = make_epi(g, z1, z2);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (row >= g.M) continue;
-      bool pad = false;
-      if (g.n_valid) {
-        const int doc = z1 * g.nv_zdoc + row / g.nv_rows;
-        pad = (row % g.nv_rows) >= g.n_valid[doc];
-      }
-      const float ra_ = rowadd ? rowadd[row] : 0.f;
-      const float rs_ = rowscale ? rowscale[row] : 1.f;
+      if (!ALIGNED && row >= g.M) continue;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int col = n0 + (wc * TN + j) * 32 + l31;
-        if (col >= g.N) continue;
-        float v = g.alpha * acc[i][j][r];
-        if (add) v += add[(long)row * g.ldadd + col];
-        if (g.bias) v += g.bias[col];
-        v += ra_;
-        v *= rs_;
-        if (g.relu) v = fmaxf(v, 0.f);
-        const long oc = (long)row * g.ldc + col;
-        if (g.accumulate) v += C[oc];
-        if (pad) v = 0.f;
-        C[oc] = v;
-        if (C2) {
-          const long o2 = (long)row * g.ldc2 + col;
-          float w = v;
-          if (dodrop) w = (rng_u32(key, (uint64_t)(g.drop_base + offC2 + o2)) >= g.drop.thresh) ? w * g.drop.scale : 0.f;
-          if (add2) w += add2[(long)row * g.ldadd2 + col];
-          if (pad) w = 0.f;
-          C2[o2] = w;
-        }
+        if (!ALIGNED && col >= g.N) continue;
+        epi_store(g, e, row, col, acc[i][j][r]);
       }
     }
-  }
+}
+
+// Sum the split-K partials in split order (bitwise reproducible) and run the epilogue.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
+  const long mn = (long)g.M * g.N;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int z = blockIdx.y;
+  if (idx >= mn) return;
+  const long nb = (long)g.batch1 * g.batch2;
+  const float* w = g.ws + (long)z * mn + idx;
+  float acc = 0.f;
+  for (int s = 0; s < g.splits; ++s) acc += w[(long)s * nb * mn];
+  const int z1 = z / g.batch2, z2 = z - z1 * g.batch2;
+  const Epi e = make_epi(g, z1, z2);
+  const int row = (int)(idx / g.N), col = (int)(idx - (long)row * g.N);
+  epi_store(g, e, row, col, acc);
 }
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-template <int TM, int TN>
+template <int TM, int TN, bool ALIGNED>
 static int launch(const GemmArgs& g, hipStream_t stream) {
-  dim3 grid(cdiv(g.N, 64 * TN), cdiv(g.M, 64 * TM), g.batch1 * g.batch2), block(256);
-  ProfScope ps(g.tag, stream);
-  if (g.a_kc && !g.b_kc)
-    hipLaunchKernelGGL((gemm_kernel<TM, TN, true, false>), grid, block, 0, stream, g);
-  else if (g.a_kc && g.b_kc)
-    hipLaunchKernelGGL((gemm_kernel<TM, TN, true, true>), grid, block, 0, stream, g);
-  else if (!g.a_kc && !g.b_kc)
-    hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false>), grid, block, 0, stream, g);
-  else
-    hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true>), grid, block, 0, stream, g);
-  return check_launch("gemm");
+  dim3 grid(cdiv(g.N, 64 * TN), cdiv(g.M, 64 * TM), g.batch1 * g.batch2 * g.splits), block(256);
+  {
+    ProfScope ps(g.tag, stream);
+    if (g.a_kc && !g.b_kc)
+      hipLaunchKernelGGL((gemm_kernel<TM, TN, true, false, ALIGNED>), grid, block, 0, stream, g);
+    else if (g.a_kc && g.b_kc)
+      hipLaunchKernelGGL((gemm_kernel<TM, TN, true, true, ALIGNED>), grid, block, 0, stream, g);
+    else if (!g.a_kc && !g.b_kc)
+      hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false, ALIGNED>), grid, block, 0, stream, g);
+    else
+      hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true, ALIGNED>), grid, block, 0, stream, g);
+  }
+  if (int e = check_launch("gemm")) return e;
+  if (g.splits > 1) {
+    ProfScope ps("gemm_splitk_reduce", stream);
+    dim3 rgrid(cdiv((long)g.M * g.N, 256), g.batch1 * g.batch2);
+    hipLaunchKernelGGL(splitk_reduce_kernel, rgrid, dim3(256), 0, stream, g);
+    return check_launch("gemm_splitk_reduce");
+  }
+  return 0;
 }
 
-int gemm(const GemmArgs& g_in, hipStream_t stream, int tile) {
+int gemm(const GemmArgs& g_in, hipStream_t stream, int tile, int splits) {
   GemmArgs g = g_in;
   GC_REQUIRE(g.A && g.B && g.C, "gemm: null operand");
   GC_REQUIRE(g.M >= 0 && g.N >= 0 && g.K >= 0 && g.batch1 >= 1 && g.batch2 >= 1, "gemm: bad shape");
   if (g.M == 0 || g.N == 0) return 0;
-  GC_REQUIRE((long)g.batch1 * g.batch2 <= 65535, "gemm: batch %ld exceeds grid.z", (long)g.batch1 * g.batch2);
-  GC_REQUIRE(cdiv(g.M, 64) <= 65535, "gemm: M %d exceeds grid.y", g.M);
+  const long nb = (long)g.batch1 * g.batch2;
   g.vecA = aligned16(g.A) && g.lda % 4 == 0 && g.sA1 % 4 == 0 && g.sA2 % 4 == 0;
   g.vecB = aligned16(g.B) && g.ldb % 4 == 0 && g.sB1 % 4 == 0 && g.sB2 % 4 == 0;
-  if (tile == 0) {
-    // 128x128 blocks halve operand traffic per flop; use them once they fill the 256 CUs.
-    const long big = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * g.batch1 * g.batch2;
-    tile = (big >= 192) ? 2 : 1;
+  const long t64 = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * nb;
+  if (tile == 0) tile = (t64 >= 4096) ? 2 : 1;  // 128x128 only when it still leaves >= 4 blocks per CU
+  const long tiles = (tile == 2) ? (long)cdiv(g.M, 128) * cdiv(g.N, 128) * nb : t64;
+  if (splits == 0) {
+    // split K until ~3 blocks per CU are resident, keeping >= 2 k-steps of 32 per split
+    splits = 1;
+    while (tiles * splits < 768 && splits < 16 && g.K % (splits * 2 * BK) == 0 && g.K / (splits * 2) >= 2 * BK) splits *= 2;
   }
-  return tile == 2 ? launch<2, 2>(g, stream) : launch<1, 1>(g, stream);
+  if (splits > 1 && (!g.ws || (long)splits * nb * g.M * g.N > g.ws_elems || g.K % (splits * BK) != 0)) splits = 1;
+  g.splits = splits;
+  g.ksplit = (splits > 1) ? g.K / splits : g.K;
+  GC_REQUIRE(nb * splits <= 65535, "gemm: batch %ld x splits %d exceeds grid.z", nb, splits);
+  GC_REQUIRE(cdiv(g.M, 64) <= 65535, "gemm: M %d exceeds grid.y", g.M);
+  const int bm = (tile == 2) ? 128 : 64;
+  const bool al = g.vecA && g.vecB && g.M % bm == 0 && g.N % bm == 0 && g.ksplit % BK == 0;
+  if (tile == 2) return al ? launch<2, 2, true>(g, stream) : launch<2, 2, false>(g, stream);
+  return al ? launch<1, 1, true>(g, stream) : launch<1, 1, false>(g, stream);
 }
 
 }  // namespace gc

@@ -50,11 +50,24 @@ struct GemmArgs {
   const int* n_valid = nullptr;
   int nv_rows = 1, nv_zdoc = 0;
   const char* tag = "gemm";  // name seen by the per-kernel timer
+  // split-K workspace (optional): partial sums [splits][batch][M][N]
+  float* ws = nullptr;
+  long ws_elems = 0;
   // filled by the launcher
   int vecA = 0, vecB = 0;
+  int splits = 1, ksplit = 0;
 };
 
-// Enqueue on `stream`.  tile: 0 = pick by grid fill, 1 = 64x64 block, 2 = 128x128 block.
-int gemm(const GemmArgs& g, hipStream_t stream, int tile = 0);
+// Enqueue on `stream`.  tile: 0 = pick by residency, 1 = 64x64 block, 2 = 128x128 block.
+// splits: 0 = pick (needs g.ws), 1 = none, n = split K n ways (partials in g.ws, then one
+// deterministic reduce + epilogue kernel).
+int gemm(const GemmArgs& g, hipStream_t stream, int tile = 0, int splits = 0);
+
+// Floats of split-K workspace that lets every GEMM of a [rows x cols]-sized problem split freely.
+inline long gemm_ws_elems(long rows, long cols) {
+  long need = 16 * rows * cols;
+  const long cap = 8L << 20;
+  return need < cap ? need : cap;
+}
 
 }  // namespace gc

@@ -146,8 +146,9 @@ class MhaFn(torch.autograd.Function):
         Q = torch.empty(B, N, D, device=dev)
         P = torch.empty(B, H, N, N, device=dev)
         A = torch.empty(B, H, N, N, device=dev) if snap is not None else None
+        scratch = torch.empty(max(_lib.lib().gcgcn_mha_scratch(B, N, D), 1), device=dev)
         call("gcgcn_mha_fwd", B, N, D, H, _p(x), _p(n_valid), _p(flat), _p(snap), float(p), _p(Q), _p(P), _p(A),
-             _stream())
+             _p(scratch), _stream())
         ctx.save_for_backward(x, flat, Q, P)
         ctx.H, ctx.p, ctx.snap = H, float(p), snap
         return P if A is None else A
@@ -162,7 +163,7 @@ class MhaFn(torch.autograd.Function):
         dflat = torch.empty_like(flat)
         dS = torch.empty(B, H, N, N, device=dev)
         dQ = torch.empty(B, N, D, device=dev)
-        scratch = torch.empty(max(_lib.lib().gcgcn_mha_bwd_scratch(B, N, D), 1), device=dev)
+        scratch = torch.empty(max(_lib.lib().gcgcn_mha_scratch(B, N, D), 1), device=dev)
         call("gcgcn_mha_bwd", B, N, D, H, _p(x), _p(flat), _p(ctx.snap), ctx.p, _p(Q), _p(P), _p(dA), _p(dX),
              _p(dflat), _p(dS), _p(dQ), _p(scratch), _stream())
         return dX, dflat, None, None, None, None
@@ -183,8 +184,9 @@ class GcnFn(torch.autograd.Function):
         HO = torch.empty(B, N, HD, device=dev)
         rinv = torch.empty(B, H, N, device=dev)
         G = torch.empty(B, N, HD, device=dev)
+        scratch = torch.empty(max(_lib.lib().gcgcn_gcn_scratch(B, N, D, H), 1), device=dev)
         call("gcgcn_gcn_fwd", B, N, D, L, H, _p(x), _p(ebar), _p(adj), _p(n_valid), _p(flat), _p(snap), float(p),
-             _p(out), _p(Pn), _p(Y), _p(HO), _p(rinv), _p(G), _stream())
+             _p(out), _p(Pn), _p(Y), _p(HO), _p(rinv), _p(G), _p(scratch), _stream())
         ctx.save_for_backward(x, ebar, adj, flat, Pn, Y, HO, rinv)
         ctx.n_valid, ctx.L, ctx.H, ctx.p, ctx.snap = n_valid, L, H, float(p), snap
         return out
@@ -206,7 +208,7 @@ class GcnFn(torch.autograd.Function):
         drow = torch.empty(B, H, N, device=dev)
         dXres = torch.empty(B, N, D, device=dev)
         dout_m = torch.empty(B, N, D, device=dev) if ctx.n_valid is not None else None
-        scratch = torch.empty(max(_lib.lib().gcgcn_gcn_bwd_scratch(B, N, D), 1), device=dev)
+        scratch = torch.empty(max(_lib.lib().gcgcn_gcn_scratch(B, N, D, H), 1), device=dev)
         call("gcgcn_gcn_bwd", B, N, D, L, H, _p(x), _p(ebar), _p(adj), _p(ctx.n_valid), _p(flat), _p(ctx.snap),
              ctx.p, _p(Pn), _p(Y), _p(HO), _p(rinv), _p(dout), _p(dX), _p(dEbar), _p(dA), _p(dflat), _p(W1), _p(W2),
              _p(W3), _p(drow), _p(dXres), _p(dout_m), _p(scratch), _stream())

@@ -90,11 +90,13 @@ int gcgcn_edge_mean_bwd(int B, int N, int D, const float* dEbar, const int32_t* 
  * reference projects keys with linears_q, glove:136-137).  out = {oWq, obq, total}. */
 int gcgcn_mha_layout(int D, int64_t* out3);
 /* forward(node_feat X[B,N,D]) -> A[B,H,N,N] = dropout(P), P = softmax(Q_h Q_h^T / sqrt(dh));
- * saved: Q[B,N,D], P[B,H,N,N].  A may be NULL when rng_snap is NULL. */
+ * saved: Q[B,N,D], P[B,H,N,N].  A may be NULL when rng_snap is NULL.
+ * scratch[gcgcn_mha_scratch(B,N,D)] floats (split-K partials, column-sum partials); may be NULL
+ * (then no GEMM is split). */
+int64_t gcgcn_mha_scratch(int B, int N, int D);
 int gcgcn_mha_fwd(int B, int N, int D, int H, const float* X, const int32_t* n_valid, const float* flat,
-                  const void* rng_snap, float p, float* Q, float* P, float* A, void* stream);
-/* backward.  Workspace: dS[B,H,N,N], dQ[B,N,D], scratch[gcgcn_mha_bwd_scratch]. */
-int64_t gcgcn_mha_bwd_scratch(int B, int N, int D);
+                  const void* rng_snap, float p, float* Q, float* P, float* A, float* scratch, void* stream);
+/* backward.  Workspace: dS[B,H,N,N], dQ[B,N,D], scratch[gcgcn_mha_scratch]. */
 int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat, const void* rng_snap, float p,
                   const float* Q, const float* P, const float* dA, float* dX, float* dflat, float* dS, float* dQ,
                   float* scratch, void* stream);
@@ -108,14 +110,15 @@ int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat,
  * out = {oWnX, oWe, oWd, oWlin, oblin, total, wd_floats_per_head}. */
 int gcgcn_gcn_layout(int D, int L, int H, int64_t* out7);
 /* forward(node_feat X[B,N,D], mean edge feature Ebar[B,N,D], adjacency A[B,H,N,N]) -> out[B,N,D].
- * saved for backward: Pn, Y, HO (each [B,N,H*D]) and rinv[B,H,N].  Workspace: G[B,N,H*D]. */
+ * saved for backward: Pn, Y, HO (each [B,N,H*D]) and rinv[B,H,N].  Workspace: G[B,N,H*D],
+ * scratch[gcgcn_gcn_scratch(B,N,D,H)] (split-K / column-sum partials; NULL = never split). */
+int64_t gcgcn_gcn_scratch(int B, int N, int D, int H);
 int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float* Ebar, const float* A,
                   const int32_t* n_valid, const float* flat, const void* rng_snap, float p, float* out, float* Pn,
-                  float* Y, float* HO, float* rinv, float* G, void* stream);
+                  float* Y, float* HO, float* rinv, float* G, float* scratch, void* stream);
 /* backward.  dout[B,N,D] -> dX, dEbar [B,N,D], dA[B,H,N,N], dflat.
  * Workspace: W1, W2, W3 (each [B,N,H*D]), drow[B,H,N], dXres[B,N,D], dout_m[B,N,D] (only read
- * when n_valid != NULL), scratch[gcgcn_gcn_bwd_scratch]. */
-int64_t gcgcn_gcn_bwd_scratch(int B, int N, int D);
+ * when n_valid != NULL), scratch[gcgcn_gcn_scratch]. */
 int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float* Ebar, const float* A,
                   const int32_t* n_valid, const float* flat, const void* rng_snap, float p, const float* Pn,
                   const float* Y, const float* HO, const float* rinv, const float* dout, float* dX, float* dEbar,
@@ -125,10 +128,11 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
 /* ---- raw batched GEMM (exposed for unit tests and benchmarks of the MFMA kernel) ----------- */
 /* C[z] = alpha * opA(A[z]) opB(B[z]);  a_kc: A stored [M][K] else [K][M];  b_kc: B stored [N][K]
  * else [K][N];  z < batch with element strides sA, sB, sC;  tile: 0 auto, 1 = 64x64, 2 = 128x128;
+ * splits: 0 auto, 1 none, n = split K n ways through ws[ws_elems] (>= n*batch*M*N floats);
  * bias[N] optional, relu/accumulate flags. */
 int gcgcn_gemm(int M, int N, int K, const float* A, int64_t lda, int a_kc, const float* B, int64_t ldb, int b_kc,
                float* C, int64_t ldc, int batch, int64_t sA, int64_t sB, int64_t sC, float alpha, const float* bias,
-               int relu, int accumulate, int tile, void* stream);
+               int relu, int accumulate, int tile, int splits, float* ws, int64_t ws_elems, void* stream);
 
 #ifdef __cplusplus
 }

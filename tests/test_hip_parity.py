@@ -56,13 +56,13 @@ def test_gemm(gpu_device, M, N, K, batch, a_kc, b_kc, tile):
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     biasd = bias.to(gpu_device)
     _lib.call("gcgcn_gemm", M, N, K, p(Ad), lda, a_kc, p(Bd), ldb, b_kc, p(C), N, batch, M * K, K * N, M * N,
-              0.5, p(biasd), 1, 0, tile, None)
+              0.5, p(biasd), 1, 0, tile, 1, None, 0, None)
     torch.cuda.synchronize()
     torch.testing.assert_close(C.cpu(), ref, rtol=1e-4, atol=1e-4)
     # accumulate: C += A B (no bias/relu)
     C2 = C.clone()
     _lib.call("gcgcn_gemm", M, N, K, p(Ad), lda, a_kc, p(Bd), ldb, b_kc, p(C2), N, batch, M * K, K * N, M * N,
-              1.0, None, 0, 1, tile, None)
+              1.0, None, 0, 1, tile, 1, None, 0, None)
     torch.testing.assert_close(C2.cpu(), ref + (A.double() @ B.double()).float(), rtol=1e-4, atol=2e-4)
 
 
@@ -76,8 +76,34 @@ def test_gemm_a_identity_asymmetric_b(gpu_device):
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     for tile in (1, 2):
         _lib.call("gcgcn_gemm", n, 40, n, p(Ad), n, 1, p(Bd), 40, 0, p(C), 40, 1, 0, 0, 0,
-                  1.0, None, 0, 0, tile, None)
+                  1.0, None, 0, 0, tile, 1, None, 0, None)
         assert torch.equal(C.cpu(), B)
+
+
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 0), (1, 1), (0, 0)])
+@pytest.mark.parametrize("M,N,K,batch,splits", [(256, 128, 2048, 1, 8), (128, 64, 512, 3, 4), (2048, 256, 2048, 1, 0),
+                                                 (100, 60, 256, 2, 4)])
+def test_gemm_split_k(gpu_device, M, N, K, batch, splits, a_kc, b_kc):
+    """Split-K through the workspace + reduce/epilogue kernel: same answer as the unsplit kernel to fp32
+    summation-order slack, and bitwise reproducible run to run."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(batch, M, K, generator=g)
+    B = torch.randn(batch, K, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = torch.relu((A.double() @ B.double()) + bias.double()).float()
+    Ad = (A if a_kc else A.transpose(1, 2)).contiguous().to(gpu_device)
+    Bd = (B.transpose(1, 2) if b_kc else B).contiguous().to(gpu_device)
+    biasd = bias.to(gpu_device)
+    ws = torch.empty(16 * batch * M * N, device=gpu_device)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    outs = []
+    for _ in range(2):
+        C = torch.full((batch, M, N), float("nan"), device=gpu_device)
+        _lib.call("gcgcn_gemm", M, N, K, p(Ad), K if a_kc else M, a_kc, p(Bd), K if b_kc else N, b_kc, p(C), N, batch,
+                  M * K, K * N, M * N, 1.0, p(biasd), 1, 0, 0, splits, p(ws), ws.numel(), None)
+        outs.append(C.cpu())
+    torch.testing.assert_close(outs[0], ref, rtol=1e-4, atol=2e-4 * math.sqrt(K / 256))
+    assert torch.equal(outs[0], outs[1])
 
 
 # ------------------------------------------------------------------------------------------------------
