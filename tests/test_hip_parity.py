@@ -359,8 +359,10 @@ def test_full_size_properties(gpu_device):
     f_again, dx2, de1_2, _ = run(x, e1, e2)
     assert torch.equal(f[2], f_again[2]) and torch.equal(dx, dx2) and torch.equal(de1, de1_2)   # deterministic
     # batch independence: a document alone (B=1, the reference's call shape) == the same document in the batch
+    # (not bitwise: the GEMMs pick a different split-K factor for M = 64 rows than for M = 2048)
     f1, dx1, de1_1, de2_1 = run(x[5:6], e1[5:6], e2[5:6])
-    assert torch.equal(f1[2][0], f[2][5]) and torch.equal(dx1[0], dx[5]) and torch.equal(de2_1[0], de2[5])
+    for a, b in ((f1[2][0], f[2][5]), (dx1[0], dx[5]), (de1_1[0], de1[5]), (de2_1[0], de2[5])):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=2e-5)
     # attention rows are distributions; dE2 is constant along j
     a0 = hops.get_weighted_adj_matrix(x.to(gpu_device), e1.to(gpu_device))
     torch.testing.assert_close(a0.sum(-1), torch.ones(B, N, device=gpu_device), rtol=1e-5, atol=1e-5)
