@@ -1,0 +1,81 @@
+"""Batch-DP plumbing on CPU with the gloo backend, world_size = 2: the flat gradient arena is ONE
+all-reduce operand, parameters/gradients are views of the arenas, documents shard along the batch axis.
+(The kernels themselves need a GPU; here gradients are synthetic.)"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import gcgcn_amd
+from gcgcn_amd.dist import FlatGradBucket, shard_batch
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(1337)                                   # identical replicas
+        hops = gcgcn_amd.GraphHops(16, 2, 4)
+        before = {k: v.clone() for k, v in hops.state_dict().items()}
+        bucket = FlatGradBucket(hops)
+        # re-pointing storage must not change any parameter value or the state_dict
+        after = hops.state_dict()
+        assert all(torch.equal(before[k], after[k]) for k in before)
+        assert bucket.numel == sum(p.numel() for n, p in hops.named_parameters() if not n.endswith("flat_k"))
+        for p in bucket.params:                                   # views, not copies
+            assert p.data_ptr() >= bucket.param_arena.data_ptr()
+            assert p.grad.data_ptr() >= bucket.grad_arena.data_ptr()
+        # synthetic per-rank gradients, accumulated in place the way autograd's AccumulateGrad does
+        bucket.zero_grad()
+        for i, p in enumerate(bucket.params):
+            p.grad.add_(torch.full_like(p, float((rank + 1) * (i + 1))))
+        bucket.all_reduce(global_docs=4)
+        for i, p in enumerate(bucket.params):
+            want = (1 + 2) * (i + 1) / 4.0                          # sum over ranks / global batch
+            assert torch.allclose(p.grad, torch.full_like(p, want)), (i, p.grad.flatten()[:3])
+        assert hops.get_adj_matrix[0].flat_k.grad is None         # linears_k stay out of the bucket
+        # an optimiser step on the views moves the arena
+        opt = torch.optim.SGD(bucket.params, lr=1.0)
+        a0 = bucket.param_arena.clone()
+        opt.step()
+        assert not torch.equal(a0, bucket.param_arena)
+        # batch sharding
+        x = torch.arange(8.0).view(8, 1)
+        (xs,) = shard_batch([x], rank, world)
+        assert xs.flatten().tolist() == [4.0 * rank + k for k in range(4)]
+        out.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        out.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_flat_bucket_allreduce_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=100) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_shard_batch_rejects_uneven():
+    with pytest.raises(ValueError):
+        shard_batch([torch.zeros(5, 2)], 0, 2)
