@@ -131,9 +131,9 @@ int gcgcn_prof_stop(double* total_ms, int* launches) {
   return 0;
 }
 
-int gcgcn_rng_next(void* state, void* snap, void* stream) {
-  GC_REQUIRE(state && snap, "rng_next: null pointer");
-  return rng_next(state, snap, (hipStream_t)stream);
+int gcgcn_rng_next(void* state, void* snaps, int count, void* stream) {
+  GC_REQUIRE(state && snaps && count > 0, "rng_next: bad arguments");
+  return rng_next(state, snaps, count, (hipStream_t)stream);
 }
 int gcgcn_dropout_keep(uint8_t* keep, int64_t n, const void* rng_snap, uint64_t salt, float p, void* stream) {
   GC_REQUIRE(keep && rng_snap, "dropout_keep: null pointer");
@@ -177,8 +177,7 @@ int gcgcn_gat_fwd(int B, int N, int D, const float* X, const float* E, const int
   const long M = (long)B * N;
   GC_TRY(gat_fold_fwd(flat, uvc, D, st));
   GC_TRY(node_score_fwd(X, uvc, s, M, D, st));
-  GC_TRY(edge_fwd(E, uvc + D, n_valid, Ebar, P, B, N, D, st));
-  GC_TRY(softmax_fwd(P, s, n_valid, P, A, M, N, 1, drop, st));
+  GC_TRY(edge_fwd(E, uvc + D, n_valid, Ebar, s, P, A, drop, B, N, D, st));  // + row softmax + dropout
   return 0;
 }
 
@@ -207,7 +206,8 @@ int gcgcn_gat_bwd(int B, int N, int D, const float* X, const float* E, const int
 }
 
 int gcgcn_edge_mean_fwd(int B, int N, int D, const float* E, const int32_t* n_valid, float* Ebar, void* stream) {
-  return edge_fwd(E, nullptr, n_valid, Ebar, nullptr, B, N, D, (hipStream_t)stream);
+  return edge_fwd(E, nullptr, n_valid, Ebar, nullptr, nullptr, nullptr, make_drop(nullptr, 0, 0.f), B, N, D,
+                  (hipStream_t)stream);
 }
 int gcgcn_edge_mean_bwd(int B, int N, int D, const float* dEbar, const int32_t* n_valid, float* dE, void* stream) {
   GC_REQUIRE(B > 0 && N > 0 && D > 0, "edge_mean_bwd: bad shape");
@@ -286,23 +286,18 @@ int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat,
     g.accumulate = pass;
     GC_TRY(gemm(g, st));
   }
-  {  // dX = dQ Wq
-    GemmArgs g;
-    g.ws = scratch, g.ws_elems = wse;
-    g.A = dQ, g.lda = D, g.a_kc = 1;
-    g.B = flat, g.ldb = D, g.b_kc = 0;
-    g.C = dX, g.ldc = D;
-    g.M = (int)M, g.N = D, g.K = D;
-    GC_TRY(gemm(g, st));
-  }
-  {  // dWq = dQ^T X
-    GemmArgs g;
-    g.ws = scratch, g.ws_elems = wse;
-    g.A = dQ, g.lda = D, g.a_kc = 0;
-    g.B = X, g.ldb = D, g.b_kc = 0;
-    g.C = dflat, g.ldc = D;
-    g.M = D, g.N = D, g.K = (int)M;
-    GC_TRY(gemm(g, st));
+  {  // one launch: dX = dQ Wq  and  dWq = dQ^T X
+    GemmArgs gs[2];
+    gs[0].ws = gs[1].ws = scratch, gs[0].ws_elems = gs[1].ws_elems = wse;
+    gs[0].A = dQ, gs[0].lda = D, gs[0].a_kc = 1;
+    gs[0].B = flat, gs[0].ldb = D, gs[0].b_kc = 0;
+    gs[0].C = dX, gs[0].ldc = D;
+    gs[0].M = (int)M, gs[0].N = D, gs[0].K = D;
+    gs[1].A = dQ, gs[1].lda = D, gs[1].a_kc = 0;
+    gs[1].B = X, gs[1].ldb = D, gs[1].b_kc = 0;
+    gs[1].C = dflat, gs[1].ldc = D;
+    gs[1].M = D, gs[1].N = D, gs[1].K = (int)M;
+    GC_TRY(gemm_group(gs, 2, st));
   }
   GC_TRY(colsum(dQ, nullptr, dflat + (long)D * D, M, D, D, 1, 0, 0, 0, 0, scratch, st));  // dbq
   return 0;
@@ -334,23 +329,18 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
   GC_REQUIRE(M <= 0x7fffffffL, "gcn_fwd: B*N too large");
 
   GC_TRY(rowsum_inv(A, rinv, (long)B * H * N, N, st));  // glove:47-49
-  {  // Pn = X WnX : node term of every (head, sub-layer) for the X part of the dense input
-    GemmArgs g;
-    g.ws = scratch, g.ws_elems = wse;
-    g.A = X, g.lda = D, g.a_kc = 1;
-    g.B = flat + y.oWnX, g.ldb = HD, g.b_kc = 0;
-    g.C = Pn, g.ldc = HD;
-    g.M = (int)M, g.N = (int)HD, g.K = D;
-    GC_TRY(gemm(g, st));
-  }
-  {  // G = Ebar We : edge term, mean commuted with the projection (glove:40-41)
-    GemmArgs g;
-    g.ws = scratch, g.ws_elems = wse;
-    g.A = Ebar, g.lda = D, g.a_kc = 1;
-    g.B = flat + y.oWe, g.ldb = HD, g.b_kc = 0;
-    g.C = G, g.ldc = HD;
-    g.M = (int)M, g.N = (int)HD, g.K = D;
-    GC_TRY(gemm(g, st));
+  {  // one launch: Pn = X WnX (node term of every (head, sub-layer), X part of the dense input)
+     //             G  = Ebar We (edge term, mean commuted with the projection, glove:40-41)
+    GemmArgs gs[2];
+    for (int q = 0; q < 2; ++q) {
+      GemmArgs& g = gs[q];
+      g.ws = scratch, g.ws_elems = wse;
+      g.A = q ? Ebar : X, g.lda = D, g.a_kc = 1;
+      g.B = flat + (q ? y.oWe : y.oWnX), g.ldb = HD, g.b_kc = 0;
+      g.C = q ? G : Pn, g.ldc = HD;
+      g.M = (int)M, g.N = (int)HD, g.K = D;
+    }
+    GC_TRY(gemm_group(gs, 2, st));
   }
   for (int l = 0; l < L; ++l) {
     if (l > 0) {  // Pn_l += [Y_0 .. Y_{l-1}] Wd_l : dense connection (glove:73 / 110)
@@ -422,23 +412,18 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
     GC_TRY(mask_rows(dout, dout_m, M, D, N, n_valid, st));
     dout = dout_m;
   }
-  {  // dHO = dout Wlin
-    GemmArgs g;
-    g.ws = scratch, g.ws_elems = wse;
-    g.A = dout, g.lda = D, g.a_kc = 1;
-    g.B = flat + y.oWlin, g.ldb = HD, g.b_kc = 0;
-    g.C = dYa, g.ldc = HD;
-    g.M = (int)M, g.N = (int)HD, g.K = D;
-    GC_TRY(gemm(g, st));
-  }
-  {  // dWlin = dout^T HO
-    GemmArgs g;
-    g.ws = scratch, g.ws_elems = wse;
-    g.A = dout, g.lda = D, g.a_kc = 0;
-    g.B = HO, g.ldb = HD, g.b_kc = 0;
-    g.C = dflat + y.oWlin, g.ldc = HD;
-    g.M = D, g.N = (int)HD, g.K = (int)M;
-    GC_TRY(gemm(g, st));
+  {  // one launch: dHO = dout Wlin  and  dWlin = dout^T HO
+    GemmArgs gs[2];
+    gs[0].ws = gs[1].ws = scratch, gs[0].ws_elems = gs[1].ws_elems = wse;
+    gs[0].A = dout, gs[0].lda = D, gs[0].a_kc = 1;
+    gs[0].B = flat + y.oWlin, gs[0].ldb = HD, gs[0].b_kc = 0;
+    gs[0].C = dYa, gs[0].ldc = HD;
+    gs[0].M = (int)M, gs[0].N = (int)HD, gs[0].K = D;
+    gs[1].A = dout, gs[1].lda = D, gs[1].a_kc = 0;
+    gs[1].B = HO, gs[1].ldb = HD, gs[1].b_kc = 0;
+    gs[1].C = dflat + y.oWlin, gs[1].ldc = HD;
+    gs[1].M = D, gs[1].N = (int)HD, gs[1].K = (int)M;
+    GC_TRY(gemm_group(gs, 2, st));
   }
   GC_TRY(colsum(dout, nullptr, dflat + y.oblin, M, D, D, 1, 0, 0, 0, 0, scratch, st));  // dblin
   GC_TRY(head_sum_drop_bwd(dYa, dYa, dXres, M, H, D, drop, st));  // residual + dropout backward
@@ -479,52 +464,54 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
       GC_TRY(gemm(g, st));
     }
   }
-  for (int l = 1; l < L; ++l) {  // dWd_{h,l} = [Y_0 .. Y_{l-1}]_h^T dPn_{h,l}
-    GemmArgs g;
-    g.ws = scratch, g.ws_elems = wse;
-    g.A = Y, g.lda = HD, g.a_kc = 0, g.sA2 = (long)L * gh;
-    g.B = dP + (long)l * gh, g.ldb = HD, g.b_kc = 0, g.sB2 = (long)L * gh;
-    g.C = dflat + y.wd_off(0, l), g.ldc = gh, g.sC2 = y.wd_head;
-    g.M = l * gh, g.N = gh, g.K = (int)M;
-    g.batch2 = H;
-    GC_TRY(gemm(g, st));
-  }
-  {  // dWnX = X^T dPn
-    GemmArgs g;
-    g.ws = scratch, g.ws_elems = wse;
-    g.A = X, g.lda = D, g.a_kc = 0;
-    g.B = dP, g.ldb = HD, g.b_kc = 0;
-    g.C = dflat + y.oWnX, g.ldc = HD;
-    g.M = D, g.N = (int)HD, g.K = (int)M;
-    GC_TRY(gemm(g, st));
-  }
-  {  // dWe = Ebar^T dM
-    GemmArgs g;
-    g.ws = scratch, g.ws_elems = wse;
-    g.A = Ebar, g.lda = D, g.a_kc = 0;
-    g.B = dM, g.ldb = HD, g.b_kc = 0;
-    g.C = dflat + y.oWe, g.ldc = HD;
-    g.M = D, g.N = (int)HD, g.K = (int)M;
-    GC_TRY(gemm(g, st));
-  }
-  {  // dX = dPn WnX^T + sum_h dHO_h
-    GemmArgs g;
-    g.ws = scratch, g.ws_elems = wse;
-    g.A = dP, g.lda = HD, g.a_kc = 1;
-    g.B = flat + y.oWnX, g.ldb = HD, g.b_kc = 1;
-    g.C = dX, g.ldc = D;
-    g.M = (int)M, g.N = D, g.K = (int)HD;
-    g.add = dXres, g.ldadd = D;
-    GC_TRY(gemm(g, st));
-  }
-  {  // dEbar = dM We^T
-    GemmArgs g;
-    g.ws = scratch, g.ws_elems = wse;
-    g.A = dM, g.lda = HD, g.a_kc = 1;
-    g.B = flat + y.oWe, g.ldb = HD, g.b_kc = 1;
-    g.C = dEbar, g.ldc = D;
-    g.M = (int)M, g.N = D, g.K = (int)HD;
-    GC_TRY(gemm(g, st));
+  {  // one launch for every product that only needs the finished dPn / dM:
+     //   dWnX = X^T dPn, dWe = Ebar^T dM, dX = dPn WnX^T + sum_h dHO_h, dEbar = dM We^T,
+     //   dWd_{h,l} = [Y_0 .. Y_{l-1}]_h^T dPn_{h,l}  (l >= 1, batched over heads)
+    GemmArgs gs[16];
+    int n = 0;
+    auto next = [&]() -> GemmArgs& {
+      GemmArgs& g = gs[n++];
+      g.ws = scratch, g.ws_elems = wse;
+      return g;
+    };
+    {
+      GemmArgs& g = next();
+      g.A = X, g.lda = D, g.a_kc = 0;
+      g.B = dP, g.ldb = HD, g.b_kc = 0;
+      g.C = dflat + y.oWnX, g.ldc = HD;
+      g.M = D, g.N = (int)HD, g.K = (int)M;
+    }
+    {
+      GemmArgs& g = next();
+      g.A = Ebar, g.lda = D, g.a_kc = 0;
+      g.B = dM, g.ldb = HD, g.b_kc = 0;
+      g.C = dflat + y.oWe, g.ldc = HD;
+      g.M = D, g.N = (int)HD, g.K = (int)M;
+    }
+    {
+      GemmArgs& g = next();
+      g.A = dP, g.lda = HD, g.a_kc = 1;
+      g.B = flat + y.oWnX, g.ldb = HD, g.b_kc = 1;
+      g.C = dX, g.ldc = D;
+      g.M = (int)M, g.N = D, g.K = (int)HD;
+      g.add = dXres, g.ldadd = D;
+    }
+    {
+      GemmArgs& g = next();
+      g.A = dM, g.lda = HD, g.a_kc = 1;
+      g.B = flat + y.oWe, g.ldb = HD, g.b_kc = 1;
+      g.C = dEbar, g.ldc = D;
+      g.M = (int)M, g.N = D, g.K = (int)HD;
+    }
+    for (int l = 1; l < L && n < 16; ++l) {
+      GemmArgs& g = next();
+      g.A = Y, g.lda = HD, g.a_kc = 0, g.sA2 = (long)L * gh;
+      g.B = dP + (long)l * gh, g.ldb = HD, g.b_kc = 0, g.sB2 = (long)L * gh;
+      g.C = dflat + y.wd_off(0, l), g.ldc = gh, g.sC2 = y.wd_head;
+      g.M = l * gh, g.N = gh, g.K = (int)M;
+      g.batch2 = H;
+    }
+    GC_TRY(gemm_group(gs, n, st));
   }
   return 0;
 }

@@ -44,21 +44,27 @@ constexpr int EUNR = 4;  // rows in flight per wave
 // ---------------------------------------------------------------------------------------------
 // forward: Ebar (always) and raw logits v.e_ij (ATT only).  dynamic LDS: EW * D floats.
 // ---------------------------------------------------------------------------------------------
+// ATT: logits stay in LDS; the row's softmax (+ coladd[b, j] = u.x_j + c, + dropout) is finished by
+// wave 0 in the same launch (GATAttention glove:162-167), so P/A are the only attention outputs.
 template <int VEC, bool ATT>
 __global__ __launch_bounds__(64 * EW) void edge_fwd_kernel(const float* __restrict__ E, const float* __restrict__ v,
                                                            const int* __restrict__ n_valid, float* __restrict__ Ebar,
-                                                           float* __restrict__ logit, int N, int D) {
-  extern __shared__ __attribute__((aligned(16))) float cs[];  // [EW][D] per-wave column sums
+                                                           const float* __restrict__ coladd, float* __restrict__ P,
+                                                           float* __restrict__ Aout, Drop drop, int N, int D) {
+  extern __shared__ __attribute__((aligned(16))) float cs[];  // [EW][D] per-wave column sums, then [N] logits
   const int bi = blockIdx.x;
   const int b = bi / N, i = bi - b * N;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
   float* eb = Ebar + (long)bi * D;
-  float* lg = ATT ? logit + (long)bi * N : nullptr;
+  float* lg = cs + (long)EW * D;  // [N] (ATT only)
   if (i >= nv) {  // padding entity: outputs are zero, nothing is read
     for (int c = t; c < D; c += 64 * EW) eb[c] = 0.f;
     if (ATT)
-      for (int j = t; j < N; j += 64 * EW) lg[j] = 0.f;
+      for (int j = t; j < N; j += 64 * EW) {
+        P[(long)bi * N + j] = 0.f;
+        if (Aout) Aout[(long)bi * N + j] = 0.f;
+      }
     return;
   }
   const float* __restrict__ Er = E + (long)bi * N * D;
@@ -125,8 +131,28 @@ __global__ __launch_bounds__(64 * EW) void edge_fwd_kernel(const float* __restri
     for (int w = 0; w < EW; ++w) s += cs[w * D + c];
     eb[c] = s * inv;
   }
-  if (ATT)
-    for (int j = nv + t; j < N; j += 64 * EW) lg[j] = 0.f;
+  if (ATT && wave == 0) {  // row softmax over the nv real columns
+    const float* ca = coladd + (long)b * N;
+    float m = -INFINITY;
+    for (int j = lane; j < nv; j += 64) m = fmaxf(m, lg[j] + ca[j]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int j = lane; j < nv; j += 64) sum += expf(lg[j] + ca[j] - m);
+    sum = wave_sum(sum);
+    const float isum = 1.f / sum;
+    const bool dd = Aout && drop.snap;
+    const uint64_t key = dd ? drop_key(drop) : 0;
+    for (int j = lane; j < N; j += 64) {
+      float pv = 0.f;
+      if (j < nv) pv = expf(lg[j] + ca[j] - m) * isum;
+      const long o = (long)bi * N + j;
+      P[o] = pv;
+      if (Aout) {
+        if (dd) pv = (rng_u32(key, (uint64_t)o) >= drop.thresh) ? pv * drop.scale : 0.f;
+        Aout[o] = pv;
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -260,23 +286,23 @@ __global__ __launch_bounds__(64 * EW) void edge_bcast_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-int edge_fwd(const float* E, const float* v, const int* n_valid, float* Ebar, float* logit, int B, int N, int D,
-             hipStream_t st) {
+int edge_fwd(const float* E, const float* v, const int* n_valid, float* Ebar, const float* coladd, float* P, float* A,
+             Drop drop, int B, int N, int D, hipStream_t st) {
   GC_REQUIRE(E && Ebar, "edge_fwd: null pointer");
   GC_REQUIRE(B > 0 && N > 0 && D > 0, "edge_fwd: bad shape B=%d N=%d D=%d", B, N, D);
-  const bool att = logit != nullptr;
-  GC_REQUIRE(!att || v, "edge_fwd: logits requested without v");
+  const bool att = P != nullptr;
+  GC_REQUIRE(!att || (v && coladd), "edge_fwd: attention requested without v / node scores");
   const bool vec = (D % 4 == 0) && al16(E) && al16(Ebar) && (!att || al16(v));
-  const size_t lds = (size_t)EW * D * sizeof(float);
-  GC_REQUIRE(lds <= 160 * 1024, "edge_fwd: D=%d needs %zu B of LDS", D, lds);
+  const size_t lds = ((size_t)EW * D + (att ? (size_t)N : 0)) * sizeof(float);
+  GC_REQUIRE(lds <= 160 * 1024, "edge_fwd: N=%d D=%d needs %zu B of LDS", N, D, lds);
   dim3 grid((unsigned)((long)B * N)), block(64 * EW);
   ProfScope ps(att ? "edge_fwd_att" : "edge_fwd_mean", st);
   if (vec) {
-    if (att) hipLaunchKernelGGL((edge_fwd_kernel<4, true>), grid, block, lds, st, E, v, n_valid, Ebar, logit, N, D);
-    else hipLaunchKernelGGL((edge_fwd_kernel<4, false>), grid, block, lds, st, E, v, n_valid, Ebar, logit, N, D);
+    if (att) hipLaunchKernelGGL((edge_fwd_kernel<4, true>), grid, block, lds, st, E, v, n_valid, Ebar, coladd, P, A, drop, N, D);
+    else hipLaunchKernelGGL((edge_fwd_kernel<4, false>), grid, block, lds, st, E, v, n_valid, Ebar, coladd, P, A, drop, N, D);
   } else {
-    if (att) hipLaunchKernelGGL((edge_fwd_kernel<1, true>), grid, block, lds, st, E, v, n_valid, Ebar, logit, N, D);
-    else hipLaunchKernelGGL((edge_fwd_kernel<1, false>), grid, block, lds, st, E, v, n_valid, Ebar, logit, N, D);
+    if (att) hipLaunchKernelGGL((edge_fwd_kernel<1, true>), grid, block, lds, st, E, v, n_valid, Ebar, coladd, P, A, drop, N, D);
+    else hipLaunchKernelGGL((edge_fwd_kernel<1, false>), grid, block, lds, st, E, v, n_valid, Ebar, coladd, P, A, drop, N, D);
   }
   return check_launch("edge_fwd");
 }

@@ -140,24 +140,23 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, const Epi& e, int r
 }
 
 template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__ lds, const int bx, const int by,
+                                          const int zs) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int LDA = AKC ? BM + 1 : BM;
   constexpr int LDB = BKC ? BN + 1 : BN;
   constexpr int SA = BK * LDA, SB = BK * LDB;  // floats per stage
   // the B image starts 16-byte aligned whatever LDA's parity
   constexpr int OFFB = (2 * SA + 3) & ~3;
-  __shared__ __attribute__((aligned(16))) float lds[OFFB + 2 * SB];
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  const int zs = blockIdx.z;
   const int z = zs / g.splits, sp = zs - z * g.splits;
   const int z1 = z / g.batch2, z2 = z - z1 * g.batch2;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = by * BM, n0 = bx * BN;
   const int kbeg = sp * g.ksplit;
   const int kend = min(g.K, kbeg + g.ksplit);
 
@@ -244,6 +243,57 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     }
 }
 
+template <int TM, int TN, bool AKC, bool BKC>
+constexpr int lds_floats() {
+  return (((2 * BK * (AKC ? 64 * TM + 1 : 64 * TM)) + 3) & ~3) + 2 * BK * (BKC ? 64 * TN + 1 : 64 * TN);
+}
+
+template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[lds_floats<TM, TN, AKC, BKC>()];
+  gemm_body<TM, TN, AKC, BKC, ALIGNED>(g, lds, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several independent problems in ONE launch (64x64 tiles, interior shapes only): block -> problem by
+// prefix sums of tile counts, layout chosen per problem by a block-uniform branch.
+__global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroup gg) {
+  __shared__ __attribute__((aligned(16))) float lds[lds_floats<1, 1, true, true>()];
+  int b = blockIdx.x, i = 0;
+  while (i + 1 < gg.nprob && b >= gg.tile_begin[i + 1]) ++i;
+  b -= gg.tile_begin[i];
+  const GemmArgs& g = gg.p[i];
+  const int tn = g.N >> 6, tm = g.M >> 6;
+  const int bx = b % tn, by = (b / tn) % tm, zs = b / (tn * tm);
+  if (g.a_kc) {
+    if (g.b_kc) gemm_body<1, 1, true, true, true>(g, lds, bx, by, zs);
+    else gemm_body<1, 1, true, false, true>(g, lds, bx, by, zs);
+  } else {
+    if (g.b_kc) gemm_body<1, 1, false, true, true>(g, lds, bx, by, zs);
+    else gemm_body<1, 1, false, false, true>(g, lds, bx, by, zs);
+  }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const GemmGroup gg) {
+  int b = blockIdx.x, i = 0;
+  while (i + 1 < gg.nprob && b >= gg.red_begin[i + 1]) ++i;
+  b -= gg.red_begin[i];
+  const GemmArgs& g = gg.p[i];
+  if (g.splits <= 1) return;
+  const long mn = (long)g.M * g.N;
+  const int per = (int)((mn + 255) / 256);
+  const int z = b / per;
+  const long idx = (long)(b - z * per) * 256 + threadIdx.x;
+  if (idx >= mn) return;
+  const long nb = (long)g.batch1 * g.batch2;
+  const float* w = g.ws + (long)z * mn + idx;
+  float acc = 0.f;
+  for (int s = 0; s < g.splits; ++s) acc += w[(long)s * nb * mn];
+  const int z1 = z / g.batch2, z2 = z - z1 * g.batch2;
+  const Epi e = make_epi(g, z1, z2);
+  const int row = (int)(idx / g.N), col = (int)(idx - (long)row * g.N);
+  epi_store(g, e, row, col, acc);
+}
+
 // Sum the split-K partials in split order (bitwise reproducible) and run the epilogue.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
   const long mn = (long)g.M * g.N;
@@ -286,17 +336,16 @@ static int launch(const GemmArgs& g, hipStream_t stream) {
   return 0;
 }
 
-int gemm(const GemmArgs& g_in, hipStream_t stream, int tile, int splits) {
-  GemmArgs g = g_in;
-  GC_REQUIRE(g.A && g.B && g.C, "gemm: null operand");
-  GC_REQUIRE(g.M >= 0 && g.N >= 0 && g.K >= 0 && g.batch1 >= 1 && g.batch2 >= 1, "gemm: bad shape");
-  if (g.M == 0 || g.N == 0) return 0;
+// Fill the launcher-owned fields (vec flags, tile, split factor).  Returns the chosen tile (1 or 2) or -1.
+static int prepare(GemmArgs& g, int tile, int splits, long resident_tiles_hint) {
+  if (!(g.A && g.B && g.C)) { set_error("gemm: null operand"); return -1; }
+  if (!(g.M >= 0 && g.N >= 0 && g.K >= 0 && g.batch1 >= 1 && g.batch2 >= 1)) { set_error("gemm: bad shape"); return -1; }
   const long nb = (long)g.batch1 * g.batch2;
   g.vecA = aligned16(g.A) && g.lda % 4 == 0 && g.sA1 % 4 == 0 && g.sA2 % 4 == 0;
   g.vecB = aligned16(g.B) && g.ldb % 4 == 0 && g.sB1 % 4 == 0 && g.sB2 % 4 == 0;
   const long t64 = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * nb;
   if (tile == 0) tile = (t64 >= 4096) ? 2 : 1;  // 128x128 only when it still leaves >= 4 blocks per CU
-  const long tiles = (tile == 2) ? (long)cdiv(g.M, 128) * cdiv(g.N, 128) * nb : t64;
+  const long tiles = ((tile == 2) ? (long)cdiv(g.M, 128) * cdiv(g.N, 128) * nb : t64) + resident_tiles_hint;
   if (splits == 0) {
     // split K until ~3 blocks per CU are resident, keeping >= 2 k-steps of 32 per split
     splits = 1;
@@ -305,12 +354,70 @@ int gemm(const GemmArgs& g_in, hipStream_t stream, int tile, int splits) {
   if (splits > 1 && (!g.ws || (long)splits * nb * g.M * g.N > g.ws_elems || g.K % (splits * BK) != 0)) splits = 1;
   g.splits = splits;
   g.ksplit = (splits > 1) ? g.K / splits : g.K;
-  GC_REQUIRE(nb * splits <= 65535, "gemm: batch %ld x splits %d exceeds grid.z", nb, splits);
+  return tile;
+}
+
+int gemm(const GemmArgs& g_in, hipStream_t stream, int tile, int splits) {
+  GemmArgs g = g_in;
+  if (g.M == 0 || g.N == 0) return 0;
+  tile = prepare(g, tile, splits, 0);
+  if (tile < 0) return 1;
+  const long nb = (long)g.batch1 * g.batch2;
+  GC_REQUIRE(nb * g.splits <= 65535, "gemm: batch %ld x splits %d exceeds grid.z", nb, g.splits);
   GC_REQUIRE(cdiv(g.M, 64) <= 65535, "gemm: M %d exceeds grid.y", g.M);
   const int bm = (tile == 2) ? 128 : 64;
   const bool al = g.vecA && g.vecB && g.M % bm == 0 && g.N % bm == 0 && g.ksplit % BK == 0;
   if (tile == 2) return al ? launch<2, 2, true>(g, stream) : launch<2, 2, false>(g, stream);
   return al ? launch<1, 1, true>(g, stream) : launch<1, 1, false>(g, stream);
+}
+
+// Independent problems in one launch (plus at most one reduce launch).  Problems that are not interior
+// 64x64 shapes fall back to their own launches.
+int gemm_group(const GemmArgs* probs, int n, hipStream_t stream) {
+  GemmGroup gg;
+  gg.nprob = 0;
+  long total = 0;
+  for (int i = 0; i < n; ++i) total += (long)cdiv(probs[i].M, 64) * cdiv(probs[i].N, 64) * probs[i].batch1 * probs[i].batch2;
+  int tiles = 0, reds = 0;
+  bool any_split = false;
+  long ws_used = 0;
+  for (int i = 0; i < n; ++i) {
+    GemmArgs g = probs[i];
+    if (g.M == 0 || g.N == 0) continue;
+    const long own = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * g.batch1 * g.batch2;
+    // the group shares one workspace: give each problem its own slice
+    float* ws0 = g.ws;
+    const long wse0 = g.ws_elems;
+    if (ws0) g.ws = ws0 + ws_used, g.ws_elems = wse0 - ws_used;
+    if (prepare(g, 1, 0, total - own) < 0) return 1;
+    const bool al = g.vecA && g.vecB && g.M % 64 == 0 && g.N % 64 == 0 && g.ksplit % BK == 0;
+    if (!al || gg.nprob == GemmGroup::MAXP) {
+      g.ws = ws0, g.ws_elems = wse0;  // runs before the group launch; the group's slices are written later
+      if (int e = gemm(g, stream, 0, 0)) return e;
+      continue;
+    }
+    const long nb = (long)g.batch1 * g.batch2;
+    if (g.splits > 1) ws_used += (long)g.splits * nb * g.M * g.N, any_split = true;
+    gg.tile_begin[gg.nprob] = tiles;
+    gg.red_begin[gg.nprob] = reds;
+    tiles += (int)(own * g.splits);
+    if (g.splits > 1) reds += (int)(nb * cdiv((long)g.M * g.N, 256));
+    gg.p[gg.nprob++] = g;
+  }
+  if (gg.nprob == 0) return 0;
+  gg.tile_begin[gg.nprob] = tiles;
+  gg.red_begin[gg.nprob] = reds;
+  {
+    ProfScope ps("gemm_group", stream);
+    hipLaunchKernelGGL(gemm_group_kernel, dim3(tiles), dim3(256), 0, stream, gg);
+  }
+  if (int e = check_launch("gemm_group")) return e;
+  if (any_split) {
+    ProfScope ps("gemm_splitk_reduce", stream);
+    hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(reds), dim3(256), 0, stream, gg);
+    return check_launch("gemm_group_reduce");
+  }
+  return 0;
 }
 
 }  // namespace gc

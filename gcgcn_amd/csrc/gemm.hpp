@@ -63,6 +63,16 @@ struct GemmArgs {
 // deterministic reduce + epilogue kernel).
 int gemm(const GemmArgs& g, hipStream_t stream, int tile = 0, int splits = 0);
 
+// Up to MAXP independent problems carried by one launch (gemm_group).
+struct GemmGroup {
+  static constexpr int MAXP = 6;
+  GemmArgs p[MAXP];
+  int tile_begin[MAXP + 1];
+  int red_begin[MAXP + 1];
+  int nprob;
+};
+int gemm_group(const GemmArgs* probs, int n, hipStream_t stream);
+
 // Floats of split-K workspace that lets every GEMM of a [rows x cols]-sized problem split freely.
 inline long gemm_ws_elems(long rows, long cols) {
   long need = 16 * rows * cols;

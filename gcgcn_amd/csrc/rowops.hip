@@ -166,10 +166,15 @@ __global__ void dropout_keep_kernel(unsigned char* keep, long n, Drop drop) {
   keep[e] = rng_u32(drop_key(drop), (uint64_t)e) >= drop.thresh;
 }
 
-__global__ void rng_next_kernel(uint64_t* state, uint64_t* snap) {
-  snap[0] = state[0];
-  snap[1] = state[1];
-  state[1] = state[1] + 1;
+// snaps[i] = {seed, counter + i} for i < count; counter += count   (one launch serves `count` dropout sites)
+__global__ void rng_next_kernel(uint64_t* state, uint64_t* snaps, int count) {
+  const uint64_t seed = state[0], ctr = state[1];
+  for (int i = threadIdx.x; i < count; i += 64) {
+    snaps[2 * i] = seed;
+    snaps[2 * i + 1] = ctr + (uint64_t)i;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) state[1] = ctr + (uint64_t)count;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -208,9 +213,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
 // flat parameter layout: [W_h D*D | b_h D | W_t D*D | b_t D | W_r D*D | b_r D | wt 3D | wtb 1]
 // uvc output: [u D | v D | c 1]
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gat_fold_fwd_kernel(const float* __restrict__ flat, float* __restrict__ uvc, int D) {
-  __shared__ float red[4][64];
-  __shared__ float redc[4];
+constexpr int FW = 16;  // waves per workgroup of the fold: all D/FW rows of a wave are in flight at once
+__global__ __launch_bounds__(64 * FW) void gat_fold_fwd_kernel(const float* __restrict__ flat, float* __restrict__ uvc, int D) {
+  __shared__ float red[2][FW][64];
+  __shared__ float redc[FW];
   const long DD = (long)D * D;
   const float* Wh = flat;
   const float* bh = Wh + DD;
@@ -222,27 +228,34 @@ __global__ __launch_bounds__(256) void gat_fold_fwd_kernel(const float* __restri
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = blockIdx.x * 64 + lane;
   float au = 0.f, av = 0.f;
-  if (k < D)
-    for (int d = wave; d < D; d += 4) {
+  if (k < D) {
+#pragma unroll 8
+    for (int d = wave; d < D; d += FW) {
       au = fmaf(Wh[(long)d * D + k], wt[d], au);
       au = fmaf(Wt[(long)d * D + k], wt[D + d], au);
       av = fmaf(Wr[(long)d * D + k], wt[2 * D + d], av);
     }
-  red[wave][lane] = au;
+  }
+  red[0][wave][lane] = au;
+  red[1][wave][lane] = av;
   __syncthreads();
-  if (wave == 0 && k < D) uvc[k] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-  __syncthreads();
-  red[wave][lane] = av;
-  __syncthreads();
-  if (wave == 0 && k < D) uvc[D + k] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+  if (wave < 2 && k < D) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int w = 0; w < FW; ++w) sacc += red[wave][w][lane];
+    uvc[wave * D + k] = sacc;
+  }
   if (blockIdx.x == 0) {
     float c = 0.f;
-    for (int d = threadIdx.x; d < D; d += 256)
-      c += wt[d] * bh[d] + wt[D + d] * bt[d] + wt[2 * D + d] * br[d];
+    for (int d = threadIdx.x; d < D; d += 64 * FW) c += wt[d] * bh[d] + wt[D + d] * bt[d] + wt[2 * D + d] * br[d];
     c = wave_sum(c);
     if (lane == 0) redc[wave] = c;
     __syncthreads();
-    if (threadIdx.x == 0) uvc[2 * D] = redc[0] + redc[1] + redc[2] + redc[3] + wt[3 * D];
+    if (threadIdx.x == 0) {
+      float tot = wt[3 * D];
+      for (int w = 0; w < FW; ++w) tot += redc[w];
+      uvc[2 * D] = tot;
+    }
   }
 }
 
@@ -365,18 +378,19 @@ int dropout_keep(unsigned char* keep, long n, Drop drop, hipStream_t st) {
   hipLaunchKernelGGL(dropout_keep_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, keep, n, drop);
   return check_launch("dropout_keep");
 }
-int rng_next(void* state, void* snap, hipStream_t st) {
-  hipLaunchKernelGGL(rng_next_kernel, dim3(1), dim3(1), 0, st, (uint64_t*)state, (uint64_t*)snap);
+int rng_next(void* state, void* snaps, int count, hipStream_t st) {
+  hipLaunchKernelGGL(rng_next_kernel, dim3(1), dim3(64), 0, st, (uint64_t*)state, (uint64_t*)snaps, count);
   return check_launch("rng_next");
 }
 
 // out[z, :] (+)= sum_r w[z,r] X[z, r, :].  `scratch` must hold batch * COLSUM_SPLITS * C floats when
 // R is large enough to be split (see colsum_scratch_elems).
-constexpr int COLSUM_MIN_ROWS = 256;
+constexpr int COLSUM_MIN_ROWS = 32;
+constexpr int COLSUM_MAX_SPLITS = 128;
 long colsum_scratch_elems(long R, int C, int batch) {
   if (R < 2 * COLSUM_MIN_ROWS) return 0;
   long ns = R / COLSUM_MIN_ROWS;
-  if (ns > 64) ns = 64;
+  if (ns > COLSUM_MAX_SPLITS) ns = COLSUM_MAX_SPLITS;
   return ns * C * batch;
 }
 int colsum(const float* X, const float* w, float* out, long R, int C, long ld, int batch, long sXz, long sWz, long sOz,
@@ -385,7 +399,11 @@ int colsum(const float* X, const float* w, float* out, long R, int C, long ld, i
   long ns = 1;
   if (R >= 2 * COLSUM_MIN_ROWS && scratch) {
     ns = R / COLSUM_MIN_ROWS;
-    if (ns > 64) ns = 64;
+    if (ns > COLSUM_MAX_SPLITS) ns = COLSUM_MAX_SPLITS;
+    // enough row splits to put ~512 workgroups on the chip, no more
+    const long want = 512 / ((long)cdiv(C, 64) * batch) + 1;
+    if (ns > want) ns = want;
+    if (ns < 2) ns = 1;
   }
   if (ns == 1) {
     hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64), 1, batch), dim3(256), 0, st, X, w, out, R, C, ld, sXz, sWz, sOz,
@@ -403,7 +421,7 @@ int colsum(const float* X, const float* w, float* out, long R, int C, long ld, i
 
 int gat_fold_fwd(const float* flat, float* uvc, int D, hipStream_t st) {
   ProfScope ps("gat_fold_fwd", st);
-  hipLaunchKernelGGL(gat_fold_fwd_kernel, dim3(cdiv(D, 64)), dim3(256), 0, st, flat, uvc, D);
+  hipLaunchKernelGGL(gat_fold_fwd_kernel, dim3(cdiv(D, 64)), dim3(64 * FW), 0, st, flat, uvc, D);
   return check_launch("gat_fold_fwd");
 }
 int gat_fold_bwd(const float* flat, const float* duvc, float* dflat, int D, hipStream_t st) {

@@ -13,7 +13,7 @@ int relu_norm_bwd(const float* dY, const float* Y, const float* rinv, float* dM,
 int head_sum_drop_bwd(const float* dHO, float* dY, float* dXres, long M, int H, int D, Drop drop, hipStream_t st);
 int dropout(const float* x, float* y, long n, Drop drop, hipStream_t st);
 int dropout_keep(unsigned char* keep, long n, Drop drop, hipStream_t st);
-int rng_next(void* state, void* snap, hipStream_t st);
+int rng_next(void* state, void* snaps, int count, hipStream_t st);
 long colsum_scratch_elems(long R, int C, int batch);
 int colsum(const float* X, const float* w, float* out, long R, int C, long ld, int batch, long sXz, long sWz, long sOz,
            int accumulate, float* scratch, hipStream_t st);
@@ -24,8 +24,8 @@ int node_score_bwd(const float* ds, const float* uvc, float* dX, long M, int D, 
 int mask_rows(const float* x, float* y, long M, int D, int N, const int* n_valid, hipStream_t st);
 int add_inplace(float* y, const float* a, long n, hipStream_t st);
 
-int edge_fwd(const float* E, const float* v, const int* n_valid, float* Ebar, float* logit, int B, int N, int D,
-             hipStream_t st);
+int edge_fwd(const float* E, const float* v, const int* n_valid, float* Ebar, const float* coladd, float* P, float* A,
+             Drop drop, int B, int N, int D, hipStream_t st);
 int edge_bwd(const float* E, const float* v, const int* n_valid, const float* dlogit, const float* dEbar, float* dE,
              float* dvpart, int B, int N, int D, hipStream_t st);
 int edge_bcast(const float* dEbar, const int* n_valid, float* dE, int B, int N, int D, hipStream_t st);

@@ -27,7 +27,9 @@ class FlatGradBucket:
         self.pg = process_group
         self.params: List[nn.Parameter] = [p for n, p in module.named_parameters()
                                            if p.requires_grad and not n.endswith("flat_k")]
-        total = sum(p.numel() for p in self.params)
+        # every parameter starts on a 256-byte boundary so the GEMM kernels keep their 16-byte vector loads
+        pad = lambda n: (n + 63) // 64 * 64
+        total = sum(pad(p.numel()) for p in self.params)
         dev = self.params[0].device
         self.param_arena = torch.empty(total, device=dev, dtype=torch.float32)
         self.grad_arena = torch.zeros(total, device=dev, dtype=torch.float32)
@@ -38,7 +40,7 @@ class FlatGradBucket:
                 self.param_arena[off:off + n].copy_(p.reshape(-1))
                 p.data = self.param_arena[off:off + n].view_as(p)
                 p.grad = self.grad_arena[off:off + n].view_as(p)
-                off += n
+                off += pad(n)
         self.numel = total
 
     def zero_grad(self):

@@ -57,15 +57,47 @@ def manual_seed(seed: int, device=None):
     _rng_state[dev.index or 0] = torch.tensor([seed, 0], dtype=torch.int64, device=dev)
 
 
-def rng_snapshot(dev: torch.device) -> Tensor:
-    """Device-side {seed, counter} for one dropout-using forward; advances the counter on the GPU,
-    so a captured hipGraph draws a fresh mask at every replay."""
+_scope = None  # [snaps tensor [count, 2], next index] while a rng_scope is active
+
+
+def _new_snaps(dev: torch.device, count: int) -> Tensor:
     idx = dev.index or 0
     if idx not in _rng_state:
         manual_seed(torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, dev)
-    snap = torch.empty(2, dtype=torch.int64, device=dev)
-    call("gcgcn_rng_next", _p(_rng_state[idx]), _p(snap), _stream())
-    return snap
+    snaps = torch.empty(count, 2, dtype=torch.int64, device=dev)
+    call("gcgcn_rng_next", _p(_rng_state[idx]), _p(snaps), count, _stream())
+    return snaps
+
+
+class rng_scope:
+    """Draw the {seed, counter} snapshots of up to `count` dropout-using forwards with ONE tiny launch
+    (GraphHops uses it for a whole hop loop); outside a scope every forward launches its own."""
+
+    def __init__(self, dev: torch.device, count: int, enabled: bool = True):
+        self.dev, self.count, self.enabled = dev, count, enabled
+
+    def __enter__(self):
+        global _scope
+        self.prev = _scope
+        if self.enabled:
+            _scope = [_new_snaps(self.dev, self.count), 0]
+        return self
+
+    def __exit__(self, *exc):
+        global _scope
+        _scope = self.prev
+        return False
+
+
+def rng_snapshot(dev: torch.device) -> Tensor:
+    """Device-side {seed, counter} for one dropout-using forward; the counter advances on the GPU, so a
+    captured hipGraph draws a fresh mask at every replay."""
+    global _scope
+    if _scope is not None and _scope[1] < _scope[0].shape[0] and _scope[0].device == dev:
+        snap = _scope[0][_scope[1]]
+        _scope[1] += 1
+        return snap
+    return _new_snaps(dev, 1)[0]
 
 
 def dropout_keep_mask(snap: Tensor, salt: int, p: float, numel: int) -> Tensor:

@@ -300,11 +300,16 @@ class GraphHops(nn.Module):
         ``[x_0, x_1, ..., x_hops]``; the model's ``node_feats`` list (glove:338) is the first ``hops``."""
         feats = [node_feat]
         x = node_feat
+        with F_.rng_scope(node_feat.device, 3 * self.graph_hop, enabled=self.training and node_feat.is_cuda):
+            return self._hops(x, feats, edge_feats, adj_matrix, n_valid)
+
+    def _hops(self, x, feats, edge_feats, adj_matrix, n_valid):
         for i in range(self.graph_hop):
             e = edge_feats[i]
             if i < 1:
-                mask = None if adj_matrix is None else torch.eq(adj_matrix, 0)               # glove:330
-                a = self.get_weighted_adj_matrix(x, e, mask, n_valid=n_valid)                # glove:332
+                # glove:330 builds mask = eq(adj_matrix, 0) and glove:163-164 then discards it; the mask is
+                # not even materialised here (adj_matrix is accepted for signature compatibility only)
+                a = self.get_weighted_adj_matrix(x, e, None, n_valid=n_valid)                # glove:332
                 new = self.graphcnn[i](x, e, a, n_valid=n_valid)                             # glove:333
             else:
                 al = self.get_adj_matrix[i - 1](x, e, n_valid=n_valid)                       # glove:336

@@ -44,8 +44,10 @@ int gcgcn_prof_start(const char* kernel_prefix, int capacity);
 int gcgcn_prof_stop(double* total_ms, int* launches);
 
 /* ---- dropout RNG state (replaces torch's global CUDA generator used by nn.Dropout) ------- */
-/* snap <- state; state.counter += 1.   state, snap: device int64[2] {seed, counter}. */
-int gcgcn_rng_next(void* state, void* snap, void* stream);
+/* snaps[i] <- {state.seed, state.counter + i} for i < count; state.counter += count.
+ * state: device int64[2] {seed, counter}; snaps: device int64[2 * count].  One launch serves `count`
+ * dropout-using forward calls (each takes its own 2-word snapshot). */
+int gcgcn_rng_next(void* state, void* snaps, int count, void* stream);
 /* keep[i] = 1 iff element i of dropout site (snap, salt, p) is kept.  Test/debug aid. */
 int gcgcn_dropout_keep(uint8_t* keep, int64_t n, const void* rng_snap, uint64_t salt, float p, void* stream);
 /* y = dropout(x); calling it on a gradient with the same snapshot is the backward.

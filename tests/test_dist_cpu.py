@@ -33,10 +33,11 @@ def _worker(rank, world, port, out):
         # re-pointing storage must not change any parameter value or the state_dict
         after = hops.state_dict()
         assert all(torch.equal(before[k], after[k]) for k in before)
-        assert bucket.numel == sum(p.numel() for n, p in hops.named_parameters() if not n.endswith("flat_k"))
+        assert bucket.numel >= sum(p.numel() for n, p in hops.named_parameters() if not n.endswith("flat_k"))
         for p in bucket.params:                                   # views, not copies
             assert p.data_ptr() >= bucket.param_arena.data_ptr()
             assert p.grad.data_ptr() >= bucket.grad_arena.data_ptr()
+            assert (p.data_ptr() - bucket.param_arena.data_ptr()) % 256 == 0
         # synthetic per-rank gradients, accumulated in place the way autograd's AccumulateGrad does
         bucket.zero_grad()
         for i, p in enumerate(bucket.params):
