@@ -7,6 +7,9 @@
 
 #include <vector>
 
+#include <stdlib.h>
+
+#include "gcn_plan.hpp"
 #include "gemm.hpp"
 #include "rowops.hpp"
 
@@ -84,6 +87,25 @@ static long scratch_elems(int B, int N, int D, int H) {
   const long rows = (long)B * N > D ? (long)B * N : D;
   const long b = gemm_ws_elems(rows, (long)H * D);
   return a > b ? a : b;
+}
+
+// GCGCN_NO_CHAIN=1 runs every per-(doc, head) product as its own batched launch (A/B testing of chain.hip).
+static bool use_chain() {
+  static const bool on = [] {
+    const char* e = getenv("GCGCN_NO_CHAIN");
+    return !(e && e[0] == '1');
+  }();
+  return on;
+}
+
+static GcnCtx make_ctx(int B, int N, int D, int L, int H, const GcnLayout& y, const float* X, const float* A,
+                       const float* flat, const int* n_valid, Drop drop) {
+  GcnCtx c;
+  memset(&c, 0, sizeof(c));
+  c.B = B, c.N = N, c.D = D, c.L = L, c.H = H, c.gh = y.gh;
+  c.HD = (long)H * D, c.oWd = y.oWd, c.wd_head = y.wd_head;
+  c.X = X, c.A = A, c.flat = flat, c.n_valid = n_valid, c.drop = drop;
+  return c;
 }
 
 }  // namespace gc
@@ -328,7 +350,6 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
   const long HD = (long)H * D;
   GC_REQUIRE(M <= 0x7fffffffL, "gcn_fwd: B*N too large");
 
-  GC_TRY(rowsum_inv(A, rinv, (long)B * H * N, N, st));  // glove:47-49
   {  // one launch: Pn = X WnX (node term of every (head, sub-layer), X part of the dense input)
      //             G  = Ebar We (edge term, mean commuted with the projection, glove:40-41)
     GemmArgs gs[2];
@@ -342,33 +363,17 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
     }
     GC_TRY(gemm_group(gs, 2, st));
   }
-  for (int l = 0; l < L; ++l) {
-    if (l > 0) {  // Pn_l += [Y_0 .. Y_{l-1}] Wd_l : dense connection (glove:73 / 110)
-      GemmArgs g;
-    g.ws = scratch, g.ws_elems = wse;
-      g.A = Y, g.lda = HD, g.a_kc = 1, g.sA2 = (long)L * gh;
-      g.B = flat + y.wd_off(0, l), g.ldb = gh, g.b_kc = 0, g.sB2 = y.wd_head;
-      g.C = Pn + (long)l * gh, g.ldc = HD, g.sC2 = (long)L * gh;
-      g.M = (int)M, g.N = gh, g.K = l * gh;
-      g.batch2 = H;
-      g.accumulate = 1;
-      GC_TRY(gemm(g, st));
-    }
-    {  // Y_l = relu((G_l + A_h Pn_l) * rinv);  HO_l = dropout(Y_l) + X_l   (glove:42-50, 71-76)
-      GemmArgs g;
-    g.ws = scratch, g.ws_elems = wse;
-      g.A = A, g.lda = N, g.a_kc = 1, g.sA1 = (long)H * N * N, g.sA2 = (long)N * N;
-      g.B = Pn + (long)l * gh, g.ldb = HD, g.b_kc = 0, g.sB1 = (long)N * HD, g.sB2 = (long)L * gh;
-      g.C = Y + (long)l * gh, g.ldc = HD, g.sC1 = (long)N * HD, g.sC2 = (long)L * gh;
-      g.M = N, g.N = gh, g.K = N;
-      g.batch1 = B, g.batch2 = H;
-      g.add = G + (long)l * gh, g.ldadd = HD, g.sAdd1 = (long)N * HD, g.sAdd2 = (long)L * gh;
-      g.rowscale = rinv, g.sRs1 = (long)H * N, g.sRs2 = N;
-      g.relu = 1;
-      g.C2 = HO + (long)l * gh, g.ldc2 = HD, g.sC21 = (long)N * HD, g.sC22 = (long)L * gh;
-      g.add2 = X + (long)l * gh, g.ldadd2 = D, g.sAdd21 = (long)N * D, g.sAdd22 = 0;
-      g.drop = drop, g.drop_base = (long)l * gh;  // dropout index = offset inside HO
-      GC_TRY(gemm(g, st));
+  {  // the dependent per-(doc, head) sequence: normaliser, then per sub-layer dense connection + aggregation
+    GcnCtx c = make_ctx(B, N, D, L, H, y, X, A, flat, n_valid, drop);
+    c.G = G, c.Pn = Pn, c.Y = Y, c.HO = HO, c.rinv = rinv;
+    if (use_chain()) {
+      GC_TRY(gcn_chain_fwd(c, st));
+    } else {
+      GC_TRY(rowsum_inv(A, rinv, (long)B * H * N, N, st));  // glove:47-49
+      for (int l = 0; l < L; ++l) {
+        if (l > 0) GC_TRY(gemm(plan_fwd_dense(c, l), st, 0, 1));
+        GC_TRY(gemm(plan_fwd_agg(c, l), st, 0, 1));
+      }
     }
   }
   {  // out = HO Wlin^T + blin   (glove:78 / 118)
@@ -428,40 +433,19 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
   GC_TRY(colsum(dout, nullptr, dflat + y.oblin, M, D, D, 1, 0, 0, 0, 0, scratch, st));  // dblin
   GC_TRY(head_sum_drop_bwd(dYa, dYa, dXres, M, H, D, drop, st));  // residual + dropout backward
 
-  for (int l = L - 1; l >= 0; --l) {
-    GC_TRY(relu_norm_bwd(dYa, Y, rinv, dM, drow, M, N, H, L, gh, l, l == L - 1, st));
-    {  // dPn_l = A_h^T dM_l
-      GemmArgs g;
-    g.ws = scratch, g.ws_elems = wse;
-      g.A = A, g.lda = N, g.a_kc = 0, g.sA1 = (long)H * N * N, g.sA2 = (long)N * N;
-      g.B = dM + (long)l * gh, g.ldb = HD, g.b_kc = 0, g.sB1 = (long)N * HD, g.sB2 = (long)L * gh;
-      g.C = dP + (long)l * gh, g.ldc = HD, g.sC1 = (long)N * HD, g.sC2 = (long)L * gh;
-      g.M = N, g.N = gh, g.K = N;
-      g.batch1 = B, g.batch2 = H;
-      GC_TRY(gemm(g, st));
-    }
-    {  // dA_h (+)= dM_l Pn_l^T ; the normaliser's gradient drow is added on the last pass
-      GemmArgs g;
-    g.ws = scratch, g.ws_elems = wse;
-      g.A = dM + (long)l * gh, g.lda = HD, g.a_kc = 1, g.sA1 = (long)N * HD, g.sA2 = (long)L * gh;
-      g.B = Pn + (long)l * gh, g.ldb = HD, g.b_kc = 1, g.sB1 = (long)N * HD, g.sB2 = (long)L * gh;
-      g.C = dA, g.ldc = N, g.sC1 = (long)H * N * N, g.sC2 = (long)N * N;
-      g.M = N, g.N = N, g.K = gh;
-      g.batch1 = B, g.batch2 = H;
-      g.accumulate = (l != L - 1);
-      if (l == 0) g.rowadd = drow, g.sRa1 = (long)H * N, g.sRa2 = N;
-      GC_TRY(gemm(g, st));
-    }
-    if (l > 0) {  // dY_{0..l-1} += dPn_l Wd_l^T
-      GemmArgs g;
-    g.ws = scratch, g.ws_elems = wse;
-      g.A = dP + (long)l * gh, g.lda = HD, g.a_kc = 1, g.sA2 = (long)L * gh;
-      g.B = flat + y.wd_off(0, l), g.ldb = gh, g.b_kc = 1, g.sB2 = y.wd_head;
-      g.C = dYa, g.ldc = HD, g.sC2 = (long)L * gh;
-      g.M = (int)M, g.N = l * gh, g.K = gh;
-      g.batch2 = H;
-      g.accumulate = 1;
-      GC_TRY(gemm(g, st));
+  {  // the dependent per-(doc, head) sequence, last sub-layer first
+    GcnCtx c = make_ctx(B, N, D, L, H, y, X, A, flat, n_valid, drop);
+    c.Pn = const_cast<float*>(Pn), c.Y = const_cast<float*>(Y), c.rinv = const_cast<float*>(rinv);
+    c.dYa = dYa, c.dM = dM, c.dP = dP, c.dA = dA, c.drow = drow;
+    if (use_chain()) {
+      GC_TRY(gcn_chain_bwd(c, st));
+    } else {
+      for (int l = L - 1; l >= 0; --l) {
+        GC_TRY(relu_norm_bwd(dYa, Y, rinv, dM, drow, M, N, H, L, gh, l, l == L - 1, st));
+        GC_TRY(gemm(plan_bwd_dP(c, l), st, 0, 1));
+        GC_TRY(gemm(plan_bwd_dA(c, l), st, 0, 1));
+        if (l > 0) GC_TRY(gemm(plan_bwd_dY(c, l), st, 0, 1));
+      }
     }
   }
   {  // one launch for every product that only needs the finished dPn / dM:

@@ -20,233 +20,9 @@
 // Codegen note (ROCm 7.2): per-lane guarded float4 loads get if-converted into predicated
 // scalar loads with a vmcnt(0) at the loop head.  The interior path (ALIGNED) is therefore a
 // separate instantiation with unconditional 16-byte loads; ragged shapes take the guarded one.
-#include "gemm.hpp"
+#include "gemm_body.hpp"
 
 namespace gc {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BK = 32;
-
-template <int BMN, bool KC, bool ALIGNED>
-__device__ __forceinline__ void load_tile(float4 (&r)[BMN / 32], const float* __restrict__ src, long ld, int mn0, int k0,
-                                          int MN, int Kend, int vec, int t) {
-#pragma unroll
-  for (int q = 0; q < BMN / 32; ++q) {
-    const int f = t + 256 * q;
-    int row, col, rlim, clim;  // row indexes the strided dim, col the contiguous one
-    if (KC) {
-      row = mn0 + (f >> 3);
-      col = k0 + ((f & 7) << 2);
-      rlim = MN;
-      clim = Kend;
-    } else {
-      row = k0 + f / (BMN / 4);
-      col = mn0 + ((f % (BMN / 4)) << 2);
-      rlim = Kend;
-      clim = MN;
-    }
-    const float* p = src + (long)row * ld + col;
-    if (ALIGNED) {
-      r[q] = *reinterpret_cast<const float4*>(p);
-    } else {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < rlim) {
-        if (vec && col + 3 < clim) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (col < clim) v.x = p[0];
-          if (col + 1 < clim) v.y = p[1];
-          if (col + 2 < clim) v.z = p[2];
-          if (col + 3 < clim) v.w = p[3];
-        }
-      }
-      r[q] = v;
-    }
-  }
-}
-
-template <int BMN, bool KC>
-__device__ __forceinline__ void store_tile(const float4 (&r)[BMN / 32], float* __restrict__ lds, int t) {
-  constexpr int LD = KC ? BMN + 1 : BMN;
-#pragma unroll
-  for (int q = 0; q < BMN / 32; ++q) {
-    const int f = t + 256 * q;
-    if (KC) {
-      const int m = f >> 3, k = (f & 7) << 2;
-      lds[(k + 0) * LD + m] = r[q].x;
-      lds[(k + 1) * LD + m] = r[q].y;
-      lds[(k + 2) * LD + m] = r[q].z;
-      lds[(k + 3) * LD + m] = r[q].w;
-    } else {
-      const int k = f / (BMN / 4), c = (f % (BMN / 4)) << 2;
-      *reinterpret_cast<float4*>(&lds[k * LD + c]) = r[q];
-    }
-  }
-}
-
-// One output element through the fused epilogue (order documented in gemm.hpp).
-struct Epi {
-  float* C;
-  const float* add;
-  const float* rowadd;
-  const float* rowscale;
-  float* C2;
-  const float* add2;
-  long offC2;
-  uint64_t key;
-  bool dodrop;
-  int z1;
-};
-__device__ __forceinline__ Epi make_epi(const GemmArgs& g, int z1, int z2) {
-  Epi e;
-  e.z1 = z1;
-  e.C = g.C + z1 * g.sC1 + z2 * g.sC2;
-  e.add = g.add ? g.add + z1 * g.sAdd1 + z2 * g.sAdd2 : nullptr;
-  e.rowadd = g.rowadd ? g.rowadd + z1 * g.sRa1 + z2 * g.sRa2 : nullptr;
-  e.rowscale = g.rowscale ? g.rowscale + z1 * g.sRs1 + z2 * g.sRs2 : nullptr;
-  e.offC2 = z1 * g.sC21 + z2 * g.sC22;
-  e.C2 = g.C2 ? g.C2 + e.offC2 : nullptr;
-  e.add2 = g.add2 ? g.add2 + z1 * g.sAdd21 + z2 * g.sAdd22 : nullptr;
-  e.dodrop = e.C2 && g.drop.snap;
-  e.key = e.dodrop ? drop_key(g.drop) : 0;
-  return e;
-}
-__device__ __forceinline__ void epi_store(const GemmArgs& g, const Epi& e, int row, int col, float acc) {
-  float v = g.alpha * acc;
-  if (e.add) v += e.add[(long)row * g.ldadd + col];
-  if (g.bias) v += g.bias[col];
-  if (e.rowadd) v += e.rowadd[row];
-  if (e.rowscale) v *= e.rowscale[row];
-  if (g.relu) v = fmaxf(v, 0.f);
-  const long oc = (long)row * g.ldc + col;
-  if (g.accumulate) v += e.C[oc];
-  bool pad = false;
-  if (g.n_valid) {
-    const int doc = e.z1 * g.nv_zdoc + row / g.nv_rows;
-    pad = (row % g.nv_rows) >= g.n_valid[doc];
-  }
-  if (pad) v = 0.f;
-  e.C[oc] = v;
-  if (e.C2) {
-    const long o2 = (long)row * g.ldc2 + col;
-    float w = v;
-    if (e.dodrop)
-      w = (rng_u32(e.key, (uint64_t)(g.drop_base + e.offC2 + o2)) >= g.drop.thresh) ? w * g.drop.scale : 0.f;
-    if (e.add2) w += e.add2[(long)row * g.ldadd2 + col];
-    if (pad) w = 0.f;
-    e.C2[o2] = w;
-  }
-}
-
-template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED>
-__device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__ lds, const int bx, const int by,
-                                          const int zs) {
-  constexpr int BM = 64 * TM, BN = 64 * TN;
-  constexpr int LDA = AKC ? BM + 1 : BM;
-  constexpr int LDB = BKC ? BN + 1 : BN;
-  constexpr int SA = BK * LDA, SB = BK * LDB;  // floats per stage
-  // the B image starts 16-byte aligned whatever LDA's parity
-  constexpr int OFFB = (2 * SA + 3) & ~3;
-
-  const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int l31 = lane & 31, lh = lane >> 5;
-
-  const int z = zs / g.splits, sp = zs - z * g.splits;
-  const int z1 = z / g.batch2, z2 = z - z1 * g.batch2;
-  const int m0 = by * BM, n0 = bx * BN;
-  const int kbeg = sp * g.ksplit;
-  const int kend = min(g.K, kbeg + g.ksplit);
-
-  const float* __restrict__ A = g.A + z1 * g.sA1 + z2 * g.sA2;
-  const float* __restrict__ B = g.B + z1 * g.sB1 + z2 * g.sB2;
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  float4 ra[BM / 32], rb[BN / 32];
-  const int nk = (kend - kbeg + BK - 1) / BK;
-  if (nk > 0) {
-    load_tile<BM, AKC, ALIGNED>(ra, A, g.lda, m0, kbeg, g.M, kend, g.vecA, t);
-    load_tile<BN, BKC, ALIGNED>(rb, B, g.ldb, n0, kbeg, g.N, kend, g.vecB, t);
-    store_tile<BM, AKC>(ra, lds, t);
-    store_tile<BN, BKC>(rb, lds + OFFB, t);
-  }
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      load_tile<BM, AKC, ALIGNED>(ra, A, g.lda, m0, kbeg + (kt + 1) * BK, g.M, kend, g.vecA, t);
-      load_tile<BN, BKC, ALIGNED>(rb, B, g.ldb, n0, kbeg + (kt + 1) * BK, g.N, kend, g.vecB, t);
-    }
-    const float* as = lds + cur * SA + wr * 32 * TM + l31;
-    const float* bs = lds + OFFB + cur * SB + wc * 32 * TN + l31;
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = as[(kk + lh) * LDA + i * 32];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = bs[(kk + lh) * LDB + j * 32];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < nk) {
-      store_tile<BM, AKC>(ra, lds + (cur ^ 1) * SA, t);
-      store_tile<BN, BKC>(rb, lds + OFFB + (cur ^ 1) * SB, t);
-    }
-    __syncthreads();
-  }
-
-  // ---- store ------------------------------------------------------------------------------
-  if (g.splits > 1) {  // raw partial sums -> workspace [split][batch][M][N]
-    float* __restrict__ W = g.ws + ((long)sp * g.batch1 * g.batch2 + z) * g.M * g.N;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (!ALIGNED && row >= g.M) continue;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int col = n0 + (wc * TN + j) * 32 + l31;
-          if (!ALIGNED && col >= g.N) continue;
-          W[(long)row * g.N + col] = acc[i][j][r];
-        }
-      }
-    return;
-  }
-  const Epi e = make_epi(g, z1, z2);
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (!ALIGNED && row >= g.M) continue;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = n0 + (wc * TN + j) * 32 + l31;
-        if (!ALIGNED && col >= g.N) continue;
-        epi_store(g, e, row, col, acc[i][j][r]);
-      }
-    }
-}
-
-template <int TM, int TN, bool AKC, bool BKC>
-constexpr int lds_floats() {
-  return (((2 * BK * (AKC ? 64 * TM + 1 : 64 * TM)) + 3) & ~3) + 2 * BK * (BKC ? 64 * TN + 1 : 64 * TN);
-}
 
 template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
