@@ -197,7 +197,7 @@ def main():
     breakdown = {}
     if args.breakdown and graph is None:
         for grp in ("edge_fwd_att", "edge_fwd_mean", "edge_bwd", "edge_bcast", "gemm", "gemm_splitk", "softmax", "relu_norm_bwd",
-                    "head_sum", "rowsum", "dropout", "gat_fold", "node_score", "mask_rows"):
+                    "head_sum", "rowsum", "dropout", "gat_fold", "node_score", "mask_rows", "gcn_chain_fwd", "gcn_chain_bwd", "colsum"):
             _lib.call("gcgcn_prof_start", grp.encode(), 4096)
             for _ in range(5):
                 step()

@@ -24,17 +24,29 @@
 
 namespace gc {
 
+// Workgroups are dealt round-robin over the 8 XCDs (ids b and b + 8 share an XCD and its 4 MiB L2).
+// Give each XCD one CONTIGUOUS run of the row-major tile list instead of every 8th tile, so that the
+// tiles resident on an XCD share A row panels / B column panels in its L2 (speed only; any placement
+// is correct).  Bijective for every grid size.
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+  const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
 template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float lds[lds_floats<TM, TN, AKC, BKC>()];
-  gemm_body<TM, TN, AKC, BKC, ALIGNED>(g, lds, blockIdx.x, blockIdx.y, blockIdx.z);
+  const int gx = gridDim.x, gy = gridDim.y;
+  const int nwg = gx * gy * gridDim.z;
+  const int b = xcd_remap(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), nwg);
+  gemm_body<TM, TN, AKC, BKC, ALIGNED>(g, lds, b % gx, (b / gx) % gy, b / (gx * gy));
 }
 
 // Several independent problems in ONE launch (64x64 tiles, interior shapes only): block -> problem by
 // prefix sums of tile counts, layout chosen per problem by a block-uniform branch.
 __global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroup gg) {
   __shared__ __attribute__((aligned(16))) float lds[lds_floats<1, 1, true, true>()];
-  int b = blockIdx.x, i = 0;
+  int b = xcd_remap(blockIdx.x, gridDim.x), i = 0;
   while (i + 1 < gg.nprob && b >= gg.tile_begin[i + 1]) ++i;
   b -= gg.tile_begin[i];
   const GemmArgs& g = gg.p[i];
@@ -115,7 +127,7 @@ static int launch(const GemmArgs& g, hipStream_t stream) {
 // Fill the launcher-owned fields (vec flags, tile, split factor).  Returns the chosen tile (1 or 2) or -1.
 static int prepare(GemmArgs& g, int tile, int splits, long resident_tiles_hint) {
   if (!(g.A && g.B && g.C)) { set_error("gemm: null operand"); return -1; }
-  if (!(g.M >= 0 && g.N >= 0 && g.K >= 0 && g.batch1 >= 1 && g.batch2 >= 1)) { set_error("gemm: bad shape"); return -1; }
+  if (!(g.M >= 0 && g.N >= 0 && g.K >= 1 && g.batch1 >= 1 && g.batch2 >= 1)) { set_error("gemm: bad shape"); return -1; }
   const long nb = (long)g.batch1 * g.batch2;
   g.vecA = aligned16(g.A) && g.lda % 4 == 0 && g.sA1 % 4 == 0 && g.sA2 % 4 == 0;
   g.vecB = aligned16(g.B) && g.ldb % 4 == 0 && g.sB1 % 4 == 0 && g.sB2 % 4 == 0;

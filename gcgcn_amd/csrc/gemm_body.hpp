@@ -120,6 +120,55 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, const Epi& e, int r
   }
 }
 
+// The 16 outputs a lane holds of one 32x32 accumulator tile (one column, 16 rows), four rows at a
+// time: the epilogue operands of a 4-row group are gathered first (up to 20 loads in flight), then
+// the arithmetic, then the stores.  Element by element the loads form 16 dependent round trips,
+// which a chain kernel with one workgroup per CU cannot hide; all 16 at once costs ~100 VGPRs of
+// addresses and halves the residency of the plain GEMM kernels.
+template <bool ALIGNED>
+__device__ __forceinline__ void epi_tile(const GemmArgs& g, const Epi& e, const int row0, const int col, const f32x16& acc) {
+  if (!ALIGNED && col >= g.N) return;
+  const float bias = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float addv[4], accv[4], a2v[4], rsv[4], rav[4];
+    bool ok[4], pad[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = row0 + u + 8 * q;
+      ok[u] = ALIGNED || row < g.M;
+      addv[u] = 0.f, accv[u] = 0.f, a2v[u] = 0.f, rsv[u] = 1.f, rav[u] = 0.f, pad[u] = false;
+      if (ok[u]) {
+        if (e.add) addv[u] = e.add[(long)row * g.ldadd + col];
+        if (e.rowadd) rav[u] = e.rowadd[row];
+        if (e.rowscale) rsv[u] = e.rowscale[row];
+        if (g.accumulate) accv[u] = e.C[(long)row * g.ldc + col];
+        if (e.add2) a2v[u] = e.add2[(long)row * g.ldadd2 + col];
+        if (g.n_valid) pad[u] = (row % g.nv_rows) >= g.n_valid[e.z1 * g.nv_zdoc + row / g.nv_rows];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!ok[u]) continue;
+      const int row = row0 + u + 8 * q;
+      float v = (g.alpha * acc[4 * q + u] + addv[u] + bias + rav[u]) * rsv[u];
+      if (g.relu) v = fmaxf(v, 0.f);
+      v += accv[u];
+      if (pad[u]) v = 0.f;
+      e.C[(long)row * g.ldc + col] = v;
+      if (e.C2) {
+        const long o2 = (long)row * g.ldc2 + col;
+        float w = v;
+        if (e.dodrop)
+          w = (rng_u32(e.key, (uint64_t)(g.drop_base + e.offC2 + o2)) >= g.drop.thresh) ? w * g.drop.scale : 0.f;
+        w += a2v[u];
+        if (pad[u]) w = 0.f;
+        e.C2[o2] = w;
+      }
+    }
+  }
+}
+
 template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__ lds, const int bx, const int by,
                                           const int zs) {
@@ -154,20 +203,15 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
 
   float4 ra[BM / 32], rb[BN / 32];
   const int nk = (kend - kbeg + BK - 1) / BK;
-  if (nk > 0) {
-    load_tile<BM, AKC, ALIGNED>(ra, A, g.lda, m0, kbeg, g.M, kend, g.vecA, t);
-    load_tile<BN, BKC, ALIGNED>(rb, B, g.ldb, n0, kbeg, g.N, kend, g.vecB, t);
-    store_tile<BM, AKC>(ra, lds, t);
-    store_tile<BN, BKC>(rb, lds + OFFB, t);
-  }
+  // (K >= 1 is checked on the host; an unconditional first tile keeps ra/rb in registers -- a guarded
+  // one makes hipcc park the prefetch registers in scratch)
+  load_tile<BM, AKC, ALIGNED>(ra, A, g.lda, m0, kbeg, g.M, kend, g.vecA, t);
+  load_tile<BN, BKC, ALIGNED>(rb, B, g.ldb, n0, kbeg, g.N, kend, g.vecB, t);
+  store_tile<BM, AKC>(ra, lds, t);
+  store_tile<BN, BKC>(rb, lds + OFFB, t);
   __syncthreads();
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      load_tile<BM, AKC, ALIGNED>(ra, A, g.lda, m0, kbeg + (kt + 1) * BK, g.M, kend, g.vecA, t);
-      load_tile<BN, BKC, ALIGNED>(rb, B, g.ldb, n0, kbeg + (kt + 1) * BK, g.N, kend, g.vecB, t);
-    }
+  auto compute = [&](const int cur) {
     const float* as = lds + cur * SA + wr * 32 * TM + l31;
     const float* bs = lds + OFFB + cur * SB + wc * 32 * TN + l31;
 #pragma unroll
@@ -183,12 +227,21 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) {
-      store_tile<BM, AKC>(ra, lds + (cur ^ 1) * SA, t);
-      store_tile<BN, BKC>(rb, lds + OFFB + (cur ^ 1) * SB, t);
-    }
+  };
+  // steady state: prefetch tile kt+1 into registers, multiply tile kt from LDS, park the prefetch in the
+  // other LDS stage.  The last tile is peeled so that the loads/stores are unconditional (a guarded
+  // prefetch turns the float4 registers into a scratch-resident phi).
+  for (int kt = 0; kt + 1 < nk; ++kt) {
+    const int cur = kt & 1;
+    load_tile<BM, AKC, ALIGNED>(ra, A, g.lda, m0, kbeg + (kt + 1) * BK, g.M, kend, g.vecA, t);
+    load_tile<BN, BKC, ALIGNED>(rb, B, g.ldb, n0, kbeg + (kt + 1) * BK, g.N, kend, g.vecB, t);
+    compute(cur);
+    store_tile<BM, AKC>(ra, lds + (cur ^ 1) * SA, t);
+    store_tile<BN, BKC>(rb, lds + OFFB + (cur ^ 1) * SB, t);
     __syncthreads();
   }
+  compute((nk - 1) & 1);
+  __syncthreads();
 
   // ---- store ------------------------------------------------------------------------------
   if (g.splits > 1) {  // raw partial sums -> workspace [split][batch][M][N]
@@ -212,16 +265,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (!ALIGNED && row >= g.M) continue;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = n0 + (wc * TN + j) * 32 + l31;
-        if (!ALIGNED && col >= g.N) continue;
-        epi_store(g, e, row, col, acc[i][j][r]);
-      }
-    }
+    for (int j = 0; j < TN; ++j)
+      epi_tile<ALIGNED>(g, e, m0 + (wr * TM + i) * 32 + 4 * lh, n0 + (wc * TN + j) * 32 + l31, acc[i][j]);
 }
 
 template <int TM, int TN, bool AKC, bool BKC>
