@@ -17,7 +17,9 @@ namespace gc {
 
 __device__ __forceinline__ bool dev_al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-// Every 64x64 tile of batch entry z of product g, one after the other, by this workgroup.
+// Every tile of batch entry z of product g, one after the other, by this workgroup.  With one
+// workgroup per CU every tile pass costs a prologue + an epilogue round trip to L2, so the widest tile
+// the LDS image allows is used: 64x128 (each wave 32x64) when N is a multiple of 128, else 64x64.
 template <bool AKC, bool BKC, bool ALIGNED>
 __device__ __forceinline__ void run_product(GemmArgs g, float* lds, int z) {
   g.ksplit = g.K;
@@ -26,24 +28,46 @@ __device__ __forceinline__ void run_product(GemmArgs g, float* lds, int z) {
     g.vecA = dev_al16(g.A) && g.lda % 4 == 0 && g.sA1 % 4 == 0 && g.sA2 % 4 == 0;
     g.vecB = dev_al16(g.B) && g.ldb % 4 == 0 && g.sB1 % 4 == 0 && g.sB2 % 4 == 0;
   }
-  const int tm = (g.M + 63) >> 6, tn = (g.N + 63) >> 6;
-  for (int ty = 0; ty < tm; ++ty)
-    for (int tx = 0; tx < tn; ++tx) gemm_body<1, 1, AKC, BKC, ALIGNED>(g, lds, tx, ty, z);
+  const int tm = (g.M + 63) >> 6;
+  if ((g.N & 127) == 0) {
+    const int tn = g.N >> 7;
+    for (int ty = 0; ty < tm; ++ty)
+      for (int tx = 0; tx < tn; ++tx) gemm_body<1, 2, AKC, BKC, ALIGNED, 16>(g, lds, tx, ty, z);
+  } else {
+    const int tn = (g.N + 63) >> 6;
+    for (int ty = 0; ty < tm; ++ty)
+      for (int tx = 0; tx < tn; ++tx) gemm_body<1, 1, AKC, BKC, ALIGNED, 16>(g, lds, tx, ty, z);
+  }
 }
+
+constexpr int CHAIN_LDS = lds_floats<1, 2, true, true>();
+constexpr int RB = 8;  // rows a wave keeps in flight in the row-wise phases
 
 template <bool ALIGNED>
 __global__ __launch_bounds__(256) void gcn_chain_fwd_kernel(const GcnCtx c) {
-  __shared__ __attribute__((aligned(16))) float lds[lds_floats<1, 1, true, true>()];
+  __shared__ __attribute__((aligned(16))) float lds[CHAIN_LDS];
   const int z = blockIdx.x;  // b * H + h
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // GraphConv row normaliser (glove:47-49): rinv[i] = 1 / (sum_j A[i,j] + [sum == 0])
-  {
+  {  // RB rows per wave in flight: the loads of a row batch are independent, one round trip per batch
     const float* a = c.A + (long)z * c.N * c.N;
-    for (int i = wave; i < c.N; i += 4) {
-      float s = 0.f;
-      for (int j = lane; j < c.N; j += 64) s += a[(long)i * c.N + j];
-      s = wave_sum(s);
-      if (lane == 0) c.rinv[(long)z * c.N + i] = 1.f / (s + (s == 0.f ? 1.f : 0.f));
+    for (int i0 = wave; i0 < c.N; i0 += 4 * RB) {
+      float s[RB];
+#pragma unroll
+      for (int u = 0; u < RB; ++u) s[u] = 0.f;
+      for (int j = lane; j < c.N; j += 64) {
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+          const int i = i0 + 4 * u;
+          if (i < c.N) s[u] += a[(long)i * c.N + j];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const int i = i0 + 4 * u;
+        const float t = wave_sum(s[u]);
+        if (lane == 0 && i < c.N) c.rinv[(long)z * c.N + i] = 1.f / (t + (t == 0.f ? 1.f : 0.f));
+      }
     }
   }
   __syncthreads();
@@ -59,27 +83,47 @@ __global__ __launch_bounds__(256) void gcn_chain_fwd_kernel(const GcnCtx c) {
 
 template <bool ALIGNED>
 __global__ __launch_bounds__(256) void gcn_chain_bwd_kernel(const GcnCtx c) {
-  __shared__ __attribute__((aligned(16))) float lds[lds_floats<1, 1, true, true>()];
+  __shared__ __attribute__((aligned(16))) float lds[CHAIN_LDS];
   const int z = blockIdx.x;
   const int b = z / c.H, h = z - b * c.H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int l = c.L - 1; l >= 0; --l) {
     // through Y = relu(S), S = M * rinv:  dS = dY [Y > 0];  dM = dS rinv;  drow -= rinv sum_c dS Y
-    for (int i = wave; i < c.N; i += 4) {
-      const long off = ((((long)b * c.N + i) * c.H + h) * c.L + l) * c.gh;
-      const long ri = (long)z * c.N + i;
-      const float rv = c.rinv[ri];
-      float acc = 0.f;
-      for (int k = lane; k < c.gh; k += 64) {
-        const float y = c.Y[off + k];
-        const float g = y > 0.f ? c.dYa[off + k] : 0.f;
-        c.dM[off + k] = g * rv;
-        acc = fmaf(g, y, acc);
+    for (int i0 = wave; i0 < c.N; i0 += 4 * RB) {
+      float acc[RB], rv[RB];
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const int i = i0 + 4 * u;
+        acc[u] = 0.f;
+        rv[u] = (i < c.N) ? c.rinv[(long)z * c.N + i] : 0.f;
       }
-      acc = wave_sum(acc);
-      if (lane == 0) {  // row i is always handled by this lane: plain read-modify-write is ordered
-        const float d = -rv * acc;
-        c.drow[ri] = (l == c.L - 1) ? d : c.drow[ri] + d;
+      for (int k = lane; k < c.gh; k += 64) {
+        float y[RB], gy[RB];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+          const int i = i0 + 4 * u;
+          const long off = ((((long)b * c.N + i) * c.H + h) * c.L + l) * c.gh + k;
+          y[u] = 0.f, gy[u] = 0.f;
+          if (i < c.N) y[u] = c.Y[off], gy[u] = c.dYa[off];
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+          const int i = i0 + 4 * u;
+          const long off = ((((long)b * c.N + i) * c.H + h) * c.L + l) * c.gh + k;
+          const float g = y[u] > 0.f ? gy[u] : 0.f;
+          if (i < c.N) c.dM[off] = g * rv[u];
+          acc[u] = fmaf(g, y[u], acc[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const int i = i0 + 4 * u;
+        const float t = wave_sum(acc[u]);
+        if (lane == 0 && i < c.N) {  // row i is always handled by this lane: plain read-modify-write is ordered
+          const long ri = (long)z * c.N + i;
+          const float d = -rv[u] * t;
+          c.drow[ri] = (l == c.L - 1) ? d : c.drow[ri] + d;
+        }
       }
     }
     __syncthreads();

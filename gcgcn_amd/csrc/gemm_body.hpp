@@ -120,47 +120,52 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, const Epi& e, int r
   }
 }
 
-// The 16 outputs a lane holds of one 32x32 accumulator tile (one column, 16 rows), four rows at a
-// time: the epilogue operands of a 4-row group are gathered first (up to 20 loads in flight), then
-// the arithmetic, then the stores.  Element by element the loads form 16 dependent round trips,
-// which a chain kernel with one workgroup per CU cannot hide; all 16 at once costs ~100 VGPRs of
-// addresses and halves the residency of the plain GEMM kernels.
-template <bool ALIGNED>
+// The 16 outputs a lane holds of one 32x32 accumulator tile (one column, 16 rows), EG rows at a
+// time: the epilogue operands of a row group are gathered first (all loads in flight together), then
+// the arithmetic, then the stores.  Element by element the loads are 16 dependent round trips.
+// EG = 4 for the plain GEMM kernels (keeps them at ~75 VGPRs / 4-5 waves per SIMD, other waves hide the
+// 4 round trips); EG = 16 for the chain kernels (one workgroup per CU: nothing else hides latency).
+// Offsets are 32-bit on purpose: uniform base + 32-bit lane offset addressing keeps the gather to one
+// VGPR per load instead of a 64-bit address pair (a [rows x ld] slice of this path is < 2^31 elements).
+template <bool ALIGNED, int EG>
 __device__ __forceinline__ void epi_tile(const GemmArgs& g, const Epi& e, const int row0, const int col, const f32x16& acc) {
   if (!ALIGNED && col >= g.N) return;
   const float bias = g.bias ? g.bias[col] : 0.f;
+  const unsigned ldadd = (unsigned)g.ldadd, ldc = (unsigned)g.ldc, ldadd2 = (unsigned)g.ldadd2, ldc2 = (unsigned)g.ldc2;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    float addv[4], accv[4], a2v[4], rsv[4], rav[4];
-    bool ok[4], pad[4];
+  for (int q0 = 0; q0 < 16; q0 += EG) {
+    float addv[EG], accv[EG], a2v[EG], rsv[EG], rav[EG];
+    bool ok[EG], pad[EG];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int row = row0 + u + 8 * q;
-      ok[u] = ALIGNED || row < g.M;
+    for (int u = 0; u < EG; ++u) {
+      const int r = q0 + u;
+      const unsigned row = (unsigned)(row0 + (r & 3) + 8 * (r >> 2));
+      ok[u] = ALIGNED || (int)row < g.M;
       addv[u] = 0.f, accv[u] = 0.f, a2v[u] = 0.f, rsv[u] = 1.f, rav[u] = 0.f, pad[u] = false;
       if (ok[u]) {
-        if (e.add) addv[u] = e.add[(long)row * g.ldadd + col];
+        if (e.add) addv[u] = e.add[row * ldadd + (unsigned)col];
         if (e.rowadd) rav[u] = e.rowadd[row];
         if (e.rowscale) rsv[u] = e.rowscale[row];
-        if (g.accumulate) accv[u] = e.C[(long)row * g.ldc + col];
-        if (e.add2) a2v[u] = e.add2[(long)row * g.ldadd2 + col];
-        if (g.n_valid) pad[u] = (row % g.nv_rows) >= g.n_valid[e.z1 * g.nv_zdoc + row / g.nv_rows];
+        if (g.accumulate) accv[u] = e.C[row * ldc + (unsigned)col];
+        if (e.add2) a2v[u] = e.add2[row * ldadd2 + (unsigned)col];
+        if (g.n_valid) pad[u] = ((int)row % g.nv_rows) >= g.n_valid[e.z1 * g.nv_zdoc + (int)row / g.nv_rows];
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < EG; ++u) {
       if (!ok[u]) continue;
-      const int row = row0 + u + 8 * q;
-      float v = (g.alpha * acc[4 * q + u] + addv[u] + bias + rav[u]) * rsv[u];
+      const int r = q0 + u;
+      const unsigned row = (unsigned)(row0 + (r & 3) + 8 * (r >> 2));
+      float v = (g.alpha * acc[r] + addv[u] + bias + rav[u]) * rsv[u];
       if (g.relu) v = fmaxf(v, 0.f);
       v += accv[u];
       if (pad[u]) v = 0.f;
-      e.C[(long)row * g.ldc + col] = v;
+      e.C[row * ldc + (unsigned)col] = v;
       if (e.C2) {
-        const long o2 = (long)row * g.ldc2 + col;
+        const unsigned o2 = row * ldc2 + (unsigned)col;
         float w = v;
         if (e.dodrop)
-          w = (rng_u32(e.key, (uint64_t)(g.drop_base + e.offC2 + o2)) >= g.drop.thresh) ? w * g.drop.scale : 0.f;
+          w = (rng_u32(e.key, (uint64_t)(g.drop_base + e.offC2 + (long)o2)) >= g.drop.thresh) ? w * g.drop.scale : 0.f;
         w += a2v[u];
         if (pad[u]) w = 0.f;
         e.C2[o2] = w;
@@ -169,7 +174,7 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, const Epi& e, const 
   }
 }
 
-template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED>
+template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED, int EG = 4>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__ lds, const int bx, const int by,
                                           const int zs) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -266,7 +271,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
-      epi_tile<ALIGNED>(g, e, m0 + (wr * TM + i) * 32 + 4 * lh, n0 + (wc * TN + j) * 32 + l31, acc[i][j]);
+      epi_tile<ALIGNED, EG>(g, e, m0 + (wr * TM + i) * 32 + 4 * lh, n0 + (wc * TN + j) * 32 + l31, acc[i][j]);
 }
 
 template <int TM, int TN, bool AKC, bool BKC>
