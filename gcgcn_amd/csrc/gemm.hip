@@ -169,8 +169,18 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream) {
   int tiles = 0, reds = 0;
   bool any_split = false;
   long ws_used = 0;
-  for (int i = 0; i < n; ++i) {
-    GemmArgs g = probs[i];
+  // longest blocks first: workgroups are dispatched in tile order, and a K = 2048 tile started last would
+  // run alone long after the K = 256 tiles of the same launch have drained
+  int order[64];
+  GC_REQUIRE(n <= 64, "gemm_group: too many problems");
+  for (int i = 0; i < n; ++i) order[i] = i;
+  for (int i = 1; i < n; ++i)
+    for (int j = i; j > 0 && probs[order[j]].K > probs[order[j - 1]].K; --j) {
+      const int t = order[j];
+      order[j] = order[j - 1], order[j - 1] = t;
+    }
+  for (int oi = 0; oi < n; ++oi) {
+    GemmArgs g = probs[order[oi]];
     if (g.M == 0 || g.N == 0) continue;
     const long own = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * g.batch1 * g.batch2;
     // the group shares one workspace: give each problem its own slice

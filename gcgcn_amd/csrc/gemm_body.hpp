@@ -216,21 +216,30 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
   store_tile<BN, BKC>(rb, lds + OFFB, t);
   __syncthreads();
 
+  // One k-tile from LDS stage `cur`.  The operands of k-step kk+2 are read while the MFMAs of step kk
+  // issue (register double buffer), so a wave does not serialise LDS latency with its matrix work.
   auto compute = [&](const int cur) {
-    const float* as = lds + cur * SA + wr * 32 * TM + l31;
-    const float* bs = lds + OFFB + cur * SB + wc * 32 * TN + l31;
+    const float* as = lds + cur * SA + wr * 32 * TM + l31 + lh * LDA;
+    const float* bs = lds + OFFB + cur * SB + wc * 32 * TN + l31 + lh * LDB;
+    float a[2][TM], b[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[0][i] = as[i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[0][j] = bs[j * 32];
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
-      float a[TM], b[TN];
+      const int c = (kk >> 1) & 1, n = c ^ 1;
+      if (kk + 2 < BK) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = as[(kk + lh) * LDA + i * 32];
+        for (int i = 0; i < TM; ++i) a[n][i] = as[(kk + 2) * LDA + i * 32];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = bs[(kk + lh) * LDB + j * 32];
+        for (int j = 0; j < TN; ++j) b[n][j] = bs[(kk + 2) * LDB + j * 32];
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
     }
   };
   // steady state: prefetch tile kt+1 into registers, multiply tile kt from LDS, park the prefetch in the
