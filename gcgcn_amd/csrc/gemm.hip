@@ -124,8 +124,21 @@ static int launch(const GemmArgs& g, hipStream_t stream) {
   return 0;
 }
 
+// Split factor of a problem inside a launch whose 64x64 tiles carry `work` tile-k-steps in total: no
+// workgroup should run much longer than the average load of one of the 256 x 4 resident slots
+// (a K = 2048 tile next to K = 256 tiles would otherwise drain alone), and a launch that cannot fill
+// the slots at all is cut until its blocks are ~8 k-steps long.
+static int pick_splits(int K, long work) {
+  const long iters = cdiv(K, BK);
+  long thr = work / 1024 * 5 / 4;
+  if (thr < 8) thr = 8;
+  int splits = 1;
+  while (iters / splits > thr && splits < 16 && K % (splits * 2 * BK) == 0) splits *= 2;
+  return splits;
+}
+
 // Fill the launcher-owned fields (vec flags, tile, split factor).  Returns the chosen tile (1 or 2) or -1.
-static int prepare(GemmArgs& g, int tile, int splits, long resident_tiles_hint) {
+static int prepare(GemmArgs& g, int tile, int splits, long group_work) {
   if (!(g.A && g.B && g.C)) { set_error("gemm: null operand"); return -1; }
   if (!(g.M >= 0 && g.N >= 0 && g.K >= 1 && g.batch1 >= 1 && g.batch2 >= 1)) { set_error("gemm: bad shape"); return -1; }
   const long nb = (long)g.batch1 * g.batch2;
@@ -133,12 +146,7 @@ static int prepare(GemmArgs& g, int tile, int splits, long resident_tiles_hint) 
   g.vecB = aligned16(g.B) && g.ldb % 4 == 0 && g.sB1 % 4 == 0 && g.sB2 % 4 == 0;
   const long t64 = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * nb;
   if (tile == 0) tile = (t64 >= 4096) ? 2 : 1;  // 128x128 only when it still leaves >= 4 blocks per CU
-  const long tiles = ((tile == 2) ? (long)cdiv(g.M, 128) * cdiv(g.N, 128) * nb : t64) + resident_tiles_hint;
-  if (splits == 0) {
-    // split K until ~3 blocks per CU are resident, keeping >= 2 k-steps of 32 per split
-    splits = 1;
-    while (tiles * splits < 768 && splits < 16 && g.K % (splits * 2 * BK) == 0 && g.K / (splits * 2) >= 2 * BK) splits *= 2;
-  }
+  if (splits == 0) splits = (tile == 2) ? 1 : pick_splits(g.K, group_work > 0 ? group_work : t64 * cdiv(g.K, BK));
   if (splits > 1 && (!g.ws || (long)splits * nb * g.M * g.N > g.ws_elems || g.K % (splits * BK) != 0)) splits = 1;
   g.splits = splits;
   g.ksplit = (splits > 1) ? g.K / splits : g.K;
@@ -164,8 +172,9 @@ int gemm(const GemmArgs& g_in, hipStream_t stream, int tile, int splits) {
 int gemm_group(const GemmArgs* probs, int n, hipStream_t stream) {
   GemmGroup gg;
   gg.nprob = 0;
-  long total = 0;
-  for (int i = 0; i < n; ++i) total += (long)cdiv(probs[i].M, 64) * cdiv(probs[i].N, 64) * probs[i].batch1 * probs[i].batch2;
+  long work = 0;  // tile-k-steps of the whole launch
+  for (int i = 0; i < n; ++i)
+    work += (long)cdiv(probs[i].M, 64) * cdiv(probs[i].N, 64) * probs[i].batch1 * probs[i].batch2 * cdiv(probs[i].K, BK);
   int tiles = 0, reds = 0;
   bool any_split = false;
   long ws_used = 0;
@@ -187,7 +196,7 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream) {
     float* ws0 = g.ws;
     const long wse0 = g.ws_elems;
     if (ws0) g.ws = ws0 + ws_used, g.ws_elems = wse0 - ws_used;
-    if (prepare(g, 1, 0, total - own) < 0) return 1;
+    if (prepare(g, 1, 0, work) < 0) return 1;
     const bool al = g.vecA && g.vecB && g.M % 64 == 0 && g.N % 64 == 0 && g.ksplit % BK == 0;
     if (!al || gg.nprob == GemmGroup::MAXP) {
       g.ws = ws0, g.ws_elems = wse0;  // runs before the group launch; the group's slices are written later
