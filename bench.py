@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--mode", default=os.environ.get("GCGCN_BENCH_MODE", "eager"), choices=["eager", "graph"])
     ap.add_argument("--prof-kernel", default="edge_bwd", help="kernel-name prefix timed with HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="keep the E2 mean on the main stream (A/B)")
     ap.add_argument("--breakdown", action="store_true", help="extra untimed passes: per-kernel-group times to stderr")
     args = ap.parse_args()
 
@@ -135,6 +136,7 @@ def main():
     B, N, D, L, H = (cfg[k] for k in "BNDLH")
     torch.manual_seed(1337)                       # identical parameters on every rank
     hops = gcgcn_amd.GraphHops(D, L, H).to(dev).train()
+    hops.overlap_edge_mean = not args.no_overlap
     gcgcn_amd.manual_seed(1337 + rank, dev)
     bucket = FlatGradBucket(hops)
     x, e1, e2, adj = synth(cfg, 1337 + rank, dev)

@@ -20,6 +20,8 @@
 // Codegen note (ROCm 7.2): per-lane guarded float4 loads get if-converted into predicated
 // scalar loads with a vmcnt(0) at the loop head.  The interior path (ALIGNED) is therefore a
 // separate instantiation with unconditional 16-byte loads; ragged shapes take the guarded one.
+#include <stdlib.h>
+
 #include "gemm_body.hpp"
 
 namespace gc {
@@ -129,8 +131,12 @@ static int launch(const GemmArgs& g, hipStream_t stream) {
 // (a K = 2048 tile next to K = 256 tiles would otherwise drain alone), and a launch that cannot fill
 // the slots at all is cut until its blocks are ~8 k-steps long.
 static int pick_splits(int K, long work) {
+  static const int thr_pct = [] {  // GCGCN_SPLIT_PCT: tuning knob (percent of the average slot load), default 125
+    const char* e = getenv("GCGCN_SPLIT_PCT");
+    return e ? atoi(e) : 125;
+  }();
   const long iters = cdiv(K, BK);
-  long thr = work / 1024 * 5 / 4;
+  long thr = work / 1024 * thr_pct / 100;
   if (thr < 8) thr = 8;
   int splits = 1;
   while (iters / splits > thr && splits < 16 && K % (splits * 2 * BK) == 0) splits *= 2;
