@@ -105,10 +105,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--mode", default=os.environ.get("GCGCN_BENCH_MODE", "eager"), choices=["eager", "graph"])
-    ap.add_argument("--prof-kernel", default="edge_bwd", help="kernel-name prefix timed with HIP events")
+    ap.add_argument("--prof-kernel", default="auto",
+                    help="kernel family timed with HIP events inside the timed region (auto = the one with the largest time share)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="keep the E2 mean on the main stream (A/B)")
-    ap.add_argument("--breakdown", action="store_true", help="extra untimed passes: per-kernel-group times to stderr")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -175,51 +175,81 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    FAMILIES = {  # kernel-name prefix -> (bound, peak, unit of work)
+        "gemm": ("mfma", MFMA_F32_PEAK), "gcn_chain": ("mfma", MFMA_F32_PEAK),
+        "edge_bwd": ("hbm", HBM_PEAK), "edge_fwd_att": ("hbm", HBM_PEAK), "edge_fwd_mean": ("hbm", HBM_PEAK),
+        "edge_bcast": ("hbm", HBM_PEAK),
+    }
+    SMALL = ("softmax", "head_sum", "dropout", "gat_fold", "node_score", "colsum", "mask_rows", "rowsum", "relu_norm")
+
+    def profile(prefix, nsteps):
+        """HIP-event time of every launch whose kernel name starts with `prefix` over nsteps steps."""
+        _lib.call("gcgcn_prof_start", prefix.encode(), nsteps * 64 + 64)
+        for _ in range(nsteps):
+            step()
+        torch.cuda.synchronize()
+        ms, n, w = ctypes.c_double(0), ctypes.c_int(0), ctypes.c_double(0)
+        _lib.call("gcgcn_prof_stop", ctypes.byref(ms), ctypes.byref(n), ctypes.byref(w))
+        return ms.value, n.value, w.value
+
     for _ in range(args.warmup):
         step()
     sync()
-    lib = _lib.lib()
     use_prof = graph is None
+    # which kernel family dominates the step?  (untimed pre-pass, 3 steps per family)
+    shares = {}
+    dominant = args.prof_kernel
     if use_prof:
-        _lib.call("gcgcn_prof_start", args.prof_kernel.encode(), args.steps * 4 + 8)
+        for fam in list(FAMILIES) + list(SMALL):
+            ms, n, _ = profile(fam, 3)
+            shares[fam] = {"ms_per_step": round(ms / 3, 4), "launches_per_step": round(n / 3, 2)}
+        if dominant == "auto":
+            dominant = max(FAMILIES, key=lambda f: shares[f]["ms_per_step"])
+        sync()
+
+    # ---- the timed region: exactly K steps, the dominant family's launches bracketed by HIP events ----------
+    if use_prof:
+        _lib.call("gcgcn_prof_start", dominant.encode(), args.steps * 64 + 64)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync()
     dt = time.perf_counter() - t0
-    kms, kn = ctypes.c_double(0), ctypes.c_int(0)
+    kms, kn, kw = ctypes.c_double(0), ctypes.c_int(0), ctypes.c_double(0)
     if use_prof:
-        _lib.call("gcgcn_prof_stop", ctypes.byref(kms), ctypes.byref(kn))
+        _lib.call("gcgcn_prof_stop", ctypes.byref(kms), ctypes.byref(kn), ctypes.byref(kw))
 
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
 
-    breakdown = {}
-    if args.breakdown and graph is None:
-        for grp in ("edge_fwd_att", "edge_fwd_mean", "edge_bwd", "edge_bcast", "gemm", "gemm_splitk", "softmax", "relu_norm_bwd",
-                    "head_sum", "rowsum", "dropout", "gat_fold", "node_score", "mask_rows", "gcn_chain_fwd", "gcn_chain_bwd", "colsum"):
-            _lib.call("gcgcn_prof_start", grp.encode(), 4096)
-            for _ in range(5):
-                step()
-            torch.cuda.synchronize()
-            ms, n = ctypes.c_double(0), ctypes.c_int(0)
-            _lib.call("gcgcn_prof_stop", ctypes.byref(ms), ctypes.byref(n))
-            breakdown[grp] = {"ms_per_step": round(ms.value / 5, 4), "launches_per_step": n.value / 5}
+    def roof(fam, ms, n, work):
+        bound, peak = FAMILIES[fam]
+        if n == 0 or ms <= 0:
+            return None
+        ach = work / (ms * 1e-3)                           # work/s over the time those launches were running
+        r = {"bound": bound, "kernel": fam + "*", "achieved": round(ach / (1e9 if bound == "hbm" else 1e12), 2),
+             "peak": peak / (1e9 if bound == "hbm" else 1e12), "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+             "frac": round(ach / peak, 4), "traffic": None, "avg_launch_us": round(ms / n * 1e3, 2),
+             "launches": n, "work_per_launch": work / n,
+             "work": "executed fp32 flops (2MNK)" if bound == "mfma" else "algorithmic HBM bytes"}
+        pmc = os.path.join(ROOT, "profiles", "r01_c2_pmc_hbm.json")
+        if bound == "hbm" and args.config == "c2" and os.path.exists(pmc):   # PMC passes are offline (rocprofv3 --pmc)
+            for k, v in json.load(open(pmc))["kernels"].items():
+                if ("gc::" + fam.replace("_att", "").replace("_mean", "") + "_kernel") in k and \
+                        (("true" in k) == fam.endswith("_att") if fam.startswith("edge_fwd") else True):
+                    r["traffic"] = v["hbm_bytes_per_launch_corrected"]
+        return r
+
+    roofline = roof(dominant, kms.value, kn.value, kw.value) if use_prof else None
+    roofline_hbm = None
+    if use_prof and rank == 0 and dominant != "edge_bwd":
+        roofline_hbm = roof("edge_bwd", *profile("edge_bwd", 5))
 
     if rank == 0:
         docs = B * world * args.steps
         value = docs / dt
-        bytes_per_doc = {"edge_bwd": 8, "edge_fwd_att": 4, "edge_fwd_mean": 4, "edge_bcast": 4}
-        roof = None
-        if use_prof and kn.value > 0 and args.prof_kernel in bytes_per_doc:
-            per_launch = bytes_per_doc[args.prof_kernel] * N * N * D * B        # algorithmic bytes of one launch
-            avg_s = kms.value / kn.value * 1e-3
-            ach = per_launch / avg_s
-            roof = {"bound": "hbm", "kernel": args.prof_kernel, "achieved": round(ach / 1e9, 2), "peak": HBM_PEAK / 1e9,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4), "traffic": None,
-                    "avg_launch_us": round(avg_s * 1e6, 2), "launches": kn.value, "bytes_per_launch": per_launch}
         flops = algorithmic_flops_per_doc(N, D, L, H)
         line = {
             "metric": "docs/sec fwd+bwd through CAGGC+MAGGC", "value": round(value, 2), "unit": "docs/s",
@@ -229,13 +259,13 @@ def main():
             "config": {"workload": f"{args.config}: GraphHops fwd+bwd, B={B}/GPU N={N} D={D} L={L} H={H}, train mode, "
                                    f"E1/E2/X/params require grad", "global_batch": B * world, "mode": args.mode,
                        "parallelism": f"dp{world}"},
-            "roofline": roof,
+            "roofline": roofline,
+            "roofline_hbm": roofline_hbm,
             "whole_step": {"hbm_frac": round(value / world * 20 * N * N * D / HBM_PEAK, 4),
                            "mfma_frac": round(value / world * flops / MFMA_F32_PEAK, 4),
                            "algorithmic_bytes_per_doc": 20 * N * N * D, "algorithmic_flops_per_doc": flops},
+            "time_shares_ms_per_step": {k: v for k, v in shares.items() if v["launches_per_step"]},
         }
-        if breakdown:
-            line["breakdown"] = breakdown
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)

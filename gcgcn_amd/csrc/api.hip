@@ -39,12 +39,14 @@ static struct {
   char filter[48] = "";
   std::vector<hipEvent_t> ev;  // pairs: start, stop
   int used = 0;                // pairs recorded
+  double work = 0;             // summed work of the recorded launches
 } g_prof;
 
-ProfScope::ProfScope(const char* tag, hipStream_t s) : slot(-1), st(s) {
+ProfScope::ProfScope(const char* tag, hipStream_t s, double work) : slot(-1), st(s) {
   if (!g_prof.on || strncmp(tag, g_prof.filter, strlen(g_prof.filter)) != 0) return;
   if (2 * (g_prof.used + 1) > (int)g_prof.ev.size()) return;  // ring full: stop recording
   slot = g_prof.used++;
+  g_prof.work += work;
   (void)hipEventRecord(g_prof.ev[2 * slot], st);
 }
 ProfScope::~ProfScope() {
@@ -129,11 +131,13 @@ int gcgcn_prof_start(const char* kernel_prefix, int capacity) {
   }
   strncpy(g_prof.filter, kernel_prefix, sizeof(g_prof.filter) - 1);
   g_prof.used = 0;
+  g_prof.work = 0;
   g_prof.on = true;
   return 0;
 }
-int gcgcn_prof_stop(double* total_ms, int* launches) {
+int gcgcn_prof_stop(double* total_ms, int* launches, double* work) {
   GC_REQUIRE(total_ms && launches, "prof_stop: null pointer");
+  if (work) *work = g_prof.work;
   g_prof.on = false;
   double tot = 0;
   for (int i = 0; i < g_prof.used; ++i) {

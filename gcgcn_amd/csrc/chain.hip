@@ -148,7 +148,9 @@ static bool chain_aligned(const GcnCtx& c, bool bwd) {
 int gcn_chain_fwd(const GcnCtx& c, hipStream_t st) {
   GC_REQUIRE((long)c.B * c.H <= 0x7fffffffL, "gcn_chain_fwd: too many (doc, head) pairs");
   dim3 grid((unsigned)(c.B * c.H)), block(256);
-  ProfScope ps("gcn_chain_fwd", st);
+  double fl = 0;
+  for (int l = 0; l < c.L; ++l) fl += 2.0 * c.N * c.gh * (c.N + (double)l * c.gh);
+  ProfScope ps("gcn_chain_fwd", st, fl * c.B * c.H);
   if (chain_aligned(c, false)) hipLaunchKernelGGL(gcn_chain_fwd_kernel<true>, grid, block, 0, st, c);
   else hipLaunchKernelGGL(gcn_chain_fwd_kernel<false>, grid, block, 0, st, c);
   return check_launch("gcn_chain_fwd");
@@ -156,7 +158,9 @@ int gcn_chain_fwd(const GcnCtx& c, hipStream_t st) {
 
 int gcn_chain_bwd(const GcnCtx& c, hipStream_t st) {
   dim3 grid((unsigned)(c.B * c.H)), block(256);
-  ProfScope ps("gcn_chain_bwd", st);
+  double fl = 0;
+  for (int l = 0; l < c.L; ++l) fl += 4.0 * c.N * c.gh * c.N + 2.0 * c.N * c.gh * (double)l * c.gh;
+  ProfScope ps("gcn_chain_bwd", st, fl * c.B * c.H);
   if (chain_aligned(c, true)) hipLaunchKernelGGL(gcn_chain_bwd_kernel<true>, grid, block, 0, st, c);
   else hipLaunchKernelGGL(gcn_chain_bwd_kernel<false>, grid, block, 0, st, c);
   return check_launch("gcn_chain_bwd");

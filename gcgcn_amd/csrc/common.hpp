@@ -83,7 +83,7 @@ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // with two hipEvents on the launch stream; bench.py reads the summed duration.  Off by default
 // (one predictable branch per launch); must stay off while a hipGraph is being captured.
 struct ProfScope {
-  ProfScope(const char* tag, hipStream_t st);
+  ProfScope(const char* tag, hipStream_t st, double work = 0.0);  // work: flops (GEMM) or algorithmic bytes (edge)
   ~ProfScope();
   int slot;
   hipStream_t st;

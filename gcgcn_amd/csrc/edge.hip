@@ -296,7 +296,7 @@ int edge_fwd(const float* E, const float* v, const int* n_valid, float* Ebar, co
   const size_t lds = ((size_t)EW * D + (att ? (size_t)N : 0)) * sizeof(float);
   GC_REQUIRE(lds <= 160 * 1024, "edge_fwd: N=%d D=%d needs %zu B of LDS", N, D, lds);
   dim3 grid((unsigned)((long)B * N)), block(64 * EW);
-  ProfScope ps(att ? "edge_fwd_att" : "edge_fwd_mean", st);
+  ProfScope ps(att ? "edge_fwd_att" : "edge_fwd_mean", st, 4.0 * B * N * N * D);
   if (vec) {
     if (att) hipLaunchKernelGGL((edge_fwd_kernel<4, true>), grid, block, lds, st, E, v, n_valid, Ebar, coladd, P, A, drop, N, D);
     else hipLaunchKernelGGL((edge_fwd_kernel<4, false>), grid, block, lds, st, E, v, n_valid, Ebar, coladd, P, A, drop, N, D);
@@ -314,7 +314,7 @@ int edge_bwd(const float* E, const float* v, const int* n_valid, const float* dl
   const size_t lds = ((size_t)((N + 3) & ~3) + (size_t)EW * D) * sizeof(float);
   GC_REQUIRE(lds <= 160 * 1024, "edge_bwd: N=%d D=%d needs %zu B of LDS", N, D, lds);
   dim3 grid((unsigned)((long)B * N)), block(64 * EW);
-  ProfScope ps("edge_bwd", st);
+  ProfScope ps("edge_bwd", st, (dE ? 8.0 : 4.0) * B * N * N * D);
   if (vec)
     hipLaunchKernelGGL((edge_bwd_kernel<4>), grid, block, lds, st, E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D);
   else
@@ -326,7 +326,7 @@ int edge_bcast(const float* dEbar, const int* n_valid, float* dE, int B, int N, 
   GC_REQUIRE(dEbar && dE, "edge_bcast: null pointer");
   const bool vec = (D % 4 == 0) && al16(dE) && al16(dEbar);
   dim3 grid((unsigned)((long)B * N)), block(64 * EW);
-  ProfScope ps("edge_bcast", st);
+  ProfScope ps("edge_bcast", st, 4.0 * B * N * N * D);
   if (vec) hipLaunchKernelGGL((edge_bcast_kernel<4>), grid, block, 0, st, dEbar, n_valid, dE, N, D);
   else hipLaunchKernelGGL((edge_bcast_kernel<1>), grid, block, 0, st, dEbar, n_valid, dE, N, D);
   return check_launch("edge_bcast");

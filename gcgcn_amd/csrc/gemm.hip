@@ -106,7 +106,7 @@ template <int TM, int TN, bool ALIGNED>
 static int launch(const GemmArgs& g, hipStream_t stream) {
   dim3 grid(cdiv(g.N, 64 * TN), cdiv(g.M, 64 * TM), g.batch1 * g.batch2 * g.splits), block(256);
   {
-    ProfScope ps(g.tag, stream);
+    ProfScope ps(g.tag, stream, 2.0 * g.M * g.N * g.K * g.batch1 * g.batch2);
     if (g.a_kc && !g.b_kc)
       hipLaunchKernelGGL((gemm_kernel<TM, TN, true, false, ALIGNED>), grid, block, 0, stream, g);
     else if (g.a_kc && g.b_kc)
@@ -182,6 +182,7 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream) {
   for (int i = 0; i < n; ++i)
     work += (long)cdiv(probs[i].M, 64) * cdiv(probs[i].N, 64) * probs[i].batch1 * probs[i].batch2 * cdiv(probs[i].K, BK);
   int tiles = 0, reds = 0;
+  double flops = 0;
   bool any_split = false;
   long ws_used = 0;
   // longest blocks first: workgroups are dispatched in tile order, and a K = 2048 tile started last would
@@ -215,13 +216,14 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream) {
     gg.red_begin[gg.nprob] = reds;
     tiles += (int)(own * g.splits);
     if (g.splits > 1) reds += (int)(nb * cdiv((long)g.M * g.N, 256));
+    flops += 2.0 * g.M * g.N * g.K * nb;
     gg.p[gg.nprob++] = g;
   }
   if (gg.nprob == 0) return 0;
   gg.tile_begin[gg.nprob] = tiles;
   gg.red_begin[gg.nprob] = reds;
   {
-    ProfScope ps("gemm_group", stream);
+    ProfScope ps("gemm_group", stream, flops);
     hipLaunchKernelGGL(gemm_group_kernel, dim3(tiles), dim3(256), 0, stream, gg);
   }
   if (int e = check_launch("gemm_group")) return e;

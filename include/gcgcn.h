@@ -38,10 +38,11 @@ const char* gcgcn_last_error(void); /* message of the last failing call on this 
 /* ---- per-kernel timing for roofline reports (bench.py) ------------------------------------------- */
 /* While active, every kernel launch whose name starts with kernel_prefix ("edge_bwd", "edge_fwd",
  * "edge_bcast", "gemm", "softmax", ...) is bracketed by hipEvents on its launch stream (at most
- * `capacity` launches).  prof_stop synchronises those events and returns their summed duration and
- * count.  Not thread-safe; keep it off while capturing a hipGraph. */
+ * `capacity` launches).  prof_stop synchronises those events and returns their summed duration, their
+ * count and (optional) the work they did: executed flops for GEMM kernels, algorithmic HBM bytes for the
+ * edge kernels.  Not thread-safe; keep it off while capturing a hipGraph. */
 int gcgcn_prof_start(const char* kernel_prefix, int capacity);
-int gcgcn_prof_stop(double* total_ms, int* launches);
+int gcgcn_prof_stop(double* total_ms, int* launches, double* work);
 
 /* ---- dropout RNG state (replaces torch's global CUDA generator used by nn.Dropout) ------- */
 /* snaps[i] <- {state.seed, state.counter + i} for i < count; state.counter += count.
