@@ -27,6 +27,7 @@ SIGNATURES = {
     "gcgcn_version": (I, []),
     "gcgcn_last_error": (c_char_p, []),
     "gcgcn_prof_start": (I, [c_char_p, I]),
+    "gcgcn_prof_enable": (I, [I]),
     "gcgcn_prof_stop": (I, [P, P, P]),
     "gcgcn_rng_next": (I, [P, P, I, P]),
     "gcgcn_dropout_keep": (I, [P, L, P, c_uint64, F, P]),

@@ -135,6 +135,10 @@ int gcgcn_prof_start(const char* kernel_prefix, int capacity) {
   g_prof.on = true;
   return 0;
 }
+int gcgcn_prof_enable(int on) {  // pause / resume recording without touching what was recorded
+  g_prof.on = on != 0 && !g_prof.ev.empty();
+  return 0;
+}
 int gcgcn_prof_stop(double* total_ms, int* launches, double* work) {
   GC_REQUIRE(total_ms && launches, "prof_stop: null pointer");
   if (work) *work = g_prof.work;

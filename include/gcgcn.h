@@ -42,6 +42,7 @@ const char* gcgcn_last_error(void); /* message of the last failing call on this 
  * count and (optional) the work they did: executed flops for GEMM kernels, algorithmic HBM bytes for the
  * edge kernels.  Not thread-safe; keep it off while capturing a hipGraph. */
 int gcgcn_prof_start(const char* kernel_prefix, int capacity);
+int gcgcn_prof_enable(int on); /* pause (0) / resume (1) between prof_start and prof_stop: sample some steps only */
 int gcgcn_prof_stop(double* total_ms, int* launches, double* work);
 
 /* ---- dropout RNG state (replaces torch's global CUDA generator used by nn.Dropout) ------- */
