@@ -10,7 +10,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 32;
 
 template <int BMN, bool KC, bool ALIGNED>
-__device__ __forceinline__ void load_tile(float4 (&r)[BMN / 32], const float* __restrict__ src, long ld, int mn0, int k0,
+__device__ __forceinline__ void load_tile(float (&r)[BMN / 32][4], const float* __restrict__ src, long ld, int mn0, int k0,
                                           int MN, int Kend, int vec, int t) {
 #pragma unroll
   for (int q = 0; q < BMN / 32; ++q) {
@@ -29,7 +29,8 @@ __device__ __forceinline__ void load_tile(float4 (&r)[BMN / 32], const float* __
     }
     const float* p = src + (long)row * ld + col;
     if (ALIGNED) {
-      r[q] = *reinterpret_cast<const float4*>(p);
+      const float4 v = *reinterpret_cast<const float4*>(p);
+      r[q][0] = v.x, r[q][1] = v.y, r[q][2] = v.z, r[q][3] = v.w;
     } else {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < rlim) {
@@ -42,26 +43,27 @@ __device__ __forceinline__ void load_tile(float4 (&r)[BMN / 32], const float* __
           if (col + 3 < clim) v.w = p[3];
         }
       }
-      r[q] = v;
+      r[q][0] = v.x, r[q][1] = v.y, r[q][2] = v.z, r[q][3] = v.w;
     }
   }
 }
 
+// (the prefetch sets are plain float arrays: hipcc keeps float4 arrays that are copied whole in scratch)
 template <int BMN, bool KC>
-__device__ __forceinline__ void store_tile(const float4 (&r)[BMN / 32], float* __restrict__ lds, int t) {
+__device__ __forceinline__ void store_tile(const float (&r)[BMN / 32][4], float* __restrict__ lds, int t) {
   constexpr int LD = KC ? BMN + 1 : BMN;
 #pragma unroll
   for (int q = 0; q < BMN / 32; ++q) {
     const int f = t + 256 * q;
     if (KC) {
       const int m = f >> 3, k = (f & 7) << 2;
-      lds[(k + 0) * LD + m] = r[q].x;
-      lds[(k + 1) * LD + m] = r[q].y;
-      lds[(k + 2) * LD + m] = r[q].z;
-      lds[(k + 3) * LD + m] = r[q].w;
+      lds[(k + 0) * LD + m] = r[q][0];
+      lds[(k + 1) * LD + m] = r[q][1];
+      lds[(k + 2) * LD + m] = r[q][2];
+      lds[(k + 3) * LD + m] = r[q][3];
     } else {
       const int k = f / (BMN / 4), c = (f % (BMN / 4)) << 2;
-      *reinterpret_cast<float4*>(&lds[k * LD + c]) = r[q];
+      *reinterpret_cast<float4*>(&lds[k * LD + c]) = make_float4(r[q][0], r[q][1], r[q][2], r[q][3]);
     }
   }
 }
@@ -206,14 +208,20 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[BM / 32], rb[BN / 32];
+  // Two register sets: while tile kt is multiplied from LDS, tile kt+1 waits in one set (it was requested a
+  // whole k-step ago) and tile kt+2 is being requested into the other.  Every global load therefore has two
+  // k-steps (~2 x 1024 MFMA cycles per wave) to land before its LDS store needs it.  Tile indices are clamped
+  // to the last tile so that all loads/stores are unconditional (a guarded prefetch makes hipcc keep the
+  // float4 sets in scratch); the clamped extra loads re-read the last tile from L2 and are never consumed.
+  float ra0[BM / 32][4], rb0[BN / 32][4], ra1[BM / 32][4], rb1[BN / 32][4];
   const int nk = (kend - kbeg + BK - 1) / BK;
-  // (K >= 1 is checked on the host; an unconditional first tile keeps ra/rb in registers -- a guarded
-  // one makes hipcc park the prefetch registers in scratch)
-  load_tile<BM, AKC, ALIGNED>(ra, A, g.lda, m0, kbeg, g.M, kend, g.vecA, t);
-  load_tile<BN, BKC, ALIGNED>(rb, B, g.ldb, n0, kbeg, g.N, kend, g.vecB, t);
-  store_tile<BM, AKC>(ra, lds, t);
-  store_tile<BN, BKC>(rb, lds + OFFB, t);
+  auto kof = [&](int kt) { return kbeg + min(kt, nk - 1) * BK; };
+  load_tile<BM, AKC, ALIGNED>(ra0, A, g.lda, m0, kof(0), g.M, kend, g.vecA, t);
+  load_tile<BN, BKC, ALIGNED>(rb0, B, g.ldb, n0, kof(0), g.N, kend, g.vecB, t);
+  store_tile<BM, AKC>(ra0, lds, t);
+  store_tile<BN, BKC>(rb0, lds + OFFB, t);
+  load_tile<BM, AKC, ALIGNED>(ra0, A, g.lda, m0, kof(1), g.M, kend, g.vecA, t);
+  load_tile<BN, BKC, ALIGNED>(rb0, B, g.ldb, n0, kof(1), g.N, kend, g.vecB, t);
   __syncthreads();
 
   // One k-tile from LDS stage `cur`.  The operands of k-step kk+2 are read while the MFMAs of step kk
@@ -242,20 +250,21 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
     }
   };
-  // steady state: prefetch tile kt+1 into registers, multiply tile kt from LDS, park the prefetch in the
-  // other LDS stage.  The last tile is peeled so that the loads/stores are unconditional (a guarded
-  // prefetch turns the float4 registers into a scratch-resident phi).
-  for (int kt = 0; kt + 1 < nk; ++kt) {
-    const int cur = kt & 1;
-    load_tile<BM, AKC, ALIGNED>(ra, A, g.lda, m0, kbeg + (kt + 1) * BK, g.M, kend, g.vecA, t);
-    load_tile<BN, BKC, ALIGNED>(rb, B, g.ldb, n0, kbeg + (kt + 1) * BK, g.N, kend, g.vecB, t);
-    compute(cur);
-    store_tile<BM, AKC>(ra, lds + (cur ^ 1) * SA, t);
-    store_tile<BN, BKC>(rb, lds + OFFB + (cur ^ 1) * SB, t);
+  for (int kt = 0; kt < nk; kt += 2) {
+    load_tile<BM, AKC, ALIGNED>(ra1, A, g.lda, m0, kof(kt + 2), g.M, kend, g.vecA, t);
+    load_tile<BN, BKC, ALIGNED>(rb1, B, g.ldb, n0, kof(kt + 2), g.N, kend, g.vecB, t);
+    compute(0);
+    store_tile<BM, AKC>(ra0, lds + SA, t);
+    store_tile<BN, BKC>(rb0, lds + OFFB + SB, t);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    load_tile<BM, AKC, ALIGNED>(ra0, A, g.lda, m0, kof(kt + 3), g.M, kend, g.vecA, t);
+    load_tile<BN, BKC, ALIGNED>(rb0, B, g.ldb, n0, kof(kt + 3), g.N, kend, g.vecB, t);
+    compute(1);
+    store_tile<BM, AKC>(ra1, lds, t);
+    store_tile<BN, BKC>(rb1, lds + OFFB, t);
     __syncthreads();
   }
-  compute((nk - 1) & 1);
-  __syncthreads();
 
   // ---- store ------------------------------------------------------------------------------
   if (g.splits > 1) {  // raw partial sums -> workspace [split][batch][M][N]

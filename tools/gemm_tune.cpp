@@ -42,7 +42,17 @@ static void run(const char* name, int M, int N, int K, int akc, int bkc, int bat
   hipFree(A), hipFree(B), hipFree(C), hipFree(ws);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1) {  // layout sweep on a large problem: which operand path limits the steady state?
+    run("NN big", 4096, 4096, 4096, 1, 0, 1, 1, 1);
+    run("NT big", 4096, 4096, 4096, 1, 1, 1, 1, 1);
+    run("TN big", 4096, 4096, 4096, 0, 0, 1, 1, 1);
+    run("TT big", 4096, 4096, 4096, 0, 1, 1, 1, 1);
+    run("NN big t2", 4096, 4096, 4096, 1, 0, 1, 2, 1);
+    run("TN big t2", 4096, 4096, 4096, 0, 0, 1, 2, 1);
+    return 0;
+  }
+
   for (int tile = 1; tile <= 2; ++tile) {
     run("NN K=256", 2048, 2048, 256, 1, 0, 1, tile, 1);
     run("NN K=2048", 2048, 2048, 2048, 1, 0, 1, tile, 1);
