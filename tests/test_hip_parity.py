@@ -231,7 +231,9 @@ def _oracle_stack(x, e1, e2, adj, sd, L, H, nv=None, keeps=None):
     return outs, gx, ge1, ge2, sdl
 
 
-@pytest.mark.parametrize("B,N,D,L,H", [(3, 64, 256, 2, 8), (2, 24, 96, 4, 4), (2, 70, 64, 2, 2)])
+@pytest.mark.parametrize("B,N,D,L,H", [(3, 64, 256, 2, 8), (2, 24, 96, 4, 4), (2, 70, 64, 2, 2),
+                                       (1, 64, 768, 4, 4),      # cfg 3 (bert) document shape
+                                       (1, 256, 512, 2, 8)])    # cfg 5 (stress) document shape
 def test_batched_matches_per_doc_oracle(gpu_device, B, N, D, L, H):
     sd = O.init_stack_params(D, L, H, seed=1337)
     x, e1, e2, adj = O.synth_docs(B, N, D, seed=5)
