@@ -508,6 +508,87 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// GraphConv (the leaf layer, glove:18-50): out = (Ebar We + A X Wn (+ bias)) / rowsum(A)
+// ---------------------------------------------------------------------------------------------
+int gcgcn_graphconv_fwd(int B, int N, int Din, int De, int Dout, const float* X, const float* Ebar, const float* A,
+                        const float* We, const float* Wn, const float* bias, float* out, float* T, float* rinv,
+                        float* scratch, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  GC_REQUIRE(B > 0 && N > 0 && Din > 0 && De > 0 && Dout > 0, "graphconv_fwd: bad shape");
+  GC_REQUIRE(X && Ebar && A && We && Wn && out && T && rinv, "graphconv_fwd: null pointer");
+  const long M = (long)B * N;
+  const long wse = scratch ? scratch_elems(B, N, Dout > Din ? Dout : Din, 1) : 0;
+  GC_TRY(rowsum_inv(A, rinv, M, N, st));
+  {  // one launch: out <- Ebar We (edge term),  T <- X Wn
+    GemmArgs gs[2];
+    gs[0].ws = gs[1].ws = scratch, gs[0].ws_elems = gs[1].ws_elems = wse;
+    gs[0].A = Ebar, gs[0].lda = De, gs[0].a_kc = 1, gs[0].B = We, gs[0].ldb = Dout, gs[0].b_kc = 0;
+    gs[0].C = out, gs[0].ldc = Dout, gs[0].M = (int)M, gs[0].N = Dout, gs[0].K = De;
+    gs[1].A = X, gs[1].lda = Din, gs[1].a_kc = 1, gs[1].B = Wn, gs[1].ldb = Dout, gs[1].b_kc = 0;
+    gs[1].C = T, gs[1].ldc = Dout, gs[1].M = (int)M, gs[1].N = Dout, gs[1].K = Din;
+    GC_TRY(gemm_group(gs, 2, st));
+  }
+  {  // out = (out + A T + bias) * rinv        (glove:42-50; the bias joins before the division, glove:45-46)
+    GemmArgs g;
+    g.A = A, g.lda = N, g.a_kc = 1, g.sA1 = (long)N * N;
+    g.B = T, g.ldb = Dout, g.b_kc = 0, g.sB1 = (long)N * Dout;
+    g.C = out, g.ldc = Dout, g.sC1 = (long)N * Dout;
+    g.M = N, g.N = Dout, g.K = N, g.batch1 = B;
+    g.add = out, g.ldadd = Dout, g.sAdd1 = (long)N * Dout;
+    g.bias = bias;
+    g.rowscale = rinv, g.sRs1 = N;
+    GC_TRY(gemm(g, st, 0, 1));
+  }
+  return 0;
+}
+
+int gcgcn_graphconv_bwd(int B, int N, int Din, int De, int Dout, const float* X, const float* Ebar, const float* A,
+                        const float* We, const float* Wn, const float* out, const float* T, const float* rinv,
+                        const float* dout, float* dX, float* dEbar, float* dA, float* dWe, float* dWn, float* dbias,
+                        float* dS, float* dT, float* drow, float* scratch, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  GC_REQUIRE(B > 0 && N > 0 && Din > 0 && De > 0 && Dout > 0, "graphconv_bwd: bad shape");
+  GC_REQUIRE(X && Ebar && A && We && Wn && out && T && rinv && dout && dX && dEbar && dA && dWe && dWn && dS && dT &&
+                 drow,
+             "graphconv_bwd: null pointer");
+  const long M = (long)B * N;
+  const long wse = scratch ? scratch_elems(B, N, Dout > Din ? Dout : Din, 1) : 0;
+  // dS = dout * rinv ;  drow = -rinv * sum_c dout * out      (no relu in the leaf)
+  GC_TRY(relu_norm_bwd(dout, out, rinv, dS, drow, M, N, 1, 1, Dout, 0, 1, st, 0));
+  if (dbias) GC_TRY(colsum(dS, nullptr, dbias, M, Dout, Dout, 1, 0, 0, 0, 0, scratch, st));
+  {  // dT = A^T dS
+    GemmArgs g;
+    g.A = A, g.lda = N, g.a_kc = 0, g.sA1 = (long)N * N;
+    g.B = dS, g.ldb = Dout, g.b_kc = 0, g.sB1 = (long)N * Dout;
+    g.C = dT, g.ldc = Dout, g.sC1 = (long)N * Dout;
+    g.M = N, g.N = Dout, g.K = N, g.batch1 = B;
+    GC_TRY(gemm(g, st, 0, 1));
+  }
+  GemmArgs gs[5];
+  for (auto& g : gs) g.ws = scratch, g.ws_elems = wse;
+  // dA = dS T^T + drow (broadcast along j)
+  gs[0].A = dS, gs[0].lda = Dout, gs[0].a_kc = 1, gs[0].sA1 = (long)N * Dout;
+  gs[0].B = T, gs[0].ldb = Dout, gs[0].b_kc = 1, gs[0].sB1 = (long)N * Dout;
+  gs[0].C = dA, gs[0].ldc = N, gs[0].sC1 = (long)N * N;
+  gs[0].M = N, gs[0].N = N, gs[0].K = Dout, gs[0].batch1 = B;
+  gs[0].rowadd = drow, gs[0].sRa1 = N;
+  // dWe = Ebar^T dS
+  gs[1].A = Ebar, gs[1].lda = De, gs[1].a_kc = 0, gs[1].B = dS, gs[1].ldb = Dout, gs[1].b_kc = 0;
+  gs[1].C = dWe, gs[1].ldc = Dout, gs[1].M = De, gs[1].N = Dout, gs[1].K = (int)M;
+  // dEbar = dS We^T
+  gs[2].A = dS, gs[2].lda = Dout, gs[2].a_kc = 1, gs[2].B = We, gs[2].ldb = Dout, gs[2].b_kc = 1;
+  gs[2].C = dEbar, gs[2].ldc = De, gs[2].M = (int)M, gs[2].N = De, gs[2].K = Dout;
+  // dWn = X^T dT
+  gs[3].A = X, gs[3].lda = Din, gs[3].a_kc = 0, gs[3].B = dT, gs[3].ldb = Dout, gs[3].b_kc = 0;
+  gs[3].C = dWn, gs[3].ldc = Dout, gs[3].M = Din, gs[3].N = Dout, gs[3].K = (int)M;
+  // dX = dT Wn^T
+  gs[4].A = dT, gs[4].lda = Dout, gs[4].a_kc = 1, gs[4].B = Wn, gs[4].ldb = Dout, gs[4].b_kc = 1;
+  gs[4].C = dX, gs[4].ldc = Din, gs[4].M = (int)M, gs[4].N = Din, gs[4].K = Dout;
+  GC_TRY(gemm_group(gs, 5, st));
+  return 0;
+}
+
 int gcgcn_gemm(int M, int N, int K, const float* A, int64_t lda, int a_kc, const float* B, int64_t ldb, int b_kc,
                float* C, int64_t ldc, int batch, int64_t sA, int64_t sB, int64_t sC, float alpha, const float* bias,
                int relu, int accumulate, int tile, int splits, float* ws, int64_t ws_elems, void* stream) {

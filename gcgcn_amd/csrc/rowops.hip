@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64 * RW) void rowsum_inv_kernel(const float* __rest
 __global__ __launch_bounds__(64 * RW) void relu_norm_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
                                                                 const float* __restrict__ rinv, float* __restrict__ dM,
                                                                 float* __restrict__ drow, long rows_m, int N, int H,
-                                                                int L, int gh, int l, int first) {
+                                                                int L, int gh, int l, int first, int relu) {
   const long w = (long)blockIdx.x * RW + (threadIdx.x >> 6);
   if (w >= rows_m * H) return;
   const int lane = threadIdx.x & 63;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64 * RW) void relu_norm_bwd_kernel(const float* __r
   float acc = 0.f;
   for (int c = lane; c < gh; c += 64) {
     const float y = Y[off + c];
-    const float g = y > 0.f ? dY[off + c] : 0.f;
+    const float g = (!relu || y > 0.f) ? dY[off + c] : 0.f;
     dM[off + c] = g * rv;
     acc = fmaf(g, y, acc);
   }
@@ -354,10 +354,10 @@ int rowsum_inv(const float* A, float* rinv, long rows, int N, hipStream_t st) {
   return check_launch("rowsum_inv");
 }
 int relu_norm_bwd(const float* dY, const float* Y, const float* rinv, float* dM, float* drow, long rows_m, int N, int H,
-                  int L, int gh, int l, int first, hipStream_t st) {
+                  int L, int gh, int l, int first, hipStream_t st, int relu) {
   ProfScope ps("relu_norm_bwd", st);
   hipLaunchKernelGGL(relu_norm_bwd_kernel, dim3(cdiv(rows_m * H, RW)), dim3(64 * RW), 0, st, dY, Y, rinv, dM, drow,
-                     rows_m, N, H, L, gh, l, first);
+                     rows_m, N, H, L, gh, l, first, relu);
   return check_launch("relu_norm_bwd");
 }
 int head_sum_drop_bwd(const float* dHO, float* dY, float* dXres, long M, int H, int D, Drop drop, hipStream_t st) {

@@ -247,6 +247,43 @@ class GcnFn(torch.autograd.Function):
         return dX, dEbar, dA, dflat, None, None, None, None, None
 
 
+class GraphConvFn(torch.autograd.Function):
+    """(X[B,N,Din], Ebar[B,N,De], A[B,N,N], We, Wn, bias|None) -> out[B,N,Dout].  GraphConv.forward, glove:36-50."""
+
+    @staticmethod
+    def forward(ctx, x, ebar, adj, we, wn, bias):
+        B, N, Din = x.shape
+        De, Dout = we.shape
+        dev = x.device
+        out = torch.empty(B, N, Dout, device=dev)
+        T = torch.empty(B, N, Dout, device=dev)
+        rinv = torch.empty(B, N, device=dev)
+        scratch = torch.empty(max(_lib.lib().gcgcn_gcn_scratch(B, N, max(Din, Dout), 1), 1), device=dev)
+        call("gcgcn_graphconv_fwd", B, N, Din, De, Dout, _p(x), _p(ebar), _p(adj), _p(we), _p(wn), _p(bias), _p(out),
+             _p(T), _p(rinv), _p(scratch), _stream())
+        ctx.save_for_backward(x, ebar, adj, we, wn, out, T, rinv)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, ebar, adj, we, wn, out, T, rinv = ctx.saved_tensors
+        B, N, Din = x.shape
+        De, Dout = we.shape
+        dev = x.device
+        dout = dout.contiguous()
+        dX, dEbar, dA = torch.empty_like(x), torch.empty_like(ebar), torch.empty_like(adj)
+        dWe, dWn = torch.empty_like(we), torch.empty_like(wn)
+        dbias = torch.empty(Dout, device=dev) if ctx.has_bias else None
+        dS, dT = torch.empty(B, N, Dout, device=dev), torch.empty(B, N, Dout, device=dev)
+        drow = torch.empty(B, N, device=dev)
+        scratch = torch.empty(max(_lib.lib().gcgcn_gcn_scratch(B, N, max(Din, Dout), 1), 1), device=dev)
+        call("gcgcn_graphconv_bwd", B, N, Din, De, Dout, _p(x), _p(ebar), _p(adj), _p(we), _p(wn), _p(out), _p(T),
+             _p(rinv), _p(dout), _p(dX), _p(dEbar), _p(dA), _p(dWe), _p(dWn), _p(dbias), _p(dS), _p(dT), _p(drow),
+             _p(scratch), _stream())
+        return dX, dEbar, dA, dWe, dWn, dbias
+
+
 class DropoutFn(torch.autograd.Function):
     """Elementwise dropout of the hop glue (GCGCN_glove.py:341); backward replays the same mask."""
 
@@ -298,6 +335,12 @@ def gcn_stack(x, ebar, adj, flat, L, H, n_valid=None, p=0.2, training=False):
         raise ValueError(f"gcn_stack: shapes x{tuple(x.shape)} ebar{tuple(ebar.shape)} adj{tuple(adj.shape)} H={H}")
     return GcnFn.apply(x, ebar, adj, _chk(flat, "flat"), _nv(n_valid, B, N, x.device), L, H, p,
                        _snap_for(training, p, x.device))
+
+
+def graph_conv(x, ebar, adj, we, wn, bias=None):
+    x, ebar, adj = _chk(x, "inputs", 3), _chk(ebar, "edge_mean", 3), _chk(adj, "adjacency_matrix", 3)
+    return GraphConvFn.apply(x, ebar, adj, _chk(we, "weights_edge", 2), _chk(wn, "weights_node", 2),
+                             None if bias is None else _chk(bias, "bias", 1))
 
 
 def dropout(x, p=0.2, training=False, salt=SALT_GLUE):

@@ -222,6 +222,40 @@ class _GcnBase(_FlatBlock):
         return ebar
 
 
+class GraphConv(nn.Module):
+    """The leaf layer (GCGCN_glove.py:18-50): ``(mean_j(E) W_e + A X W_n (+ bias)) / rowsum(A)`` with the
+    reference's parameter names (``weights_edge``, ``weights_node``, optional ``bias``) and xavier init.
+    ``GraphConvolution`` / ``MultiGraphConvolution`` do not instantiate it: they run all their GraphConvs
+    fused (params.py); this class exists so that code using the leaf directly keeps working."""
+
+    def __init__(self, input_dim: int, edge_dim: int, output_dim: int, bias: bool = False):
+        super().__init__()
+        self.input_dim, self.output_dim = input_dim, output_dim
+        self.weights_edge = nn.Parameter(torch.empty(edge_dim, output_dim))
+        self.weights_node = nn.Parameter(torch.empty(input_dim, output_dim))
+        if bias:
+            # the reference leaves this tensor uninitialised (torch.FloatTensor, glove:27); zeros here
+            self.bias = nn.Parameter(torch.zeros(output_dim))
+        else:
+            self.register_parameter("bias", None)
+        self.init()
+
+    def init(self):
+        nn.init.xavier_uniform_(self.weights_edge.data)          # glove:33
+        nn.init.xavier_uniform_(self.weights_node.data)          # glove:34
+
+    def forward(self, inputs: Tensor, edge_inputs: Tensor, adjacency_matrix: Tensor,
+                n_valid: Optional[Tensor] = None) -> Tensor:
+        x, batched = _batched(inputs, 2)
+        adj, _ = _batched(adjacency_matrix, 2)
+        ebar = F_.take_edge_mean(edge_inputs, n_valid)
+        if ebar is None:
+            e, _ = _batched(edge_inputs, 3)
+            ebar = F_.edge_mean(e, n_valid)
+        out = F_.graph_conv(x, ebar, adj, self.weights_edge, self.weights_node, self.bias)
+        return out if batched else out.squeeze(0)
+
+
 class GraphConvolution(_GcnBase):
     """CAGGC convolution (GCGCN_glove.py:52-80): ``layer_num`` densely connected GraphConv layers over one
     adjacency, dropout 0.2 on the emitted copies, residual, Linear(D, D)."""

@@ -129,6 +129,21 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
                   float* dA, float* dflat, float* W1, float* W2, float* W3, float* drow, float* dXres, float* dout_m,
                   float* scratch, void* stream);
 
+/* ---- GraphConv, the leaf layer  GCGCN_glove.py:18-50 ------------------------------------------ */
+/* forward(inputs X[B,N,Din], mean edge feature Ebar[B,N,De], adjacency A[B,N,N]):
+ *   out[B,N,Dout] = (Ebar We + A X Wn (+ bias)) / (rowsum(A) + [rowsum == 0])
+ * We[De,Dout] = weights_edge, Wn[Din,Dout] = weights_node, bias[Dout] or NULL.  Saved: T = X Wn, rinv[B,N].
+ * (Inside GraphConvolution / MultiGraphConvolution this layer is fused into gcgcn_gcn_fwd.) */
+int gcgcn_graphconv_fwd(int B, int N, int Din, int De, int Dout, const float* X, const float* Ebar, const float* A,
+                        const float* We, const float* Wn, const float* bias, float* out, float* T, float* rinv,
+                        float* scratch, void* stream);
+/* backward.  Workspace: dS, dT [B,N,Dout], drow[B,N], scratch[gcgcn_gcn_scratch(B,N,max(Din,Dout),1)].
+ * dbias may be NULL. */
+int gcgcn_graphconv_bwd(int B, int N, int Din, int De, int Dout, const float* X, const float* Ebar, const float* A,
+                        const float* We, const float* Wn, const float* out, const float* T, const float* rinv,
+                        const float* dout, float* dX, float* dEbar, float* dA, float* dWe, float* dWn, float* dbias,
+                        float* dS, float* dT, float* drow, float* scratch, void* stream);
+
 /* ---- raw batched GEMM (exposed for unit tests and benchmarks of the MFMA kernel) ----------- */
 /* C[z] = alpha * opA(A[z]) opB(B[z]);  a_kc: A stored [M][K] else [K][M];  b_kc: B stored [N][K]
  * else [K][N];  z < batch with element strides sA, sB, sC;  tile: 0 auto, 1 = 64x64, 2 = 128x128;

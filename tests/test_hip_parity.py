@@ -109,6 +109,46 @@ def test_gemm_split_k(gpu_device, M, N, K, batch, splits, a_kc, b_kc):
 # ------------------------------------------------------------------------------------------------------
 # blocks against the reference's golden vectors
 # ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", golden_files("graphconv"), ids=ids(golden_files("graphconv")))
+def test_graphconv_leaf_golden(gpu_device, path):
+    """GraphConv (glove:18-50) with an all-zero adjacency row (the +1 normaliser branch, glove:47-49)."""
+    g = load_golden(path)
+    D, L = g["meta"]["d"], g["meta"]["l"]
+    m = gcgcn_amd.GraphConv(D, D, D // L).to(gpu_device)
+    m.load_state_dict(g["sd"], strict=True)
+    ins = {k: dev_leaf(v, gpu_device) for k, v in g["in"].items()}
+    out = m(ins["x"], ins["e"], ins["adj"])
+    close(out, g["out"], "graphconv out")
+    out.backward(g["cot"].to(gpu_device))
+    for k in ("x", "e", "adj"):
+        close(ins[k].grad, g["grad_in"][k], f"d{k}")
+    close(m.weights_edge.grad, g["grad_sd"]["weights_edge"], "dWe")
+    close(m.weights_node.grad, g["grad_sd"]["weights_node"], "dWn")
+
+
+def test_graphconv_leaf_bias(gpu_device):
+    """bias=True (never used by the reference model, but part of the leaf's signature): bias joins before the
+    division by the row sum (glove:45-50)."""
+    torch.manual_seed(3)
+    N, D, G = 9, 16, 8
+    m = gcgcn_amd.GraphConv(D, D, G, bias=True).to(gpu_device)
+    with torch.no_grad():
+        m.bias.copy_(torch.randn(G))
+    x, e, a = torch.randn(N, D), torch.randn(N, N, D), torch.rand(N, N)
+    xs = [dev_leaf(t, gpu_device) for t in (x, e, a)]
+    out = m(*xs)
+    out.sum().backward()
+    we, wn, b = (t.detach().cpu().requires_grad_() for t in (m.weights_edge, m.weights_node, m.bias))
+    xr = [t.clone().requires_grad_() for t in (x, e, a)]
+    r = xr[2].sum(1)
+    ref = (torch.einsum("ijk,kp->ijp", xr[1], we).mean(1) + xr[2] @ (xr[0] @ wn) + b) / (r + (r == 0).float()).unsqueeze(1)
+    ref.sum().backward()
+    close(out, ref, "out")
+    close(m.bias.grad, b.grad, "dbias")
+    close(xs[2].grad, xr[2].grad, "dA")
+    close(xs[1].grad, xr[1].grad, "dE")
+
+
 @pytest.mark.parametrize("path", golden_files("gat"), ids=ids(golden_files("gat")))
 def test_gat_golden(gpu_device, path):
     g = load_golden(path)
