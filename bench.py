@@ -138,7 +138,7 @@ def main():
     hops = gcgcn_amd.GraphHops(D, L, H).to(dev).train()
     hops.overlap_edge_mean = not args.no_overlap
     gcgcn_amd.manual_seed(1337 + rank, dev)
-    bucket = FlatGradBucket(hops)
+    bucket = FlatGradBucket(hops, overlap=world > 1)   # N > 1: gradient slices travel while backward still runs
     x, e1, e2, adj = synth(cfg, 1337 + rank, dev)
     for t in (x, e1, e2):
         t.requires_grad_()

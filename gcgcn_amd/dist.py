@@ -23,8 +23,16 @@ from torch import nn
 
 
 class FlatGradBucket:
-    def __init__(self, module: nn.Module, process_group=None):
+    """overlap=False: one all-reduce of the whole arena after backward (``all_reduce()``).
+    overlap=True : each block's slice is all-reduced asynchronously the moment autograd has finished
+    accumulating that block's gradient (post-accumulate hook), so the MAGGC gradients travel over xGMI while
+    the MHA / CAGGC / GAT backward kernels still run; ``all_reduce()`` then only waits for the handles.
+    Every rank issues the slices in the same (reverse-topological) order, as RCCL requires."""
+
+    def __init__(self, module: nn.Module, process_group=None, overlap: bool = False):
         self.pg = process_group
+        self.overlap = overlap
+        self._pending = []
         self.params: List[nn.Parameter] = [p for n, p in module.named_parameters()
                                            if p.requires_grad and not n.endswith("flat_k")]
         # every parameter starts on a 256-byte boundary so the GEMM kernels keep their 16-byte vector loads
@@ -40,8 +48,20 @@ class FlatGradBucket:
                 self.param_arena[off:off + n].copy_(p.reshape(-1))
                 p.data = self.param_arena[off:off + n].view_as(p)
                 p.grad = self.grad_arena[off:off + n].view_as(p)
+                if overlap:
+                    p.register_post_accumulate_grad_hook(self._make_hook(off, n))
                 off += pad(n)
         self.numel = total
+
+    def _distributed(self) -> bool:
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1
+
+    def _make_hook(self, off: int, n: int):
+        def hook(param):
+            if self._distributed():
+                self._pending.append(dist.all_reduce(self.grad_arena[off:off + n], op=dist.ReduceOp.SUM,
+                                                     group=self.pg, async_op=True))
+        return hook
 
     def zero_grad(self):
         self.grad_arena.zero_()
@@ -53,7 +73,11 @@ class FlatGradBucket:
         """Sum gradients over ranks (in place, one collective); optionally divide by the global document count
         (the reference's total_loss / batch_size)."""
         work = None
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1:
+        if self.overlap:
+            for w in self._pending:      # the slices were launched from the backward hooks
+                w.wait()
+            self._pending.clear()
+        elif self._distributed():
             work = dist.all_reduce(self.grad_arena, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
         if global_docs is not None and not async_op:
             self.grad_arena.div_(float(global_docs))

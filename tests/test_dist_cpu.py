@@ -21,6 +21,39 @@ def _free_port():
     return p
 
 
+def _worker_overlap(rank, world, port, out):
+    """overlap=True: slices are all-reduced from post-accumulate hooks during backward."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(1337)
+        hops = gcgcn_amd.GraphHops(16, 2, 4)
+        bucket = FlatGradBucket(hops, overlap=True)
+        bucket.zero_grad()
+        # a stand-in backward: a loss that touches every bucketed parameter through autograd
+        loss = sum((p * float((rank + 1) * (i + 1))).sum() for i, p in enumerate(bucket.params))
+        loss.backward()
+        assert len(bucket._pending) == len(bucket.params)        # one async slice per block, launched by the hooks
+        bucket.all_reduce(global_docs=4)
+        assert not bucket._pending
+        for i, p in enumerate(bucket.params):
+            want = (1 + 2) * (i + 1) / 4.0
+            assert torch.allclose(p.grad, torch.full_like(p, want)), (i, p.grad.flatten()[:3])
+        # second step: zero_grad keeps the views and the hooks alive
+        bucket.zero_grad()
+        loss = sum((p * 2.0).sum() for p in bucket.params)
+        loss.backward()
+        bucket.all_reduce()
+        for p in bucket.params:
+            assert torch.allclose(p.grad, torch.full_like(p, 4.0))
+        out.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        out.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
 def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -64,11 +97,12 @@ def _worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(120)
-def test_flat_bucket_allreduce_gloo_world2():
+@pytest.mark.parametrize("target", [_worker, _worker_overlap], ids=["single_allreduce", "overlapped_slices"])
+def test_flat_bucket_allreduce_gloo_world2(target):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=100) for _ in procs]
