@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--prof-kernel", default="auto",
                     help="kernel family timed with HIP events inside the timed region (auto = the one with the largest time share)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="keep the E2 mean on the main stream (A/B)")
+    ap.add_argument("--overlap", action="store_true", help="stream the E2 mean on a side stream (A/B; default off)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -136,7 +136,7 @@ def main():
     B, N, D, L, H = (cfg[k] for k in "BNDLH")
     torch.manual_seed(1337)                       # identical parameters on every rank
     hops = gcgcn_amd.GraphHops(D, L, H).to(dev).train()
-    hops.overlap_edge_mean = not args.no_overlap
+    hops.overlap_edge_mean = args.overlap
     gcgcn_amd.manual_seed(1337 + rank, dev)
     bucket = FlatGradBucket(hops, overlap=world > 1)   # N > 1: gradient slices travel while backward still runs
     x, e1, e2, adj = synth(cfg, 1337 + rank, dev)

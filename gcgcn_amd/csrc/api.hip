@@ -211,7 +211,10 @@ int gcgcn_gat_fwd(int B, int N, int D, const float* X, const float* E, const int
   return 0;
 }
 
-int64_t gcgcn_gat_bwd_scratch(int B, int N, int D) { return colsum_scratch_elems((long)B * N, D, 1); }
+int64_t gcgcn_gat_bwd_scratch(int B, int N, int D) {
+  const long a = colsum_scratch_elems((long)B * N, D, 1), b = 3L * 64 * (2 * D + 1);
+  return a > b ? a : b;
+}
 
 int gcgcn_gat_bwd(int B, int N, int D, const float* X, const float* E, const int32_t* n_valid, const float* flat,
                   const void* rng_snap, float p, const float* uvc, const float* P, const float* dA, const float* dEbar,
@@ -227,9 +230,10 @@ int gcgcn_gat_bwd(int B, int N, int D, const float* X, const float* E, const int
   // ds[b, j] = sum_i dlogit[b, i, j]
   GC_TRY(colsum(dlogit, nullptr, ds, N, N, N, B, (long)N * N, 0, N, 0, nullptr, st));
   GC_TRY(edge_bwd(E, uvc + D, n_valid, dlogit, dEbar, dE, dvpart, B, N, D, st));
-  GC_TRY(colsum(dvpart, nullptr, duvc + D, M, D, D, 1, 0, 0, 0, 0, scratch, st));  // dv
-  GC_TRY(colsum(X, ds, duvc, M, D, D, 1, 0, 0, 0, 0, scratch, st));               // du = sum ds[m] X[m,:]
-  GC_TRY(colsum(ds, nullptr, duvc + 2 * D, M, 1, 1, 1, 0, 0, 0, 0, scratch, st));  // dc
+  // du = sum_m ds[m] X[m,:],  dv = sum partials,  dc = sum_m ds[m]: one two-stage launch pair
+  GC_REQUIRE(scratch, "gat_bwd: scratch is required");
+  GC_TRY(colsum3(X, ds, duvc, M, D, D, dvpart, nullptr, duvc + D, M, D, D, ds, nullptr, duvc + 2 * D, M, 1, 1, scratch,
+                 st));
   GC_TRY(node_score_bwd(ds, uvc, dX, M, D, st));
   GC_TRY(gat_fold_bwd(flat, duvc, dflat, D, st));
   return 0;

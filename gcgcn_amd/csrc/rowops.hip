@@ -206,6 +206,48 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
   }
 }
 
+// Several independent column reductions in one two-stage launch pair (GAT backward: du, dv, dc).
+struct ColJobs {
+  static constexpr int MAXJ = 4;
+  const float* X[MAXJ];
+  const float* w[MAXJ];
+  float* out[MAXJ];
+  long R[MAXJ], ld[MAXJ];
+  int C[MAXJ];
+  long part_off[MAXJ];  // offset of the job's partials inside scratch
+  int n;
+};
+__global__ __launch_bounds__(256) void colsum_multi_kernel(const ColJobs j, float* __restrict__ scratch, int ns, int stage) {
+  __shared__ float red[4][64];
+  const int job = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = j.C[job];
+  const int c = blockIdx.x * 64 + lane;
+  if (blockIdx.x * 64 >= C) return;
+  float acc = 0.f;
+  if (stage == 0) {
+    const long R = j.R[job], rps = (R + ns - 1) / ns;
+    const long r0 = (long)blockIdx.y * rps;
+    const long r1 = r0 + rps < R ? r0 + rps : R;
+    const float* x = j.X[job];
+    const float* w = j.w[job];
+    const long ld = j.ld[job];
+    if (c < C)
+      for (long r = r0 + wave; r < r1; r += 4) acc = fmaf(w ? w[r] : 1.f, x[r * ld + c], acc);
+  } else {
+    const float* x = scratch + j.part_off[job];
+    if (c < C)
+      for (int r = wave; r < ns; r += 4) acc += x[(long)r * C + c];
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && c < C) {
+    const float s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    if (stage == 0) scratch[j.part_off[job] + (long)blockIdx.y * C + c] = s;
+    else j.out[job][c] = s;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // GATAttention folded (glove:156-162 has no non-linearity between the three
 // Linear(D,D) and wt):  energy[i,j] = u.x_j + v.e_ij + c
@@ -417,6 +459,36 @@ int colsum(const float* X, const float* w, float* out, long R, int C, long ld, i
   hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64), 1, batch), dim3(256), 0, st, scratch, (const float*)nullptr, out, ns, C,
                      (long)C, ns * C, 0L, sOz, ns, accumulate);
   return check_launch("colsum/2");
+}
+
+// Three column sums in two launches; scratch needs 3 * 64 * maxC floats.
+int colsum3(const float* X0, const float* w0, float* o0, long R0, int C0, long ld0, const float* X1, const float* w1,
+            float* o1, long R1, int C1, long ld1, const float* X2, const float* w2, float* o2, long R2, int C2, long ld2,
+            float* scratch, hipStream_t st) {
+  ColJobs j;
+  j.n = 3;
+  const float* Xs[3] = {X0, X1, X2};
+  const float* ws[3] = {w0, w1, w2};
+  float* os[3] = {o0, o1, o2};
+  const long Rs[3] = {R0, R1, R2}, lds[3] = {ld0, ld1, ld2};
+  const int Cs[3] = {C0, C1, C2};
+  const int ns = 64;
+  long off = 0;
+  int maxC = 1;
+  for (int i = 0; i < 3; ++i) {
+    j.X[i] = Xs[i], j.w[i] = ws[i], j.out[i] = os[i], j.R[i] = Rs[i], j.ld[i] = lds[i], j.C[i] = Cs[i];
+    j.part_off[i] = off;
+    off += (long)ns * Cs[i];
+    if (Cs[i] > maxC) maxC = Cs[i];
+  }
+  {
+    ProfScope ps("colsum", st);
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3(cdiv(maxC, 64), ns, 3), dim3(256), 0, st, j, scratch, ns, 0);
+  }
+  if (int e = check_launch("colsum3/1")) return e;
+  ProfScope ps("colsum", st);
+  hipLaunchKernelGGL(colsum_multi_kernel, dim3(cdiv(maxC, 64), 1, 3), dim3(256), 0, st, j, scratch, ns, 1);
+  return check_launch("colsum3/2");
 }
 
 int gat_fold_fwd(const float* flat, float* uvc, int D, hipStream_t st) {

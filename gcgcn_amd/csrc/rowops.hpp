@@ -17,6 +17,9 @@ int rng_next(void* state, void* snaps, int count, hipStream_t st);
 long colsum_scratch_elems(long R, int C, int batch);
 int colsum(const float* X, const float* w, float* out, long R, int C, long ld, int batch, long sXz, long sWz, long sOz,
            int accumulate, float* scratch, hipStream_t st);
+int colsum3(const float* X0, const float* w0, float* o0, long R0, int C0, long ld0, const float* X1, const float* w1,
+            float* o1, long R1, int C1, long ld1, const float* X2, const float* w2, float* o2, long R2, int C2, long ld2,
+            float* scratch, hipStream_t st);
 int gat_fold_fwd(const float* flat, float* uvc, int D, hipStream_t st);
 int gat_fold_bwd(const float* flat, const float* duvc, float* dflat, int D, hipStream_t st);
 int node_score_fwd(const float* X, const float* uvc, float* s, long M, int D, hipStream_t st);

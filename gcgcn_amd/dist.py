@@ -1,17 +1,24 @@
 """Batch data-parallelism for the graph blocks: one process per GPU, documents sharded along the
-batch axis, ONE fp32 all-reduce (RCCL over xGMI through torch.distributed backend "nccl") of a single
-contiguous gradient bucket per step.
+batch axis, gradients summed with RCCL over xGMI through torch.distributed (backend "nccl").
 
 The reference has no distributed code at all; its "batch" is gradient accumulation
 over documents followed by one backward of ``total_loss / batch_size`` (config/Config.py:366-373).
 Summing per-rank gradients and dividing by the global document count reproduces exactly that.
 
-Because every block already keeps its parameters (and therefore its gradients) in one flat buffer,
-bucketing is a re-pointing of storage, not a copy: all ``.flat`` parameters become views of one
-parameter arena and all ``.flat.grad`` views of one gradient arena.  The HIP backward kernels write
-into fresh tensors that autograd accumulates into those views in place, so after ``backward()`` the
-arena IS the all-reduce operand.  ``linears_k.*`` never receive gradients (reference quirk) and are
-left out of the bucket on every rank alike.
+Every block keeps its parameters -- and therefore its gradient -- in ONE flat fp32 tensor in kernel
+layout (params.py), so the gradients ARE the buckets: no flattening copies, no per-tensor collectives
+(4 tensors for the whole path instead of the reference's 48 parameters).  The HIP backward writes a
+block's gradient into a fresh contiguous tensor that autograd installs as ``.grad`` without a copy
+(``.grad`` is reset to None each step), and
+
+* overlap=True (default for N > 1): a post-accumulate hook launches the asynchronous all-reduce of
+  that tensor the moment it exists, so the MAGGC gradient (the big one, 8.5 MB at cfg 2) travels
+  while the MHA / CAGGC / GAT backward kernels still run; ``all_reduce()`` only waits for the handles.
+  Every rank issues the collectives in the same (reverse-topological) order, as RCCL requires.
+* overlap=False: ``all_reduce()`` issues the collectives after backward and waits.
+
+``linears_k.*`` never receive gradients (reference quirk) and are skipped on every rank
+alike.
 """
 from __future__ import annotations
 
@@ -23,65 +30,44 @@ from torch import nn
 
 
 class FlatGradBucket:
-    """overlap=False: one all-reduce of the whole arena after backward (``all_reduce()``).
-    overlap=True : each block's slice is all-reduced asynchronously the moment autograd has finished
-    accumulating that block's gradient (post-accumulate hook), so the MAGGC gradients travel over xGMI while
-    the MHA / CAGGC / GAT backward kernels still run; ``all_reduce()`` then only waits for the handles.
-    Every rank issues the slices in the same (reverse-topological) order, as RCCL requires."""
-
     def __init__(self, module: nn.Module, process_group=None, overlap: bool = False):
         self.pg = process_group
         self.overlap = overlap
         self._pending = []
         self.params: List[nn.Parameter] = [p for n, p in module.named_parameters()
                                            if p.requires_grad and not n.endswith("flat_k")]
-        # every parameter starts on a 256-byte boundary so the GEMM kernels keep their 16-byte vector loads
-        pad = lambda n: (n + 63) // 64 * 64
-        total = sum(pad(p.numel()) for p in self.params)
-        dev = self.params[0].device
-        self.param_arena = torch.empty(total, device=dev, dtype=torch.float32)
-        self.grad_arena = torch.zeros(total, device=dev, dtype=torch.float32)
-        off = 0
-        with torch.no_grad():
+        self.numel = sum(p.numel() for p in self.params)
+        if overlap:
             for p in self.params:
-                n = p.numel()
-                self.param_arena[off:off + n].copy_(p.reshape(-1))
-                p.data = self.param_arena[off:off + n].view_as(p)
-                p.grad = self.grad_arena[off:off + n].view_as(p)
-                if overlap:
-                    p.register_post_accumulate_grad_hook(self._make_hook(off, n))
-                off += pad(n)
-        self.numel = total
+                p.register_post_accumulate_grad_hook(self._hook)
 
     def _distributed(self) -> bool:
         return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1
 
-    def _make_hook(self, off: int, n: int):
-        def hook(param):
-            if self._distributed():
-                self._pending.append(dist.all_reduce(self.grad_arena[off:off + n], op=dist.ReduceOp.SUM,
-                                                     group=self.pg, async_op=True))
-        return hook
+    def _hook(self, param):
+        if self._distributed():
+            self._pending.append(dist.all_reduce(param.grad, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def zero_grad(self):
-        self.grad_arena.zero_()
-        for p in self.params:          # keep the views attached (zero_grad(set_to_none=True) would detach them)
-            if p.grad is None:
-                raise RuntimeError("FlatGradBucket: a gradient view was detached; do not set grads to None")
+        """Drop the gradients: the next backward installs its freshly written flat tensors without any
+        accumulate kernel."""
+        for p in self.params:
+            p.grad = None
 
-    def all_reduce(self, global_docs: Optional[int] = None, async_op: bool = False):
-        """Sum gradients over ranks (in place, one collective); optionally divide by the global document count
-        (the reference's total_loss / batch_size)."""
-        work = None
-        if self.overlap:
-            for w in self._pending:      # the slices were launched from the backward hooks
+    def all_reduce(self, global_docs: Optional[int] = None):
+        """Sum gradients over ranks in place; optionally divide by the global document count (the reference's
+        total_loss / batch_size)."""
+        if self._distributed():
+            if not self.overlap:
+                self._pending = [dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                                 for p in self.params if p.grad is not None]
+            for w in self._pending:
                 w.wait()
-            self._pending.clear()
-        elif self._distributed():
-            work = dist.all_reduce(self.grad_arena, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
-        if global_docs is not None and not async_op:
-            self.grad_arena.div_(float(global_docs))
-        return work
+        self._pending.clear()
+        if global_docs is not None:
+            for p in self.params:
+                if p.grad is not None:
+                    p.grad.div_(float(global_docs))
 
 
 def shard_batch(tensors: Iterable[torch.Tensor], rank: int, world: int) -> List[torch.Tensor]:

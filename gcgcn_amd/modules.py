@@ -342,21 +342,26 @@ class GraphHops(nn.Module):
         # anything computed here: stream those HBM-bound passes on a side stream while the CAGGC hop's
         # matrix work runs (autograd replays the same placement for the dE broadcast in backward).
         pre = {}
-        if x.is_cuda and self.graph_hop > 1 and self.overlap_edge_mean:
+
+        def fork_edge_means():
+            # side stream (lowest priority): starts after everything enqueued so far, i.e. after GATAttention's own
+            # pass over E1, so the two HBM streams do not compete
             cur = torch.cuda.current_stream()
             side = self._side_stream(x.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 for i in range(1, self.graph_hop):
-                    e = edge_feats[i]
-                    eb, _ = _batched(e, 3)
+                    eb, _ = _batched(edge_feats[i], 3)
                     pre[i] = F_.edge_mean(eb, n_valid)
+
         for i in range(self.graph_hop):
             e = edge_feats[i]
             if i < 1:
                 # glove:330 builds mask = eq(adj_matrix, 0) and glove:163-164 then discards it; the mask is
                 # not even materialised here (adj_matrix is accepted for signature compatibility only)
                 a = self.get_weighted_adj_matrix(x, e, None, n_valid=n_valid)                # glove:332
+                if x.is_cuda and self.graph_hop > 1 and self.overlap_edge_mean:
+                    fork_edge_means()
                 new = self.graphcnn[i](x, e, a, n_valid=n_valid)                             # glove:333
             else:
                 al = self.get_adj_matrix[i - 1](x, e, n_valid=n_valid)                       # glove:336
@@ -379,5 +384,6 @@ class GraphHops(nn.Module):
     def _side_stream(cls, dev):
         key = (dev.type, dev.index)
         if key not in cls._streams:
-            cls._streams[key] = torch.cuda.Stream(device=dev)
+            lo, _hi = torch.cuda.Stream.priority_range()
+            cls._streams[key] = torch.cuda.Stream(device=dev, priority=lo)
         return cls._streams[key]

@@ -40,7 +40,7 @@ def _worker_overlap(rank, world, port, out):
         for i, p in enumerate(bucket.params):
             want = (1 + 2) * (i + 1) / 4.0
             assert torch.allclose(p.grad, torch.full_like(p, want)), (i, p.grad.flatten()[:3])
-        # second step: zero_grad keeps the views and the hooks alive
+        # second step: zero_grad drops the tensors, the hooks stay
         bucket.zero_grad()
         loss = sum((p * 2.0).sum() for p in bucket.params)
         loss.backward()
@@ -55,36 +55,25 @@ def _worker_overlap(rank, world, port, out):
 
 
 def _worker(rank, world, port, out):
+    """overlap=False: the per-block flat gradients are all-reduced after backward."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.manual_seed(1337)                                   # identical replicas
         hops = gcgcn_amd.GraphHops(16, 2, 4)
-        before = {k: v.clone() for k, v in hops.state_dict().items()}
         bucket = FlatGradBucket(hops)
-        # re-pointing storage must not change any parameter value or the state_dict
-        after = hops.state_dict()
-        assert all(torch.equal(before[k], after[k]) for k in before)
-        assert bucket.numel >= sum(p.numel() for n, p in hops.named_parameters() if not n.endswith("flat_k"))
-        for p in bucket.params:                                   # views, not copies
-            assert p.data_ptr() >= bucket.param_arena.data_ptr()
-            assert p.grad.data_ptr() >= bucket.grad_arena.data_ptr()
-            assert (p.data_ptr() - bucket.param_arena.data_ptr()) % 256 == 0
-        # synthetic per-rank gradients, accumulated in place the way autograd's AccumulateGrad does
+        assert bucket.numel == sum(p.numel() for n, p in hops.named_parameters() if not n.endswith("flat_k"))
+        assert len(bucket.params) == 4                            # gat, caggc conv, mha, maggc conv
         bucket.zero_grad()
-        for i, p in enumerate(bucket.params):
-            p.grad.add_(torch.full_like(p, float((rank + 1) * (i + 1))))
+        assert all(p.grad is None for p in bucket.params)
+        loss = sum((p * float((rank + 1) * (i + 1))).sum() for i, p in enumerate(bucket.params))
+        loss.backward()
         bucket.all_reduce(global_docs=4)
         for i, p in enumerate(bucket.params):
             want = (1 + 2) * (i + 1) / 4.0                          # sum over ranks / global batch
             assert torch.allclose(p.grad, torch.full_like(p, want)), (i, p.grad.flatten()[:3])
         assert hops.get_adj_matrix[0].flat_k.grad is None         # linears_k stay out of the bucket
-        # an optimiser step on the views moves the arena
-        opt = torch.optim.SGD(bucket.params, lr=1.0)
-        a0 = bucket.param_arena.clone()
-        opt.step()
-        assert not torch.equal(a0, bucket.param_arena)
         # batch sharding
         x = torch.arange(8.0).view(8, 1)
         (xs,) = shard_batch([x], rank, world)
