@@ -68,6 +68,14 @@ __device__ __forceinline__ void store_tile(const float (&r)[BMN / 32][4], float*
   }
 }
 
+// Compile-time epilogue feature mask: a product that is known not to use a feature does not even compile
+// its branch (the chain kernels inline ten tile bodies; with every option live in each, they are
+// instruction-fetch bound).  EPI_ALL keeps every feature behind its run-time flag.
+enum : int {
+  EPI_ADD = 1, EPI_BIAS = 2, EPI_ROWADD = 4, EPI_ROWSCALE = 8, EPI_RELU = 16, EPI_ACCUM = 32, EPI_NVALID = 64,
+  EPI_C2 = 128, EPI_ALPHA = 256, EPI_ALL = 511
+};
+
 // One output element through the fused epilogue (order documented in gemm.hpp).
 struct Epi {
   float* C;
@@ -129,10 +137,15 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, const Epi& e, int r
 // 4 round trips); EG = 16 for the chain kernels (one workgroup per CU: nothing else hides latency).
 // Offsets are 32-bit on purpose: uniform base + 32-bit lane offset addressing keeps the gather to one
 // VGPR per load instead of a 64-bit address pair (a [rows x ld] slice of this path is < 2^31 elements).
-template <bool ALIGNED, int EG>
+template <bool ALIGNED, int EG, int MASK>
 __device__ __forceinline__ void epi_tile(const GemmArgs& g, const Epi& e, const int row0, const int col, const f32x16& acc) {
   if (!ALIGNED && col >= g.N) return;
-  const float bias = g.bias ? g.bias[col] : 0.f;
+  const bool hadd = (MASK & EPI_ADD) && e.add, hra = (MASK & EPI_ROWADD) && e.rowadd;
+  const bool hrs = (MASK & EPI_ROWSCALE) && e.rowscale, hacc = (MASK & EPI_ACCUM) && g.accumulate;
+  const bool hc2 = (MASK & EPI_C2) && e.C2, ha2 = hc2 && e.add2, hnv = (MASK & EPI_NVALID) && g.n_valid;
+  const bool hrelu = (MASK & EPI_RELU) && g.relu;
+  const float bias = ((MASK & EPI_BIAS) && g.bias) ? g.bias[col] : 0.f;
+  const float alpha = (MASK & EPI_ALPHA) ? g.alpha : 1.f;
   const unsigned ldadd = (unsigned)g.ldadd, ldc = (unsigned)g.ldc, ldadd2 = (unsigned)g.ldadd2, ldc2 = (unsigned)g.ldc2;
 #pragma unroll
   for (int q0 = 0; q0 < 16; q0 += EG) {
@@ -145,12 +158,12 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, const Epi& e, const 
       ok[u] = ALIGNED || (int)row < g.M;
       addv[u] = 0.f, accv[u] = 0.f, a2v[u] = 0.f, rsv[u] = 1.f, rav[u] = 0.f, pad[u] = false;
       if (ok[u]) {
-        if (e.add) addv[u] = e.add[row * ldadd + (unsigned)col];
-        if (e.rowadd) rav[u] = e.rowadd[row];
-        if (e.rowscale) rsv[u] = e.rowscale[row];
-        if (g.accumulate) accv[u] = e.C[row * ldc + (unsigned)col];
-        if (e.add2) a2v[u] = e.add2[row * ldadd2 + (unsigned)col];
-        if (g.n_valid) pad[u] = ((int)row % g.nv_rows) >= g.n_valid[e.z1 * g.nv_zdoc + (int)row / g.nv_rows];
+        if (hadd) addv[u] = e.add[row * ldadd + (unsigned)col];
+        if (hra) rav[u] = e.rowadd[row];
+        if (hrs) rsv[u] = e.rowscale[row];
+        if (hacc) accv[u] = e.C[row * ldc + (unsigned)col];
+        if (ha2) a2v[u] = e.add2[row * ldadd2 + (unsigned)col];
+        if (hnv) pad[u] = ((int)row % g.nv_rows) >= g.n_valid[e.z1 * g.nv_zdoc + (int)row / g.nv_rows];
       }
     }
 #pragma unroll
@@ -158,12 +171,12 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, const Epi& e, const 
       if (!ok[u]) continue;
       const int r = q0 + u;
       const unsigned row = (unsigned)(row0 + (r & 3) + 8 * (r >> 2));
-      float v = (g.alpha * acc[r] + addv[u] + bias + rav[u]) * rsv[u];
-      if (g.relu) v = fmaxf(v, 0.f);
+      float v = (alpha * acc[r] + addv[u] + bias + rav[u]) * rsv[u];
+      if (hrelu) v = fmaxf(v, 0.f);
       v += accv[u];
       if (pad[u]) v = 0.f;
       e.C[row * ldc + (unsigned)col] = v;
-      if (e.C2) {
+      if (hc2) {
         const unsigned o2 = row * ldc2 + (unsigned)col;
         float w = v;
         if (e.dodrop)
@@ -176,7 +189,7 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, const Epi& e, const 
   }
 }
 
-template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED, int EG = 4>
+template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED, int EG = 4, int MASK = EPI_ALL>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__ lds, const int bx, const int by,
                                           const int zs) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -285,11 +298,21 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
     return;
   }
   const Epi e = make_epi(g, z1, z2);
+  if (MASK == EPI_ALL && !(g.add || g.bias || g.rowadd || g.rowscale || g.relu || g.accumulate || g.n_valid || g.C2) &&
+      g.alpha == 1.f) {
+    // the common case of the stand-alone kernels (weight / data gradients): a bare store
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        epi_tile<ALIGNED, EG, 0>(g, e, m0 + (wr * TM + i) * 32 + 4 * lh, n0 + (wc * TN + j) * 32 + l31, acc[i][j]);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
-      epi_tile<ALIGNED, EG>(g, e, m0 + (wr * TM + i) * 32 + 4 * lh, n0 + (wc * TN + j) * 32 + l31, acc[i][j]);
+      epi_tile<ALIGNED, EG, MASK>(g, e, m0 + (wr * TM + i) * 32 + 4 * lh, n0 + (wc * TN + j) * 32 + l31, acc[i][j]);
 }
 
 template <int TM, int TN, bool AKC, bool BKC>
