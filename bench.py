@@ -111,6 +111,13 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="stream the E2 mean on a side stream (A/B; default off)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON).  This image's RCCL writes a version banner (and, at
+    # NCCL_DEBUG=WARN, warnings) to fd 1 when the communicator is created, so fd 1 is pointed at stderr for
+    # the whole run and the JSON goes to a saved copy of the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,9 +131,11 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
-    if world > 1:
+    force_dist = os.environ.get("GCGCN_FORCE_DIST") == "1"      # 1-rank RCCL group: exercises the N > 1 code path
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     import gcgcn_amd
     from gcgcn_amd import _lib
@@ -138,7 +147,7 @@ def main():
     hops = gcgcn_amd.GraphHops(D, L, H).to(dev).train()
     hops.overlap_edge_mean = args.overlap
     gcgcn_amd.manual_seed(1337 + rank, dev)
-    bucket = FlatGradBucket(hops, overlap=world > 1)   # N > 1: gradient slices travel while backward still runs
+    bucket = FlatGradBucket(hops, overlap=world > 1 or force_dist)   # N > 1: gradient slices travel while backward still runs
     x, e1, e2, adj = synth(cfg, 1337 + rank, dev)
     for t in (x, e1, e2):
         t.requires_grad_()
@@ -167,11 +176,11 @@ def main():
             graph.replay()
         else:
             fwd_bwd()
-        if world > 1:
+        if world > 1 or force_dist:
             bucket.all_reduce()
 
     def sync():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -228,7 +237,7 @@ def main():
         _lib.call("gcgcn_prof_stop", ctypes.byref(kms), ctypes.byref(kn), ctypes.byref(kw))
 
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
 
@@ -277,8 +286,9 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        real_stdout.write(json.dumps(line) + "\n")
+        real_stdout.flush()
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

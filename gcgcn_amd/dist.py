@@ -22,6 +22,7 @@ alike.
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, List, Optional
 
 import torch
@@ -42,7 +43,10 @@ class FlatGradBucket:
                 p.register_post_accumulate_grad_hook(self._hook)
 
     def _distributed(self) -> bool:
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1
+        # GCGCN_FORCE_DIST=1: issue the collectives even in a 1-rank group (exercises the RCCL path on one GPU)
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size(self.pg) > 1 or os.environ.get("GCGCN_FORCE_DIST") == "1"
 
     def _hook(self, param):
         if self._distributed():
