@@ -147,6 +147,13 @@ static int pick_splits(int K, long work) {
 static int prepare(GemmArgs& g, int tile, int splits, long group_work) {
   if (!(g.A && g.B && g.C)) { set_error("gemm: null operand"); return -1; }
   if (!(g.M >= 0 && g.N >= 0 && g.K >= 1 && g.batch1 >= 1 && g.batch2 >= 1)) { set_error("gemm: bad shape"); return -1; }
+  {  // the epilogue addresses one (batch entry's) [M x ld] slice with 32-bit offsets
+    long ldmax = g.ldc;
+    if (g.add && g.ldadd > ldmax) ldmax = g.ldadd;
+    if (g.C2 && g.ldc2 > ldmax) ldmax = g.ldc2;
+    if (g.add2 && g.ldadd2 > ldmax) ldmax = g.ldadd2;
+    if ((long)g.M * ldmax >= (1L << 32)) { set_error("gemm: M * ld = %ld exceeds 32-bit epilogue offsets", (long)g.M * ldmax); return -1; }
+  }
   const long nb = (long)g.batch1 * g.batch2;
   g.vecA = aligned16(g.A) && g.lda % 4 == 0 && g.sA1 % 4 == 0 && g.sA2 % 4 == 0;
   g.vecB = aligned16(g.B) && g.ldb % 4 == 0 && g.sB1 % 4 == 0 && g.sB2 % 4 == 0;
