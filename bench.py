@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--prof-kernel", default="auto",
                     help="kernel family timed with HIP events inside the timed region (auto = the one with the largest time share)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--early-mean", action="store_true", help="issue the E2 mean before GATAttention (A/B; default off)")
     ap.add_argument("--overlap", action="store_true", help="stream the E2 mean on a side stream (A/B; default off)")
     args = ap.parse_args()
 
@@ -146,6 +147,7 @@ def main():
     torch.manual_seed(1337)                       # identical parameters on every rank
     hops = gcgcn_amd.GraphHops(D, L, H).to(dev).train()
     hops.overlap_edge_mean = args.overlap
+    hops.early_edge_mean = args.early_mean
     gcgcn_amd.manual_seed(1337 + rank, dev)
     bucket = FlatGradBucket(hops, overlap=world > 1 or force_dist)   # N > 1: gradient slices travel while backward still runs
     x, e1, e2, adj = synth(cfg, 1337 + rank, dev)

@@ -39,7 +39,7 @@ __device__ __forceinline__ void vstore(float* p, const float (&r)[VEC]) {
 }
 
 constexpr int EW = 4;    // waves per workgroup
-constexpr int EUNR = 4;  // rows in flight per wave
+constexpr int EUNR = 4;  // rows in flight per wave (8 was tried: no faster in the step, 152 VGPRs in edge_bwd)
 
 // ---------------------------------------------------------------------------------------------
 // forward: Ebar (always) and raw logits v.e_ij (ATT only).  dynamic LDS: EW * D floats.

@@ -354,6 +354,14 @@ class GraphHops(nn.Module):
                     eb, _ = _batched(edge_feats[i], 3)
                     pre[i] = F_.edge_mean(eb, n_valid)
 
+        if x.is_cuda and self.graph_hop > 1 and self.early_edge_mean and not self.overlap_edge_mean:
+            # Same stream, just earlier: the E means of the MAGGC hops depend on nothing computed here.  Issued first,
+            # they run back to back with GATAttention's own pass over E1 (HBM clocks already up), and their autograd
+            # nodes are the oldest of the step, so the dE broadcasts run last in backward, next to the dE1 kernel.
+            for i in range(1, self.graph_hop):
+                eb, _ = _batched(edge_feats[i], 3)
+                pre[i] = F_.edge_mean(eb, n_valid)
+
         for i in range(self.graph_hop):
             e = edge_feats[i]
             if i < 1:
@@ -366,8 +374,9 @@ class GraphHops(nn.Module):
             else:
                 al = self.get_adj_matrix[i - 1](x, e, n_valid=n_valid)                       # glove:336
                 if i in pre:
-                    torch.cuda.current_stream().wait_stream(self._side_stream(x.device))
-                    pre[i].record_stream(torch.cuda.current_stream())
+                    if self.overlap_edge_mean:
+                        torch.cuda.current_stream().wait_stream(self._side_stream(x.device))
+                        pre[i].record_stream(torch.cuda.current_stream())
                     F_.park_edge_mean(e, n_valid, pre.pop(i))
                 new = self.graphcnn[i](x, e, al, n_valid=n_valid)                            # glove:337
             x = new if self.alpha == 1.0 else self.alpha * new + (1 - self.alpha) * x        # glove:339
@@ -378,6 +387,9 @@ class GraphHops(nn.Module):
     # measured on MI355X (cfg 2): 1.005 ms/step with the side stream vs 0.935 without -- the HBM stream slows the
     # latency-bound kernels it overlaps and the cross-stream waits cost more than the 40 us they hide.  Off.
     overlap_edge_mean = False
+    # measured: issuing the E2 mean before GATAttention evicts E1 from the Infinity Cache (left there by the previous
+    # step's backward): edge_fwd_att 31 -> 52 us, step 0.883 -> 0.892 ms.  Off.
+    early_edge_mean = False
     _streams = {}
 
     @classmethod
