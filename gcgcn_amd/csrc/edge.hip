@@ -16,6 +16,8 @@
 //
 // Ragged batches: n_valid[b] <= N entities are real; padding rows/columns are neither read nor
 // averaged, and their outputs are zero.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace gc {
@@ -35,6 +37,31 @@ __device__ __forceinline__ void vstore(float* p, const float (&r)[VEC]) {
     *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
   } else {
     p[0] = r[0];
+  }
+}
+
+// Streaming variants: dE is written once and never read on this path, E of a mean-only hop is read once per
+// step.  Non-temporal accesses keep them from displacing E1 (re-read by the next forward) and the GEMM
+// operands in the 256 MiB Infinity Cache.
+template <int VEC>
+__device__ __forceinline__ void vload_nt(float (&r)[VEC], const float* p) {
+  if constexpr (VEC == 4) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
+    r[0] = v.x, r[1] = v.y, r[2] = v.z, r[3] = v.w;
+  } else {
+    r[0] = __builtin_nontemporal_load(p);
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void vstore_nt(float* p, const float (&r)[VEC]) {
+  if constexpr (VEC == 4) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 v;
+    v.x = r[0], v.y = r[1], v.z = r[2], v.w = r[3];
+    __builtin_nontemporal_store(v, reinterpret_cast<f4*>(p));
+  } else {
+    __builtin_nontemporal_store(r[0], p);
   }
 }
 
@@ -83,7 +110,10 @@ __global__ __launch_bounds__(64 * EW) void edge_fwd_kernel(const float* __restri
       for (int u = 0; u < EUNR; ++u) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) x[u][e] = 0.f;
-        if (act) vload<VEC>(x[u], Er + (long)(j + u * EW) * D + c);
+        if (act) {
+          if (ATT) vload<VEC>(x[u], Er + (long)(j + u * EW) * D + c);
+          else vload_nt<VEC>(x[u], Er + (long)(j + u * EW) * D + c);
+        }
       }
 #pragma unroll
       for (int u = 0; u < EUNR; ++u) {
@@ -164,7 +194,7 @@ __global__ __launch_bounds__(64 * EW) void edge_bwd_kernel(const float* __restri
                                                            const int* __restrict__ n_valid,
                                                            const float* __restrict__ dlogit,
                                                            const float* __restrict__ dEbar, float* __restrict__ dE,
-                                                           float* __restrict__ dvpart, int N, int D) {
+                                                           float* __restrict__ dvpart, int N, int D, int nt) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* dl = sm;                    // [N]
   float* cs = sm + ((N + 3) & ~3);   // [EW][D]
@@ -219,7 +249,10 @@ __global__ __launch_bounds__(64 * EW) void edge_bwd_kernel(const float* __restri
           acc[e] = fmaf(d, x[u][e], acc[e]);
           o[e] = fmaf(d, vr[e], g[e]);
         }
-        if (dEr && act) vstore<VEC>(dEr + (long)(j + u * EW) * D + c, o);
+        if (dEr && act) {
+          if (nt) vstore_nt<VEC>(dEr + (long)(j + u * EW) * D + c, o);
+          else vstore<VEC>(dEr + (long)(j + u * EW) * D + c, o);
+        }
       }
     }
     for (; j < nv; j += EW) {
@@ -233,7 +266,10 @@ __global__ __launch_bounds__(64 * EW) void edge_bwd_kernel(const float* __restri
         acc[e] = fmaf(d, x[e], acc[e]);
         o[e] = fmaf(d, vr[e], g[e]);
       }
-      if (dEr && act) vstore<VEC>(dEr + (long)j * D + c, o);
+      if (dEr && act) {
+        if (nt) vstore_nt<VEC>(dEr + (long)j * D + c, o);
+        else vstore<VEC>(dEr + (long)j * D + c, o);
+      }
     }
     if (dEr && act) {  // padding columns of a real row
       float z[VEC];
@@ -258,7 +294,7 @@ __global__ __launch_bounds__(64 * EW) void edge_bwd_kernel(const float* __restri
 template <int VEC>
 __global__ __launch_bounds__(64 * EW) void edge_bcast_kernel(const float* __restrict__ dEbar,
                                                              const int* __restrict__ n_valid, float* __restrict__ dE,
-                                                             int N, int D) {
+                                                             int N, int D, int nt) {
   const int bi = blockIdx.x;
   const int b = bi / N, i = bi - b * N;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -275,8 +311,9 @@ __global__ __launch_bounds__(64 * EW) void edge_bcast_kernel(const float* __rest
 #pragma unroll
     for (int e = 0; e < VEC; ++e) g[e] *= inv, z[e] = 0.f;
     for (int j = wave; j < N; j += EW) {
-      if (!rowpad && j < nv) vstore<VEC>(dEr + (long)j * D + c, g);
-      else vstore<VEC>(dEr + (long)j * D + c, z);
+      const bool live = !rowpad && j < nv;
+      if (nt) vstore_nt<VEC>(dEr + (long)j * D + c, live ? g : z);
+      else vstore<VEC>(dEr + (long)j * D + c, live ? g : z);
     }
   }
 }
@@ -285,6 +322,17 @@ __global__ __launch_bounds__(64 * EW) void edge_bcast_kernel(const float* __rest
 // host launchers
 // ---------------------------------------------------------------------------------------------
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+// GCGCN_NT_STORE=1 switches the dE stores to non-temporal (A/B knob).  Measured in the step (cfg 2): E1 then
+// survives in the Infinity Cache (edge_fwd_att 31 -> 27 us) but the stores themselves get slower (edge_bwd 56 -> 69 us,
+// edge_bcast 24 -> 26 us): 0.873 vs 0.867 ms per step.  Off.  (The non-temporal E2 LOADS of the mean-only pass stay:
+// edge_fwd_mean 43 -> 25 us.)
+static int nt_store() {
+  static const int v = [] {
+    const char* e = getenv("GCGCN_NT_STORE");
+    return (e && e[0] == '1') ? 1 : 0;
+  }();
+  return v;
+}
 
 int edge_fwd(const float* E, const float* v, const int* n_valid, float* Ebar, const float* coladd, float* P, float* A,
              Drop drop, int B, int N, int D, hipStream_t st) {
@@ -316,9 +364,9 @@ int edge_bwd(const float* E, const float* v, const int* n_valid, const float* dl
   dim3 grid((unsigned)((long)B * N)), block(64 * EW);
   ProfScope ps("edge_bwd", st, (dE ? 8.0 : 4.0) * B * N * N * D);
   if (vec)
-    hipLaunchKernelGGL((edge_bwd_kernel<4>), grid, block, lds, st, E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D);
+    hipLaunchKernelGGL((edge_bwd_kernel<4>), grid, block, lds, st, E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D, nt_store());
   else
-    hipLaunchKernelGGL((edge_bwd_kernel<1>), grid, block, lds, st, E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D);
+    hipLaunchKernelGGL((edge_bwd_kernel<1>), grid, block, lds, st, E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D, nt_store());
   return check_launch("edge_bwd");
 }
 
@@ -327,8 +375,8 @@ int edge_bcast(const float* dEbar, const int* n_valid, float* dE, int B, int N, 
   const bool vec = (D % 4 == 0) && al16(dE) && al16(dEbar);
   dim3 grid((unsigned)((long)B * N)), block(64 * EW);
   ProfScope ps("edge_bcast", st, 4.0 * B * N * N * D);
-  if (vec) hipLaunchKernelGGL((edge_bcast_kernel<4>), grid, block, 0, st, dEbar, n_valid, dE, N, D);
-  else hipLaunchKernelGGL((edge_bcast_kernel<1>), grid, block, 0, st, dEbar, n_valid, dE, N, D);
+  if (vec) hipLaunchKernelGGL((edge_bcast_kernel<4>), grid, block, 0, st, dEbar, n_valid, dE, N, D, nt_store());
+  else hipLaunchKernelGGL((edge_bcast_kernel<1>), grid, block, 0, st, dEbar, n_valid, dE, N, D, nt_store());
   return check_launch("edge_bcast");
 }
 
