@@ -73,7 +73,7 @@ constexpr int EUNR = 4;  // rows in flight per wave (8 was tried: no faster in t
 // ---------------------------------------------------------------------------------------------
 // ATT: logits stay in LDS; the row's softmax (+ coladd[b, j] = u.x_j + c, + dropout) is finished by
 // wave 0 in the same launch (GATAttention glove:162-167), so P/A are the only attention outputs.
-template <int VEC, bool ATT>
+template <int VEC, bool ATT, bool NTL>
 __global__ __launch_bounds__(64 * EW) void edge_fwd_kernel(const float* __restrict__ E, const float* __restrict__ v,
                                                            const int* __restrict__ n_valid, float* __restrict__ Ebar,
                                                            const float* __restrict__ coladd, float* __restrict__ P,
@@ -111,8 +111,8 @@ __global__ __launch_bounds__(64 * EW) void edge_fwd_kernel(const float* __restri
 #pragma unroll
         for (int e = 0; e < VEC; ++e) x[u][e] = 0.f;
         if (act) {
-          if (ATT) vload<VEC>(x[u], Er + (long)(j + u * EW) * D + c);
-          else vload_nt<VEC>(x[u], Er + (long)(j + u * EW) * D + c);
+          if (NTL) vload_nt<VEC>(x[u], Er + (long)(j + u * EW) * D + c);
+          else vload<VEC>(x[u], Er + (long)(j + u * EW) * D + c);
         }
       }
 #pragma unroll
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64 * EW) void edge_fwd_kernel(const float* __restri
 // backward of the CAGGC hop: dE = dlogit (x) v + dEbar / n ;  dv partial per workgroup.
 // dynamic LDS: N + EW * D floats.
 // ---------------------------------------------------------------------------------------------
-template <int VEC>
+template <int VEC, bool NTL>
 __global__ __launch_bounds__(64 * EW) void edge_bwd_kernel(const float* __restrict__ E, const float* __restrict__ v,
                                                            const int* __restrict__ n_valid,
                                                            const float* __restrict__ dlogit,
@@ -238,7 +238,10 @@ __global__ __launch_bounds__(64 * EW) void edge_bwd_kernel(const float* __restri
       for (int u = 0; u < EUNR; ++u) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) x[u][e] = 0.f;
-        if (act) vload<VEC>(x[u], Er + (long)(j + u * EW) * D + c);
+        if (act) {
+          if (NTL) vload_nt<VEC>(x[u], Er + (long)(j + u * EW) * D + c);
+          else vload<VEC>(x[u], Er + (long)(j + u * EW) * D + c);
+        }
       }
 #pragma unroll
       for (int u = 0; u < EUNR; ++u) {
@@ -326,6 +329,13 @@ static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 // survives in the Infinity Cache (edge_fwd_att 31 -> 27 us) but the stores themselves get slower (edge_bwd 56 -> 69 us,
 // edge_bcast 24 -> 26 us): 0.873 vs 0.867 ms per step.  Off.  (The non-temporal E2 LOADS of the mean-only pass stay:
 // edge_fwd_mean 43 -> 25 us.)
+static int nt_e1() {
+  static const int v = [] {
+    const char* e = getenv("GCGCN_NT_E1");
+    return (e && e[0] == '1') ? 1 : 0;
+  }();
+  return v;
+}
 static int nt_store() {
   static const int v = [] {
     const char* e = getenv("GCGCN_NT_STORE");
@@ -345,13 +355,19 @@ int edge_fwd(const float* E, const float* v, const int* n_valid, float* Ebar, co
   GC_REQUIRE(lds <= 160 * 1024, "edge_fwd: N=%d D=%d needs %zu B of LDS", N, D, lds);
   dim3 grid((unsigned)((long)B * N)), block(64 * EW);
   ProfScope ps(att ? "edge_fwd_att" : "edge_fwd_mean", st, 4.0 * B * N * N * D);
+  // the mean-only pass reads E once per step: always non-temporal.  The attention pass over E1 keeps ordinary
+  // loads by default (part of E1 is still in the Infinity Cache from the previous backward); GCGCN_NT_E1=1 streams it too.
+  const bool ntl = !att || nt_e1();
+#define GC_EDGE_FWD(V, AT, NT) \
+  hipLaunchKernelGGL((edge_fwd_kernel<V, AT, NT>), grid, block, lds, st, E, v, n_valid, Ebar, coladd, P, A, drop, N, D)
   if (vec) {
-    if (att) hipLaunchKernelGGL((edge_fwd_kernel<4, true>), grid, block, lds, st, E, v, n_valid, Ebar, coladd, P, A, drop, N, D);
-    else hipLaunchKernelGGL((edge_fwd_kernel<4, false>), grid, block, lds, st, E, v, n_valid, Ebar, coladd, P, A, drop, N, D);
+    if (att) { if (ntl) GC_EDGE_FWD(4, true, true); else GC_EDGE_FWD(4, true, false); }
+    else GC_EDGE_FWD(4, false, true);
   } else {
-    if (att) hipLaunchKernelGGL((edge_fwd_kernel<1, true>), grid, block, lds, st, E, v, n_valid, Ebar, coladd, P, A, drop, N, D);
-    else hipLaunchKernelGGL((edge_fwd_kernel<1, false>), grid, block, lds, st, E, v, n_valid, Ebar, coladd, P, A, drop, N, D);
+    if (att) { if (ntl) GC_EDGE_FWD(1, true, true); else GC_EDGE_FWD(1, true, false); }
+    else GC_EDGE_FWD(1, false, true);
   }
+#undef GC_EDGE_FWD
   return check_launch("edge_fwd");
 }
 
@@ -363,10 +379,11 @@ int edge_bwd(const float* E, const float* v, const int* n_valid, const float* dl
   GC_REQUIRE(lds <= 160 * 1024, "edge_bwd: N=%d D=%d needs %zu B of LDS", N, D, lds);
   dim3 grid((unsigned)((long)B * N)), block(64 * EW);
   ProfScope ps("edge_bwd", st, (dE ? 8.0 : 4.0) * B * N * N * D);
-  if (vec)
-    hipLaunchKernelGGL((edge_bwd_kernel<4>), grid, block, lds, st, E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D, nt_store());
-  else
-    hipLaunchKernelGGL((edge_bwd_kernel<1>), grid, block, lds, st, E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D, nt_store());
+#define GC_EDGE_BWD(V, NT) \
+  hipLaunchKernelGGL((edge_bwd_kernel<V, NT>), grid, block, lds, st, E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D, nt_store())
+  if (vec) { if (nt_e1()) GC_EDGE_BWD(4, true); else GC_EDGE_BWD(4, false); }
+  else { if (nt_e1()) GC_EDGE_BWD(1, true); else GC_EDGE_BWD(1, false); }
+#undef GC_EDGE_BWD
   return check_launch("edge_bwd");
 }
 

@@ -63,41 +63,52 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroup gg) {
   }
 }
 
+// Split-K reduce: one thread sums the partials of 4 consecutive outputs (16-byte loads, split order => bitwise
+// reproducible) and runs the epilogue.  N % 4 == 0 is guaranteed for split problems (they are interior shapes).
+__device__ __forceinline__ void reduce4(const GemmArgs& g, int z, long idx4) {
+  const long mn = (long)g.M * g.N;
+  const long idx = idx4 * 4;
+  if (idx >= mn) return;
+  const long nb = (long)g.batch1 * g.batch2;
+  const float4* w = reinterpret_cast<const float4*>(g.ws + (long)z * mn + idx);
+  const long stride4 = nb * mn / 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < g.splits; ++s) {
+    const float4 v = w[(long)s * stride4];
+    acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+  }
+  const int row = (int)(idx / g.N), col = (int)(idx - (long)row * g.N);
+  const int z1 = z / g.batch2, z2 = z - z1 * g.batch2;
+  if (!(g.add || g.bias || g.rowadd || g.rowscale || g.relu || g.accumulate || g.n_valid || g.C2) && g.alpha == 1.f) {
+    float* c = g.C + z1 * g.sC1 + z2 * g.sC2 + (long)row * g.ldc + col;
+    if ((((uintptr_t)c) & 15) == 0) {
+      *reinterpret_cast<float4*>(c) = acc;
+    } else {
+      c[0] = acc.x, c[1] = acc.y, c[2] = acc.z, c[3] = acc.w;
+    }
+    return;
+  }
+  const Epi e = make_epi(g, z1, z2);
+  epi_store(g, e, row, col, acc.x);
+  epi_store(g, e, row, col + 1, acc.y);
+  epi_store(g, e, row, col + 2, acc.z);
+  epi_store(g, e, row, col + 3, acc.w);
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const GemmGroup gg) {
   int b = blockIdx.x, i = 0;
   while (i + 1 < gg.nprob && b >= gg.red_begin[i + 1]) ++i;
   b -= gg.red_begin[i];
   const GemmArgs& g = gg.p[i];
   if (g.splits <= 1) return;
-  const long mn = (long)g.M * g.N;
-  const int per = (int)((mn + 255) / 256);
+  const int per = (int)(((long)g.M * g.N / 4 + 255) / 256);
   const int z = b / per;
-  const long idx = (long)(b - z * per) * 256 + threadIdx.x;
-  if (idx >= mn) return;
-  const long nb = (long)g.batch1 * g.batch2;
-  const float* w = g.ws + (long)z * mn + idx;
-  float acc = 0.f;
-  for (int s = 0; s < g.splits; ++s) acc += w[(long)s * nb * mn];
-  const int z1 = z / g.batch2, z2 = z - z1 * g.batch2;
-  const Epi e = make_epi(g, z1, z2);
-  const int row = (int)(idx / g.N), col = (int)(idx - (long)row * g.N);
-  epi_store(g, e, row, col, acc);
+  reduce4(g, z, (long)(b - z * per) * 256 + threadIdx.x);
 }
 
 // Sum the split-K partials in split order (bitwise reproducible) and run the epilogue.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
-  const long mn = (long)g.M * g.N;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  const int z = blockIdx.y;
-  if (idx >= mn) return;
-  const long nb = (long)g.batch1 * g.batch2;
-  const float* w = g.ws + (long)z * mn + idx;
-  float acc = 0.f;
-  for (int s = 0; s < g.splits; ++s) acc += w[(long)s * nb * mn];
-  const int z1 = z / g.batch2, z2 = z - z1 * g.batch2;
-  const Epi e = make_epi(g, z1, z2);
-  const int row = (int)(idx / g.N), col = (int)(idx - (long)row * g.N);
-  epi_store(g, e, row, col, acc);
+  reduce4(g, blockIdx.y, (long)blockIdx.x * 256 + threadIdx.x);
 }
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -119,7 +130,7 @@ static int launch(const GemmArgs& g, hipStream_t stream) {
   if (int e = check_launch("gemm")) return e;
   if (g.splits > 1) {
     ProfScope ps("gemm_splitk_reduce", stream);
-    dim3 rgrid(cdiv((long)g.M * g.N, 256), g.batch1 * g.batch2);
+    dim3 rgrid(cdiv((long)g.M * g.N / 4, 256), g.batch1 * g.batch2);
     hipLaunchKernelGGL(splitk_reduce_kernel, rgrid, dim3(256), 0, stream, g);
     return check_launch("gemm_splitk_reduce");
   }
@@ -161,7 +172,9 @@ static int prepare(GemmArgs& g, int tile, int splits, long group_work) {
   (void)t64;
   if (tile == 0) tile = 1;  // measured: 64x64 tiles beat 128x128 at every size up to 4096^3 (117 vs 104 TF/s)
   if (splits == 0) splits = (tile == 2) ? 1 : pick_splits(g.K, group_work > 0 ? group_work : t64 * cdiv(g.K, BK));
-  if (splits > 1 && (!g.ws || (long)splits * nb * g.M * g.N > g.ws_elems || g.K % (splits * BK) != 0)) splits = 1;
+  if (splits > 1 && (!g.ws || (long)splits * nb * g.M * g.N > g.ws_elems || g.K % (splits * BK) != 0 || g.N % 4 != 0 ||
+                     (((uintptr_t)g.ws) & 15) != 0))
+    splits = 1;
   g.splits = splits;
   g.ksplit = (splits > 1) ? g.K / splits : g.K;
   return tile;
@@ -223,7 +236,7 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream) {
     gg.tile_begin[gg.nprob] = tiles;
     gg.red_begin[gg.nprob] = reds;
     tiles += (int)(own * g.splits);
-    if (g.splits > 1) reds += (int)(nb * cdiv((long)g.M * g.N, 256));
+    if (g.splits > 1) reds += (int)(nb * cdiv((long)g.M * g.N / 4, 256));
     flops += 2.0 * g.M * g.N * g.K * nb;
     gg.p[gg.nprob++] = g;
   }
