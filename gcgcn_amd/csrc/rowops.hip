@@ -194,9 +194,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
   if (r1 > R) r1 = R;
   const float* x = X + z * sXz;
   const float* ww = w ? w + z * sWz : nullptr;
+  // 8 rows in flight per lane: the loads of a batch are independent, one round trip instead of eight
   float acc = 0.f;
-  if (c < C)
-    for (long r = r0 + wave; r < r1; r += 4) acc = fmaf(ww ? ww[r] : 1.f, x[r * ld + c], acc);
+  if (c < C) {
+    long r = r0 + wave;
+    for (; r + 28 < r1; r += 32) {
+      float v[8], wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = x[(r + 4 * u) * ld + c], wv[u] = ww ? ww[r + 4 * u] : 1.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = fmaf(wv[u], v[u], acc);
+    }
+    for (; r < r1; r += 4) acc = fmaf(ww ? ww[r] : 1.f, x[r * ld + c], acc);
+  }
   red[wave][lane] = acc;
   __syncthreads();
   if (wave == 0 && c < C) {
@@ -232,12 +242,30 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(const ColJobs j, floa
     const float* x = j.X[job];
     const float* w = j.w[job];
     const long ld = j.ld[job];
-    if (c < C)
-      for (long r = r0 + wave; r < r1; r += 4) acc = fmaf(w ? w[r] : 1.f, x[r * ld + c], acc);
+    if (c < C) {
+      long r = r0 + wave;
+      for (; r + 28 < r1; r += 32) {
+        float v[8], wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = x[(r + 4 * u) * ld + c], wv[u] = w ? w[r + 4 * u] : 1.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fmaf(wv[u], v[u], acc);
+      }
+      for (; r < r1; r += 4) acc = fmaf(w ? w[r] : 1.f, x[r * ld + c], acc);
+    }
   } else {
     const float* x = scratch + j.part_off[job];
-    if (c < C)
-      for (int r = wave; r < ns; r += 4) acc += x[(long)r * C + c];
+    if (c < C) {
+      int r = wave;
+      for (; r + 28 < ns; r += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = x[(long)(r + 4 * u) * C + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+      }
+      for (; r < ns; r += 4) acc += x[(long)r * C + c];
+    }
   }
   red[wave][lane] = acc;
   __syncthreads();
@@ -447,6 +475,7 @@ int colsum(const float* X, const float* w, float* out, long R, int C, long ld, i
     if (ns > want) ns = want;
     if (ns < 2) ns = 1;
   }
+  ProfScope ps("colsum", st);
   if (ns == 1) {
     hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64), 1, batch), dim3(256), 0, st, X, w, out, R, C, ld, sXz, sWz, sOz,
                        R > 0 ? R : 1, accumulate);

@@ -438,3 +438,23 @@ def test_edge_mean_handoff_is_used_and_safe(gpu_device):
         y4 = conv(x, e, a)
     assert torch.equal(y1, y2) and torch.equal(y1, y3)
     assert not torch.allclose(y1, y4)
+
+
+def test_kernel_timer_api(gpu_device):
+    """gcgcn_prof_start/enable/stop: HIP-event timing of the launches of one kernel family + their work."""
+    import ctypes as ct
+    B, N, D = 4, 32, 64
+    e = torch.randn(B, N, N, D, device=gpu_device)
+    _lib.call("gcgcn_prof_start", b"edge_fwd_mean", 16)
+    for _ in range(3):
+        F_.edge_mean(e)
+    _lib.call("gcgcn_prof_enable", 0)
+    F_.edge_mean(e)                      # not recorded
+    _lib.call("gcgcn_prof_enable", 1)
+    F_.edge_mean(e)
+    torch.cuda.synchronize()
+    ms, n, w = ct.c_double(0), ct.c_int(0), ct.c_double(0)
+    _lib.call("gcgcn_prof_stop", ct.byref(ms), ct.byref(n), ct.byref(w))
+    assert n.value == 4 and ms.value > 0
+    assert w.value == 4 * 4.0 * B * N * N * D          # algorithmic bytes of the recorded launches
+    F_.edge_mean(e)                      # timer off again: nothing recorded, nothing crashes
