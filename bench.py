@@ -255,9 +255,13 @@ def main():
              "work": "executed fp32 flops (2MNK)" if bound == "mfma" else "algorithmic HBM bytes"}
         pmc = os.path.join(ROOT, "profiles", "r01_c2_pmc_hbm.json")
         if bound == "hbm" and args.config == "c2" and os.path.exists(pmc):   # PMC passes are offline (rocprofv3 --pmc)
+            import re
             for k, v in json.load(open(pmc))["kernels"].items():
-                if ("gc::" + fam.replace("_att", "").replace("_mean", "") + "_kernel") in k and \
-                        (("true" in k) == fam.endswith("_att") if fam.startswith("edge_fwd") else True):
+                m = re.search(r"gc::(edge_\w+)_kernel<\d+(?:, (true|false))?", k)
+                if not m:
+                    continue
+                name = m.group(1) + ({"true": "_att", "false": "_mean"}[m.group(2)] if m.group(1) == "edge_fwd" else "")
+                if name == fam:
                     r["traffic"] = v["hbm_bytes_per_launch_corrected"]
         return r
 
