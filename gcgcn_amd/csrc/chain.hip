@@ -20,7 +20,7 @@ __device__ __forceinline__ bool dev_al16(const void* p) { return (((uintptr_t)p)
 // Every tile of batch entry z of product g, one after the other, by this workgroup.  With one
 // workgroup per CU every tile pass costs a prologue + an epilogue round trip to L2, so the widest tile
 // the LDS image allows is used: 64x128 (each wave 32x64) when N is a multiple of 128, else 64x64.
-template <bool AKC, bool BKC, bool ALIGNED, int MASK>
+template <bool AKC, bool BKC, bool ALIGNED, int MASK, int RT>
 __device__ __forceinline__ void run_product(GemmArgs g, float* lds, int z) {
   g.ksplit = g.K;
   g.splits = 1;
@@ -32,11 +32,11 @@ __device__ __forceinline__ void run_product(GemmArgs g, float* lds, int z) {
   if ((g.N & 127) == 0) {
     const int tn = g.N >> 7;
     for (int ty = 0; ty < tm; ++ty)
-      for (int tx = 0; tx < tn; ++tx) gemm_body<1, 2, AKC, BKC, ALIGNED, 16, MASK>(g, lds, tx, ty, z);
+      for (int tx = 0; tx < tn; ++tx) gemm_body<1, 2, AKC, BKC, ALIGNED, 16, MASK, RT>(g, lds, tx, ty, z);
   } else {
     const int tn = (g.N + 63) >> 6;
     for (int ty = 0; ty < tm; ++ty)
-      for (int tx = 0; tx < tn; ++tx) gemm_body<1, 1, AKC, BKC, ALIGNED, 16, MASK>(g, lds, tx, ty, z);
+      for (int tx = 0; tx < tn; ++tx) gemm_body<1, 1, AKC, BKC, ALIGNED, 16, MASK, RT>(g, lds, tx, ty, z);
   }
 }
 
@@ -73,10 +73,10 @@ __global__ __launch_bounds__(256) void gcn_chain_fwd_kernel(const GcnCtx c) {
   __syncthreads();
   for (int l = 0; l < c.L; ++l) {
     if (l > 0) {
-      run_product<true, false, ALIGNED, EPI_ACCUM>(plan_fwd_dense(c, l), lds, z);
+      run_product<true, false, ALIGNED, EPI_ACCUM, 0>(plan_fwd_dense(c, l), lds, z);
       __syncthreads();
     }
-    run_product<true, false, ALIGNED, EPI_ADD | EPI_ROWSCALE | EPI_RELU | EPI_C2>(plan_fwd_agg(c, l), lds, z);
+    run_product<true, false, ALIGNED, EPI_ADD | EPI_ROWSCALE | EPI_RELU | EPI_C2, 0>(plan_fwd_agg(c, l), lds, z);
     __syncthreads();
   }
 }
@@ -127,11 +127,11 @@ __global__ __launch_bounds__(256) void gcn_chain_bwd_kernel(const GcnCtx c) {
       }
     }
     __syncthreads();
-    run_product<false, false, ALIGNED, 0>(plan_bwd_dP(c, l), lds, z);
-    run_product<true, true, ALIGNED, EPI_ACCUM | EPI_ROWADD>(plan_bwd_dA(c, l), lds, z);
+    run_product<false, false, ALIGNED, 0, 0>(plan_bwd_dP(c, l), lds, z);
+    run_product<true, true, ALIGNED, 0, EPI_ACCUM | EPI_ROWADD>(plan_bwd_dA(c, l), lds, z);
     __syncthreads();
     if (l > 0) {
-      run_product<true, true, ALIGNED, EPI_ACCUM>(plan_bwd_dY(c, l), lds, z);
+      run_product<true, true, ALIGNED, EPI_ACCUM, 0>(plan_bwd_dY(c, l), lds, z);
       __syncthreads();
     }
   }

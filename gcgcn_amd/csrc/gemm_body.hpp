@@ -137,15 +137,22 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, const Epi& e, int r
 // 4 round trips); EG = 16 for the chain kernels (one workgroup per CU: nothing else hides latency).
 // Offsets are 32-bit on purpose: uniform base + 32-bit lane offset addressing keeps the gather to one
 // VGPR per load instead of a 64-bit address pair (a [rows x ld] slice of this path is < 2^31 elements).
-template <bool ALIGNED, int EG, int MASK>
+// MASK: features the caller guarantees are present (no run-time test, no branch: the operand gathers of a row
+// group then really are one straight block of loads).  RT: features tested at run time.  Everything else is
+// compiled out.
+template <bool ALIGNED, int EG, int MASK, int RT>
 __device__ __forceinline__ void epi_tile(const GemmArgs& g, const Epi& e, const int row0, const int col, const f32x16& acc) {
   if (!ALIGNED && col >= g.N) return;
-  const bool hadd = (MASK & EPI_ADD) && e.add, hra = (MASK & EPI_ROWADD) && e.rowadd;
-  const bool hrs = (MASK & EPI_ROWSCALE) && e.rowscale, hacc = (MASK & EPI_ACCUM) && g.accumulate;
-  const bool hc2 = (MASK & EPI_C2) && e.C2, ha2 = hc2 && e.add2, hnv = (MASK & EPI_NVALID) && g.n_valid;
-  const bool hrelu = (MASK & EPI_RELU) && g.relu;
-  const float bias = ((MASK & EPI_BIAS) && g.bias) ? g.bias[col] : 0.f;
-  const float alpha = (MASK & EPI_ALPHA) ? g.alpha : 1.f;
+  const bool hadd = (MASK & EPI_ADD) || ((RT & EPI_ADD) && e.add);
+  const bool hra = (MASK & EPI_ROWADD) || ((RT & EPI_ROWADD) && e.rowadd);
+  const bool hrs = (MASK & EPI_ROWSCALE) || ((RT & EPI_ROWSCALE) && e.rowscale);
+  const bool hacc = (MASK & EPI_ACCUM) || ((RT & EPI_ACCUM) && g.accumulate);
+  const bool hc2 = (MASK & EPI_C2) || ((RT & EPI_C2) && e.C2);
+  const bool ha2 = (MASK & EPI_C2) || ((RT & EPI_C2) && e.C2 && e.add2);   // MASK: C2 comes with add2
+  const bool hnv = (MASK & EPI_NVALID) || ((RT & EPI_NVALID) && g.n_valid);
+  const bool hrelu = (MASK & EPI_RELU) || ((RT & EPI_RELU) && g.relu);
+  const float bias = ((MASK & EPI_BIAS) || ((RT & EPI_BIAS) && g.bias)) ? g.bias[col] : 0.f;
+  const float alpha = ((MASK | RT) & EPI_ALPHA) ? g.alpha : 1.f;
   const unsigned ldadd = (unsigned)g.ldadd, ldc = (unsigned)g.ldc, ldadd2 = (unsigned)g.ldadd2, ldc2 = (unsigned)g.ldc2;
 #pragma unroll
   for (int q0 = 0; q0 < 16; q0 += EG) {
@@ -176,20 +183,33 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, const Epi& e, const 
       v += accv[u];
       if (pad[u]) v = 0.f;
       e.C[row * ldc + (unsigned)col] = v;
-      if (hc2) {
-        const unsigned o2 = row * ldc2 + (unsigned)col;
-        float w = v;
-        if (e.dodrop)
-          w = (rng_u32(e.key, (uint64_t)(g.drop_base + e.offC2 + (long)o2)) >= g.drop.thresh) ? w * g.drop.scale : 0.f;
-        w += a2v[u];
-        if (pad[u]) w = 0.f;
-        e.C2[o2] = w;
+      accv[u] = v;  // reused below as the value feeding the second output
+    }
+    if (hc2) {  // second output: dropout(v) + add2.  The dropout test is hoisted: one uniform branch per row group.
+      if (e.dodrop) {
+#pragma unroll
+        for (int u = 0; u < EG; ++u) {
+          if (!ok[u]) continue;
+          const int r = q0 + u;
+          const unsigned o2 = (unsigned)(row0 + (r & 3) + 8 * (r >> 2)) * ldc2 + (unsigned)col;
+          float w = (rng_u32(e.key, (uint64_t)(g.drop_base + e.offC2 + (long)o2)) >= g.drop.thresh) ? accv[u] * g.drop.scale : 0.f;
+          w += a2v[u];
+          e.C2[o2] = pad[u] ? 0.f : w;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < EG; ++u) {
+          if (!ok[u]) continue;
+          const int r = q0 + u;
+          const unsigned o2 = (unsigned)(row0 + (r & 3) + 8 * (r >> 2)) * ldc2 + (unsigned)col;
+          e.C2[o2] = pad[u] ? 0.f : accv[u] + a2v[u];
+        }
       }
     }
   }
 }
 
-template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED, int EG = 4, int MASK = EPI_ALL>
+template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED, int EG = 4, int MASK = 0, int RT = EPI_ALL>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__ lds, const int bx, const int by,
                                           const int zs) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -298,21 +318,21 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
     return;
   }
   const Epi e = make_epi(g, z1, z2);
-  if (MASK == EPI_ALL && !(g.add || g.bias || g.rowadd || g.rowscale || g.relu || g.accumulate || g.n_valid || g.C2) &&
+  if (RT == EPI_ALL && !(g.add || g.bias || g.rowadd || g.rowscale || g.relu || g.accumulate || g.n_valid || g.C2) &&
       g.alpha == 1.f) {
     // the common case of the stand-alone kernels (weight / data gradients): a bare store
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        epi_tile<ALIGNED, EG, 0>(g, e, m0 + (wr * TM + i) * 32 + 4 * lh, n0 + (wc * TN + j) * 32 + l31, acc[i][j]);
+        epi_tile<ALIGNED, EG, 0, 0>(g, e, m0 + (wr * TM + i) * 32 + 4 * lh, n0 + (wc * TN + j) * 32 + l31, acc[i][j]);
     return;
   }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
-      epi_tile<ALIGNED, EG, MASK>(g, e, m0 + (wr * TM + i) * 32 + 4 * lh, n0 + (wc * TN + j) * 32 + l31, acc[i][j]);
+      epi_tile<ALIGNED, EG, MASK, RT>(g, e, m0 + (wr * TM + i) * 32 + 4 * lh, n0 + (wc * TN + j) * 32 + l31, acc[i][j]);
 }
 
 template <int TM, int TN, bool AKC, bool BKC>
