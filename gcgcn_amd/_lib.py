@@ -10,7 +10,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgcgcn_hip.so")
+# GCGCN_LIB=<path> loads another build of the same ABI (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("GCGCN_LIB") or os.path.join(_HERE, "lib", "libgcgcn_hip.so")
 
 SALT_GAT = 0x47415431
 SALT_MHA = 0x4D484131

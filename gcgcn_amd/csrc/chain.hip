@@ -17,9 +17,16 @@ namespace gc {
 
 __device__ __forceinline__ bool dev_al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-// Every tile of batch entry z of product g, one after the other, by this workgroup.  With one
-// workgroup per CU every tile pass costs a prologue + an epilogue round trip to L2, so the widest tile
-// the LDS image allows is used: 64x128 (each wave 32x64) when N is a multiple of 128, else 64x64.
+// A chain workgroup is 512 threads = two 256-thread tile teams with an LDS image each.  The teams walk the
+// 64x64 tiles of a product side by side (team 0 the even ones, team 1 the odd ones), so every SIMD hosts two
+// waves whose instruction and memory latencies overlap -- with one workgroup per CU nothing else would.
+// Both teams execute the same number of barriers (same K); when the tile count is odd, team 1 recomputes the
+// last tile without storing it.
+constexpr int TEAM_LDS = lds_floats<1, 1, true, true>();
+constexpr int CHAIN_LDS = 2 * TEAM_LDS;
+constexpr int CW = 8;   // waves per chain workgroup
+constexpr int RB = 4;   // rows a wave keeps in flight in the row-wise phases
+
 template <bool AKC, bool BKC, bool ALIGNED, int MASK, int RT>
 __device__ __forceinline__ void run_product(GemmArgs g, float* lds, int z) {
   g.ksplit = g.K;
@@ -28,43 +35,39 @@ __device__ __forceinline__ void run_product(GemmArgs g, float* lds, int z) {
     g.vecA = dev_al16(g.A) && g.lda % 4 == 0 && g.sA1 % 4 == 0 && g.sA2 % 4 == 0;
     g.vecB = dev_al16(g.B) && g.ldb % 4 == 0 && g.sB1 % 4 == 0 && g.sB2 % 4 == 0;
   }
-  const int tm = (g.M + 63) >> 6;
-  if ((g.N & 127) == 0) {
-    const int tn = g.N >> 7;
-    for (int ty = 0; ty < tm; ++ty)
-      for (int tx = 0; tx < tn; ++tx) gemm_body<1, 2, AKC, BKC, ALIGNED, 16, MASK, RT>(g, lds, tx, ty, z);
-  } else {
-    const int tn = (g.N + 63) >> 6;
-    for (int ty = 0; ty < tm; ++ty)
-      for (int tx = 0; tx < tn; ++tx) gemm_body<1, 1, AKC, BKC, ALIGNED, 16, MASK, RT>(g, lds, tx, ty, z);
+  const int team = threadIdx.x >> 8, t = threadIdx.x & 255;
+  float* tl = lds + team * TEAM_LDS;
+  const int tn = (g.N + 63) >> 6, tiles = ((g.M + 63) >> 6) * tn;
+  for (int p = 0; p < tiles; p += 2) {
+    int q = p + team;
+    const bool live = q < tiles;
+    if (!live) q = tiles - 1;
+    gemm_body<1, 1, AKC, BKC, ALIGNED, 16, MASK, RT>(g, tl, q % tn, q / tn, z, t, live);
   }
 }
 
-constexpr int CHAIN_LDS = lds_floats<1, 2, true, true>();
-constexpr int RB = 8;  // rows a wave keeps in flight in the row-wise phases
-
 template <bool ALIGNED>
-__global__ __launch_bounds__(256) void gcn_chain_fwd_kernel(const GcnCtx c) {
+__global__ __launch_bounds__(64 * CW) void gcn_chain_fwd_kernel(const GcnCtx c) {
   __shared__ __attribute__((aligned(16))) float lds[CHAIN_LDS];
   const int z = blockIdx.x;  // b * H + h
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // GraphConv row normaliser (glove:47-49): rinv[i] = 1 / (sum_j A[i,j] + [sum == 0])
   {  // RB rows per wave in flight: the loads of a row batch are independent, one round trip per batch
     const float* a = c.A + (long)z * c.N * c.N;
-    for (int i0 = wave; i0 < c.N; i0 += 4 * RB) {
+    for (int i0 = wave; i0 < c.N; i0 += CW * RB) {
       float s[RB];
 #pragma unroll
       for (int u = 0; u < RB; ++u) s[u] = 0.f;
       for (int j = lane; j < c.N; j += 64) {
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
-          const int i = i0 + 4 * u;
+          const int i = i0 + CW * u;
           if (i < c.N) s[u] += a[(long)i * c.N + j];
         }
       }
 #pragma unroll
       for (int u = 0; u < RB; ++u) {
-        const int i = i0 + 4 * u;
+        const int i = i0 + CW * u;
         const float t = wave_sum(s[u]);
         if (lane == 0 && i < c.N) c.rinv[(long)z * c.N + i] = 1.f / (t + (t == 0.f ? 1.f : 0.f));
       }
@@ -82,18 +85,18 @@ __global__ __launch_bounds__(256) void gcn_chain_fwd_kernel(const GcnCtx c) {
 }
 
 template <bool ALIGNED>
-__global__ __launch_bounds__(256) void gcn_chain_bwd_kernel(const GcnCtx c) {
+__global__ __launch_bounds__(64 * CW) void gcn_chain_bwd_kernel(const GcnCtx c) {
   __shared__ __attribute__((aligned(16))) float lds[CHAIN_LDS];
   const int z = blockIdx.x;
   const int b = z / c.H, h = z - b * c.H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int l = c.L - 1; l >= 0; --l) {
     // through Y = relu(S), S = M * rinv:  dS = dY [Y > 0];  dM = dS rinv;  drow -= rinv sum_c dS Y
-    for (int i0 = wave; i0 < c.N; i0 += 4 * RB) {
+    for (int i0 = wave; i0 < c.N; i0 += CW * RB) {
       float acc[RB], rv[RB];
 #pragma unroll
       for (int u = 0; u < RB; ++u) {
-        const int i = i0 + 4 * u;
+        const int i = i0 + CW * u;
         acc[u] = 0.f;
         rv[u] = (i < c.N) ? c.rinv[(long)z * c.N + i] : 0.f;
       }
@@ -101,14 +104,14 @@ __global__ __launch_bounds__(256) void gcn_chain_bwd_kernel(const GcnCtx c) {
         float y[RB], gy[RB];
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
-          const int i = i0 + 4 * u;
+          const int i = i0 + CW * u;
           const long off = ((((long)b * c.N + i) * c.H + h) * c.L + l) * c.gh + k;
           y[u] = 0.f, gy[u] = 0.f;
           if (i < c.N) y[u] = c.Y[off], gy[u] = c.dYa[off];
         }
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
-          const int i = i0 + 4 * u;
+          const int i = i0 + CW * u;
           const long off = ((((long)b * c.N + i) * c.H + h) * c.L + l) * c.gh + k;
           const float g = y[u] > 0.f ? gy[u] : 0.f;
           if (i < c.N) c.dM[off] = g * rv[u];
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256) void gcn_chain_bwd_kernel(const GcnCtx c) {
       }
 #pragma unroll
       for (int u = 0; u < RB; ++u) {
-        const int i = i0 + 4 * u;
+        const int i = i0 + CW * u;
         const float t = wave_sum(acc[u]);
         if (lane == 0 && i < c.N) {  // row i is always handled by this lane: plain read-modify-write is ordered
           const long ri = (long)z * c.N + i;
@@ -147,7 +150,7 @@ static bool chain_aligned(const GcnCtx& c, bool bwd) {
 
 int gcn_chain_fwd(const GcnCtx& c, hipStream_t st) {
   GC_REQUIRE((long)c.B * c.H <= 0x7fffffffL, "gcn_chain_fwd: too many (doc, head) pairs");
-  dim3 grid((unsigned)(c.B * c.H)), block(256);
+  dim3 grid((unsigned)(c.B * c.H)), block(64 * CW);
   double fl = 0;
   for (int l = 0; l < c.L; ++l) fl += 2.0 * c.N * c.gh * (c.N + (double)l * c.gh);
   ProfScope ps("gcn_chain_fwd", st, fl * c.B * c.H);
@@ -157,7 +160,7 @@ int gcn_chain_fwd(const GcnCtx& c, hipStream_t st) {
 }
 
 int gcn_chain_bwd(const GcnCtx& c, hipStream_t st) {
-  dim3 grid((unsigned)(c.B * c.H)), block(256);
+  dim3 grid((unsigned)(c.B * c.H)), block(64 * CW);
   double fl = 0;
   for (int l = 0; l < c.L; ++l) fl += 4.0 * c.N * c.gh * c.N + 2.0 * c.N * c.gh * (double)l * c.gh;
   ProfScope ps("gcn_chain_bwd", st, fl * c.B * c.H);

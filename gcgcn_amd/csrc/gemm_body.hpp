@@ -211,7 +211,7 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, const Epi& e, const 
 
 template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED, int EG = 4, int MASK = 0, int RT = EPI_ALL>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__ lds, const int bx, const int by,
-                                          const int zs) {
+                                          const int zs, const int t = threadIdx.x, const bool do_store = true) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int LDA = AKC ? BM + 1 : BM;
   constexpr int LDB = BKC ? BN + 1 : BN;
@@ -219,7 +219,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
   // the B image starts 16-byte aligned whatever LDA's parity
   constexpr int OFFB = (2 * SA + 3) & ~3;
 
-  const int t = threadIdx.x;
+  // t: this thread's index inside the 256-thread tile team (a chain workgroup runs two teams side by side);
+  // do_store = false: the team only keeps the barriers company (its tile duplicates the other team's)
   const int lane = t & 63, wave = t >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -300,6 +301,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
   }
 
   // ---- store ------------------------------------------------------------------------------
+  if (!do_store) return;
   if (g.splits > 1) {  // raw partial sums -> workspace [split][batch][M][N]
     float* __restrict__ W = g.ws + ((long)sp * g.batch1 * g.batch2 + z) * g.M * g.N;
 #pragma unroll
