@@ -91,13 +91,15 @@ static long scratch_elems(int B, int N, int D, int H) {
   return a > b ? a : b;
 }
 
-// GCGCN_NO_CHAIN=1 runs every per-(doc, head) product as its own batched launch (A/B testing of chain.hip).
+// GCGCN_NO_CHAIN=1 (or gcgcn_set_option("chain", 0)) runs every per-(doc, head) product as its own batched
+// launch instead of inside the chain kernels (A/B testing of chain.hip).
+static int g_chain = -1;
 static bool use_chain() {
-  static const bool on = [] {
+  if (g_chain < 0) {
     const char* e = getenv("GCGCN_NO_CHAIN");
-    return !(e && e[0] == '1');
-  }();
-  return on;
+    g_chain = (e && e[0] == '1') ? 0 : 1;
+  }
+  return g_chain != 0;
 }
 
 static GcnCtx make_ctx(int B, int N, int D, int L, int H, const GcnLayout& y, const float* X, const float* A,
@@ -118,6 +120,16 @@ extern "C" {
 
 int gcgcn_version(void) { return 1; }
 const char* gcgcn_last_error(void) { return g_err; }
+
+int gcgcn_set_option(const char* name, int value) {
+  GC_REQUIRE(name, "set_option: null name");
+  if (strcmp(name, "chain") == 0) {
+    g_chain = value ? 1 : 0;
+    return 0;
+  }
+  set_error("set_option: unknown option '%s'", name);
+  return 1;
+}
 
 int gcgcn_prof_start(const char* kernel_prefix, int capacity) {
   GC_REQUIRE(kernel_prefix && capacity > 0, "prof_start: bad arguments");

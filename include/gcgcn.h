@@ -35,6 +35,10 @@ extern "C" {
 int gcgcn_version(void);            /* ABI version, currently 1 */
 const char* gcgcn_last_error(void); /* message of the last failing call on this thread */
 
+/* Run-time switches for A/B tests.  "chain": 1 (default) = the per-(doc, head) products of a conv run inside the
+ * chain kernels, 0 = one batched launch per product.  Results are identical up to fp32 summation order. */
+int gcgcn_set_option(const char* name, int value);
+
 /* ---- per-kernel timing for roofline reports (bench.py) ------------------------------------------- */
 /* While active, every kernel launch whose name starts with kernel_prefix ("edge_bwd", "edge_fwd",
  * "edge_bcast", "gemm", "softmax", ...) is bracketed by hipEvents on its launch stream (at most

@@ -458,3 +458,27 @@ def test_kernel_timer_api(gpu_device):
     assert n.value == 4 and ms.value > 0
     assert w.value == 4 * 4.0 * B * N * N * D          # algorithmic bytes of the recorded launches
     F_.edge_mean(e)                      # timer off again: nothing recorded, nothing crashes
+
+
+def test_chain_and_per_product_paths_agree(gpu_device):
+    """chain.hip (one persistent workgroup per (doc, head)) against one launch per product: same numbers."""
+    B, N, D, L, H = 3, 64, 128, 2, 4
+    sd = O.init_stack_params(D, L, H, seed=5)
+    x, e1, e2, adj = O.synth_docs(B, N, D, seed=6)
+    hops = gcgcn_amd.GraphHops(D, L, H).to(gpu_device).eval()
+    hops.load_state_dict(sd, strict=True)
+    res = []
+    try:
+        for chain in (1, 0):
+            _lib.call("gcgcn_set_option", b"chain", chain)
+            xs = [dev_leaf(t, gpu_device) for t in (x, e1, e2)]
+            out = hops(xs[0], [xs[1], xs[2]])[-1]
+            out.sum().backward()
+            res.append((out.detach(), xs[0].grad, xs[1].grad, hops.graphcnn[1].flat.grad.clone()))
+            hops.zero_grad()
+    finally:
+        _lib.call("gcgcn_set_option", b"chain", 1)
+    for a, b in zip(*res):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
+    with pytest.raises(RuntimeError, match="unknown option"):
+        _lib.call("gcgcn_set_option", b"bogus", 1)
