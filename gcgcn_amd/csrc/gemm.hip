@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
 
 // Several independent problems in ONE launch (64x64 tiles, interior shapes only): block -> problem by
 // prefix sums of tile counts, layout chosen per problem by a block-uniform branch.
-__global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroup gg) {
+__global__ __launch_bounds__(256, 4) void gemm_group_kernel(const GemmGroup gg) {
   __shared__ __attribute__((aligned(16))) float lds[lds_floats<1, 1, true, true>()];
   int b = xcd_remap(blockIdx.x, gridDim.x), i = 0;
   while (i + 1 < gg.nprob && b >= gg.tile_begin[i + 1]) ++i;
