@@ -216,23 +216,57 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream) {
       const int t = order[j];
       order[j] = order[j - 1], order[j - 1] = t;
     }
+  // pass 1: fix every problem's split factor and count its workgroups
+  GemmArgs prep[64];
+  long blocks[64];
+  bool groupable[64];
+  long total_blocks = 0;
+  int ng = 0;
   for (int oi = 0; oi < n; ++oi) {
-    GemmArgs g = probs[order[oi]];
+    GemmArgs& g = prep[oi];
+    g = probs[order[oi]];
+    blocks[oi] = 0, groupable[oi] = false;
     if (g.M == 0 || g.N == 0) continue;
-    const long own = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * g.batch1 * g.batch2;
-    // the group shares one workspace: give each problem its own slice
-    float* ws0 = g.ws;
-    const long wse0 = g.ws_elems;
-    if (ws0) g.ws = ws0 + ws_used, g.ws_elems = wse0 - ws_used;
     if (prepare(g, 1, 0, work) < 0) return 1;
     const bool al = g.vecA && g.vecB && g.M % 64 == 0 && g.N % 64 == 0 && g.ksplit % BK == 0;
-    if (!al || gg.nprob == GemmGroup::MAXP) {
-      g.ws = ws0, g.ws_elems = wse0;  // runs before the group launch; the group's slices are written later
-      if (int e = gemm(g, stream, 0, 0)) return e;
-      continue;
+    groupable[oi] = al && ng < GemmGroup::MAXP;
+    if (groupable[oi]) {
+      ++ng;
+      blocks[oi] = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * g.batch1 * g.batch2 * g.splits;
+      total_blocks += blocks[oi];
     }
+  }
+  // Wave quantisation: the kernel is resident 4 workgroups per CU (1024 slots).  A launch that overflows the
+  // slots by a few workgroups runs a whole extra round for them; the smallest problem is then peeled into its
+  // own launch (it re-picks its split factor for a launch of its own).
+  constexpr long SLOTS = 256 * 4;
+  const long over = total_blocks % SLOTS;
+  if (total_blocks > SLOTS && over > 0 && over <= SLOTS / 8 && ng > 1) {
+    int best = -1;
+    for (int oi = 0; oi < n; ++oi)
+      if (groupable[oi] && blocks[oi] >= over && blocks[oi] <= 4 * over && (best < 0 || blocks[oi] < blocks[best])) best = oi;
+    if (best >= 0) groupable[best] = false;
+  }
+  // pass 2: peeled / ungroupable problems first (own launches), then the group
+  for (int oi = 0; oi < n; ++oi) {
+    if (groupable[oi] || probs[order[oi]].M == 0 || probs[order[oi]].N == 0) continue;
+    if (int e = gemm(probs[order[oi]], stream, 0, 0)) return e;
+  }
+  for (int oi = 0; oi < n; ++oi) {
+    if (!groupable[oi]) continue;
+    GemmArgs g = prep[oi];
     const long nb = (long)g.batch1 * g.batch2;
-    if (g.splits > 1) ws_used += (long)g.splits * nb * g.M * g.N, any_split = true;
+    const long own = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * nb;
+    // the group shares one workspace: give each split problem its own slice
+    if (g.splits > 1) {
+      const long need = (long)g.splits * nb * g.M * g.N;
+      if (ws_used + need > g.ws_elems) {  // no room left: this problem goes unsplit
+        g.splits = 1, g.ksplit = g.K;
+      } else {
+        g.ws = g.ws + ws_used;
+        ws_used += need, any_split = true;
+      }
+    }
     gg.tile_begin[gg.nprob] = tiles;
     gg.red_begin[gg.nprob] = reds;
     tiles += (int)(own * g.splits);
