@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--prof-kernel", default="auto",
                     help="kernel family timed with HIP events inside the timed region (auto = the one with the largest time share)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ragged", action="store_true",
+                    help="secondary run (SURVEY 8d): DocRED-like entity counts n_valid ~ clip(round(N(19.5, 6^2)), 2, 42) padded to N")
     ap.add_argument("--early-mean", action="store_true", help="issue the E2 mean before GATAttention (A/B; default off)")
     ap.add_argument("--overlap", action="store_true", help="stream the E2 mean on a side stream (A/B; default off)")
     args = ap.parse_args()
@@ -154,11 +156,17 @@ def main():
     for t in (x, e1, e2):
         t.requires_grad_()
     cot = torch.ones(B, N, D, device=dev)         # d(sum(out))/d(out)
+    n_valid = None
+    if args.ragged:
+        g = torch.Generator().manual_seed(4242 + rank)
+        n_valid = torch.clamp(torch.round(torch.randn(B, generator=g) * 6.0 + 19.5), 2, min(42, N)).to(torch.int32).to(dev)
+        with torch.no_grad():                      # padding rows of X must be zero (include/gcgcn.h)
+            x.mul_((torch.arange(N, device=dev)[None, :] < n_valid[:, None]).unsqueeze(-1).float())
 
     def fwd_bwd():
         x.grad = e1.grad = e2.grad = None
         bucket.zero_grad()
-        out = hops(x, [e1, e2], adj)[-1]
+        out = hops(x, [e1, e2], adj, n_valid=n_valid)[-1]
         torch.autograd.backward(out, cot)
 
     graph = None
@@ -281,7 +289,9 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: GraphHops fwd+bwd, B={B}/GPU N={N} D={D} L={L} H={H}, train mode, "
-                                   f"E1/E2/X/params require grad", "global_batch": B * world, "mode": args.mode,
+                                   f"E1/E2/X/params require grad" + (", ragged n_valid (mean %.1f)" % n_valid.float().mean().item()
+                                                                      if n_valid is not None else ""),
+                       "global_batch": B * world, "mode": args.mode,
                        "parallelism": f"dp{world}"},
             "roofline": roofline,
             "roofline_hbm": roofline_hbm,
