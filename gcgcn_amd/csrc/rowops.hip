@@ -384,12 +384,6 @@ __global__ __launch_bounds__(256) void node_score_bwd_kernel(const float* __rest
   dX[e] = ds[m] * uvc[e - m * D];
 }
 
-// y (+)= a   elementwise
-__global__ __launch_bounds__(256) void add_kernel(float* __restrict__ y, const float* __restrict__ a, long n) {
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
-  if (e < n) y[e] += a[e];
-}
-
 // y[m, :] = x[m, :] for real entities, 0 for padding rows (m = b * N + i, i >= n_valid[b])
 __global__ __launch_bounds__(256) void mask_rows_kernel(const float* __restrict__ x, float* __restrict__ y, long M, int D,
                                                         int N, const int* __restrict__ n_valid) {
@@ -544,11 +538,6 @@ int mask_rows(const float* x, float* y, long M, int D, int N, const int* n_valid
   ProfScope ps("mask_rows", st);
   hipLaunchKernelGGL(mask_rows_kernel, dim3(cdiv(M * D, 256)), dim3(256), 0, st, x, y, M, D, N, n_valid);
   return check_launch("mask_rows");
-}
-int add_inplace(float* y, const float* a, long n, hipStream_t st) {
-  if (n == 0) return 0;
-  hipLaunchKernelGGL(add_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, y, a, n);
-  return check_launch("add");
 }
 
 }  // namespace gc

@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import SALT_GAT, SALT_GCN, SALT_GLUE, SALT_MHA, call
+from ._lib import SALT_GLUE, call
 
 Tensor = torch.Tensor
 

@@ -1,6 +1,5 @@
 """The CPU oracle (oracle/gcgcn_oracle.py) against golden vectors produced by the reference's
 own classes (oracle/make_golden.py).  This is what pins the oracle; tolerance 1e-5."""
-import numpy as np
 import pytest
 import torch
 
