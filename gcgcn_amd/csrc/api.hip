@@ -102,6 +102,17 @@ static bool use_chain() {
   return g_chain != 0;
 }
 
+// GCGCN_NO_MHA_CORE=1 (or gcgcn_set_option("mha_core", 0)) sends small graphs through the generic batched-GEMM +
+// row-softmax attention path as well (A/B testing of mha_core.hip).
+static int g_mha_core = -1;
+static bool use_mha_core() {
+  if (g_mha_core < 0) {
+    const char* e = getenv("GCGCN_NO_MHA_CORE");
+    g_mha_core = (e && e[0] == '1') ? 0 : 1;
+  }
+  return g_mha_core != 0;
+}
+
 static GcnCtx make_ctx(int B, int N, int D, int L, int H, const GcnLayout& y, const float* X, const float* A,
                        const float* flat, const int* n_valid, Drop drop) {
   GcnCtx c;
@@ -125,6 +136,10 @@ int gcgcn_set_option(const char* name, int value) {
   GC_REQUIRE(name, "set_option: null name");
   if (strcmp(name, "chain") == 0) {
     g_chain = value ? 1 : 0;
+    return 0;
+  }
+  if (strcmp(name, "mha_core") == 0) {
+    g_mha_core = value ? 1 : 0;
     return 0;
   }
   set_error("set_option: unknown option '%s'", name);
@@ -291,6 +306,9 @@ int gcgcn_mha_fwd(int B, int N, int D, int H, const float* X, const int32_t* n_v
     g.bias = flat + (long)D * D;
     GC_TRY(gemm(g, st));
   }
+  const float alpha = 1.f / sqrtf((float)dh);
+  if (use_mha_core() && mha_core_ok(N, D, H, Q, nullptr))  // small graph: scores stay in LDS
+    return mha_core_fwd(Q, n_valid, P, A, B, N, D, H, alpha, drop, st);
   {  // S[b,h] = Q_h Q_h^T / sqrt(dh)   (glove:137-138: keys use the query projection)
     GemmArgs g;
     g.ws = scratch, g.ws_elems = wse;
@@ -299,7 +317,7 @@ int gcgcn_mha_fwd(int B, int N, int D, int H, const float* X, const int32_t* n_v
     g.C = P, g.ldc = N, g.sC1 = (long)H * N * N, g.sC2 = (long)N * N;
     g.M = N, g.N = N, g.K = dh;
     g.batch1 = B, g.batch2 = H;
-    g.alpha = 1.f / sqrtf((float)dh);
+    g.alpha = alpha;
     GC_TRY(gemm(g, st));
   }
   GC_TRY(softmax_fwd(P, nullptr, n_valid, P, A, M * H, N, H, drop, st));
@@ -319,18 +337,22 @@ int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat,
   const long M = (long)B * N;
   const int dh = D / H;
   const float alpha = 1.f / sqrtf((float)dh);
-  GC_TRY(softmax_bwd(P, dA, dS, M * H, N, drop, st));
-  for (int pass = 0; pass < 2; ++pass) {  // dQ_h = alpha (dS + dS^T) Q_h
-    GemmArgs g;
-    g.ws = scratch, g.ws_elems = wse;
-    g.A = dS, g.lda = N, g.a_kc = (pass == 0), g.sA1 = (long)H * N * N, g.sA2 = (long)N * N;
-    g.B = Q, g.ldb = D, g.b_kc = 0, g.sB1 = (long)N * D, g.sB2 = dh;
-    g.C = dQ, g.ldc = D, g.sC1 = (long)N * D, g.sC2 = dh;
-    g.M = N, g.N = dh, g.K = N;
-    g.batch1 = B, g.batch2 = H;
-    g.alpha = alpha;
-    g.accumulate = pass;
-    GC_TRY(gemm(g, st));
+  if (use_mha_core() && mha_core_ok(N, D, H, Q, dQ)) {
+    GC_TRY(mha_core_bwd(Q, P, dA, dQ, B, N, D, H, alpha, drop, st));
+  } else {
+    GC_TRY(softmax_bwd(P, dA, dS, M * H, N, drop, st));
+    for (int pass = 0; pass < 2; ++pass) {  // dQ_h = alpha (dS + dS^T) Q_h
+      GemmArgs g;
+      g.ws = scratch, g.ws_elems = wse;
+      g.A = dS, g.lda = N, g.a_kc = (pass == 0), g.sA1 = (long)H * N * N, g.sA2 = (long)N * N;
+      g.B = Q, g.ldb = D, g.b_kc = 0, g.sB1 = (long)N * D, g.sB2 = dh;
+      g.C = dQ, g.ldc = D, g.sC1 = (long)N * D, g.sC2 = dh;
+      g.M = N, g.N = dh, g.K = N;
+      g.batch1 = B, g.batch2 = H;
+      g.alpha = alpha;
+      g.accumulate = pass;
+      GC_TRY(gemm(g, st));
+    }
   }
   {  // one launch: dX = dQ Wq  and  dWq = dQ^T X
     GemmArgs gs[2];
@@ -370,7 +392,6 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
   const GcnLayout y = gcn_layout(D, L, H);
   const Drop drop = make_drop(rng_snap, GCGCN_SALT_GCN, p);
   const long M = (long)B * N;
-  const int gh = y.gh;
   const long HD = (long)H * D;
   GC_REQUIRE(M <= 0x7fffffffL, "gcn_fwd: B*N too large");
 

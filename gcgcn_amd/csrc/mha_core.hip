@@ -1,0 +1,188 @@
+// Attention core of MultiHeadAttention for small graphs (N <= 64 entities, the DocRED regime).
+//
+// Per (document b, head h) the reference computes  A = dropout(softmax(Q_h Q_h^T / sqrt(dh)))  (glove:136-140; the
+// keys reuse the query projection).  With N <= 64 the whole N x N score matrix of one (b, h) fits in LDS, so one
+// workgroup produces P and A straight from Q_h -- scores never touch HBM -- and, backward, turns dA into
+// dQ_h = alpha (dS + dS^T) Q_h without materialising dS; both products run on the fp32 MFMA from LDS operands.  Replaces three launches forward (batched score GEMM at
+// 64x64x32 per problem, softmax) and three backward (softmax gradient, two batched 64x32x64 GEMMs).
+// Larger graphs take the generic GEMM + row-softmax path in api.hip.
+#include "rowops.hpp"
+
+namespace gc {
+
+constexpr int MT = 64;       // padded graph size
+constexpr int MS = MT + 1;   // row stride of the score tile in LDS
+constexpr int MKC = 128;     // head-feature chunk held in LDS at a time
+
+static inline int mha_chunk(int dh) { return dh < MKC ? (dh + 31) / 32 * 32 : MKC; }
+static inline size_t mha_lds_bytes(int dh) { return sizeof(float) * (MT * MS + MT * (mha_chunk(dh) + 1)); }
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+// Q_h chunk [N x kc] (row stride D in global) -> LDS rows of odd stride ld (conflict-free for both the k-contiguous
+// reads of the score product and the column-contiguous reads of the gradient product); rows >= N and columns
+// kc .. kpad are zero.
+__device__ __forceinline__ void load_q_chunk(float* qs, const float* __restrict__ q, int N, int D, int k0, int kc, int kpad,
+                                             int ld, int t) {
+  const int k4 = kpad >> 2;
+  for (int base = t; base < MT * k4; base += 4 * 256) {  // four independent loads in flight per thread
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + u * 256, n = idx / k4, k = (idx - n * k4) << 2;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < MT * k4 && n < N && k < kc) v[u] = *reinterpret_cast<const float4*>(q + (long)n * D + k0 + k);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + u * 256, n = idx / k4, k = (idx - n * k4) << 2;
+      if (idx < MT * k4) {
+        float* d = qs + n * ld + k;
+        d[0] = v[u].x, d[1] = v[u].y, d[2] = v[u].z, d[3] = v[u].w;
+      }
+    }
+  }
+}
+
+// v_mfma_f32_32x32x2_f32 operand / result mapping (wave of 64 lanes): A[row = lane & 31][k = lane >> 5],
+// B[k = lane >> 5][col = lane & 31], D[row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)][col = lane & 31].
+__device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+__global__ __launch_bounds__(256) void mha_core_fwd_kernel(const float* __restrict__ Q, const int* __restrict__ n_valid,
+                                                           float* __restrict__ P, float* __restrict__ A, int N, int D, int H,
+                                                           int dh, int kchunk, float alpha, Drop drop) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* S = sm;             // [MT][MS]
+  float* qs = sm + MT * MS;  // [MT][kchunk + 1]
+  const int z = blockIdx.x, b = z / H, h = z - b * H;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
+  const float* q = Q + (long)b * N * D + (long)h * dh;
+  // scores: wave (wr, wc) owns the 32 x 32 quadrant S[32 wr .., 32 wc ..] = Q[32 wr ..] Q[32 wc ..]^T
+  const int wr = wave >> 1, wc = wave & 1, ld = kchunk + 1;
+  f16v acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = 0; k0 < dh; k0 += kchunk) {
+    const int kc = min(kchunk, dh - k0);
+    if (k0) __syncthreads();
+    load_q_chunk(qs, q, N, D, k0, kc, (kc + 3) & ~3, ld, t);
+    __syncthreads();
+    const float* pa = qs + (32 * wr + (lane & 31)) * ld + (lane >> 5);
+    const float* pb = qs + (32 * wc + (lane & 31)) * ld + (lane >> 5);
+    for (int k = 0; k < kc; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k], pb[k], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) S[(32 * wr + mfma_row(r, lane)) * MS + 32 * wc + (lane & 31)] = acc[r] * alpha;
+  __syncthreads();
+  // row softmax over the valid columns, dropout; lane = column
+  const bool dd = A && drop.snap;
+  const uint64_t key = dd ? drop_key(drop) : 0;
+  for (int i = wave; i < N; i += 4) {
+    const long r = (long)z * N + i;
+    float v = 0.f;
+    if (i < nv) {
+      const float s = (lane < nv) ? S[i * MS + lane] : -INFINITY;
+      const float m = wave_max(s);
+      const float e = (lane < nv) ? expf(s - m) : 0.f;
+      v = e / wave_sum(e);
+    }
+    if (lane < N) {
+      P[r * N + lane] = v;
+      if (A) {
+        if (dd) v = (rng_u32(key, (uint64_t)(r * N + lane)) >= drop.thresh) ? v * drop.scale : 0.f;
+        A[r * N + lane] = v;
+      }
+    }
+  }
+}
+
+// dQ_h = alpha (dS + dS^T) Q_h,  dS = P (dP - sum_j dP P),  dP = dropout_bwd(dA).   Padding entries have P == 0.
+__global__ __launch_bounds__(256) void mha_core_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ P,
+                                                           const float* __restrict__ dA, float* __restrict__ dQ, int N, int D,
+                                                           int H, int dh, int kchunk, float alpha, Drop drop) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* T = sm;             // [MT][MS]
+  float* qs = sm + MT * MS;  // [MT][kchunk + 1]
+  const int z = blockIdx.x, b = z / H, h = z - b * H;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const bool dd = drop.snap != nullptr;
+  const uint64_t key = dd ? drop_key(drop) : 0;
+  for (int i = wave; i < MT; i += 4) {
+    float ds = 0.f;
+    if (i < N) {  // wave-uniform
+      const long r = (long)z * N + i;
+      float p = 0.f, g = 0.f;
+      if (lane < N) {
+        p = P[r * N + lane], g = dA[r * N + lane];
+        if (dd) g = (rng_u32(key, (uint64_t)(r * N + lane)) >= drop.thresh) ? g * drop.scale : 0.f;
+      }
+      const float dot = wave_sum(g * p);
+      ds = p * (g - dot);
+    }
+    T[i * MS + lane] = ds;
+  }
+  __syncthreads();
+  // symmetrise in place: the pair (i, j), (j, i) belongs to one thread
+  for (int idx = t; idx < MT * MT; idx += 256) {
+    const int i = idx >> 6, j = idx & 63;
+    if (i < j) {
+      const float s = T[i * MS + j] + T[j * MS + i];
+      T[i * MS + j] = s, T[j * MS + i] = s;
+    } else if (i == j) {
+      T[i * MS + i] *= 2.f;
+    }
+  }
+  const float* q = Q + (long)b * N * D + (long)h * dh;
+  float* dq = dQ + (long)b * N * D + (long)h * dh;
+  const int ld = kchunk + 1;
+  for (int k0 = 0; k0 < dh; k0 += kchunk) {
+    const int kc = min(kchunk, dh - k0), kpad = (kc + 31) & ~31;
+    __syncthreads();  // T symmetrised / previous chunk consumed
+    load_q_chunk(qs, q, N, D, k0, kc, kpad, ld, t);
+    __syncthreads();
+    // 32 x 32 output blocks (row block rb, column block cb) of the chunk, dealt round-robin to the waves
+    for (int blk = wave; blk < 2 * (kpad >> 5); blk += 4) {
+      const int rb = blk & 1, cb = blk >> 1;
+      const float* pa = T + (32 * rb + (lane & 31)) * MS + (lane >> 5);
+      const float* pb = qs + (lane >> 5) * ld + 32 * cb + (lane & 31);
+      f16v acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 4
+      for (int j = 0; j < MT; j += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[j], pb[j * ld], acc, 0, 0, 0);
+      const int c = 32 * cb + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = 32 * rb + mfma_row(r, lane);
+        if (i < N && c < kc) dq[(long)i * D + k0 + c] = acc[r] * alpha;
+      }
+    }
+  }
+}
+
+bool mha_core_ok(int N, int D, int H, const void* Q, const void* dQ) {
+  const int dh = D / H;
+  auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+  return N >= 1 && N <= MT && dh % 4 == 0 && D % 4 == 0 && al(Q) && (!dQ || al(dQ));
+}
+
+int mha_core_fwd(const float* Q, const int* n_valid, float* P, float* A, int B, int N, int D, int H, float alpha, Drop drop,
+                 hipStream_t st) {
+  const int dh = D / H;
+  ProfScope ps("mha_core_fwd", st);
+  hipLaunchKernelGGL(mha_core_fwd_kernel, dim3(B * H), dim3(256), mha_lds_bytes(dh), st, Q, n_valid, P, A, N, D, H, dh,
+                     mha_chunk(dh), alpha, drop);
+  return check_launch("mha_core_fwd");
+}
+
+int mha_core_bwd(const float* Q, const float* P, const float* dA, float* dQ, int B, int N, int D, int H, float alpha, Drop drop,
+                 hipStream_t st) {
+  const int dh = D / H;
+  ProfScope ps("mha_core_bwd", st);
+  hipLaunchKernelGGL(mha_core_bwd_kernel, dim3(B * H), dim3(256), mha_lds_bytes(dh), st, Q, P, dA, dQ, N, D, H, dh,
+                     mha_chunk(dh), alpha, drop);
+  return check_launch("mha_core_bwd");
+}
+
+}  // namespace gc

@@ -32,4 +32,11 @@ int edge_bwd(const float* E, const float* v, const int* n_valid, const float* dl
              float* dvpart, int B, int N, int D, hipStream_t st);
 int edge_bcast(const float* dEbar, const int* n_valid, float* dE, int B, int N, int D, hipStream_t st);
 
+// mha_core.hip: fused attention core of MultiHeadAttention for N <= 64
+bool mha_core_ok(int N, int D, int H, const void* Q, const void* dQ);
+int mha_core_fwd(const float* Q, const int* n_valid, float* P, float* A, int B, int N, int D, int H, float alpha, Drop drop,
+                 hipStream_t st);
+int mha_core_bwd(const float* Q, const float* P, const float* dA, float* dQ, int B, int N, int D, int H, float alpha, Drop drop,
+                 hipStream_t st);
+
 }  // namespace gc

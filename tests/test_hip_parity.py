@@ -482,3 +482,34 @@ def test_chain_and_per_product_paths_agree(gpu_device):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
     with pytest.raises(RuntimeError, match="unknown option"):
         _lib.call("gcgcn_set_option", b"bogus", 1)
+
+
+@pytest.mark.parametrize("B,N,D,H,ragged", [(3, 64, 256, 8, False), (2, 42, 128, 4, True), (2, 7, 64, 4, False),
+                                              (2, 64, 768, 4, True), (1, 13, 512, 2, False)])
+def test_mha_core_and_generic_paths_agree(gpu_device, B, N, D, H, ragged):
+    """mha_core.hip (scores of one (doc, head) kept in LDS, N <= 64) against the batched-GEMM + row-softmax path,
+    train mode with the same dropout snapshot: same adjacency, same gradients."""
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    x = torch.randn(B, N, D, generator=g) * 0.5
+    n_valid = None
+    if ragged:
+        n_valid = torch.randint(1, N + 1, (B,), generator=g).to(torch.int32)
+        x = x * (torch.arange(N)[None, :] < n_valid[:, None]).unsqueeze(-1).float()
+        n_valid = n_valid.to(gpu_device)
+    cot = torch.randn(B, H, N, N, generator=g).to(gpu_device)
+    mha = gcgcn_amd.MultiHeadAttention(H, D).to(gpu_device).train()
+    res = []
+    try:
+        for core in (1, 0):
+            _lib.call("gcgcn_set_option", b"mha_core", core)
+            gcgcn_amd.manual_seed(77, gpu_device)
+            xs = dev_leaf(x, gpu_device)
+            a = torch.stack(mha(xs, None, n_valid=n_valid), 1)
+            torch.autograd.backward(a, cot)
+            res.append((a.detach(), xs.grad, mha.flat.grad.clone()))
+            mha.zero_grad()
+    finally:
+        _lib.call("gcgcn_set_option", b"mha_core", 1)
+    assert (res[0][0] == 0).float().mean() > 0.05          # dropout was on
+    for a, b in zip(*res):
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-5)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Print the per-dispatch timeline of the last full step from a rocprofv3 --kernel-trace CSV."""
-import csv, glob, sys
+import csv, glob, os, sys
 d = sys.argv[1]
-f = glob.glob(d + '/*/*_kernel_trace.csv')[0]
+f = max(glob.glob(d + '/*/*_kernel_trace.csv') + glob.glob(d + '/*_kernel_trace.csv'), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'gat_fold_fwd' in r['Kernel_Name']]
