@@ -23,6 +23,12 @@ I = c_int
 F = c_float
 L = c_int64
 
+class EdgeRide(ctypes.Structure):
+    """gcgcn_edge_ride: an edge-tensor pass riding along with a gcn_fwd / gcn_bwd call (include/gcgcn.h)."""
+    _fields_ = [("B", ctypes.c_int32), ("N", ctypes.c_int32), ("D", ctypes.c_int32),
+                ("inp", c_void_p), ("n_valid", c_void_p), ("out", c_void_p)]
+
+
 # name -> (restype, argtypes); kept in the order of include/gcgcn.h
 SIGNATURES = {
     "gcgcn_version": (I, []),
@@ -46,8 +52,8 @@ SIGNATURES = {
     "gcgcn_mha_bwd": (I, [I, I, I, I, P, P, P, F, P, P, P, P, P, P, P, P, P]),
     "gcgcn_gcn_layout": (I, [I, I, I, P]),
     "gcgcn_gcn_scratch": (L, [I, I, I, I]),
-    "gcgcn_gcn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, P, P, P, P, P, P, P]),
-    "gcgcn_gcn_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_gcn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_gcn_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_graphconv_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_graphconv_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_gemm": (I, [I, I, I, P, L, I, P, L, I, P, L, I, L, L, L, F, P, I, I, I, I, P, L, P]),

@@ -113,6 +113,18 @@ static bool use_mha_core() {
   return g_mha_core != 0;
 }
 
+// gcgcn_edge_ride -> EdgeRide (kind 1: edge mean forward, 2: its backward); NULL = no passenger
+static int make_ride(const char* who, const gcgcn_edge_ride* ride, int kind, EdgeRide& r) {
+  memset(&r, 0, sizeof(r));
+  if (!ride) return 0;
+  GC_REQUIRE(ride->B > 0 && ride->N > 0 && ride->D > 0 && ride->in && ride->out, "%s: bad edge ride B=%d N=%d D=%d", who,
+             ride->B, ride->N, ride->D);
+  GC_REQUIRE((long)ride->B * ride->N <= 0x3fffffffL, "%s: edge ride too large", who);
+  r.kind = kind, r.B = ride->B, r.N = ride->N, r.D = ride->D;
+  r.in = ride->in, r.n_valid = ride->n_valid, r.out = ride->out;
+  return 0;
+}
+
 static GcnCtx make_ctx(int B, int N, int D, int L, int H, const GcnLayout& y, const float* X, const float* A,
                        const float* flat, const int* n_valid, Drop drop) {
   GcnCtx c;
@@ -384,9 +396,11 @@ int gcgcn_gcn_layout(int D, int L, int H, int64_t* o) {
 
 int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float* Ebar, const float* A,
                   const int32_t* n_valid, const float* flat, const void* rng_snap, float p, float* out, float* Pn,
-                  float* Y, float* HO, float* rinv, float* G, float* scratch, void* stream) {
+                  float* Y, float* HO, float* rinv, float* G, float* scratch, const gcgcn_edge_ride* ride, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("gcn_fwd", B, N, D, L, H));
+  EdgeRide er;
+  GC_TRY(make_ride("gcn_fwd", ride, 1, er));
   const long wse = scratch ? scratch_elems(B, N, D, H) : 0;
   GC_REQUIRE(X && Ebar && A && flat && out && Pn && Y && HO && rinv && G, "gcn_fwd: null pointer");
   const GcnLayout y = gcn_layout(D, L, H);
@@ -411,6 +425,11 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
   {  // the dependent per-(doc, head) sequence: normaliser, then per sub-layer dense connection + aggregation
     GcnCtx c = make_ctx(B, N, D, L, H, y, X, A, flat, n_valid, drop);
     c.G = G, c.Pn = Pn, c.Y = Y, c.HO = HO, c.rinv = rinv;
+    if (er.kind && !(use_chain() && chain_can_carry(er))) {  // the riding pass as its own launch
+      GC_TRY(edge_fwd(er.in, nullptr, er.n_valid, er.out, nullptr, nullptr, nullptr, Drop(), er.B, er.N, er.D, st));
+      er.kind = 0;
+    }
+    c.ride = er;
     if (use_chain()) {
       GC_TRY(gcn_chain_fwd(c, st));
     } else {
@@ -441,9 +460,11 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
                   const int32_t* n_valid, const float* flat, const void* rng_snap, float p, const float* Pn,
                   const float* Y, const float* HO, const float* rinv, const float* dout, float* dX, float* dEbar,
                   float* dA, float* dflat, float* W1, float* W2, float* W3, float* drow, float* dXres, float* dout_m,
-                  float* scratch, void* stream) {
+                  float* scratch, const gcgcn_edge_ride* ride, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("gcn_bwd", B, N, D, L, H));
+  EdgeRide er;
+  GC_TRY(make_ride("gcn_bwd", ride, 2, er));
   const long wse = scratch ? scratch_elems(B, N, D, H) : 0;
   GC_REQUIRE(X && Ebar && A && flat && Pn && Y && HO && rinv && dout && dX && dEbar && dA && dflat && W1 && W2 && W3 &&
                  drow && dXres,
@@ -482,6 +503,11 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
     GcnCtx c = make_ctx(B, N, D, L, H, y, X, A, flat, n_valid, drop);
     c.Pn = const_cast<float*>(Pn), c.Y = const_cast<float*>(Y), c.rinv = const_cast<float*>(rinv);
     c.dYa = dYa, c.dM = dM, c.dP = dP, c.dA = dA, c.drow = drow;
+    if (er.kind && !(use_chain() && chain_can_carry(er))) {
+      GC_TRY(edge_bcast(er.in, er.n_valid, er.out, er.B, er.N, er.D, st));
+      er.kind = 0;
+    }
+    c.ride = er;
     if (use_chain()) {
       GC_TRY(gcn_chain_bwd(c, st));
     } else {

@@ -9,6 +9,7 @@
 // workgroup share the CU's vector L1, so no cache maintenance is needed at workgroup scope.
 // Pairs never touch each other's slices, so there is no inter-workgroup synchronisation at all
 // and every wave reaches the end of the phase list (no spin, no flag).
+#include "edge_body.hpp"
 #include "gcn_plan.hpp"
 #include "gemm_body.hpp"
 #include "rowops.hpp"
@@ -49,6 +50,12 @@ __device__ __forceinline__ void run_product(GemmArgs g, float* lds, int z) {
 template <bool ALIGNED>
 __global__ __launch_bounds__(64 * CW) void gcn_chain_fwd_kernel(const GcnCtx c) {
   __shared__ __attribute__((aligned(16))) float lds[CHAIN_LDS];
+  if (blockIdx.x >= c.B * c.H) {  // passenger workgroup: one entity row of the riding edge mean
+    const EdgeRide& r = c.ride;
+    edge_fwd_row<4, false, true, CW>(r.in, nullptr, r.n_valid, r.out, nullptr, nullptr, nullptr, Drop(), r.N, r.D,
+                                     blockIdx.x - c.B * c.H, lds);
+    return;
+  }
   const int z = blockIdx.x;  // b * H + h
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // GraphConv row normaliser (glove:47-49): rinv[i] = 1 / (sum_j A[i,j] + [sum == 0])
@@ -87,6 +94,11 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_fwd_kernel(const GcnCtx c) 
 template <bool ALIGNED>
 __global__ __launch_bounds__(64 * CW) void gcn_chain_bwd_kernel(const GcnCtx c) {
   __shared__ __attribute__((aligned(16))) float lds[CHAIN_LDS];
+  if (blockIdx.x >= c.B * c.H) {  // passenger workgroup: one entity row of the riding dE broadcast
+    const EdgeRide& r = c.ride;
+    edge_bcast_row<4, CW>(r.in, r.n_valid, r.out, r.N, r.D, 0, blockIdx.x - c.B * c.H);
+    return;
+  }
   const int z = blockIdx.x;
   const int b = z / c.H, h = z - b * c.H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -148,9 +160,21 @@ static bool chain_aligned(const GcnCtx& c, bool bwd) {
   return ok;
 }
 
+// The riding pass uses the 16-byte row bodies and the chain kernel's static LDS for its per-wave column sums.
+bool chain_can_carry(const EdgeRide& r) {
+  auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+  return r.kind != 0 && r.D % 4 == 0 && al(r.in) && al(r.out) && (long)CW * r.D <= CHAIN_LDS &&
+         (long)r.B * r.N <= 0x3fffffffL;
+}
+
+static unsigned chain_grid(const GcnCtx& c, int kind) {
+  return (unsigned)(c.B * c.H) + (c.ride.kind == kind ? (unsigned)(c.ride.B * c.ride.N) : 0u);
+}
+
 int gcn_chain_fwd(const GcnCtx& c, hipStream_t st) {
-  GC_REQUIRE((long)c.B * c.H <= 0x7fffffffL, "gcn_chain_fwd: too many (doc, head) pairs");
-  dim3 grid((unsigned)(c.B * c.H)), block(64 * CW);
+  GC_REQUIRE((long)c.B * c.H <= 0x3fffffffL, "gcn_chain_fwd: too many (doc, head) pairs");
+  GC_REQUIRE(c.ride.kind == 0 || (c.ride.kind == 1 && chain_can_carry(c.ride)), "gcn_chain_fwd: bad passenger");
+  dim3 grid(chain_grid(c, 1)), block(64 * CW);
   double fl = 0;
   for (int l = 0; l < c.L; ++l) fl += 2.0 * c.N * c.gh * (c.N + (double)l * c.gh);
   ProfScope ps("gcn_chain_fwd", st, fl * c.B * c.H);
@@ -160,7 +184,8 @@ int gcn_chain_fwd(const GcnCtx& c, hipStream_t st) {
 }
 
 int gcn_chain_bwd(const GcnCtx& c, hipStream_t st) {
-  dim3 grid((unsigned)(c.B * c.H)), block(64 * CW);
+  GC_REQUIRE(c.ride.kind == 0 || (c.ride.kind == 2 && chain_can_carry(c.ride)), "gcn_chain_bwd: bad passenger");
+  dim3 grid(chain_grid(c, 2)), block(64 * CW);
   double fl = 0;
   for (int l = 0; l < c.L; ++l) fl += 4.0 * c.N * c.gh * c.N + 2.0 * c.N * c.gh * (double)l * c.gh;
   ProfScope ps("gcn_chain_bwd", st, fl * c.B * c.H);

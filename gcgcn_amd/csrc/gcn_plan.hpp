@@ -10,8 +10,20 @@
 
 namespace gc {
 
+// An edge-tensor streaming pass that depends on nothing the chain computes (the NEXT hop's mean_j E forward, its
+// dE = dEbar / n backward).  A chain launch of few (doc, head) pairs leaves most compute units idle, and the chain
+// is latency-bound where the pass is HBM-bound: the pass rides in extra workgroups of the same launch.
+struct EdgeRide {
+  int kind;  // 0 none, 1: out[B,N,D] = mean_j in[B,N,N,D], 2: out[B,N,N,D] = in[B,N,D] / n
+  int B, N, D;
+  const float* in;
+  const int* n_valid;
+  float* out;
+};
+
 struct GcnCtx {
   int B, N, D, L, H, gh;
+  EdgeRide ride;
   long HD, oWd, wd_head;
   const float* X;
   const float* A;
@@ -113,6 +125,7 @@ __host__ __device__ inline GemmArgs plan_bwd_dY(const GcnCtx& c, int l) {
 }
 
 // chain.hip
+bool chain_can_carry(const EdgeRide& r);
 int gcn_chain_fwd(const GcnCtx& c, hipStream_t st);
 int gcn_chain_bwd(const GcnCtx& c, hipStream_t st);
 

@@ -201,12 +201,20 @@ class MhaFn(torch.autograd.Function):
         return dX, dflat, None, None, None, None
 
 
+def _ride(inp, n_valid, out, B, N, D):
+    """ctypes gcgcn_edge_ride for (inp -> out); the caller keeps the struct alive across the call."""
+    r = _lib.EdgeRide(B, N, D, inp.data_ptr(), None if n_valid is None else n_valid.data_ptr(), out.data_ptr())
+    return r, ctypes.cast(ctypes.pointer(r), ctypes.c_void_p)
+
+
 class GcnFn(torch.autograd.Function):
-    """(X[B,N,D], Ebar[B,N,D], A[B,H,N,N], flat) -> out[B,N,D].
-    GraphConvolution.forward (H = 1) / MultiGraphConvolution.forward, GCGCN_glove.py:63-80 / 97-120."""
+    """(X[B,N,D], Ebar[B,N,D], A[B,H,N,N], flat[, E_next[B,N,N,D]]) -> out[B,N,D][, mean_j E_next].
+    GraphConvolution.forward (H = 1) / MultiGraphConvolution.forward, GCGCN_glove.py:63-80 / 97-120.  The optional
+    E_next is the NEXT hop's edge tensor: its mean (all that hop needs of it, glove:40-41) rides inside this block's
+    latency-bound chain launch, and so does its backward."""
 
     @staticmethod
-    def forward(ctx, x, ebar, adj, flat, n_valid, L, H, p, snap):
+    def forward(ctx, x, ebar, adj, flat, n_valid, L, H, p, snap, e_next):
         B, N, D = x.shape
         dev = x.device
         HD = H * D
@@ -217,14 +225,20 @@ class GcnFn(torch.autograd.Function):
         rinv = torch.empty(B, H, N, device=dev)
         G = torch.empty(B, N, HD, device=dev)
         scratch = torch.empty(max(_lib.lib().gcgcn_gcn_scratch(B, N, D, H), 1), device=dev)
+        ebar_next, ride, ride_p = None, None, None
+        if e_next is not None:
+            ebar_next = torch.empty(e_next.shape[0], e_next.shape[1], e_next.shape[3], device=dev)
+            ride, ride_p = _ride(e_next, n_valid, ebar_next, *ebar_next.shape)
         call("gcgcn_gcn_fwd", B, N, D, L, H, _p(x), _p(ebar), _p(adj), _p(n_valid), _p(flat), _p(snap), float(p),
-             _p(out), _p(Pn), _p(Y), _p(HO), _p(rinv), _p(G), _p(scratch), _stream())
+             _p(out), _p(Pn), _p(Y), _p(HO), _p(rinv), _p(G), _p(scratch), ride_p, _stream())
+        del ride
         ctx.save_for_backward(x, ebar, adj, flat, Pn, Y, HO, rinv)
         ctx.n_valid, ctx.L, ctx.H, ctx.p, ctx.snap = n_valid, L, H, float(p), snap
-        return out
+        ctx.next_shape = None if e_next is None else tuple(e_next.shape)
+        return out, ebar_next
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, debar_next):
         x, ebar, adj, flat, Pn, Y, HO, rinv = ctx.saved_tensors
         B, N, D = x.shape
         L, H, dev = ctx.L, ctx.H, x.device
@@ -241,10 +255,16 @@ class GcnFn(torch.autograd.Function):
         dXres = torch.empty(B, N, D, device=dev)
         dout_m = torch.empty(B, N, D, device=dev) if ctx.n_valid is not None else None
         scratch = torch.empty(max(_lib.lib().gcgcn_gcn_scratch(B, N, D, H), 1), device=dev)
+        dE_next, ride, ride_p = None, None, None
+        if ctx.next_shape is not None and ctx.needs_input_grad[9] and debar_next is not None:
+            debar_next = debar_next.contiguous()
+            dE_next = torch.empty(ctx.next_shape, device=dev)
+            ride, ride_p = _ride(debar_next, ctx.n_valid, dE_next, *debar_next.shape)
         call("gcgcn_gcn_bwd", B, N, D, L, H, _p(x), _p(ebar), _p(adj), _p(ctx.n_valid), _p(flat), _p(ctx.snap),
              ctx.p, _p(Pn), _p(Y), _p(HO), _p(rinv), _p(dout), _p(dX), _p(dEbar), _p(dA), _p(dflat), _p(W1), _p(W2),
-             _p(W3), _p(drow), _p(dXres), _p(dout_m), _p(scratch), _stream())
-        return dX, dEbar, dA, dflat, None, None, None, None, None
+             _p(W3), _p(drow), _p(dXres), _p(dout_m), _p(scratch), ride_p, _stream())
+        del ride
+        return dX, dEbar, dA, dflat, None, None, None, None, None, dE_next
 
 
 class GraphConvFn(torch.autograd.Function):
@@ -328,13 +348,19 @@ def multi_head_adjacency(x, flat, H, n_valid=None, p=0.1, training=False):
     return MhaFn.apply(x, _chk(flat, "flat"), _nv(n_valid, B, N, x.device), H, p, _snap_for(training, p, x.device))
 
 
-def gcn_stack(x, ebar, adj, flat, L, H, n_valid=None, p=0.2, training=False):
+def gcn_stack(x, ebar, adj, flat, L, H, n_valid=None, p=0.2, training=False, e_next=None):
+    """Returns ``out`` -- or ``(out, mean_j e_next)`` when the next hop's edge tensor ``e_next[B,N,N,D']`` is given."""
     x, ebar, adj = _chk(x, "node_feat", 3), _chk(ebar, "edge_mean", 3), _chk(adj, "adjacency", 4)
     B, N, D = x.shape
     if ebar.shape != (B, N, D) or adj.shape != (B, H, N, N):
         raise ValueError(f"gcn_stack: shapes x{tuple(x.shape)} ebar{tuple(ebar.shape)} adj{tuple(adj.shape)} H={H}")
-    return GcnFn.apply(x, ebar, adj, _chk(flat, "flat"), _nv(n_valid, B, N, x.device), L, H, p,
-                       _snap_for(training, p, x.device))
+    nv = _nv(n_valid, B, N, x.device)
+    if e_next is not None:
+        e_next = _chk(e_next, "next edge_feat", 4)
+        if e_next.shape[:3] != (B, N, N):
+            raise ValueError(f"gcn_stack: next edge tensor {tuple(e_next.shape)} does not match B={B} N={N}")
+    out, ebar_next = GcnFn.apply(x, ebar, adj, _chk(flat, "flat"), nv, L, H, p, _snap_for(training, p, x.device), e_next)
+    return out if e_next is None else (out, ebar_next)
 
 
 def graph_conv(x, ebar, adj, we, wn, bias=None):

@@ -221,6 +221,17 @@ class _GcnBase(_FlatBlock):
             ebar = F_.edge_mean(e, n_valid)
         return ebar
 
+    def _stack(self, x, ebar, adj, n_valid, ride_edge):
+        """The fused block.  ``ride_edge`` (extension) is the edge tensor the NEXT hop's convolution will be called
+        with: its mean is computed inside this block's chain launch and parked for that call (functional.GcnFn)."""
+        if ride_edge is None:
+            return F_.gcn_stack(x, ebar, adj, self.flat, self.layer_num, self.head_num, n_valid, self.p, self.training)
+        e_next, _ = _batched(ride_edge, 3)
+        out, ebar_next = F_.gcn_stack(x, ebar, adj, self.flat, self.layer_num, self.head_num, n_valid, self.p,
+                                      self.training, e_next=e_next)
+        F_.park_edge_mean(ride_edge, n_valid, ebar_next)
+        return out
+
 
 class GraphConv(nn.Module):
     """The leaf layer (GCGCN_glove.py:18-50): ``(mean_j(E) W_e + A X W_n (+ bias)) / rowsum(A)`` with the
@@ -265,11 +276,11 @@ class GraphConvolution(_GcnBase):
         self._setup(layer_num, 1, input_dim, output_dim, bias)
 
     def forward(self, node_feat: Tensor, edge_feat: Tensor, adj_matrix: Tensor,
-                n_valid: Optional[Tensor] = None) -> Tensor:
+                n_valid: Optional[Tensor] = None, ride_edge: Optional[Tensor] = None) -> Tensor:
         x, batched = _batched(node_feat, 2)
         adj, _ = _batched(adj_matrix, 2)
         ebar = self._edge_mean(edge_feat, n_valid)
-        out = F_.gcn_stack(x, ebar, adj.unsqueeze(1), self.flat, self.layer_num, 1, n_valid, self.p, self.training)
+        out = self._stack(x, ebar, adj.unsqueeze(1), n_valid, ride_edge)
         return out if batched else out.squeeze(0)
 
 
@@ -296,11 +307,11 @@ class MultiGraphConvolution(_GcnBase):
         return stacked if batched else stacked.unsqueeze(0)
 
     def forward(self, node_feat: Tensor, edge_feat: Tensor, adj_matrix_list: Union[Tensor, Sequence[Tensor]],
-                n_valid: Optional[Tensor] = None) -> Tensor:
+                n_valid: Optional[Tensor] = None, ride_edge: Optional[Tensor] = None) -> Tensor:
         x, batched = _batched(node_feat, 2)
         adj = self._stack_heads(adj_matrix_list, batched)
         ebar = self._edge_mean(edge_feat, n_valid)
-        out = F_.gcn_stack(x, ebar, adj, self.flat, self.layer_num, self.head_num, n_valid, self.p, self.training)
+        out = self._stack(x, ebar, adj, n_valid, ride_edge)
         return out if batched else out.squeeze(0)
 
 
@@ -362,6 +373,12 @@ class GraphHops(nn.Module):
                 eb, _ = _batched(edge_feats[i], 3)
                 pre[i] = F_.edge_mean(eb, n_valid)
 
+        def ride(i):
+            # hop i + 1 needs its edge tensor only as mean_j E: let that HBM-bound pass ride in hop i's chain launch
+            on = self.ride_edge_mean and x.is_cuda and i + 1 < self.graph_hop and (i + 1) not in pre \
+                and not self.overlap_edge_mean
+            return edge_feats[i + 1] if on else None
+
         for i in range(self.graph_hop):
             e = edge_feats[i]
             if i < 1:
@@ -370,7 +387,7 @@ class GraphHops(nn.Module):
                 a = self.get_weighted_adj_matrix(x, e, None, n_valid=n_valid)                # glove:332
                 if x.is_cuda and self.graph_hop > 1 and self.overlap_edge_mean:
                     fork_edge_means()
-                new = self.graphcnn[i](x, e, a, n_valid=n_valid)                             # glove:333
+                new = self.graphcnn[i](x, e, a, n_valid=n_valid, ride_edge=ride(i))          # glove:333
             else:
                 al = self.get_adj_matrix[i - 1](x, e, n_valid=n_valid)                       # glove:336
                 if i in pre:
@@ -378,7 +395,7 @@ class GraphHops(nn.Module):
                         torch.cuda.current_stream().wait_stream(self._side_stream(x.device))
                         pre[i].record_stream(torch.cuda.current_stream())
                     F_.park_edge_mean(e, n_valid, pre.pop(i))
-                new = self.graphcnn[i](x, e, al, n_valid=n_valid)                            # glove:337
+                new = self.graphcnn[i](x, e, al, n_valid=n_valid, ride_edge=ride(i))         # glove:337
             x = new if self.alpha == 1.0 else self.alpha * new + (1 - self.alpha) * x        # glove:339
             x = F_.dropout(x, self.p, self.training)                                         # glove:341
             feats.append(x)
@@ -387,6 +404,8 @@ class GraphHops(nn.Module):
     # measured on MI355X (cfg 2): 1.005 ms/step with the side stream vs 0.935 without -- the HBM stream slows the
     # latency-bound kernels it overlaps and the cross-stream waits cost more than the 40 us they hide.  Off.
     overlap_edge_mean = False
+    # the next hop's edge mean as a passenger of this hop's chain launch (chain.hip): on
+    ride_edge_mean = True
     # measured: issuing the E2 mean before GATAttention evicts E1 from the Infinity Cache (left there by the previous
     # step's backward): edge_fwd_att 31 -> 52 us, step 0.883 -> 0.892 ms.  Off.
     early_edge_mean = False

@@ -121,9 +121,21 @@ int gcgcn_gcn_layout(int D, int L, int H, int64_t* out7);
  * saved for backward: Pn, Y, HO (each [B,N,H*D]) and rinv[B,H,N].  Workspace: G[B,N,H*D],
  * scratch[gcgcn_gcn_scratch(B,N,D,H)] (split-K / column-sum partials; NULL = never split). */
 int64_t gcgcn_gcn_scratch(int B, int N, int D, int H);
+/* An edge-tensor pass that depends on nothing the block computes may ride along with it: the NEXT hop's
+ * edge mean (forward; == gcgcn_edge_mean_fwd(B,N,D,in=E,n_valid,out=Ebar)) and its backward
+ * (== gcgcn_edge_mean_bwd(B,N,D,in=dEbar,n_valid,out=dE)).  The dependent per-(doc, head) part of a block
+ * is latency-bound and, for few documents x heads, occupies a fraction of the chip; the HBM-bound pass
+ * runs in extra workgroups of that same launch (or as its own launch when that is not possible).  The
+ * result is complete when the call's work is.  NULL = nothing rides. */
+typedef struct gcgcn_edge_ride {
+  int32_t B, N, D;
+  const float* in;
+  const int32_t* n_valid; /* may be NULL */
+  float* out;
+} gcgcn_edge_ride;
 int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float* Ebar, const float* A,
                   const int32_t* n_valid, const float* flat, const void* rng_snap, float p, float* out, float* Pn,
-                  float* Y, float* HO, float* rinv, float* G, float* scratch, void* stream);
+                  float* Y, float* HO, float* rinv, float* G, float* scratch, const gcgcn_edge_ride* ride, void* stream);
 /* backward.  dout[B,N,D] -> dX, dEbar [B,N,D], dA[B,H,N,N], dflat.
  * Workspace: W1, W2, W3 (each [B,N,H*D]), drow[B,H,N], dXres[B,N,D], dout_m[B,N,D] (only read
  * when n_valid != NULL), scratch[gcgcn_gcn_scratch]. */
@@ -131,7 +143,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
                   const int32_t* n_valid, const float* flat, const void* rng_snap, float p, const float* Pn,
                   const float* Y, const float* HO, const float* rinv, const float* dout, float* dX, float* dEbar,
                   float* dA, float* dflat, float* W1, float* W2, float* W3, float* drow, float* dXres, float* dout_m,
-                  float* scratch, void* stream);
+                  float* scratch, const gcgcn_edge_ride* ride, void* stream);
 
 /* ---- GraphConv, the leaf layer  GCGCN_glove.py:18-50 ------------------------------------------ */
 /* forward(inputs X[B,N,Din], mean edge feature Ebar[B,N,De], adjacency A[B,N,N]):

@@ -513,3 +513,32 @@ def test_mha_core_and_generic_paths_agree(gpu_device, B, N, D, H, ragged):
     assert (res[0][0] == 0).float().mean() > 0.05          # dropout was on
     for a, b in zip(*res):
         torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,N,D,L,H,ragged", [(3, 64, 128, 2, 4, False), (2, 21, 64, 2, 2, True), (2, 9, 6, 1, 2, False)])
+def test_riding_edge_mean_equals_separate_launches(gpu_device, B, N, D, L, H, ragged):
+    """The next hop's edge mean / dE broadcast as passengers of the chain launches (chain.hip) against their own
+    launches: same outputs, same gradients (D = 6 is not 16-byte aligned: the library falls back to own launches)."""
+    sd = O.init_stack_params(D, L, H, seed=11)
+    x, e1, e2, adj = O.synth_docs(B, N, D, seed=12)
+    n_valid = None
+    if ragged:
+        n_valid = torch.tensor([N, max(1, N // 3)][:B], dtype=torch.int32)
+        x = x * (torch.arange(N)[None, :] < n_valid[:, None]).unsqueeze(-1).float()
+        n_valid = n_valid.to(gpu_device)
+    hops = gcgcn_amd.GraphHops(D, L, H).to(gpu_device).eval()
+    hops.load_state_dict(sd, strict=True)
+    res = []
+    try:
+        for ride in (True, False):
+            hops.ride_edge_mean = ride
+            xs = [dev_leaf(t, gpu_device) for t in (x, e1, e2)]
+            out = hops(xs[0], [xs[1], xs[2]], n_valid=n_valid)[-1]
+            out.sum().backward()
+            res.append((out.detach(), xs[0].grad, xs[1].grad, xs[2].grad, hops.graphcnn[1].flat.grad.clone()))
+            hops.zero_grad()
+    finally:
+        hops.ride_edge_mean = True
+    for a, b in zip(*res):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+    assert res[0][3].abs().sum() > 0            # dE2 really flowed through the riding broadcast
