@@ -199,7 +199,8 @@ def main():
         "edge_bwd": ("hbm", HBM_PEAK), "edge_fwd_att": ("hbm", HBM_PEAK), "edge_fwd_mean": ("hbm", HBM_PEAK),
         "edge_bcast": ("hbm", HBM_PEAK),
     }
-    SMALL = ("softmax", "head_sum", "dropout", "gat_fold", "node_score", "colsum", "mask_rows", "rowsum", "relu_norm")
+    SMALL = ("softmax", "mha_core", "head_sum", "dropout", "gat_fold", "node_score", "colsum", "mask_rows", "rowsum",
+             "relu_norm")
 
     def profile(prefix, nsteps):
         """HIP-event time of every launch whose kernel name starts with `prefix` over nsteps steps."""

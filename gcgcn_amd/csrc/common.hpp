@@ -23,16 +23,31 @@ int check_launch(const char* what);
     }                                              \
   } while (0)
 
-// ---- wave-level reductions (64 lanes, shuffle based) --------------------------------------
+// ---- wave-level reductions (64 lanes) -------------------------------------------------------------
+// DPP lane swizzles instead of ds_bpermute shuffles: four data-parallel-primitive moves fold each row of 16 lanes
+// (quad swap, quad-pair swap, half-row mirror, row mirror -- afterwards every lane holds its row's total), then
+// the four row totals are read out as scalars.  ~12 short VALU/SALU instructions against six LDS-pipeline round
+// trips; every lane receives the result.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_value(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, GC_WAVE);
-  return v;
+  v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);  // row_half_mirror
+  v += dpp_move<0x140>(v);  // row_mirror
+  return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, GC_WAVE));
-  return v;
+  v = fmaxf(v, dpp_move<0xB1>(v));
+  v = fmaxf(v, dpp_move<0x4E>(v));
+  v = fmaxf(v, dpp_move<0x141>(v));
+  v = fmaxf(v, dpp_move<0x140>(v));
+  return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
 }
 
 // ---- counter-based dropout RNG ------------------------------------------------------------
