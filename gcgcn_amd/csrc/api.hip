@@ -84,12 +84,15 @@ static int check_dims(const char* who, int B, int N, int D, int L, int H) {
   return 0;
 }
 
-static long scratch_elems(int B, int N, int D, int H) {
+// Workspace of one block call: [split-K partials / column-sum partials | partials of a riding column sum]
+static long col_ride_elems(int D) { return (long)COL_RIDE_SLICES * D; }
+static long gemm_scratch_elems(int B, int N, int D, int H) {
   const long a = colsum_scratch_elems((long)B * N, D, 1);
   const long rows = (long)B * N > D ? (long)B * N : D;
   const long b = gemm_ws_elems(rows, (long)H * D);
   return a > b ? a : b;
 }
+static long scratch_elems(int B, int N, int D, int H) { return gemm_scratch_elems(B, N, D, H) + col_ride_elems(D); }
 
 // GCGCN_NO_CHAIN=1 (or gcgcn_set_option("chain", 0)) runs every per-(doc, head) product as its own batched
 // launch instead of inside the chain kernels (A/B testing of chain.hip).
@@ -302,7 +305,7 @@ int gcgcn_mha_fwd(int B, int N, int D, int H, const float* X, const int32_t* n_v
                   const void* rng_snap, float p, float* Q, float* P, float* A, float* scratch, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("mha_fwd", B, N, D, 1, H));
-  const long wse = scratch ? scratch_elems(B, N, D, 1) : 0;
+  const long wse = scratch ? gemm_scratch_elems(B, N, D, 1) : 0;
   GC_REQUIRE(X && flat && Q && P, "mha_fwd: null pointer");
   const Drop drop = make_drop(rng_snap, GCGCN_SALT_MHA, p);
   GC_REQUIRE(!drop.snap || A, "mha_fwd: dropout on but A is NULL");
@@ -343,7 +346,7 @@ int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat,
                   float* scratch, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("mha_bwd", B, N, D, 1, H));
-  const long wse = scratch ? scratch_elems(B, N, D, 1) : 0;
+  const long wse = scratch ? gemm_scratch_elems(B, N, D, 1) : 0;
   GC_REQUIRE(X && flat && Q && P && dA && dX && dflat && dS && dQ, "mha_bwd: null pointer");
   const Drop drop = make_drop(rng_snap, GCGCN_SALT_MHA, p);
   const long M = (long)B * N;
@@ -377,9 +380,15 @@ int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat,
     gs[1].B = X, gs[1].ldb = D, gs[1].b_kc = 0;
     gs[1].C = dflat, gs[1].ldc = D;
     gs[1].M = D, gs[1].N = D, gs[1].K = (int)M;
-    GC_TRY(gemm_group(gs, 2, st));
+    if (scratch) {  // dbq = column sums of dQ ride in the same two launches
+      ColRide cr;
+      cr.X = dQ, cr.out = dflat + (long)D * D, cr.part = scratch + wse, cr.R = M, cr.ld = D, cr.C = D;
+      GC_TRY(gemm_group(gs, 2, st, &cr));
+    } else {
+      GC_TRY(gemm_group(gs, 2, st));
+      GC_TRY(colsum(dQ, nullptr, dflat + (long)D * D, M, D, D, 1, 0, 0, 0, 0, scratch, st));
+    }
   }
-  GC_TRY(colsum(dQ, nullptr, dflat + (long)D * D, M, D, D, 1, 0, 0, 0, 0, scratch, st));  // dbq
   return 0;
 }
 
@@ -401,7 +410,7 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
   GC_TRY(check_dims("gcn_fwd", B, N, D, L, H));
   EdgeRide er;
   GC_TRY(make_ride("gcn_fwd", ride, 1, er));
-  const long wse = scratch ? scratch_elems(B, N, D, H) : 0;
+  const long wse = scratch ? gemm_scratch_elems(B, N, D, H) : 0;
   GC_REQUIRE(X && Ebar && A && flat && out && Pn && Y && HO && rinv && G, "gcn_fwd: null pointer");
   const GcnLayout y = gcn_layout(D, L, H);
   const Drop drop = make_drop(rng_snap, GCGCN_SALT_GCN, p);
@@ -465,7 +474,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
   GC_TRY(check_dims("gcn_bwd", B, N, D, L, H));
   EdgeRide er;
   GC_TRY(make_ride("gcn_bwd", ride, 2, er));
-  const long wse = scratch ? scratch_elems(B, N, D, H) : 0;
+  const long wse = scratch ? gemm_scratch_elems(B, N, D, H) : 0;
   GC_REQUIRE(X && Ebar && A && flat && Pn && Y && HO && rinv && dout && dX && dEbar && dA && dflat && W1 && W2 && W3 &&
                  drow && dXres,
              "gcn_bwd: null pointer");
@@ -494,9 +503,15 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
     gs[1].B = HO, gs[1].ldb = HD, gs[1].b_kc = 0;
     gs[1].C = dflat + y.oWlin, gs[1].ldc = HD;
     gs[1].M = D, gs[1].N = (int)HD, gs[1].K = (int)M;
-    GC_TRY(gemm_group(gs, 2, st));
+    if (scratch) {  // dblin = column sums of dout ride in the same two launches
+      ColRide cr;
+      cr.X = dout, cr.out = dflat + y.oblin, cr.part = scratch + wse, cr.R = M, cr.ld = D, cr.C = D;
+      GC_TRY(gemm_group(gs, 2, st, &cr));
+    } else {
+      GC_TRY(gemm_group(gs, 2, st));
+      GC_TRY(colsum(dout, nullptr, dflat + y.oblin, M, D, D, 1, 0, 0, 0, 0, scratch, st));
+    }
   }
-  GC_TRY(colsum(dout, nullptr, dflat + y.oblin, M, D, D, 1, 0, 0, 0, 0, scratch, st));  // dblin
   GC_TRY(head_sum_drop_bwd(dYa, dYa, dXres, M, H, D, drop, st));  // residual + dropout backward
 
   {  // the dependent per-(doc, head) sequence, last sub-layer first

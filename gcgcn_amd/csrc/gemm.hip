@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "gemm_body.hpp"
+#include "rowops.hpp"
 
 namespace gc {
 
@@ -44,13 +45,49 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   gemm_body<TM, TN, AKC, BKC, ALIGNED>(g, lds, b % gx, (b / gx) % gy, b / (gx * gy));
 }
 
+// Stage 1 of a riding column sum: workgroup cb sums one slice of rows for 64 columns (4 waves stride the rows,
+// lanes own columns, 8 independent loads in flight per lane).
+__device__ __forceinline__ void col_ride_stage1(const ColRide& cr, int cb, float* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ncb = (cr.C + 63) >> 6;
+  const int sp = cb / ncb, c = (cb - sp * ncb) * 64 + lane;
+  const long rps = (cr.R + COL_RIDE_SLICES - 1) / COL_RIDE_SLICES;
+  const long r0 = sp * rps, r1 = min(cr.R, r0 + rps);
+  float acc = 0.f;
+  if (c < cr.C) {
+    long r = r0 + wave;
+    for (; r + 28 < r1; r += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = cr.X[(r + 4 * u) * cr.ld + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; r < r1; r += 4) acc += cr.X[r * cr.ld + c];
+  }
+  red[wave * 64 + lane] = acc;
+  __syncthreads();
+  if (wave == 0 && c < cr.C) cr.part[(long)sp * cr.C + c] = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+}
+
 // Several independent problems in ONE launch (64x64 tiles, interior shapes only): block -> problem by
 // prefix sums of tile counts, layout chosen per problem by a block-uniform branch.
+// Problems are laid out longest-K first and every problem starts at a workgroup id that is a multiple of 8, so
+// that the XCD-contiguous remap can be applied PER PROBLEM: each XCD receives an equal, contiguous share of every
+// problem's tile list.  (One remap over the whole launch would hand XCD 0 the longest problem and XCD 7 the
+// shortest.)  The <= 7 padding workgroups per problem exit at once.
 __global__ __launch_bounds__(256, 4) void gemm_group_kernel(const GemmGroup gg) {
   __shared__ __attribute__((aligned(16))) float lds[lds_floats<1, 1, true, true>()];
-  int b = xcd_remap(blockIdx.x, gridDim.x), i = 0;
+  const int tiles = gg.tile_begin[gg.nprob];
+  if ((int)blockIdx.x >= tiles) {  // past the GEMM tiles (dispatched last, round-robin over the XCDs): the riding column sum
+    col_ride_stage1(gg.col, blockIdx.x - tiles, lds);
+    return;
+  }
+  int b = blockIdx.x, i = 0;
   while (i + 1 < gg.nprob && b >= gg.tile_begin[i + 1]) ++i;
   b -= gg.tile_begin[i];
+  if (b >= gg.tile_count[i]) return;
+  b = xcd_remap(b, gg.tile_count[i]);
   const GemmArgs& g = gg.p[i];
   const int tn = g.N >> 6, tm = g.M >> 6;
   const int bx = b % tn, by = (b / tn) % tm, zs = b / (tn * tm);
@@ -97,6 +134,16 @@ __device__ __forceinline__ void reduce4(const GemmArgs& g, int z, long idx4) {
 
 __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const GemmGroup gg) {
   int b = blockIdx.x, i = 0;
+  if (b >= gg.red_begin[gg.nprob]) {  // stage 2 of the riding column sum, slices in order
+    const ColRide& cr = gg.col;
+    const int c = (b - gg.red_begin[gg.nprob]) * 256 + threadIdx.x;
+    if (c < cr.C) {
+      float s = 0.f;
+      for (int q = 0; q < COL_RIDE_SLICES; ++q) s += cr.part[(long)q * cr.C + c];
+      cr.out[c] = s;
+    }
+    return;
+  }
   while (i + 1 < gg.nprob && b >= gg.red_begin[i + 1]) ++i;
   b -= gg.red_begin[i];
   const GemmArgs& g = gg.p[i];
@@ -196,7 +243,7 @@ int gemm(const GemmArgs& g_in, hipStream_t stream, int tile, int splits) {
 
 // Independent problems in one launch (plus at most one reduce launch).  Problems that are not interior
 // 64x64 shapes fall back to their own launches.
-int gemm_group(const GemmArgs* probs, int n, hipStream_t stream) {
+int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* col) {
   GemmGroup gg;
   gg.nprob = 0;
   long work = 0;  // tile-k-steps of the whole launch
@@ -267,24 +314,34 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream) {
         ws_used += need, any_split = true;
       }
     }
+    tiles = (tiles + 7) & ~7;
     gg.tile_begin[gg.nprob] = tiles;
+    gg.tile_count[gg.nprob] = (int)(own * g.splits);
     gg.red_begin[gg.nprob] = reds;
     tiles += (int)(own * g.splits);
     if (g.splits > 1) reds += (int)(nb * cdiv((long)g.M * g.N / 4, 256));
     flops += 2.0 * g.M * g.N * g.K * nb;
     gg.p[gg.nprob++] = g;
   }
-  if (gg.nprob == 0) return 0;
+  const bool ride = col && col->X && col->C > 0 && col->R > 0;
+  if (ride) GC_REQUIRE(col->out && col->part, "gemm_group: column ride without out / part");
+  if (gg.nprob == 0)  // nothing to ride on
+    return ride ? colsum(col->X, nullptr, col->out, col->R, col->C, col->ld, 1, 0, 0, 0, 0, col->part, stream) : 0;
   gg.tile_begin[gg.nprob] = tiles;
   gg.red_begin[gg.nprob] = reds;
+  int col1 = 0, col2 = 0;
+  if (ride) {
+    gg.col = *col;
+    col1 = cdiv(col->C, 64) * COL_RIDE_SLICES, col2 = cdiv(col->C, 256);
+  }
   {
     ProfScope ps("gemm_group", stream, flops);
-    hipLaunchKernelGGL(gemm_group_kernel, dim3(tiles), dim3(256), 0, stream, gg);
+    hipLaunchKernelGGL(gemm_group_kernel, dim3(tiles + col1), dim3(256), 0, stream, gg);
   }
   if (int e = check_launch("gemm_group")) return e;
-  if (any_split) {
+  if (any_split || ride) {
     ProfScope ps("gemm_splitk_reduce", stream);
-    hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(reds), dim3(256), 0, stream, gg);
+    hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(reds + col2), dim3(256), 0, stream, gg);
     return check_launch("gemm_group_reduce");
   }
   return 0;

@@ -63,15 +63,29 @@ struct GemmArgs {
 // deterministic reduce + epilogue kernel).
 int gemm(const GemmArgs& g, hipStream_t stream, int tile = 0, int splits = 0);
 
+// A column sum riding in a group launch: out[c] = sum_{r < R} X[r * ld + c]  (bias gradients).  Stage 1 (COL_RIDE_SLICES
+// row slices -> part[slice][C]) runs in extra workgroups of the GEMM launch, stage 2 in extra workgroups of its
+// split-K reduce: the two launches of a stand-alone column sum disappear.  part: COL_RIDE_SLICES * C floats.
+constexpr int COL_RIDE_SLICES = 64;
+struct ColRide {
+  const float* X = nullptr;
+  float* out = nullptr;
+  float* part = nullptr;
+  long R = 0, ld = 0;
+  int C = 0;
+};
+
 // Up to MAXP independent problems carried by one launch (gemm_group).
 struct GemmGroup {
   static constexpr int MAXP = 6;
   GemmArgs p[MAXP];
-  int tile_begin[MAXP + 1];
+  int tile_begin[MAXP + 1];  // first workgroup of each problem, a multiple of 8 (see gemm_group_kernel)
+  int tile_count[MAXP];
   int red_begin[MAXP + 1];
   int nprob;
+  ColRide col;  // col.X == nullptr: nothing rides
 };
-int gemm_group(const GemmArgs* probs, int n, hipStream_t stream);
+int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* col = nullptr);
 
 // Floats of split-K workspace that lets every GEMM of a [rows x cols]-sized problem split freely.
 inline long gemm_ws_elems(long rows, long cols) {
