@@ -112,6 +112,9 @@ def main():
                     help="secondary run (SURVEY 8d): DocRED-like entity counts n_valid ~ clip(round(N(19.5, 6^2)), 2, 42) padded to N")
     ap.add_argument("--early-mean", action="store_true", help="issue the E2 mean before GATAttention (A/B; default off)")
     ap.add_argument("--overlap", action="store_true", help="stream the E2 mean on a side stream (A/B; default off)")
+    ap.add_argument("--overlap-grads", action="store_true",
+                    help="all-reduce each block's gradient asynchronously from a backward hook (A/B; default: one "
+                         "coalesced collective after backward)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON).  This image's RCCL writes a version banner (and, at
@@ -151,7 +154,7 @@ def main():
     hops.overlap_edge_mean = args.overlap
     hops.early_edge_mean = args.early_mean
     gcgcn_amd.manual_seed(1337 + rank, dev)
-    bucket = FlatGradBucket(hops, overlap=world > 1 or force_dist)   # N > 1: gradient slices travel while backward still runs
+    bucket = FlatGradBucket(hops, overlap=args.overlap_grads)   # default: one coalesced all-reduce after backward
     x, e1, e2, adj = synth(cfg, 1337 + rank, dev)
     for t in (x, e1, e2):
         t.requires_grad_()
