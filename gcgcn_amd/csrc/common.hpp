@@ -63,8 +63,18 @@ __host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 __host__ __device__ __forceinline__ uint64_t rng_key(uint64_t seed, uint64_t ctr, uint64_t salt) {
   return mix64(mix64(seed + 0x9E3779B97F4A7C15ull) ^ mix64(ctr * 0xD1342543DE82EF95ull + salt));
 }
+// Per-element draw: the 64-bit site key (full mix64 quality, computed once per kernel) seeds a 32-bit
+// multiply-xorshift finaliser over the element index -- 4 integer multiplies per element instead of the ~12 a
+// 64-bit mix costs on a 32-bit ALU; the draws sit in the epilogue of latency-bound kernels.
 __host__ __device__ __forceinline__ uint32_t rng_u32(uint64_t key, uint64_t idx) {
-  return (uint32_t)(mix64(key + idx * 0x9E3779B97F4A7C15ull) >> 32);
+  uint32_t x = ((uint32_t)idx ^ (uint32_t)(key >> 32)) * 0x9E3779B1u + (uint32_t)key;
+  x ^= (uint32_t)(idx >> 32) * 0x85EBCA77u;
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
 }
 __host__ __device__ __forceinline__ uint32_t drop_thresh(float p) {
   double t = (double)p * 4294967296.0;

@@ -542,3 +542,24 @@ def test_riding_edge_mean_equals_separate_launches(gpu_device, B, N, D, L, H, ra
     for a, b in zip(*res):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
     assert res[0][3].abs().sum() > 0            # dE2 really flowed through the riding broadcast
+
+
+def test_dropout_draws_are_unbiased_and_uncorrelated(gpu_device):
+    """The per-element draw (common.hpp rng_u32): keep rate, neighbour / row / site / step independence on 4M draws."""
+    gcgcn_amd.manual_seed(99)
+    n, p, W = 1 << 22, 0.2, 2048
+    s1, s2 = F_.rng_snapshot(gpu_device), F_.rng_snapshot(gpu_device)        # consecutive steps of one site
+    m = [F_.dropout_keep_mask(s, salt, p, n).float() for s, salt in
+         ((s1, _lib.SALT_GCN), (s2, _lib.SALT_GCN), (s1, _lib.SALT_GLUE))]
+    for k in m:
+        assert abs(k.mean().item() - (1 - p)) < 2e-3
+
+    def corr(a, b):
+        a, b = a - a.mean(), b - b.mean()
+        return (a * b).mean().item() / (a.std() * b.std()).item()
+    k = m[0]
+    assert abs(corr(k[:-1], k[1:])) < 3e-3                 # neighbouring elements
+    assert abs(corr(k[:-W], k[W:])) < 3e-3                 # same column, next row
+    assert abs(corr(k[:-65536], k[65536:])) < 3e-3         # index bit 16 (the finaliser's first shift)
+    assert abs(corr(m[0], m[1])) < 3e-3                    # next step, same site
+    assert abs(corr(m[0], m[2])) < 3e-3                    # same step, another site
