@@ -43,13 +43,13 @@ SIGNATURES = {
     "gcgcn_gat_layout": (I, [I, P]),
     "gcgcn_gat_fwd": (I, [I, I, I, P, P, P, P, P, F, P, P, P, P, P, P]),
     "gcgcn_gat_bwd_scratch": (L, [I, I, I]),
-    "gcgcn_gat_bwd": (I, [I, I, I, P, P, P, P, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_gat_bwd": (I, [I, I, I, P, P, P, P, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_edge_mean_fwd": (I, [I, I, I, P, P, P, P]),
     "gcgcn_edge_mean_bwd": (I, [I, I, I, P, P, P, P]),
     "gcgcn_mha_layout": (I, [I, P]),
     "gcgcn_mha_scratch": (L, [I, I, I]),
     "gcgcn_mha_fwd": (I, [I, I, I, I, P, P, P, P, F, P, P, P, P, P]),
-    "gcgcn_mha_bwd": (I, [I, I, I, I, P, P, P, F, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_mha_bwd": (I, [I, I, I, I, P, P, P, F, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_gcn_layout": (I, [I, I, I, P]),
     "gcgcn_gcn_scratch": (L, [I, I, I, I]),
     "gcgcn_gcn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, P, P, P, P, P, P, P, P]),

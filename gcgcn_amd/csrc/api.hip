@@ -260,8 +260,8 @@ int64_t gcgcn_gat_bwd_scratch(int B, int N, int D) {
 
 int gcgcn_gat_bwd(int B, int N, int D, const float* X, const float* E, const int32_t* n_valid, const float* flat,
                   const void* rng_snap, float p, const float* uvc, const float* P, const float* dA, const float* dEbar,
-                  float* dX, float* dE, float* dflat, float* dlogit, float* ds, float* dvpart, float* duvc,
-                  float* scratch, void* stream) {
+                  const float* dX_in, float* dX, float* dE, float* dflat, float* dlogit, float* ds, float* dvpart,
+                  float* duvc, float* scratch, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("gat_bwd", B, N, D, 1, 1));
   GC_REQUIRE(X && E && flat && uvc && P && dA && dX && dflat && dlogit && ds && dvpart && duvc,
@@ -276,7 +276,7 @@ int gcgcn_gat_bwd(int B, int N, int D, const float* X, const float* E, const int
   GC_REQUIRE(scratch, "gat_bwd: scratch is required");
   GC_TRY(colsum3(X, ds, duvc, M, D, D, dvpart, nullptr, duvc + D, M, D, D, ds, nullptr, duvc + 2 * D, M, 1, 1, scratch,
                  st));
-  GC_TRY(node_score_bwd(ds, uvc, dX, M, D, st));
+  GC_TRY(node_score_bwd(ds, uvc, dX_in, dX, M, D, st));
   GC_TRY(gat_fold_bwd(flat, duvc, dflat, D, st));
   return 0;
 }
@@ -342,8 +342,8 @@ int gcgcn_mha_fwd(int B, int N, int D, int H, const float* X, const int32_t* n_v
 int64_t gcgcn_mha_scratch(int B, int N, int D) { return scratch_elems(B, N, D, 1); }
 
 int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat, const void* rng_snap, float p,
-                  const float* Q, const float* P, const float* dA, float* dX, float* dflat, float* dS, float* dQ,
-                  float* scratch, void* stream) {
+                  const float* Q, const float* P, const float* dA, const float* dX_in, float* dX, float* dflat, float* dS,
+                  float* dQ, float* scratch, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("mha_bwd", B, N, D, 1, H));
   const long wse = scratch ? gemm_scratch_elems(B, N, D, 1) : 0;
@@ -376,6 +376,7 @@ int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat,
     gs[0].B = flat, gs[0].ldb = D, gs[0].b_kc = 0;
     gs[0].C = dX, gs[0].ldc = D;
     gs[0].M = (int)M, gs[0].N = D, gs[0].K = D;
+    gs[0].add = dX_in, gs[0].ldadd = D;  // + the gradient X already collected downstream (NULL = none)
     gs[1].A = dQ, gs[1].lda = D, gs[1].a_kc = 0;
     gs[1].B = X, gs[1].ldb = D, gs[1].b_kc = 0;
     gs[1].C = dflat, gs[1].ldc = D;

@@ -375,13 +375,15 @@ __global__ __launch_bounds__(64 * RW) void node_score_fwd_kernel(const float* __
   if (lane == 0) s[m] = a + uvc[2 * D];
 }
 
-// dX[m, :] = ds[m] * u
+// dX[m, :] = ds[m] * u (+ dXin[m, :], the gradient X already collected downstream)
 __global__ __launch_bounds__(256) void node_score_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ uvc,
-                                                             float* __restrict__ dX, long M, int D) {
+                                                             const float* __restrict__ dXin, float* __restrict__ dX, long M,
+                                                             int D) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= M * D) return;
   const long m = e / D;
-  dX[e] = ds[m] * uvc[e - m * D];
+  const float v = ds[m] * uvc[e - m * D];
+  dX[e] = dXin ? v + dXin[e] : v;
 }
 
 // y[m, :] = x[m, :] for real entities, 0 for padding rows (m = b * N + i, i >= n_valid[b])
@@ -529,9 +531,9 @@ int node_score_fwd(const float* X, const float* uvc, float* s, long M, int D, hi
   hipLaunchKernelGGL(node_score_fwd_kernel, dim3(cdiv(M, RW)), dim3(64 * RW), 0, st, X, uvc, s, M, D);
   return check_launch("node_score_fwd");
 }
-int node_score_bwd(const float* ds, const float* uvc, float* dX, long M, int D, hipStream_t st) {
+int node_score_bwd(const float* ds, const float* uvc, const float* dXin, float* dX, long M, int D, hipStream_t st) {
   ProfScope ps("node_score_bwd", st);
-  hipLaunchKernelGGL(node_score_bwd_kernel, dim3(cdiv(M * D, 256)), dim3(256), 0, st, ds, uvc, dX, M, D);
+  hipLaunchKernelGGL(node_score_bwd_kernel, dim3(cdiv(M * D, 256)), dim3(256), 0, st, ds, uvc, dXin, dX, M, D);
   return check_launch("node_score_bwd");
 }
 int mask_rows(const float* x, float* y, long M, int D, int N, const int* n_valid, hipStream_t st) {

@@ -109,7 +109,9 @@ def dropout_keep_mask(snap: Tensor, salt: int, p: float, numel: int) -> Tensor:
 
 # ---- GATAttention + single pass over E -------------------------------------------------------------
 class GatFn(torch.autograd.Function):
-    """(X[B,N,D], E[B,N,N,D], flat) -> (A[B,N,N], Ebar[B,N,D]).  GCGCN_glove.py:154-168 (+ :40-41)."""
+    """(X[B,N,D], E[B,N,N,D], flat) -> (A[B,N,N], Ebar[B,N,D], X).  GCGCN_glove.py:154-168 (+ :40-41).
+    The third output is X itself: a hop that hands THIS alias to its convolution lets the convolution's dX arrive
+    here, where the attention's own dX kernel adds it -- instead of autograd summing the two with one more launch."""
 
     @staticmethod
     def forward(ctx, x, e, flat, n_valid, p, snap):
@@ -124,15 +126,16 @@ class GatFn(torch.autograd.Function):
              _p(P), _p(A), _p(ebar), _stream())
         ctx.save_for_backward(x, e, flat, uvc, P)
         ctx.n_valid, ctx.p, ctx.snap = n_valid, float(p), snap
-        return (P if A is None else A), ebar
+        return (P if A is None else A), ebar, x.view_as(x)
 
     @staticmethod
-    def backward(ctx, dA, dEbar):
+    def backward(ctx, dA, dEbar, dXin):
         x, e, flat, uvc, P = ctx.saved_tensors
         B, N, D = x.shape
         dev = x.device
         dA = torch.zeros(B, N, N, device=dev) if dA is None else dA.contiguous()
         dEbar = None if dEbar is None else dEbar.contiguous()
+        dXin = None if dXin is None else dXin.contiguous()
         dX = torch.empty_like(x)
         dE = torch.empty_like(e) if ctx.needs_input_grad[1] else None
         dflat = torch.empty_like(flat)
@@ -143,8 +146,8 @@ class GatFn(torch.autograd.Function):
         nscr = _lib.lib().gcgcn_gat_bwd_scratch(B, N, D)
         scratch = torch.empty(max(nscr, 1), device=dev)
         call("gcgcn_gat_bwd", B, N, D, _p(x), _p(e), _p(ctx.n_valid), _p(flat), _p(ctx.snap), ctx.p, _p(uvc), _p(P),
-             _p(dA), _p(dEbar), _p(dX), _p(dE), _p(dflat), _p(dlogit), _p(ds), _p(dvpart), _p(duvc), _p(scratch),
-             _stream())
+             _p(dA), _p(dEbar), _p(dXin), _p(dX), _p(dE), _p(dflat), _p(dlogit), _p(ds), _p(dvpart), _p(duvc),
+             _p(scratch), _stream())
         return dX, dE, dflat, None, None, None
 
 
@@ -169,7 +172,8 @@ class EdgeMeanFn(torch.autograd.Function):
 
 
 class MhaFn(torch.autograd.Function):
-    """(X[B,N,D], flat) -> A[B,H,N,N].  MultiHeadAttention.forward, GCGCN_glove.py:133-142."""
+    """(X[B,N,D], flat) -> (A[B,H,N,N], X).  MultiHeadAttention.forward, GCGCN_glove.py:133-142.  The second output
+    is the alias of X described at GatFn."""
 
     @staticmethod
     def forward(ctx, x, flat, n_valid, H, p, snap):
@@ -183,20 +187,21 @@ class MhaFn(torch.autograd.Function):
              _p(scratch), _stream())
         ctx.save_for_backward(x, flat, Q, P)
         ctx.H, ctx.p, ctx.snap = H, float(p), snap
-        return P if A is None else A
+        return (P if A is None else A), x.view_as(x)
 
     @staticmethod
-    def backward(ctx, dA):
+    def backward(ctx, dA, dXin):
         x, flat, Q, P = ctx.saved_tensors
         B, N, D = x.shape
         H, dev = ctx.H, x.device
-        dA = dA.contiguous()
+        dA = torch.zeros(B, H, N, N, device=dev) if dA is None else dA.contiguous()
+        dXin = None if dXin is None else dXin.contiguous()
         dX = torch.empty_like(x)
         dflat = torch.empty_like(flat)
         dS = torch.empty(B, H, N, N, device=dev)
         dQ = torch.empty(B, N, D, device=dev)
         scratch = torch.empty(max(_lib.lib().gcgcn_mha_scratch(B, N, D), 1), device=dev)
-        call("gcgcn_mha_bwd", B, N, D, H, _p(x), _p(flat), _p(ctx.snap), ctx.p, _p(Q), _p(P), _p(dA), _p(dX),
+        call("gcgcn_mha_bwd", B, N, D, H, _p(x), _p(flat), _p(ctx.snap), ctx.p, _p(Q), _p(P), _p(dA), _p(dXin), _p(dX),
              _p(dflat), _p(dS), _p(dQ), _p(scratch), _stream())
         return dX, dflat, None, None, None, None
 
@@ -333,7 +338,7 @@ def gat_attention(x, e, flat, n_valid=None, p=0.1, training=False):
     if e.shape != (B, N, N, D):
         raise ValueError(f"edge_feat: expected {(B, N, N, D)}, got {tuple(e.shape)}")
     nv = _nv(n_valid, B, N, x.device)
-    return GatFn.apply(x, e, _chk(flat, "flat"), nv, p, _snap_for(training, p, x.device))
+    return GatFn.apply(x, e, _chk(flat, "flat"), nv, p, _snap_for(training, p, x.device))   # (A, Ebar, alias of x)
 
 
 def edge_mean(e, n_valid=None):

@@ -121,12 +121,15 @@ class GATAttention(_FlatBlock):
         return P_.unpack_gat(self.flat.grad, self.dim) if self.flat.grad is not None else {}
 
     def forward(self, node_feat: Tensor, edge_feat: Tensor, mask: Optional[Tensor] = None,
-                n_valid: Optional[Tensor] = None) -> Tensor:
+                n_valid: Optional[Tensor] = None, return_input_alias: bool = False) -> Tensor:
         x, batched = _batched(node_feat, 2)
         e, _ = _batched(edge_feat, 3)
-        a, ebar = F_.gat_attention(x, e, self.flat, n_valid, self.p, self.training)
+        a, ebar, xa = F_.gat_attention(x, e, self.flat, n_valid, self.p, self.training)
         F_.park_edge_mean(edge_feat, n_valid, ebar)
-        return a if batched else a.squeeze(0)
+        a = a if batched else a.squeeze(0)
+        # extension: (A, alias of node_feat).  Feeding the alias to the convolution of the same hop routes the
+        # convolution's d(node_feat) through this block's backward, which adds it in its own dX kernel
+        return (a, xa if batched else xa.squeeze(0)) if return_input_alias else a
 
 
 # ======================================================================================================
@@ -175,10 +178,12 @@ class MultiHeadAttention(_FlatBlock):
             return {}
         return P_.unpack_mha(self.flat.grad, self.dim, self.head_num, "q")
 
-    def forward(self, node_feat: Tensor, mask: Optional[Tensor] = None, n_valid: Optional[Tensor] = None) -> List[Tensor]:
+    def forward(self, node_feat: Tensor, mask: Optional[Tensor] = None, n_valid: Optional[Tensor] = None,
+                return_input_alias: bool = False) -> List[Tensor]:
         x, batched = _batched(node_feat, 2)
-        a = F_.multi_head_adjacency(x, self.flat, self.head_num, n_valid, self.p, self.training)  # [B,H,N,N]
-        return list(a.unbind(1)) if batched else list(a.squeeze(0).unbind(0))
+        a, xa = F_.multi_head_adjacency(x, self.flat, self.head_num, n_valid, self.p, self.training)  # [B,H,N,N]
+        heads = list(a.unbind(1)) if batched else list(a.squeeze(0).unbind(0))
+        return (heads, xa if batched else xa.squeeze(0)) if return_input_alias else heads   # see GATAttention
 
 
 # ======================================================================================================
@@ -384,18 +389,18 @@ class GraphHops(nn.Module):
             if i < 1:
                 # glove:330 builds mask = eq(adj_matrix, 0) and glove:163-164 then discards it; the mask is
                 # not even materialised here (adj_matrix is accepted for signature compatibility only)
-                a = self.get_weighted_adj_matrix(x, e, None, n_valid=n_valid)                # glove:332
+                a, xa = self.get_weighted_adj_matrix(x, e, None, n_valid=n_valid, return_input_alias=True)  # glove:332
                 if x.is_cuda and self.graph_hop > 1 and self.overlap_edge_mean:
                     fork_edge_means()
-                new = self.graphcnn[i](x, e, a, n_valid=n_valid, ride_edge=ride(i))          # glove:333
+                new = self.graphcnn[i](xa, e, a, n_valid=n_valid, ride_edge=ride(i))         # glove:333
             else:
-                al = self.get_adj_matrix[i - 1](x, e, n_valid=n_valid)                       # glove:336
+                al, xa = self.get_adj_matrix[i - 1](x, e, n_valid=n_valid, return_input_alias=True)  # glove:336
                 if i in pre:
                     if self.overlap_edge_mean:
                         torch.cuda.current_stream().wait_stream(self._side_stream(x.device))
                         pre[i].record_stream(torch.cuda.current_stream())
                     F_.park_edge_mean(e, n_valid, pre.pop(i))
-                new = self.graphcnn[i](x, e, al, n_valid=n_valid, ride_edge=ride(i))         # glove:337
+                new = self.graphcnn[i](xa, e, al, n_valid=n_valid, ride_edge=ride(i))        # glove:337
             x = new if self.alpha == 1.0 else self.alpha * new + (1 - self.alpha) * x        # glove:339
             x = F_.dropout(x, self.p, self.training)                                         # glove:341
             feats.append(x)

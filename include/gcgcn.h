@@ -80,14 +80,15 @@ int gcgcn_gat_layout(int D, int64_t* out9);
 int gcgcn_gat_fwd(int B, int N, int D, const float* X, const float* E, const int32_t* n_valid, const float* flat,
                   const void* rng_snap, float p, float* uvc, float* s, float* P, float* A, float* Ebar, void* stream);
 
-/* backward.  dA[B,N,N], dEbar[B,N,D] (NULL = zero) -> dX[B,N,D], dE[B,N,N,D] (NULL = not
- * wanted), dflat.  Workspace: dlogit[B,N,N], ds[B,N], dvpart[B*N*D], duvc[2D+1],
+/* backward.  dA[B,N,N], dEbar[B,N,D] (NULL = zero), dX_in[B,N,D] (NULL = zero: gradient node_feat has
+ * already collected from its other consumers -- the convolution of the same hop -- added here instead of
+ * by a separate kernel) -> dX[B,N,D], dE[B,N,N,D] (NULL = not wanted), dflat.  Workspace: dlogit[B,N,N], ds[B,N], dvpart[B*N*D], duvc[2D+1],
  * scratch[gcgcn_gat_bwd_scratch(B,N,D)]. */
 int64_t gcgcn_gat_bwd_scratch(int B, int N, int D);
 int gcgcn_gat_bwd(int B, int N, int D, const float* X, const float* E, const int32_t* n_valid, const float* flat,
                   const void* rng_snap, float p, const float* uvc, const float* P, const float* dA, const float* dEbar,
-                  float* dX, float* dE, float* dflat, float* dlogit, float* ds, float* dvpart, float* duvc,
-                  float* scratch, void* stream);
+                  const float* dX_in, float* dX, float* dE, float* dflat, float* dlogit, float* ds, float* dvpart,
+                  float* duvc, float* scratch, void* stream);
 
 /* ---- edge mean alone (MAGGC hop: E enters only through GraphConv's mean, glove:40-41) ------ */
 int gcgcn_edge_mean_fwd(int B, int N, int D, const float* E, const int32_t* n_valid, float* Ebar, void* stream);
@@ -104,10 +105,11 @@ int gcgcn_mha_layout(int D, int64_t* out3);
 int64_t gcgcn_mha_scratch(int B, int N, int D);
 int gcgcn_mha_fwd(int B, int N, int D, int H, const float* X, const int32_t* n_valid, const float* flat,
                   const void* rng_snap, float p, float* Q, float* P, float* A, float* scratch, void* stream);
-/* backward.  Workspace: dS[B,H,N,N], dQ[B,N,D], scratch[gcgcn_mha_scratch]. */
+/* backward.  dX_in[B,N,D] (NULL = zero) as in gcgcn_gat_bwd.  Workspace: dS[B,H,N,N], dQ[B,N,D],
+ * scratch[gcgcn_mha_scratch]. */
 int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat, const void* rng_snap, float p,
-                  const float* Q, const float* P, const float* dA, float* dX, float* dflat, float* dS, float* dQ,
-                  float* scratch, void* stream);
+                  const float* Q, const float* P, const float* dA, const float* dX_in, float* dX, float* dflat,
+                  float* dS, float* dQ, float* scratch, void* stream);
 
 /* ---- GraphConvolution (H = 1) / MultiGraphConvolution  GCGCN_glove.py:52-120 --------------- */
 /* flat = [WnX D x H*D | We D x H*D | Wd | Wlin D x H*D | blin D]
