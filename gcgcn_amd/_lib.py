@@ -52,8 +52,8 @@ SIGNATURES = {
     "gcgcn_mha_bwd": (I, [I, I, I, I, P, P, P, F, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_gcn_layout": (I, [I, I, I, P]),
     "gcgcn_gcn_scratch": (L, [I, I, I, I]),
-    "gcgcn_gcn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, P, P, P, P, P, P, P, P]),
-    "gcgcn_gcn_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_gcn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, F, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_gcn_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_graphconv_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_graphconv_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_gemm": (I, [I, I, I, P, L, I, P, L, I, P, L, I, L, L, L, F, P, I, I, I, I, P, L, P]),

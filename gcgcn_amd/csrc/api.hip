@@ -405,8 +405,9 @@ int gcgcn_gcn_layout(int D, int L, int H, int64_t* o) {
 }
 
 int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float* Ebar, const float* A,
-                  const int32_t* n_valid, const float* flat, const void* rng_snap, float p, float* out, float* Pn,
-                  float* Y, float* HO, float* rinv, float* G, float* scratch, const gcgcn_edge_ride* ride, void* stream) {
+                  const int32_t* n_valid, const float* flat, const void* rng_snap, float p, const void* out_rng_snap,
+                  float out_p, float* out, float* Pn, float* Y, float* HO, float* rinv, float* G, float* scratch,
+                  const gcgcn_edge_ride* ride, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("gcn_fwd", B, N, D, L, H));
   EdgeRide er;
@@ -459,6 +460,12 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
     g.M = (int)M, g.N = D, g.K = (int)HD;
     g.bias = flat + y.oblin;
     g.n_valid = n_valid, g.nv_rows = N, g.nv_zdoc = 0;
+    const Drop odrop = make_drop(out_rng_snap, GCGCN_SALT_GLUE, out_p);
+    if (odrop.snap) {  // the hop's output dropout (glove:341) in the same epilogue: out = dropout(linear)
+      g.C = G;         // the undropped values go to workspace that is free by now; nobody reads them
+      g.C2 = out, g.ldc2 = D;
+      g.drop = odrop;
+    }
     GC_TRY(gemm(g, st));
   }
   return 0;
@@ -467,10 +474,12 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
 int64_t gcgcn_gcn_scratch(int B, int N, int D, int H) { return scratch_elems(B, N, D, H); }
 
 int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float* Ebar, const float* A,
-                  const int32_t* n_valid, const float* flat, const void* rng_snap, float p, const float* Pn,
-                  const float* Y, const float* HO, const float* rinv, const float* dout, float* dX, float* dEbar,
+                  const int32_t* n_valid, const float* flat, const void* rng_snap, float p, const void* out_rng_snap,
+                  float out_p, const float* Pn, const float* Y, const float* HO, const float* rinv, const float* dout,
+                  float* dX, float* dEbar,
                   float* dA, float* dflat, float* W1, float* W2, float* W3, float* drow, float* dXres, float* dout_m,
                   float* scratch, const gcgcn_edge_ride* ride, void* stream) {
+  const Drop odrop = make_drop(out_rng_snap, GCGCN_SALT_GLUE, out_p);
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("gcn_bwd", B, N, D, L, H));
   EdgeRide er;
@@ -479,7 +488,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
   GC_REQUIRE(X && Ebar && A && flat && Pn && Y && HO && rinv && dout && dX && dEbar && dA && dflat && W1 && W2 && W3 &&
                  drow && dXres,
              "gcn_bwd: null pointer");
-  GC_REQUIRE(!n_valid || dout_m, "gcn_bwd: n_valid given without dout_m workspace");
+  GC_REQUIRE(!(n_valid || odrop.snap) || dout_m, "gcn_bwd: n_valid / output dropout given without dout_m workspace");
   const GcnLayout y = gcn_layout(D, L, H);
   const Drop drop = make_drop(rng_snap, GCGCN_SALT_GCN, p);
   const long M = (long)B * N;
@@ -489,8 +498,8 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
   float* dM = W2;   // gradient of M_l = G_l + A_h Pn_l  (== dG)
   float* dP = W3;   // gradient of Pn_l
 
-  if (n_valid) {  // gradients arriving on padding rows are ignored
-    GC_TRY(mask_rows(dout, dout_m, M, D, N, n_valid, st));
+  if (n_valid || odrop.snap) {  // gradients arriving on padding rows are ignored; back through the output dropout
+    GC_TRY(mask_rows(dout, dout_m, M, D, N, n_valid, odrop, st));
     dout = dout_m;
   }
   {  // one launch: dHO = dout Wlin  and  dWlin = dout^T HO

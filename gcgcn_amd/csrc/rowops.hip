@@ -386,14 +386,17 @@ __global__ __launch_bounds__(256) void node_score_bwd_kernel(const float* __rest
   dX[e] = dXin ? v + dXin[e] : v;
 }
 
-// y[m, :] = x[m, :] for real entities, 0 for padding rows (m = b * N + i, i >= n_valid[b])
+// y[m, :] = dropout_bwd(x[m, :]) for real entities, 0 for padding rows (m = b * N + i, i >= n_valid[b]);
+// n_valid == NULL: no padding, drop.snap == NULL: no dropout
 __global__ __launch_bounds__(256) void mask_rows_kernel(const float* __restrict__ x, float* __restrict__ y, long M, int D,
-                                                        int N, const int* __restrict__ n_valid) {
+                                                        int N, const int* __restrict__ n_valid, Drop drop) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= M * D) return;
   const long m = e / D;
   const long b = m / N;
-  y[e] = ((int)(m - b * N) < n_valid[b]) ? x[e] : 0.f;
+  float v = (!n_valid || (int)(m - b * N) < n_valid[b]) ? x[e] : 0.f;
+  if (drop.snap) v = (rng_u32(drop_key(drop), (uint64_t)e) >= drop.thresh) ? v * drop.scale : 0.f;
+  y[e] = v;
 }
 
 // =============================================================================================
@@ -536,9 +539,9 @@ int node_score_bwd(const float* ds, const float* uvc, const float* dXin, float* 
   hipLaunchKernelGGL(node_score_bwd_kernel, dim3(cdiv(M * D, 256)), dim3(256), 0, st, ds, uvc, dXin, dX, M, D);
   return check_launch("node_score_bwd");
 }
-int mask_rows(const float* x, float* y, long M, int D, int N, const int* n_valid, hipStream_t st) {
+int mask_rows(const float* x, float* y, long M, int D, int N, const int* n_valid, Drop drop, hipStream_t st) {
   ProfScope ps("mask_rows", st);
-  hipLaunchKernelGGL(mask_rows_kernel, dim3(cdiv(M * D, 256)), dim3(256), 0, st, x, y, M, D, N, n_valid);
+  hipLaunchKernelGGL(mask_rows_kernel, dim3(cdiv(M * D, 256)), dim3(256), 0, st, x, y, M, D, N, n_valid, drop);
   return check_launch("mask_rows");
 }
 

@@ -24,7 +24,7 @@ int gat_fold_fwd(const float* flat, float* uvc, int D, hipStream_t st);
 int gat_fold_bwd(const float* flat, const float* duvc, float* dflat, int D, hipStream_t st);
 int node_score_fwd(const float* X, const float* uvc, float* s, long M, int D, hipStream_t st);
 int node_score_bwd(const float* ds, const float* uvc, const float* dXin, float* dX, long M, int D, hipStream_t st);
-int mask_rows(const float* x, float* y, long M, int D, int N, const int* n_valid, hipStream_t st);
+int mask_rows(const float* x, float* y, long M, int D, int N, const int* n_valid, Drop drop, hipStream_t st);
 
 int edge_fwd(const float* E, const float* v, const int* n_valid, float* Ebar, const float* coladd, float* P, float* A,
              Drop drop, int B, int N, int D, hipStream_t st);

@@ -219,7 +219,7 @@ class GcnFn(torch.autograd.Function):
     latency-bound chain launch, and so does its backward."""
 
     @staticmethod
-    def forward(ctx, x, ebar, adj, flat, n_valid, L, H, p, snap, e_next):
+    def forward(ctx, x, ebar, adj, flat, n_valid, L, H, p, snap, e_next, out_p, out_snap):
         B, N, D = x.shape
         dev = x.device
         HD = H * D
@@ -235,10 +235,11 @@ class GcnFn(torch.autograd.Function):
             ebar_next = torch.empty(e_next.shape[0], e_next.shape[1], e_next.shape[3], device=dev)
             ride, ride_p = _ride(e_next, n_valid, ebar_next, *ebar_next.shape)
         call("gcgcn_gcn_fwd", B, N, D, L, H, _p(x), _p(ebar), _p(adj), _p(n_valid), _p(flat), _p(snap), float(p),
-             _p(out), _p(Pn), _p(Y), _p(HO), _p(rinv), _p(G), _p(scratch), ride_p, _stream())
+             _p(out_snap), float(out_p), _p(out), _p(Pn), _p(Y), _p(HO), _p(rinv), _p(G), _p(scratch), ride_p, _stream())
         del ride
         ctx.save_for_backward(x, ebar, adj, flat, Pn, Y, HO, rinv)
         ctx.n_valid, ctx.L, ctx.H, ctx.p, ctx.snap = n_valid, L, H, float(p), snap
+        ctx.out_p, ctx.out_snap = float(out_p), out_snap
         ctx.next_shape = None if e_next is None else tuple(e_next.shape)
         return out, ebar_next
 
@@ -258,7 +259,7 @@ class GcnFn(torch.autograd.Function):
         W3 = torch.empty(B, N, HD, device=dev)
         drow = torch.empty(B, H, N, device=dev)
         dXres = torch.empty(B, N, D, device=dev)
-        dout_m = torch.empty(B, N, D, device=dev) if ctx.n_valid is not None else None
+        dout_m = torch.empty(B, N, D, device=dev) if (ctx.n_valid is not None or ctx.out_snap is not None) else None
         scratch = torch.empty(max(_lib.lib().gcgcn_gcn_scratch(B, N, D, H), 1), device=dev)
         dE_next, ride, ride_p = None, None, None
         if ctx.next_shape is not None and ctx.needs_input_grad[9] and debar_next is not None:
@@ -266,10 +267,10 @@ class GcnFn(torch.autograd.Function):
             dE_next = torch.empty(ctx.next_shape, device=dev)
             ride, ride_p = _ride(debar_next, ctx.n_valid, dE_next, *debar_next.shape)
         call("gcgcn_gcn_bwd", B, N, D, L, H, _p(x), _p(ebar), _p(adj), _p(ctx.n_valid), _p(flat), _p(ctx.snap),
-             ctx.p, _p(Pn), _p(Y), _p(HO), _p(rinv), _p(dout), _p(dX), _p(dEbar), _p(dA), _p(dflat), _p(W1), _p(W2),
-             _p(W3), _p(drow), _p(dXres), _p(dout_m), _p(scratch), ride_p, _stream())
+             ctx.p, _p(ctx.out_snap), ctx.out_p, _p(Pn), _p(Y), _p(HO), _p(rinv), _p(dout), _p(dX), _p(dEbar), _p(dA),
+             _p(dflat), _p(W1), _p(W2), _p(W3), _p(drow), _p(dXres), _p(dout_m), _p(scratch), ride_p, _stream())
         del ride
-        return dX, dEbar, dA, dflat, None, None, None, None, None, dE_next
+        return dX, dEbar, dA, dflat, None, None, None, None, None, dE_next, None, None
 
 
 class GraphConvFn(torch.autograd.Function):
@@ -353,8 +354,9 @@ def multi_head_adjacency(x, flat, H, n_valid=None, p=0.1, training=False):
     return MhaFn.apply(x, _chk(flat, "flat"), _nv(n_valid, B, N, x.device), H, p, _snap_for(training, p, x.device))
 
 
-def gcn_stack(x, ebar, adj, flat, L, H, n_valid=None, p=0.2, training=False, e_next=None):
-    """Returns ``out`` -- or ``(out, mean_j e_next)`` when the next hop's edge tensor ``e_next[B,N,N,D']`` is given."""
+def gcn_stack(x, ebar, adj, flat, L, H, n_valid=None, p=0.2, training=False, e_next=None, out_dropout=0.0):
+    """Returns ``out`` -- or ``(out, mean_j e_next)`` when the next hop's edge tensor ``e_next[B,N,N,D']`` is given.
+    ``out_dropout`` > 0 (training only): the hop's ``x <- dropout(out)`` (glove:341) applied inside the block."""
     x, ebar, adj = _chk(x, "node_feat", 3), _chk(ebar, "edge_mean", 3), _chk(adj, "adjacency", 4)
     B, N, D = x.shape
     if ebar.shape != (B, N, D) or adj.shape != (B, H, N, N):
@@ -364,7 +366,10 @@ def gcn_stack(x, ebar, adj, flat, L, H, n_valid=None, p=0.2, training=False, e_n
         e_next = _chk(e_next, "next edge_feat", 4)
         if e_next.shape[:3] != (B, N, N):
             raise ValueError(f"gcn_stack: next edge tensor {tuple(e_next.shape)} does not match B={B} N={N}")
-    out, ebar_next = GcnFn.apply(x, ebar, adj, _chk(flat, "flat"), nv, L, H, p, _snap_for(training, p, x.device), e_next)
+    snap = _snap_for(training, p, x.device)                       # draw order: block, then the hop's output dropout
+    out_snap = _snap_for(training, out_dropout, x.device)
+    out, ebar_next = GcnFn.apply(x, ebar, adj, _chk(flat, "flat"), nv, L, H, p, snap, e_next,
+                                 out_dropout if out_snap is not None else 0.0, out_snap)
     return out if e_next is None else (out, ebar_next)
 
 

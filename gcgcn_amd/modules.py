@@ -226,14 +226,17 @@ class _GcnBase(_FlatBlock):
             ebar = F_.edge_mean(e, n_valid)
         return ebar
 
-    def _stack(self, x, ebar, adj, n_valid, ride_edge):
-        """The fused block.  ``ride_edge`` (extension) is the edge tensor the NEXT hop's convolution will be called
-        with: its mean is computed inside this block's chain launch and parked for that call (functional.GcnFn)."""
+    def _stack(self, x, ebar, adj, n_valid, ride_edge, out_dropout):
+        """The fused block.  Extensions used by GraphHops: ``ride_edge`` is the edge tensor the NEXT hop's
+        convolution will be called with -- its mean is computed inside this block's chain launch and parked for that
+        call (functional.GcnFn); ``out_dropout`` applies the hop's output dropout (glove:341) in the block's last
+        epilogue."""
         if ride_edge is None:
-            return F_.gcn_stack(x, ebar, adj, self.flat, self.layer_num, self.head_num, n_valid, self.p, self.training)
+            return F_.gcn_stack(x, ebar, adj, self.flat, self.layer_num, self.head_num, n_valid, self.p, self.training,
+                                out_dropout=out_dropout)
         e_next, _ = _batched(ride_edge, 3)
         out, ebar_next = F_.gcn_stack(x, ebar, adj, self.flat, self.layer_num, self.head_num, n_valid, self.p,
-                                      self.training, e_next=e_next)
+                                      self.training, e_next=e_next, out_dropout=out_dropout)
         F_.park_edge_mean(ride_edge, n_valid, ebar_next)
         return out
 
@@ -281,11 +284,12 @@ class GraphConvolution(_GcnBase):
         self._setup(layer_num, 1, input_dim, output_dim, bias)
 
     def forward(self, node_feat: Tensor, edge_feat: Tensor, adj_matrix: Tensor,
-                n_valid: Optional[Tensor] = None, ride_edge: Optional[Tensor] = None) -> Tensor:
+                n_valid: Optional[Tensor] = None, ride_edge: Optional[Tensor] = None,
+                out_dropout: float = 0.0) -> Tensor:
         x, batched = _batched(node_feat, 2)
         adj, _ = _batched(adj_matrix, 2)
         ebar = self._edge_mean(edge_feat, n_valid)
-        out = self._stack(x, ebar, adj.unsqueeze(1), n_valid, ride_edge)
+        out = self._stack(x, ebar, adj.unsqueeze(1), n_valid, ride_edge, out_dropout)
         return out if batched else out.squeeze(0)
 
 
@@ -312,11 +316,12 @@ class MultiGraphConvolution(_GcnBase):
         return stacked if batched else stacked.unsqueeze(0)
 
     def forward(self, node_feat: Tensor, edge_feat: Tensor, adj_matrix_list: Union[Tensor, Sequence[Tensor]],
-                n_valid: Optional[Tensor] = None, ride_edge: Optional[Tensor] = None) -> Tensor:
+                n_valid: Optional[Tensor] = None, ride_edge: Optional[Tensor] = None,
+                out_dropout: float = 0.0) -> Tensor:
         x, batched = _batched(node_feat, 2)
         adj = self._stack_heads(adj_matrix_list, batched)
         ebar = self._edge_mean(edge_feat, n_valid)
-        out = self._stack(x, ebar, adj, n_valid, ride_edge)
+        out = self._stack(x, ebar, adj, n_valid, ride_edge, out_dropout)
         return out if batched else out.squeeze(0)
 
 
@@ -384,6 +389,10 @@ class GraphHops(nn.Module):
                 and not self.overlap_edge_mean
             return edge_feats[i + 1] if on else None
 
+        # alpha == 1 (the reference's setting): x <- dropout(new) is applied in the convolution's last epilogue
+        fused_out = self.alpha == 1.0 and x.is_cuda
+        odrop = self.p if (fused_out and self.training) else 0.0
+
         for i in range(self.graph_hop):
             e = edge_feats[i]
             if i < 1:
@@ -392,7 +401,7 @@ class GraphHops(nn.Module):
                 a, xa = self.get_weighted_adj_matrix(x, e, None, n_valid=n_valid, return_input_alias=True)  # glove:332
                 if x.is_cuda and self.graph_hop > 1 and self.overlap_edge_mean:
                     fork_edge_means()
-                new = self.graphcnn[i](xa, e, a, n_valid=n_valid, ride_edge=ride(i))         # glove:333
+                new = self.graphcnn[i](xa, e, a, n_valid=n_valid, ride_edge=ride(i), out_dropout=odrop)  # glove:333
             else:
                 al, xa = self.get_adj_matrix[i - 1](x, e, n_valid=n_valid, return_input_alias=True)  # glove:336
                 if i in pre:
@@ -400,9 +409,12 @@ class GraphHops(nn.Module):
                         torch.cuda.current_stream().wait_stream(self._side_stream(x.device))
                         pre[i].record_stream(torch.cuda.current_stream())
                     F_.park_edge_mean(e, n_valid, pre.pop(i))
-                new = self.graphcnn[i](xa, e, al, n_valid=n_valid, ride_edge=ride(i))        # glove:337
-            x = new if self.alpha == 1.0 else self.alpha * new + (1 - self.alpha) * x        # glove:339
-            x = F_.dropout(x, self.p, self.training)                                         # glove:341
+                new = self.graphcnn[i](xa, e, al, n_valid=n_valid, ride_edge=ride(i), out_dropout=odrop)  # glove:337
+            if fused_out:
+                x = new                                                                      # glove:339 + :341, in the block
+            else:
+                x = self.alpha * new + (1 - self.alpha) * x                                  # glove:339
+                x = F_.dropout(x, self.p, self.training)                                     # glove:341
             feats.append(x)
         return feats
 
