@@ -268,16 +268,24 @@ int gcgcn_gat_bwd(int B, int N, int D, const float* X, const float* E, const int
              "gat_bwd: null pointer");
   const Drop drop = make_drop(rng_snap, GCGCN_SALT_GAT, p);
   const long M = (long)B * N;
-  GC_TRY(softmax_bwd(P, dA, dlogit, M, N, drop, st));
-  // ds[b, j] = sum_i dlogit[b, i, j]
-  GC_TRY(colsum(dlogit, nullptr, ds, N, N, N, B, (long)N * N, 0, N, 0, nullptr, st));
-  GC_TRY(edge_bwd(E, uvc + D, n_valid, dlogit, dEbar, dE, dvpart, B, N, D, st));
-  // du = sum_m ds[m] X[m,:],  dv = sum partials,  dc = sum_m ds[m]: one two-stage launch pair
   GC_REQUIRE(scratch, "gat_bwd: scratch is required");
+  const bool small = gat_dlogit_ok(N);
+  if (small) {  // dlogit, ds and dX = ds u + dX_in in one launch, one workgroup per document
+    GC_TRY(gat_dlogit(P, dA, uvc, dX_in, dlogit, ds, dX, B, N, D, drop, st));
+  } else {
+    GC_TRY(softmax_bwd(P, dA, dlogit, M, N, drop, st));
+    // ds[b, j] = sum_i dlogit[b, i, j]
+    GC_TRY(colsum(dlogit, nullptr, ds, N, N, N, B, (long)N * N, 0, N, 0, nullptr, st));
+    GC_TRY(node_score_bwd(ds, uvc, dX_in, dX, M, D, st));
+  }
+  GC_TRY(edge_bwd(E, uvc + D, n_valid, dlogit, dEbar, dE, dvpart, B, N, D, st));
+  // du = sum_m ds[m] X[m,:],  dv = sum partials,  dc = sum_m ds[m]: row-slice partials in one launch; the fold's
+  // backward sums the slices itself (duvc stays unused)
+  long part_off[3];
+  int ns = 0;
   GC_TRY(colsum3(X, ds, duvc, M, D, D, dvpart, nullptr, duvc + D, M, D, D, ds, nullptr, duvc + 2 * D, M, 1, 1, scratch,
-                 st));
-  GC_TRY(node_score_bwd(ds, uvc, dX_in, dX, M, D, st));
-  GC_TRY(gat_fold_bwd(flat, duvc, dflat, D, st));
+                 st, false, part_off, &ns));
+  GC_TRY(gat_fold_bwd(flat, duvc, dflat, D, st, scratch, part_off, ns));
   return 0;
 }
 

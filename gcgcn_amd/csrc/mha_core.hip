@@ -108,19 +108,23 @@ __global__ __launch_bounds__(256) void mha_core_bwd_kernel(const float* __restri
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const bool dd = drop.snap != nullptr;
   const uint64_t key = dd ? drop_key(drop) : 0;
-  for (int i = wave; i < MT; i += 4) {
-    float ds = 0.f;
-    if (i < N) {  // wave-uniform
-      const long r = (long)z * N + i;
-      float p = 0.f, g = 0.f;
-      if (lane < N) {
-        p = P[r * N + lane], g = dA[r * N + lane];
-        if (dd) g = (rng_u32(key, (uint64_t)(r * N + lane)) >= drop.thresh) ? g * drop.scale : 0.f;
-      }
-      const float dot = wave_sum(g * p);
-      ds = p * (g - dot);
+  {  // all 16 rows of a wave are requested before the first one is reduced: one memory round trip, not sixteen
+    float p[MT / 4], g[MT / 4];
+#pragma unroll
+    for (int u = 0; u < MT / 4; ++u) {
+      const int i = wave + 4 * u;
+      const long o = ((long)z * N + i) * N + lane;
+      p[u] = 0.f, g[u] = 0.f;
+      if (i < N && lane < N) p[u] = P[o], g[u] = dA[o];
     }
-    T[i * MS + lane] = ds;
+#pragma unroll
+    for (int u = 0; u < MT / 4; ++u) {
+      const int i = wave + 4 * u;
+      float gg = g[u];
+      if (dd) gg = (rng_u32(key, (uint64_t)(((long)z * N + i) * N + lane)) >= drop.thresh) ? gg * drop.scale : 0.f;
+      const float dot = wave_sum(gg * p[u]);
+      T[i * MS + lane] = p[u] * (gg - dot);
+    }
   }
   __syncthreads();
   // symmetrise in place: the pair (i, j), (j, i) belongs to one thread

@@ -329,9 +329,33 @@ __global__ __launch_bounds__(64 * FW) void gat_fold_fwd_kernel(const float* __re
   }
 }
 
-// backward of the fold; one wave per parameter row d.  duvc = [du D | dv D | dc 1]
+// backward of the fold; one wave per parameter row d.  duvc = [du D | dv D | dc 1].
+// ns > 0: duvc is not final yet -- `part` holds ns row-slice partials of du, dv, dc (colsum3 stage 1, jobs at
+// part_off[0..2]); every workgroup first sums them in slice order into LDS, which replaces the second-stage launch.
 __global__ __launch_bounds__(64 * RW) void gat_fold_bwd_kernel(const float* __restrict__ flat, const float* __restrict__ duvc,
-                                                               float* __restrict__ dflat, int D) {
+                                                               float* __restrict__ dflat, int D,
+                                                               const float* __restrict__ part, long off_dv, long off_dc,
+                                                               int ns) {
+  extern __shared__ float sduvc[];  // [2 D + 1] when ns > 0
+  if (ns > 0) {
+    for (int k = threadIdx.x; k < 2 * D + 1; k += 64 * RW) {
+      const float* src = k < D ? part + k : (k < 2 * D ? part + off_dv + (k - D) : part + off_dc);
+      const int C = k < 2 * D ? D : 1;
+      float a = 0.f;
+      int q = 0;
+      for (; q + 8 <= ns; q += 8) {  // eight independent loads in flight, summed in slice order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(long)(q + u) * C];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
+      }
+      for (; q < ns; ++q) a += src[(long)q * C];
+      sduvc[k] = a;
+    }
+    __syncthreads();
+    duvc = sduvc;
+  }
   const int d = blockIdx.x * RW + (threadIdx.x >> 6);
   if (d >= D) return;
   const int lane = threadIdx.x & 63;
@@ -360,6 +384,74 @@ __global__ __launch_bounds__(64 * RW) void gat_fold_bwd_kernel(const float* __re
     dflat[owt + D + d] = at + flat[obt + d] * dc;
     dflat[owt + 2 * D + d] = ar + flat[obr + d] * dc;
     if (d == 0) dflat[owt + 3 * D] = dc;
+  }
+}
+
+// GATAttention backward up to the edge pass, one workgroup per document (N <= 64):
+//   dlogit = softmax_bwd(P, dropout_bwd(dA))      [N x N, also kept in LDS]
+//   ds[j]  = sum_i dlogit[i, j]                   (gradient of the node score u.x_j + c)
+//   dX[j]  = ds[j] u (+ dXin[j])
+// replaces three launches (row softmax gradient, batched column sum, node-score gradient).
+constexpr int GT = 64;
+__global__ __launch_bounds__(256) void gat_dlogit_kernel(const float* __restrict__ P, const float* __restrict__ dA,
+                                                         const float* __restrict__ uvc, const float* __restrict__ dXin,
+                                                         float* __restrict__ dlogit, float* __restrict__ ds,
+                                                         float* __restrict__ dX, int N, int D, Drop drop) {
+  __shared__ float T[GT][GT + 1];
+  __shared__ float dss[GT];
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const bool dd = drop.snap != nullptr;
+  const uint64_t key = dd ? drop_key(drop) : 0;
+  {  // all 16 rows of a wave are requested before the first one is reduced: one memory round trip, not sixteen
+    float p[GT / 4], g[GT / 4];
+#pragma unroll
+    for (int u = 0; u < GT / 4; ++u) {
+      const int i = wave + 4 * u;
+      const long o = ((long)b * N + i) * N + lane;
+      p[u] = 0.f, g[u] = 0.f;
+      if (i < N && lane < N) p[u] = P[o], g[u] = dA[o];
+    }
+#pragma unroll
+    for (int u = 0; u < GT / 4; ++u) {
+      const int i = wave + 4 * u;
+      const long o = ((long)b * N + i) * N + lane;
+      float gg = g[u];
+      if (dd) gg = (rng_u32(key, (uint64_t)o) >= drop.thresh) ? gg * drop.scale : 0.f;
+      const float dot = wave_sum(gg * p[u]);
+      const float v = p[u] * (gg - dot);
+      if (i < N && lane < N && blockIdx.y == 0) dlogit[o] = v;
+      T[i][lane] = v;
+    }
+  }
+  __syncthreads();
+  if (t < GT) {
+    float a = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < GT; ++i) a += T[i][t];
+    dss[t] = a;
+    if (t < N && blockIdx.y == 0) ds[(long)b * N + t] = a;
+  }
+  __syncthreads();
+  // dX: this workgroup's slice of the feature columns (gridDim.y slices share the document; each recomputes the
+  // cheap phases above, only slice 0 stores dlogit / ds), four independent elements in flight per thread
+  const int cw = (D + gridDim.y - 1) / gridDim.y, c0 = blockIdx.y * cw;
+  const int cn = min(cw, D - c0);
+  const long base = (long)b * N * D;
+  for (int e0 = t; e0 < N * cn; e0 += 4 * 256) {
+    float v[4], xin[4];
+    long o[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * 256;
+      const bool ok = e < N * cn;
+      const int j = ok ? e / cn : 0, c = c0 + (ok ? e - j * cn : 0);
+      o[u] = ok ? base + (long)j * D + c : -1;
+      v[u] = dss[j] * uvc[c];
+      xin[u] = (ok && dXin) ? dXin[o[u]] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (o[u] >= 0) dX[o[u]] = v[u] + xin[u];
   }
 }
 
@@ -489,10 +581,11 @@ int colsum(const float* X, const float* w, float* out, long R, int C, long ld, i
   return check_launch("colsum/2");
 }
 
-// Three column sums in two launches; scratch needs 3 * 64 * maxC floats.
+// Three column sums in two launches; scratch needs 3 * 64 * maxC floats.  stage2 = false: only the row-slice
+// partials are produced (job i at scratch + part_off[i], [ns][C_i]); the consumer sums them (gat_fold_bwd).
 int colsum3(const float* X0, const float* w0, float* o0, long R0, int C0, long ld0, const float* X1, const float* w1,
             float* o1, long R1, int C1, long ld1, const float* X2, const float* w2, float* o2, long R2, int C2, long ld2,
-            float* scratch, hipStream_t st) {
+            float* scratch, hipStream_t st, bool stage2, long* part_off, int* ns_out) {
   ColJobs j;
   j.n = 3;
   const float* Xs[3] = {X0, X1, X2};
@@ -500,20 +593,23 @@ int colsum3(const float* X0, const float* w0, float* o0, long R0, int C0, long l
   float* os[3] = {o0, o1, o2};
   const long Rs[3] = {R0, R1, R2}, lds[3] = {ld0, ld1, ld2};
   const int Cs[3] = {C0, C1, C2};
-  const int ns = 64;
+  const int ns = stage2 ? 64 : 32;  // fewer slices when every consumer workgroup re-sums them
   long off = 0;
   int maxC = 1;
   for (int i = 0; i < 3; ++i) {
     j.X[i] = Xs[i], j.w[i] = ws[i], j.out[i] = os[i], j.R[i] = Rs[i], j.ld[i] = lds[i], j.C[i] = Cs[i];
     j.part_off[i] = off;
+    if (part_off) part_off[i] = off;
     off += (long)ns * Cs[i];
     if (Cs[i] > maxC) maxC = Cs[i];
   }
+  if (ns_out) *ns_out = ns;
   {
     ProfScope ps("colsum", st);
     hipLaunchKernelGGL(colsum_multi_kernel, dim3(cdiv(maxC, 64), ns, 3), dim3(256), 0, st, j, scratch, ns, 0);
   }
   if (int e = check_launch("colsum3/1")) return e;
+  if (!stage2) return 0;
   ProfScope ps("colsum", st);
   hipLaunchKernelGGL(colsum_multi_kernel, dim3(cdiv(maxC, 64), 1, 3), dim3(256), 0, st, j, scratch, ns, 1);
   return check_launch("colsum3/2");
@@ -524,10 +620,21 @@ int gat_fold_fwd(const float* flat, float* uvc, int D, hipStream_t st) {
   hipLaunchKernelGGL(gat_fold_fwd_kernel, dim3(cdiv(D, 64)), dim3(64 * FW), 0, st, flat, uvc, D);
   return check_launch("gat_fold_fwd");
 }
-int gat_fold_bwd(const float* flat, const float* duvc, float* dflat, int D, hipStream_t st) {
+int gat_fold_bwd(const float* flat, const float* duvc, float* dflat, int D, hipStream_t st, const float* part,
+                 const long* part_off, int ns) {
   ProfScope ps("gat_fold_bwd", st);
-  hipLaunchKernelGGL(gat_fold_bwd_kernel, dim3(cdiv(D, RW)), dim3(64 * RW), 0, st, flat, duvc, dflat, D);
+  const size_t lds = ns > 0 ? sizeof(float) * (2 * (size_t)D + 1) : 0;
+  hipLaunchKernelGGL(gat_fold_bwd_kernel, dim3(cdiv(D, RW)), dim3(64 * RW), lds, st, flat, duvc, dflat, D, part,
+                     ns > 0 ? part_off[1] : 0L, ns > 0 ? part_off[2] : 0L, ns);
   return check_launch("gat_fold_bwd");
+}
+bool gat_dlogit_ok(int N) { return N <= GT; }
+int gat_dlogit(const float* P, const float* dA, const float* uvc, const float* dXin, float* dlogit, float* ds, float* dX,
+               int B, int N, int D, Drop drop, hipStream_t st) {
+  ProfScope ps("gat_dlogit", st);
+  const int slices = D >= 256 ? 8 : (D >= 64 ? 4 : 1);
+  hipLaunchKernelGGL(gat_dlogit_kernel, dim3(B, slices), dim3(256), 0, st, P, dA, uvc, dXin, dlogit, ds, dX, N, D, drop);
+  return check_launch("gat_dlogit");
 }
 int node_score_fwd(const float* X, const float* uvc, float* s, long M, int D, hipStream_t st) {
   ProfScope ps("node_score_fwd", st);
