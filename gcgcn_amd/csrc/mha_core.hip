@@ -30,8 +30,10 @@ __device__ __forceinline__ void load_q_chunk(float* qs, const float* __restrict_
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int idx = base + u * 256, n = idx / k4, k = (idx - n * k4) << 2;
-      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < MT * k4 && n < N && k < kc) v[u] = *reinterpret_cast<const float4*>(q + (long)n * D + k0 + k);
+      // clamped address + select instead of a guarded load: a load inside a branch is waited for at the branch's end,
+      // which serialises the four requests
+      v[u] = *reinterpret_cast<const float4*>(q + (long)min(n, N - 1) * D + k0 + min(k, kc - 4));
+      if (!(idx < MT * k4 && n < N && k < kc)) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -113,9 +115,10 @@ __global__ __launch_bounds__(256) void mha_core_bwd_kernel(const float* __restri
 #pragma unroll
     for (int u = 0; u < MT / 4; ++u) {
       const int i = wave + 4 * u;
-      const long o = ((long)z * N + i) * N + lane;
-      p[u] = 0.f, g[u] = 0.f;
-      if (i < N && lane < N) p[u] = P[o], g[u] = dA[o];
+      const long oc = ((long)z * N + min(i, N - 1)) * N + min(lane, N - 1);  // clamped: unconditional loads
+      const bool ok = i < N && lane < N;
+      p[u] = P[oc], g[u] = dA[oc];
+      if (!ok) p[u] = 0.f, g[u] = 0.f;
     }
 #pragma unroll
     for (int u = 0; u < MT / 4; ++u) {

@@ -407,9 +407,10 @@ __global__ __launch_bounds__(256) void gat_dlogit_kernel(const float* __restrict
 #pragma unroll
     for (int u = 0; u < GT / 4; ++u) {
       const int i = wave + 4 * u;
-      const long o = ((long)b * N + i) * N + lane;
-      p[u] = 0.f, g[u] = 0.f;
-      if (i < N && lane < N) p[u] = P[o], g[u] = dA[o];
+      const long oc = ((long)b * N + min(i, N - 1)) * N + min(lane, N - 1);  // clamped: unconditional loads (a load
+      const bool ok = i < N && lane < N;                                      // inside a branch is waited for at its end)
+      p[u] = P[oc], g[u] = dA[oc];
+      if (!ok) p[u] = 0.f, g[u] = 0.f;
     }
 #pragma unroll
     for (int u = 0; u < GT / 4; ++u) {
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(256) void gat_dlogit_kernel(const float* __restrict
       const int j = ok ? e / cn : 0, c = c0 + (ok ? e - j * cn : 0);
       o[u] = ok ? base + (long)j * D + c : -1;
       v[u] = dss[j] * uvc[c];
-      xin[u] = (ok && dXin) ? dXin[o[u]] : 0.f;
+      xin[u] = dXin ? dXin[ok ? o[u] : base] : 0.f;   // dXin != NULL is uniform; the address is clamped, not guarded
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
