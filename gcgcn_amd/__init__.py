@@ -6,8 +6,8 @@ gfx950 behind a C ABI (``include/gcgcn.h`` -> ``gcgcn_amd/lib/libgcgcn_hip.so``)
 """
 from .modules import (GATAttention, GraphConv, GraphConvolution, GraphHops,  # noqa: F401
                       MultiGraphConvolution, MultiHeadAttention)
-from .functional import manual_seed  # noqa: F401
+from .functional import manual_seed, pair_bce_loss  # noqa: F401
 from . import functional, params  # noqa: F401
 
 __all__ = ["GraphConv", "GATAttention", "MultiHeadAttention", "GraphConvolution", "MultiGraphConvolution", "GraphHops",
-           "manual_seed", "functional", "params"]
+           "manual_seed", "pair_bce_loss", "functional", "params"]

@@ -402,6 +402,24 @@ int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat,
 }
 
 // ---------------------------------------------------------------------------------------------
+// trainer loss
+// ---------------------------------------------------------------------------------------------
+int gcgcn_pair_bce_fwd(int B, int N, int R, const float* logits, const float* labels, const int32_t* n_valid, float* loss,
+                       float* part, void* stream) {
+  GC_REQUIRE(B > 0 && N > 0 && R > 0 && (long)B * N <= 0x7fffffffL && (long)N * R <= 0x7fffffffL,
+             "pair_bce_fwd: bad shape B=%d N=%d R=%d", B, N, R);
+  GC_REQUIRE(logits && labels && loss && part, "pair_bce_fwd: null pointer");
+  return pair_bce_fwd(logits, labels, n_valid, loss, part, B, N, R, (hipStream_t)stream);
+}
+
+int gcgcn_pair_bce_bwd(int B, int N, int R, const float* logits, const float* labels, const int32_t* n_valid,
+                       const float* dloss, float* dlogits, void* stream) {
+  GC_REQUIRE(B > 0 && N > 0 && R > 0, "pair_bce_bwd: bad shape B=%d N=%d R=%d", B, N, R);
+  GC_REQUIRE(logits && labels && dlogits, "pair_bce_bwd: null pointer");
+  return pair_bce_bwd(logits, labels, n_valid, dloss, dlogits, B, N, R, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
 // GraphConvolution / MultiGraphConvolution
 // ---------------------------------------------------------------------------------------------
 int gcgcn_gcn_layout(int D, int L, int H, int64_t* o) {

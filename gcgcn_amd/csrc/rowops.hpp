@@ -43,4 +43,10 @@ int mha_core_fwd(const float* Q, const int* n_valid, float* P, float* A, int B, 
 int mha_core_bwd(const float* Q, const float* P, const float* dA, float* dQ, int B, int N, int D, int H, float alpha, Drop drop,
                  hipStream_t st);
 
+// loss.hip: the trainer's per-document pair loss
+int pair_bce_fwd(const float* logits, const float* labels, const int* n_valid, float* loss, float* part, int B, int N, int R,
+                 hipStream_t st);
+int pair_bce_bwd(const float* logits, const float* labels, const int* n_valid, const float* dloss, float* dlogits, int B, int N,
+                 int R, hipStream_t st);
+
 }  // namespace gc

@@ -335,6 +335,29 @@ class DropoutFn(torch.autograd.Function):
         return dx, None, None, None
 
 
+class PairBceFn(torch.autograd.Function):
+    """(logits[B,N,N,R], labels[B,N,N,R]) -> loss[B].  The trainer's per-document loss, config/Config.py:355-366."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, n_valid):
+        B, N, _, R = logits.shape
+        loss = torch.empty(B, device=logits.device)
+        part = torch.empty(B * N, device=logits.device)
+        call("gcgcn_pair_bce_fwd", B, N, R, _p(logits), _p(labels), _p(n_valid), _p(loss), _p(part), _stream())
+        ctx.save_for_backward(logits, labels)
+        ctx.n_valid = n_valid
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, labels = ctx.saved_tensors
+        B, N, _, R = logits.shape
+        dlogits = torch.empty_like(logits)
+        call("gcgcn_pair_bce_bwd", B, N, R, _p(logits), _p(labels), _p(ctx.n_valid), _p(dloss.contiguous()), _p(dlogits),
+             _stream())
+        return dlogits, None, None
+
+
 # ---- functional entry points -------------------------------------------------------------------------
 def _snap_for(training: bool, p: float, dev) -> Optional[Tensor]:
     return rng_snapshot(dev) if (training and p > 0.0) else None
@@ -414,3 +437,18 @@ def take_edge_mean(e: Tensor, n_valid) -> Optional[Tensor]:
     if ref() is e and e._version == ver and nvp is n_valid:
         return ebar
     return None
+
+
+def pair_bce_loss(logits, labels, n_valid=None):
+    """Per-document loss of the reference trainer (config/Config.py:355-366): sigmoid, BCE averaged over the relation
+    axis, summed over ordered entity pairs h != t and divided by n^2 - n.  ``logits``/``labels``: ``[N,N,R]`` (returns
+    a scalar, like the trainer's ``temp_loss``) or ``[B,N,N,R]`` (returns ``[B]``; ``n_valid[B]`` for ragged batches).
+    The reference accumulates ``total_loss`` over documents and divides by ``batch_size`` (:366-369): that is
+    ``pair_bce_loss(...).sum() / batch_size``."""
+    single = logits.dim() == 3
+    lg = _chk(logits.unsqueeze(0) if single else logits, "logits", 4)
+    lb = _chk((labels.unsqueeze(0) if single else labels).to(torch.float32), "labels", 4)
+    if lb.shape != lg.shape or lg.shape[1] != lg.shape[2]:
+        raise ValueError(f"pair_bce_loss: logits {tuple(lg.shape)} vs labels {tuple(lb.shape)}")
+    out = PairBceFn.apply(lg, lb, _nv(n_valid, lg.shape[0], lg.shape[1], lg.device))
+    return out[0] if single else out

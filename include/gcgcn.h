@@ -167,6 +167,16 @@ int gcgcn_graphconv_bwd(int B, int N, int Din, int De, int Dout, const float* X,
                         const float* dout, float* dX, float* dEbar, float* dA, float* dWe, float* dWn, float* dbias,
                         float* dS, float* dT, float* drow, float* scratch, void* stream);
 
+/* ---- trainer loss  config/Config.py:302,355-366 ---------------------------- */
+/* loss[b] = sum_{h != t < n} mean_r BCE(sigmoid(logits[b,h,t,r]), labels[b,h,t,r]) / (n^2 - n), n = n_valid[b] or N:
+ * what the trainer's double Python loop of nn.BCELoss calls computes per document (ATen arithmetic: logs clamped at
+ * -100).  logits, labels [B,N,N,R]; workspace part[B*N].  A document with n < 2 yields NaN like the reference. */
+int gcgcn_pair_bce_fwd(int B, int N, int R, const float* logits, const float* labels, const int32_t* n_valid, float* loss,
+                       float* part, void* stream);
+/* dlogits[B,N,N,R] = dloss[b] * d loss[b] / d logits (dloss NULL = ones); zero on the diagonal and on padding. */
+int gcgcn_pair_bce_bwd(int B, int N, int R, const float* logits, const float* labels, const int32_t* n_valid,
+                       const float* dloss, float* dlogits, void* stream);
+
 /* ---- raw batched GEMM (exposed for unit tests and benchmarks of the MFMA kernel) ----------- */
 /* C[z] = alpha * opA(A[z]) opB(B[z]);  a_kc: A stored [M][K] else [K][M];  b_kc: B stored [N][K]
  * else [K][N];  z < batch with element strides sA, sB, sC;  tile: 0 auto, 1 = 64x64, 2 = 128x128;

@@ -237,3 +237,51 @@ def synth_docs(b: int, n: int, d: int, seed: int = 1337, sparsity: float = 0.3):
     e1 = torch.randn(b, n, n, d, generator=g) * 0.5 * adj.unsqueeze(-1)
     e2 = torch.randn(b, n, n, d, generator=g) * 0.5
     return x, e1, e2, adj
+
+
+# --------------------------------------------------------------------------------------
+# per-document loss of the training loop          config/Config.py:355-366
+# --------------------------------------------------------------------------------------
+def pair_bce_loss_loop(logits: Tensor, labels: Tensor) -> Tensor:
+    """The loop exactly as the trainer writes it (config/Config.py:355-366): sigmoid, then one
+    ``nn.BCELoss(reduction='mean')`` (Config.py:302) per ordered pair h != t, summed and divided by N^2 - N.
+    O(N^2) Python -- small N only; it pins :func:`pair_bce_loss`."""
+    bce = torch.nn.BCELoss(reduction="mean")
+    p = torch.sigmoid(logits)                                                  # :355
+    n = labels.shape[0]
+    total = torch.zeros(1)
+    for h in range(n):                                                         # :358-363
+        for t in range(n):
+            if h == t:
+                continue
+            total = total + bce(p[h][t], labels[h][t])
+    return (total / (n * n - n)).squeeze(0)                                    # :364
+
+
+def pair_bce_loss(logits: Tensor, labels: Tensor, n_valid: Optional[int] = None) -> Tensor:
+    """Vectorised restatement of the same loss value: mean over relations of the clamped-log BCE (ATen clamps both
+    logs at -100), summed over off-diagonal pairs of the first ``n_valid`` entities, divided by n^2 - n.  Use
+    :func:`pair_bce_loss_grad` for the gradient (autograd through the clamp gives NaN where ATen's BCE backward does
+    not)."""
+    n = labels.shape[0] if n_valid is None else int(n_valid)
+    with torch.no_grad():
+        p = torch.sigmoid(logits[:n, :n])
+        y = labels[:n, :n]
+        per = -(y * torch.log(p).clamp_min(-100.0) + (1.0 - y) * torch.log(1.0 - p).clamp_min(-100.0)).mean(-1)
+        off = 1.0 - torch.eye(n)
+        return (per * off).sum() / (n * n - n)
+
+
+def pair_bce_loss_grad(logits: Tensor, labels: Tensor, n_valid: Optional[int] = None) -> Tensor:
+    """d loss / d logits as autograd produces it for sigmoid followed by ATen's binary_cross_entropy:
+    dL/dp = (p - y) / max(p (1 - p), 1e-12) / R (ATen's BCE backward), dp/dx = p (1 - p); zero on the diagonal and
+    outside the first ``n_valid`` entities."""
+    n = labels.shape[0] if n_valid is None else int(n_valid)
+    r = logits.shape[-1]
+    g = torch.zeros_like(logits)
+    p = torch.sigmoid(logits[:n, :n])
+    y = labels[:n, :n]
+    q = p * (1.0 - p)
+    d = (p - y) / q.clamp_min(1e-12) * q / (r * (n * n - n))
+    g[:n, :n] = d * (1.0 - torch.eye(n)).unsqueeze(-1)
+    return g

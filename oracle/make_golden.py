@@ -234,11 +234,32 @@ def full_model_case(ref, docs=8, n=16, t=40, s=3, vocab=200):
     return "model_c1", pk
 
 
+def loss_cases():
+    """SURVEY 8 row f2.  config/Config.py cannot be imported here (it needs torch_geometric), and the loss is not a
+    function there but a loop inside ``train`` (:355-366).  The fixtures are produced by that loop's own operations --
+    ``torch.sigmoid``, ``nn.BCELoss(reduction='mean')`` per ordered pair, sum, division by N^2 - N -- as transcribed in
+    ``gcgcn_oracle.pair_bce_loss_loop``, with autograd through ATen's BCE for the gradient."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from oracle import gcgcn_oracle as O
+    for n, scale, seed in ((2, 1.0, 0), (5, 3.0, 1), (16, 1.0, 1337), (9, 40.0, 2)):   # scale 40: saturated sigmoids
+        g = torch.Generator().manual_seed(seed)
+        logits = (torch.randn(n, n, 97, generator=g) * scale).requires_grad_()
+        labels = (torch.rand(n, n, 97, generator=g) < 0.04).float()
+        loss = O.pair_bce_loss_loop(logits, labels)
+        grad, = torch.autograd.grad(loss, logits)
+        yield f"pair_bce_n{n}_s{int(scale)}", {"logits": _np(logits), "labels": _np(labels), "loss": _np(loss),
+                                              "dlogits": _np(grad)}
+
+
 def main():
-    ref = load_reference()
     os.makedirs(OUT_DIR, exist_ok=True)
     total = 0
-    for name, pk in list(block_cases(ref)) + [full_model_case(ref)]:
+    if "--loss-only" in sys.argv:
+        cases = list(loss_cases())
+    else:
+        ref = load_reference()
+        cases = list(block_cases(ref)) + [full_model_case(ref)] + list(loss_cases())
+    for name, pk in cases:
         path = os.path.join(OUT_DIR, name + ".npz")
         np.savez_compressed(path, **pk)
         total += os.path.getsize(path)

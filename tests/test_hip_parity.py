@@ -563,3 +563,37 @@ def test_dropout_draws_are_unbiased_and_uncorrelated(gpu_device):
     assert abs(corr(k[:-65536], k[65536:])) < 3e-3         # index bit 16 (the finaliser's first shift)
     assert abs(corr(m[0], m[1])) < 3e-3                    # next step, same site
     assert abs(corr(m[0], m[2])) < 3e-3                    # same step, another site
+
+
+# ---- the trainer's per-document loss ------------------------------------------------------------
+@pytest.mark.parametrize("path", golden_files("pair_bce"), ids=ids(golden_files("pair_bce")))
+def test_pair_bce_loss_golden(gpu_device, path):
+    """HIP loss against the fixtures produced by the trainer's own loop of nn.BCELoss calls (config/Config.py:355-366),
+    value and gradient, including saturated sigmoids (scale 40)."""
+    r = load_golden(path)["raw"]
+    logits = dev_leaf(torch.from_numpy(r["logits"]), gpu_device)
+    labels = torch.from_numpy(r["labels"]).to(gpu_device)
+    loss = gcgcn_amd.pair_bce_loss(logits, labels)
+    loss.backward()
+    torch.testing.assert_close(loss.cpu(), torch.from_numpy(r["loss"]), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(logits.grad.cpu(), torch.from_numpy(r["dlogits"]), rtol=1e-4, atol=1e-9)
+
+
+def test_pair_bce_loss_batched_ragged(gpu_device):
+    """[B,N,N,R] with n_valid against the oracle per document; upstream gradients per document; full-size linearity."""
+    B, N, R = 4, 42, 97
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, N, N, R, generator=g) * 4
+    y = (torch.rand(B, N, N, R, generator=g) < 0.03).float()
+    nv = torch.tensor([42, 17, 2, 30], dtype=torch.int32)
+    w = torch.tensor([1.0, 0.5, -2.0, 3.0])
+    xd = dev_leaf(x, gpu_device)
+    loss = gcgcn_amd.pair_bce_loss(xd, y.to(gpu_device), n_valid=nv.to(gpu_device))
+    (loss * w.to(gpu_device)).sum().backward()
+    for b in range(B):
+        torch.testing.assert_close(loss[b].cpu(), O.pair_bce_loss(x[b], y[b], int(nv[b])), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(xd.grad[b].cpu(), w[b] * O.pair_bce_loss_grad(x[b], y[b], int(nv[b])), rtol=1e-4, atol=1e-9)
+    one = gcgcn_amd.pair_bce_loss(xd.detach()[:, :1, :1], y.to(gpu_device)[:, :1, :1])     # a single entity: no pairs
+    assert torch.isnan(one).all()                                                         # 0 / 0, as in the reference
+    with pytest.raises(ValueError):
+        gcgcn_amd.pair_bce_loss(xd.detach(), y.to(gpu_device)[:, :, :3])

@@ -123,3 +123,28 @@ def test_dropout_mask_convention():
     y = O._drop(x, keep, 0.2)
     assert torch.allclose(y[:, 0], torch.full((4,), 1.25)) and (y[:, 1] == 0).all()
     assert O._drop(x, None, 0.2) is x
+
+
+@pytest.mark.parametrize("path", golden_files("pair_bce"), ids=ids(golden_files("pair_bce")))
+def test_pair_bce_loss(path):
+    """the vectorised restatement (value and ATen-faithful gradient) against the trainer's loop of
+    nn.BCELoss calls (fixtures from oracle/make_golden.py::loss_cases), including saturated sigmoids."""
+    r = load_golden(path)["raw"]
+    logits, labels = torch.from_numpy(r["logits"]), torch.from_numpy(r["labels"])
+    torch.testing.assert_close(O.pair_bce_loss(logits, labels), torch.from_numpy(r["loss"]), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(O.pair_bce_loss_grad(logits, labels), torch.from_numpy(r["dlogits"]), rtol=1e-5, atol=1e-9)
+
+
+def test_pair_bce_loss_loop_and_ragged():
+    """The loop itself on a fresh case, and n_valid = the same loss on the leading sub-block."""
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn(6, 6, 11, generator=g) * 2).requires_grad_()
+    y = (torch.rand(6, 6, 11, generator=g) < 0.2).float()
+    ref = O.pair_bce_loss_loop(x, y)
+    gref, = torch.autograd.grad(ref, x)
+    torch.testing.assert_close(O.pair_bce_loss(x.detach(), y), ref.detach(), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(O.pair_bce_loss_grad(x.detach(), y), gref, rtol=1e-5, atol=1e-9)
+    sub = O.pair_bce_loss_loop(x[:4, :4].detach(), y[:4, :4])
+    torch.testing.assert_close(O.pair_bce_loss(x.detach(), y, n_valid=4), sub, rtol=1e-6, atol=1e-6)
+    gr = O.pair_bce_loss_grad(x.detach(), y, n_valid=4)
+    assert gr[4:].abs().sum() == 0 and gr[:, 4:].abs().sum() == 0
