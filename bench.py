@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- docs/sec forward+backward through the CAGGC+MAGGC stack on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5|c1] [--mode eager|graph]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5|c1] [--mode graph|eager]
 
 One step = one forward + backward of GATAttention -> GraphConvolution -> MultiHeadAttention ->
 MultiGraphConvolution (the hop loop of GCGCN_glove.py:329-341) over one batch of B synthetic
@@ -104,7 +104,10 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--mode", default=os.environ.get("GCGCN_BENCH_MODE", "eager"), choices=["eager", "graph"])
+    ap.add_argument("--mode", default=os.environ.get("GCGCN_BENCH_MODE", "graph"), choices=["eager", "graph"],
+                    help="graph (default): the step is captured once in a hipGraph and replayed; the steps whose kernels are "
+                         "bracketed by HIP events for the roofline (every 10th) run eagerly -- same kernels, same data. "
+                         "eager: every step is issued from Python (the GPU time is the same; the host's jitter is not)")
     ap.add_argument("--prof-kernel", default="auto",
                     help="kernel family timed with HIP events inside the timed region (auto = the one with the largest time share)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -183,10 +186,13 @@ def main():
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             fwd_bwd()
+        graph_grads = [(p, p.grad) for p in bucket.params]     # the tensors the replays write the gradients into
 
-    def step():
-        if graph is not None:
+    def step(eager=False):
+        if graph is not None and not eager:
             graph.replay()
+            for p, g in graph_grads:                           # an eager (profiled) step in between re-pointed .grad
+                p.grad = g
         else:
             fwd_bwd()
         if world > 1 or force_dist:
@@ -209,7 +215,7 @@ def main():
         """HIP-event time of every launch whose kernel name starts with `prefix` over nsteps steps."""
         _lib.call("gcgcn_prof_start", prefix.encode(), nsteps * 64 + 64)
         for _ in range(nsteps):
-            step()
+            step(eager=True)                                   # events cannot be recorded inside a graph replay
         torch.cuda.synchronize()
         ms, n, w = ctypes.c_double(0), ctypes.c_int(0), ctypes.c_double(0)
         _lib.call("gcgcn_prof_stop", ctypes.byref(ms), ctypes.byref(n), ctypes.byref(w))
@@ -218,7 +224,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    use_prof = graph is None
+    use_prof = True
     # which kernel family dominates the step?  (untimed pre-pass, 3 steps per family)
     shares = {}
     dominant = args.prof_kernel
@@ -233,19 +239,28 @@ def main():
     # ---- the timed region: exactly K steps, the dominant family's launches bracketed by HIP events ----------
     # Two HIP events per launch stall the queue enough to matter (19 GEMM launches a step cost +20 %), so
     # the dominant family is sampled on every 10th timed step only; edge_bwd-sized families (1 launch) always.
-    sample_every = 1 if shares.get(dominant, {}).get("launches_per_step", 99) <= 2 else 10
+    # In graph mode the sampled steps are the ones issued eagerly (same kernels on the same data; the rest replay).
+    if graph is not None:
+        sample_every = max(2, min(25, args.steps // 2))        # an eager step costs host time on top of the events
+    else:
+        sample_every = 1 if shares.get(dominant, {}).get("launches_per_step", 99) <= 2 else 10
     if use_prof:
         _lib.call("gcgcn_prof_start", dominant.encode(), args.steps * 64 + 64)
         _lib.call("gcgcn_prof_enable", 0)
+    import gc
+    gc.collect()
+    gc.disable()                                               # no collector pauses inside the timed region
     t0 = time.perf_counter()
     for i in range(args.steps):
+        sampled = (i % sample_every == sample_every // 2) if sample_every > 1 else True
         if use_prof and sample_every > 1:
-            _lib.call("gcgcn_prof_enable", 1 if i % sample_every == sample_every // 2 else 0)
+            _lib.call("gcgcn_prof_enable", 1 if sampled else 0)
         elif use_prof and i == 0:
             _lib.call("gcgcn_prof_enable", 1)
-        step()
+        step(eager=sampled)
     sync()
     dt = time.perf_counter() - t0
+    gc.enable()
     kms, kn, kw = ctypes.c_double(0), ctypes.c_int(0), ctypes.c_double(0)
     if use_prof:
         _lib.call("gcgcn_prof_stop", ctypes.byref(kms), ctypes.byref(kn), ctypes.byref(kw))
@@ -278,7 +293,7 @@ def main():
         return r
 
     nsamp = args.steps if sample_every == 1 else len([i for i in range(args.steps) if i % sample_every == sample_every // 2])
-    roofline = roof(dominant, kms.value, kn.value, kw.value, f"{nsamp} of the {args.steps} timed steps") if use_prof else None
+    roofline = roof(dominant, kms.value, kn.value, kw.value, f"{nsamp} of the {args.steps} timed steps" + (" (the eagerly issued ones; the others replay the hipGraph)" if graph is not None else ""))
     roofline_hbm = None
     if use_prof and rank == 0 and dominant != "edge_bwd":
         roofline_hbm = roof("edge_bwd", *profile("edge_bwd", 5), "5 steps after the timed region")
