@@ -175,18 +175,24 @@ def main():
         out = hops(x, [e1, e2], adj, n_valid=n_valid)[-1]
         torch.autograd.backward(out, cot)
 
-    graph = None
+    graph, graph_grads = None, []
     if args.mode == "graph":                      # capture the launch-bound step in one hipGraph
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(3):
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(3):
+                    fwd_bwd()
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
                 fwd_bwd()
-        torch.cuda.current_stream().wait_stream(s)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            fwd_bwd()
-        graph_grads = [(p, p.grad) for p in bucket.params]     # the tensors the replays write the gradients into
+            graph_grads = [(p, p.grad) for p in bucket.params]     # the tensors the replays write the gradients into
+        except Exception as ex:                   # never lose the measurement to a capture problem: issue the steps eagerly
+            print(f"bench.py: hipGraph capture failed ({ex!r}); running --mode eager", file=sys.stderr)
+            graph, graph_grads = None, []
+            args.mode = "eager"
+            torch.cuda.synchronize()
 
     def step(eager=False):
         if graph is not None and not eager:
