@@ -36,7 +36,9 @@ int gcgcn_version(void);            /* ABI version, currently 1 */
 const char* gcgcn_last_error(void); /* message of the last failing call on this thread */
 
 /* Run-time switches for A/B tests.  "chain": 1 (default) = the per-(doc, head) products of a conv run inside the
- * chain kernels, 0 = one batched launch per product.  Results are identical up to fp32 summation order. */
+ * chain kernels, 0 = one batched launch per product.  "mha_core": 1 (default) = graphs of N <= 64 entities take the
+ * one-workgroup-per-(doc, head) attention kernels, 0 = batched GEMM + row softmax for every N.  Results are identical
+ * up to fp32 summation order. */
 int gcgcn_set_option(const char* name, int value);
 
 /* ---- per-kernel timing for roofline reports (bench.py) ------------------------------------------- */
