@@ -597,3 +597,30 @@ def test_pair_bce_loss_batched_ragged(gpu_device):
     assert torch.isnan(one).all()                                                         # 0 / 0, as in the reference
     with pytest.raises(ValueError):
         gcgcn_amd.pair_bce_loss(xd.detach(), y.to(gpu_device)[:, :, :3])
+
+
+@pytest.mark.parametrize("alpha", [1.0, 0.7])
+def test_three_hops_and_alpha_mix_match_oracle(gpu_device, alpha):
+    """graph_hop = 3 (two MAGGC hops: the second rides its edge mean in the first's chain launches) and the
+    alpha-mix of the hop glue (glove:339; alpha != 1 takes the unfused dropout path), eval mode, against the oracle."""
+    B, N, D, L, H, hop = 2, 12, 32, 2, 4, 3
+    sd = O.init_stack_params(D, L, H, hops=hop, seed=41)
+    g = torch.Generator().manual_seed(42)
+    x = torch.rand(B, N, D, generator=g) * 2 - 1
+    es = [torch.randn(B, N, N, D, generator=g) * 0.5 for _ in range(hop)]
+    hops = gcgcn_amd.GraphHops(D, L, H, graph_hop=hop, alpha=alpha).to(gpu_device).eval()
+    hops.load_state_dict(sd, strict=True)
+    xs = dev_leaf(x, gpu_device)
+    eds = [dev_leaf(e, gpu_device) for e in es]
+    feats = hops(xs, eds)
+    feats[-1].sum().backward()
+    for b in range(B):
+        xr = x[b].clone().requires_grad_()
+        er = [e[b].clone().requires_grad_() for e in es]
+        ref = O.hop_stack(xr, er, None, sd, L, H, alpha=alpha)
+        ref[-1].sum().backward()
+        for k in range(hop + 1):
+            torch.testing.assert_close(feats[k][b].detach().cpu(), ref[k].detach(), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(xs.grad[b].cpu(), xr.grad, rtol=1e-3, atol=1e-4)
+        for k in range(hop):
+            torch.testing.assert_close(eds[k].grad[b].cpu(), er[k].grad, rtol=1e-3, atol=1e-5)
