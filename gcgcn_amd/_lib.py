@@ -53,7 +53,9 @@ SIGNATURES = {
     "gcgcn_gcn_layout": (I, [I, I, I, P]),
     "gcgcn_gcn_scratch": (L, [I, I, I, I]),
     "gcgcn_gcn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, F, P, P, P, P, P, P, P, P, P]),
-    "gcgcn_gcn_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_gcn_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, P]),
+    "gcgcn_deferred_count": (I, []),
+    "gcgcn_flush_deferred": (I, [P]),
     "gcgcn_graphconv_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_graphconv_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_pair_bce_fwd": (I, [I, I, I, P, P, P, P, P, P]),

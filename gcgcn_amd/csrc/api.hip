@@ -278,7 +278,7 @@ int gcgcn_gat_bwd(int B, int N, int D, const float* X, const float* E, const int
     GC_TRY(colsum(dlogit, nullptr, ds, N, N, N, B, (long)N * N, 0, N, 0, nullptr, st));
     GC_TRY(node_score_bwd(ds, uvc, dX_in, dX, M, D, st));
   }
-  GC_TRY(edge_bwd(E, uvc + D, n_valid, dlogit, dEbar, dE, dvpart, B, N, D, st));
+  GC_TRY(edge_bwd(E, uvc + D, n_valid, dlogit, dEbar, dE, dvpart, B, N, D, st, true));  // + parked weight gradients
   // du = sum_m ds[m] X[m,:],  dv = sum partials,  dc = sum_m ds[m]: row-slice partials in one launch; the fold's
   // backward sums the slices itself (duvc stays unused)
   long part_off[3];
@@ -401,6 +401,9 @@ int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat,
   return 0;
 }
 
+int gcgcn_deferred_count(void) { return gemm_deferred_count(); }
+int gcgcn_flush_deferred(void* stream) { return gemm_flush_deferred((hipStream_t)stream); }
+
 // ---------------------------------------------------------------------------------------------
 // trainer loss
 // ---------------------------------------------------------------------------------------------
@@ -504,7 +507,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
                   float out_p, const float* Pn, const float* Y, const float* HO, const float* rinv, const float* dout,
                   float* dX, float* dEbar,
                   float* dA, float* dflat, float* W1, float* W2, float* W3, float* drow, float* dXres, float* dout_m,
-                  float* scratch, const gcgcn_edge_ride* ride, void* stream) {
+                  float* scratch, const gcgcn_edge_ride* ride, int defer_weight_grads, void* stream) {
   const Drop odrop = make_drop(out_rng_snap, GCGCN_SALT_GLUE, out_p);
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("gcn_bwd", B, N, D, L, H));
@@ -539,12 +542,14 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
     gs[1].B = HO, gs[1].ldb = HD, gs[1].b_kc = 0;
     gs[1].C = dflat + y.oWlin, gs[1].ldc = HD;
     gs[1].M = D, gs[1].N = (int)HD, gs[1].K = (int)M;
+    // a weight gradient nobody needs before the end of backward: parked for a later launch with idle matrix pipes
+    const int ng1 = (defer_weight_grads && gemm_defer(gs[1])) ? 1 : 2;
     if (scratch) {  // dblin = column sums of dout ride in the same two launches
       ColRide cr;
       cr.X = dout, cr.out = dflat + y.oblin, cr.part = scratch + wse, cr.R = M, cr.ld = D, cr.C = D;
-      GC_TRY(gemm_group(gs, 2, st, &cr));
+      GC_TRY(gemm_group(gs, ng1, st, &cr));
     } else {
-      GC_TRY(gemm_group(gs, 2, st));
+      GC_TRY(gemm_group(gs, ng1, st));
       GC_TRY(colsum(dout, nullptr, dflat + y.oblin, M, D, D, 1, 0, 0, 0, 0, scratch, st));
     }
   }
@@ -577,8 +582,12 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
     int n = 0;
     auto next = [&]() -> GemmArgs& {
       GemmArgs& g = gs[n++];
+      g = GemmArgs();
       g.ws = scratch, g.ws_elems = wse;
       return g;
+    };
+    auto park = [&]() {  // the problem just described is a weight gradient: park it if asked to (and possible)
+      if (defer_weight_grads && gemm_defer(gs[n - 1])) --n;
     };
     {
       GemmArgs& g = next();
@@ -586,6 +595,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
       g.B = dP, g.ldb = HD, g.b_kc = 0;
       g.C = dflat + y.oWnX, g.ldc = HD;
       g.M = D, g.N = (int)HD, g.K = (int)M;
+      park();
     }
     {
       GemmArgs& g = next();
@@ -593,6 +603,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
       g.B = dM, g.ldb = HD, g.b_kc = 0;
       g.C = dflat + y.oWe, g.ldc = HD;
       g.M = D, g.N = (int)HD, g.K = (int)M;
+      park();
     }
     {
       GemmArgs& g = next();
@@ -616,6 +627,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
       g.C = dflat + y.wd_off(0, l), g.ldc = gh, g.sC2 = y.wd_head;
       g.M = l * gh, g.N = gh, g.K = (int)M;
       g.batch2 = H;
+      park();
     }
     GC_TRY(gemm_group(gs, n, st));
   }

@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include "edge_body.hpp"
+#include "gemm_body.hpp"
 
 namespace gc {
 
@@ -36,15 +37,13 @@ __global__ __launch_bounds__(64 * EW) void edge_fwd_kernel(const float* __restri
 // dynamic LDS: N + EW * D floats.
 // ---------------------------------------------------------------------------------------------
 template <int VEC, bool NTL>
-__global__ __launch_bounds__(64 * EW) void edge_bwd_kernel(const float* __restrict__ E, const float* __restrict__ v,
-                                                           const int* __restrict__ n_valid,
-                                                           const float* __restrict__ dlogit,
-                                                           const float* __restrict__ dEbar, float* __restrict__ dE,
-                                                           float* __restrict__ dvpart, int N, int D, int nt) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
+__device__ __forceinline__ void edge_bwd_row(const float* __restrict__ E, const float* __restrict__ v,
+                                             const int* __restrict__ n_valid, const float* __restrict__ dlogit,
+                                             const float* __restrict__ dEbar, float* __restrict__ dE,
+                                             float* __restrict__ dvpart, int N, int D, int nt, const int bi,
+                                             float* __restrict__ sm) {
   float* dl = sm;                    // [N]
   float* cs = sm + ((N + 3) & ~3);   // [EW][D]
-  const int bi = blockIdx.x;
   const int b = bi / N, i = bi - b * N;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
@@ -137,6 +136,36 @@ __global__ __launch_bounds__(64 * EW) void edge_bwd_kernel(const float* __restri
   }
 }
 
+template <int VEC, bool NTL>
+__global__ __launch_bounds__(64 * EW) void edge_bwd_kernel(const float* __restrict__ E, const float* __restrict__ v,
+                                                           const int* __restrict__ n_valid,
+                                                           const float* __restrict__ dlogit,
+                                                           const float* __restrict__ dEbar, float* __restrict__ dE,
+                                                           float* __restrict__ dvpart, int N, int D, int nt) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  edge_bwd_row<VEC, NTL>(E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D, nt, blockIdx.x, sm);
+}
+
+// The same pass carrying deferred GEMM problems (gemm.hpp): the first gg.tile_begin[gg.nprob] workgroups each run one
+// 64x64 tile of a parked weight-gradient product over its whole K -- matrix-pipe work under an HBM-bound stream --
+// the rest are the entity rows.  The tiles come first in dispatch order: they run the longest.
+template <int VEC, bool NTL>
+__global__ __launch_bounds__(64 * EW) void edge_bwd_carry_kernel(const float* __restrict__ E, const float* __restrict__ v,
+                                                                 const int* __restrict__ n_valid,
+                                                                 const float* __restrict__ dlogit,
+                                                                 const float* __restrict__ dEbar, float* __restrict__ dE,
+                                                                 float* __restrict__ dvpart, int N, int D, int nt,
+                                                                 const GemmGroup gg) {
+  __shared__ __attribute__((aligned(16))) float tile_lds[lds_floats<1, 1, true, true>()];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int ntile = gg.tile_begin[gg.nprob];
+  if ((int)blockIdx.x < ntile) {
+    gemm_group_block(gg, blockIdx.x, tile_lds);
+    return;
+  }
+  edge_bwd_row<VEC, NTL>(E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D, nt, blockIdx.x - ntile, sm);
+}
+
 template <int VEC>
 __global__ __launch_bounds__(64 * EW) void edge_bcast_kernel(const float* __restrict__ dEbar,
                                                              const int* __restrict__ n_valid, float* __restrict__ dE,
@@ -195,12 +224,31 @@ int edge_fwd(const float* E, const float* v, const int* n_valid, float* Ebar, co
 }
 
 int edge_bwd(const float* E, const float* v, const int* n_valid, const float* dlogit, const float* dEbar, float* dE,
-             float* dvpart, int B, int N, int D, hipStream_t st) {
+             float* dvpart, int B, int N, int D, hipStream_t st, bool carry_deferred) {
   GC_REQUIRE(E && v && dlogit && dvpart, "edge_bwd: null pointer");
   const bool vec = (D % 4 == 0) && al16(E) && al16(v) && (!dE || al16(dE)) && (!dEbar || al16(dEbar));
   const size_t lds = ((size_t)((N + 3) & ~3) + (size_t)EW * D) * sizeof(float);
   GC_REQUIRE(lds <= 160 * 1024, "edge_bwd: N=%d D=%d needs %zu B of LDS", N, D, lds);
-  dim3 grid((unsigned)((long)B * N)), block(64 * EW);
+  dim3 block(64 * EW);
+  GemmGroup gg;
+  double gflops = 0;
+  const int ntile = (carry_deferred && vec && lds + sizeof(float) * lds_floats<1, 1, true, true>() <= 64 * 1024)
+                        ? gemm_take_deferred(gg, &gflops)
+                        : 0;
+  if (ntile > 0) {  // parked weight-gradient products ride along
+    dim3 grid((unsigned)((long)B * N + ntile));
+    {
+      ProfScope ps("edge_bwd", st, (dE ? 8.0 : 4.0) * B * N * N * D);
+      if (nt_e1())
+        hipLaunchKernelGGL((edge_bwd_carry_kernel<4, true>), grid, block, lds, st, E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D,
+                           nt_store(), gg);
+      else
+        hipLaunchKernelGGL((edge_bwd_carry_kernel<4, false>), grid, block, lds, st, E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D,
+                           nt_store(), gg);
+    }
+    return check_launch("edge_bwd_carry");
+  }
+  dim3 grid((unsigned)((long)B * N));
   ProfScope ps("edge_bwd", st, (dE ? 8.0 : 4.0) * B * N * N * D);
 #define GC_EDGE_BWD(V, NT) \
   hipLaunchKernelGGL((edge_bwd_kernel<V, NT>), grid, block, lds, st, E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D, nt_store())

@@ -27,15 +27,6 @@
 
 namespace gc {
 
-// Workgroups are dealt round-robin over the 8 XCDs (ids b and b + 8 share an XCD and its 4 MiB L2).
-// Give each XCD one CONTIGUOUS run of the row-major tile list instead of every 8th tile, so that the
-// tiles resident on an XCD share A row panels / B column panels in its L2 (speed only; any placement
-// is correct).  Bijective for every grid size.
-__device__ __forceinline__ int xcd_remap(int b, int nwg) {
-  const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-}
-
 template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float lds[lds_floats<TM, TN, AKC, BKC>()];
@@ -83,21 +74,7 @@ __global__ __launch_bounds__(256, 4) void gemm_group_kernel(const GemmGroup gg) 
     col_ride_stage1(gg.col, blockIdx.x - tiles, lds);
     return;
   }
-  int b = blockIdx.x, i = 0;
-  while (i + 1 < gg.nprob && b >= gg.tile_begin[i + 1]) ++i;
-  b -= gg.tile_begin[i];
-  if (b >= gg.tile_count[i]) return;
-  b = xcd_remap(b, gg.tile_count[i]);
-  const GemmArgs& g = gg.p[i];
-  const int tn = g.N >> 6, tm = g.M >> 6;
-  const int bx = b % tn, by = (b / tn) % tm, zs = b / (tn * tm);
-  if (g.a_kc) {
-    if (g.b_kc) gemm_body<1, 1, true, true, true>(g, lds, bx, by, zs);
-    else gemm_body<1, 1, true, false, true>(g, lds, bx, by, zs);
-  } else {
-    if (g.b_kc) gemm_body<1, 1, false, true, true>(g, lds, bx, by, zs);
-    else gemm_body<1, 1, false, false, true>(g, lds, bx, by, zs);
-  }
+  gemm_group_block(gg, blockIdx.x, lds);
 }
 
 // Split-K reduce: one thread sums the partials of 4 consecutive outputs (16-byte loads, split order => bitwise
@@ -343,6 +320,62 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* 
     ProfScope ps("gemm_splitk_reduce", stream);
     hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(reds + col2), dim3(256), 0, stream, gg);
     return check_launch("gemm_group_reduce");
+  }
+  return 0;
+}
+
+// ---- deferred problems ------------------------------------------------------------------------------------------
+// Process-wide, not thread-local: autograd runs the blocks' backward on its device thread and the end-of-backward
+// callback (the flush) on the thread that called backward().  One backward pass at a time may park problems.
+static GemmArgs g_parked[16];
+static int g_nparked = 0;
+
+bool gemm_defer(const GemmArgs& g_in) {
+  GemmArgs g = g_in;
+  if (g_nparked >= 16 || g.M == 0 || g.N == 0) return false;
+  if (prepare(g, 1, 1, 0) < 0) return false;
+  if (!(g.vecA && g.vecB && g.M % 64 == 0 && g.N % 64 == 0 && g.K % BK == 0)) return false;
+  g.ws = nullptr, g.ws_elems = 0;  // unsplit: the whole K inside one workgroup
+  g_parked[g_nparked++] = g;
+  return true;
+}
+
+int gemm_deferred_count() { return g_nparked; }
+
+int gemm_take_deferred(GemmGroup& gg, double* flops) {
+  gg.nprob = 0;
+  if (g_nparked == 0) return 0;
+  // longest K first (they run the longest: start them first), then by size
+  for (int i = 1; i < g_nparked; ++i)
+    for (int j = i; j > 0 && g_parked[j].K > g_parked[j - 1].K; --j) {
+      const GemmArgs t = g_parked[j];
+      g_parked[j] = g_parked[j - 1], g_parked[j - 1] = t;
+    }
+  const int take = g_nparked < GemmGroup::MAXP ? g_nparked : GemmGroup::MAXP;
+  int tiles = 0;
+  for (int i = 0; i < take; ++i) {
+    const GemmArgs& g = g_parked[i];
+    const int own = (g.M >> 6) * (g.N >> 6) * g.batch1 * g.batch2;
+    tiles = (tiles + 7) & ~7;
+    gg.tile_begin[i] = tiles, gg.tile_count[i] = own, gg.red_begin[i] = 0;
+    tiles += own;
+    gg.p[i] = g;
+    if (flops) *flops += 2.0 * g.M * g.N * g.K * g.batch1 * g.batch2;
+  }
+  gg.nprob = take;
+  gg.tile_begin[take] = tiles, gg.red_begin[take] = 0;
+  for (int i = take; i < g_nparked; ++i) g_parked[i - take] = g_parked[i];
+  g_nparked -= take;
+  return tiles;
+}
+
+int gemm_flush_deferred(hipStream_t stream) {
+  while (g_nparked > 0) {
+    GemmArgs probs[GemmGroup::MAXP];
+    const int n = g_nparked < GemmGroup::MAXP ? g_nparked : GemmGroup::MAXP;
+    for (int i = 0; i < n; ++i) probs[i] = g_parked[g_nparked - n + i];
+    g_nparked -= n;
+    if (int e = gemm_group(probs, n, stream)) return e;
   }
   return 0;
 }

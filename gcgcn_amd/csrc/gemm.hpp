@@ -87,6 +87,21 @@ struct GemmGroup {
 };
 int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* col = nullptr);
 
+// ---- deferred problems ------------------------------------------------------------------------------------------
+// Weight-gradient products are needed by nobody before the end of backward, while later launches of the same
+// backward leave the matrix pipes idle (the edge-tensor stream of GATAttention's backward is HBM-bound).  A block can
+// park such a product here (host-side, one queue per process); the next launch that can carry passengers takes them along as
+// extra workgroups, unsplit (their full K runs inside one workgroup: no reduce launch).  Whoever parks a problem must
+// keep its operands alive until gemm_flush_deferred() or a carrying launch has been enqueued.
+// Only interior, 16-byte aligned shapes are parked (gemm_defer returns false otherwise: launch it now).
+bool gemm_defer(const GemmArgs& g);
+int gemm_deferred_count();
+// Move up to MAXP parked problems into gg (longest K first, per-problem XCD-aligned tile ranges); returns the number
+// of workgroups (0: nothing parked).  flops (optional) accumulates 2MNK of the taken problems.
+int gemm_take_deferred(GemmGroup& gg, double* flops);
+// Launch whatever is still parked as ordinary group launches (end of backward without a carrying launch).
+int gemm_flush_deferred(hipStream_t stream);
+
 // Floats of split-K workspace that lets every GEMM of a [rows x cols]-sized problem split freely.
 inline long gemm_ws_elems(long rows, long cols) {
   long need = 16 * rows * cols;

@@ -337,6 +337,36 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
       epi_tile<ALIGNED, EG, MASK, RT>(g, e, m0 + (wr * TM + i) * 32 + 4 * lh, n0 + (wc * TN + j) * 32 + l31, acc[i][j]);
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (ids b and b + 8 share an XCD and its 4 MiB L2).
+// Give each XCD one CONTIGUOUS run of the row-major tile list instead of every 8th tile, so that the
+// tiles resident on an XCD share A row panels / B column panels in its L2 (speed only; any placement
+// is correct).  Bijective for every grid size.
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+  const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+// Workgroup hb of a multi-problem launch (GemmGroup): find its problem by the prefix sums of (8-aligned) tile ranges,
+// remap inside the problem, run one interior 64x64 tile.  Shared by gemm_group_kernel and by kernels that carry
+// deferred problems as passengers (edge.hip).
+__device__ __forceinline__ void gemm_group_block(const GemmGroup& gg, int hb, float* __restrict__ lds) {
+  int i = 0;
+  while (i + 1 < gg.nprob && hb >= gg.tile_begin[i + 1]) ++i;
+  int b = hb - gg.tile_begin[i];
+  if (b >= gg.tile_count[i]) return;
+  b = xcd_remap(b, gg.tile_count[i]);
+  const GemmArgs& g = gg.p[i];
+  const int tn = g.N >> 6, tm = g.M >> 6;
+  const int bx = b % tn, by = (b / tn) % tm, zs = b / (tn * tm);
+  if (g.a_kc) {
+    if (g.b_kc) gemm_body<1, 1, true, true, true>(g, lds, bx, by, zs);
+    else gemm_body<1, 1, true, false, true>(g, lds, bx, by, zs);
+  } else {
+    if (g.b_kc) gemm_body<1, 1, false, true, true>(g, lds, bx, by, zs);
+    else gemm_body<1, 1, false, false, true>(g, lds, bx, by, zs);
+  }
+}
+
 template <int TM, int TN, bool AKC, bool BKC>
 constexpr int lds_floats() {
   return (((2 * BK * (AKC ? 64 * TM + 1 : 64 * TM)) + 3) & ~3) + 2 * BK * (BKC ? 64 * TN + 1 : 64 * TN);

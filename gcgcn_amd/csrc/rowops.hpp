@@ -33,7 +33,7 @@ int mask_rows(const float* x, float* y, long M, int D, int N, const int* n_valid
 int edge_fwd(const float* E, const float* v, const int* n_valid, float* Ebar, const float* coladd, float* P, float* A,
              Drop drop, int B, int N, int D, hipStream_t st);
 int edge_bwd(const float* E, const float* v, const int* n_valid, const float* dlogit, const float* dEbar, float* dE,
-             float* dvpart, int B, int N, int D, hipStream_t st);
+             float* dvpart, int B, int N, int D, hipStream_t st, bool carry_deferred = false);
 int edge_bcast(const float* dEbar, const int* n_valid, float* dE, int B, int N, int D, hipStream_t st);
 
 // mha_core.hip: fused attention core of MultiHeadAttention for N <= 64

@@ -7,6 +7,7 @@ GPU -- anything else raises (no CPU path).
 from __future__ import annotations
 
 import ctypes
+import os
 import weakref
 from typing import Optional
 
@@ -213,6 +214,29 @@ class MhaFn(torch.autograd.Function):
         return dX, dflat, None, None, None, None
 
 
+# ---- deferred weight gradients ---------------------------------------------------------------------------------
+# A MAGGC block's weight-gradient products (7 GFLOP at cfg 2) are needed by nobody before the end of backward, and the
+# last big kernel of backward -- GATAttention's pass over E -- is HBM-bound with idle matrix pipes.  gcgcn_gcn_bwd parks
+# them (include/gcgcn.h); gcgcn_gat_bwd carries them as extra workgroups of that pass; a callback at the end of the
+# backward pass launches whatever is still parked (e.g. no GATAttention in the graph) and releases the operands.
+defer_weight_grads = os.environ.get("GCGCN_DEFER", "1") != "0"      # GCGCN_DEFER=0: A/B knob
+_parked = []
+
+
+def _flush_deferred():
+    try:
+        if _lib.lib().gcgcn_deferred_count() > 0:
+            call("gcgcn_flush_deferred", _stream())
+    finally:
+        _parked.clear()
+
+
+def _park_until_flush(*tensors):
+    if not _parked:                                    # first parking of this backward pass: flush when it ends
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)
+    _parked.append(tensors)
+
+
 def _ride(inp, n_valid, out, B, N, D):
     """ctypes gcgcn_edge_ride for (inp -> out); the caller keeps the struct alive across the call."""
     r = _lib.EdgeRide(B, N, D, inp.data_ptr(), None if n_valid is None else n_valid.data_ptr(), out.data_ptr())
@@ -247,6 +271,7 @@ class GcnFn(torch.autograd.Function):
         ctx.save_for_backward(x, ebar, adj, flat, Pn, Y, HO, rinv)
         ctx.n_valid, ctx.L, ctx.H, ctx.p, ctx.snap = n_valid, L, H, float(p), snap
         ctx.out_p, ctx.out_snap = float(out_p), out_snap
+        ctx.flat_leaf = flat if flat.is_leaf else None      # to see in backward whether .grad will be installed or added to
         ctx.next_shape = None if e_next is None else tuple(e_next.shape)
         return out, ebar_next
 
@@ -273,10 +298,20 @@ class GcnFn(torch.autograd.Function):
             debar_next = debar_next.contiguous()
             dE_next = torch.empty(ctx.next_shape, device=dev)
             ride, ride_p = _ride(debar_next, ctx.n_valid, dE_next, *debar_next.shape)
+        # parking is sound only if autograd will INSTALL dflat as .grad (a leaf without a gradient yet and without hooks
+        # that read it at once); an existing .grad would be added to now, before the parked products have run
+        leaf = ctx.flat_leaf
+        defer = 1 if (defer_weight_grads and H > 1 and ctx.needs_input_grad[3] and leaf is not None and leaf.grad is None
+                      and not leaf._post_accumulate_grad_hooks and not leaf._backward_hooks) else 0
         call("gcgcn_gcn_bwd", B, N, D, L, H, _p(x), _p(ebar), _p(adj), _p(ctx.n_valid), _p(flat), _p(ctx.snap),
              ctx.p, _p(ctx.out_snap), ctx.out_p, _p(Pn), _p(Y), _p(HO), _p(rinv), _p(dout), _p(dX), _p(dEbar), _p(dA),
-             _p(dflat), _p(W1), _p(W2), _p(W3), _p(drow), _p(dXres), _p(dout_m), _p(scratch), ride_p, _stream())
+             _p(dflat), _p(W1), _p(W2), _p(W3), _p(drow), _p(dXres), _p(dout_m), _p(scratch), ride_p, defer, _stream())
         del ride
+        if defer:
+            # dflat is held through its STORAGE: the memory stays alive, but the tensor autograd receives keeps a use
+            # count of one, so AccumulateGrad installs it as .grad instead of cloning it now (before the parked products
+            # ran; a view would reference the tensor itself as its base)
+            _park_until_flush(x, ebar, Y, HO, dout, dout_m, W2, W3, dflat.untyped_storage())
         return dX, dEbar, dA, dflat, None, None, None, None, None, dE_next, None, None
 
 

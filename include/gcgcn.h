@@ -152,7 +152,15 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
                   float out_p, const float* Pn, const float* Y, const float* HO, const float* rinv, const float* dout,
                   float* dX, float* dEbar,
                   float* dA, float* dflat, float* W1, float* W2, float* W3, float* drow, float* dXres, float* dout_m,
-                  float* scratch, const gcgcn_edge_ride* ride, void* stream);
+                  float* scratch, const gcgcn_edge_ride* ride, int defer_weight_grads, void* stream);
+/* defer_weight_grads != 0: the block's weight-gradient products (dWlin, dWnX, dWe, dWd: nobody needs them before the
+ * end of backward) are not launched by this call but parked (host side, one queue per process: one backward pass at a time); the
+ * next gcgcn_gat_bwd carries them as extra workgroups of its HBM-bound edge pass, where the matrix pipes are idle.  Until then the
+ * caller must keep X, Ebar, Y, HO, dout (dout_m), W2, W3 and dflat of this call alive, and must call
+ * gcgcn_flush_deferred(stream) at the end of backward (it launches what is still parked; no-op otherwise).
+ * The parked parts of dflat are complete only after that. */
+int gcgcn_deferred_count(void);
+int gcgcn_flush_deferred(void* stream);
 
 /* ---- GraphConv, the leaf layer  GCGCN_glove.py:18-50 ------------------------------------------ */
 /* forward(inputs X[B,N,Din], mean edge feature Ebar[B,N,De], adjacency A[B,N,N]):

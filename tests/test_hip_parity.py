@@ -393,7 +393,8 @@ def test_full_size_properties(gpu_device):
 
     def run(xs, e1s, e2s):
         xg, a, b = dev_leaf(xs, gpu_device), dev_leaf(e1s, gpu_device), dev_leaf(e2s, gpu_device)
-        f = hops(xg, [a, b])
+        hops.zero_grad()        # same state for every run: with a .grad in place the weight gradients are not parked, and the
+        f = hops(xg, [a, b])    # data-gradient GEMMs they would have shared a launch with pick another split-K factor
         f[2].sum().backward()
         return f, xg.grad, a.grad, b.grad
 
@@ -624,3 +625,45 @@ def test_three_hops_and_alpha_mix_match_oracle(gpu_device, alpha):
         torch.testing.assert_close(xs.grad[b].cpu(), xr.grad, rtol=1e-3, atol=1e-4)
         for k in range(hop):
             torch.testing.assert_close(eds[k].grad[b].cpu(), er[k].grad, rtol=1e-3, atol=1e-5)
+
+
+def test_deferred_weight_gradients_equal_immediate_ones(gpu_device):
+    """MAGGC's weight gradients parked and carried by GATAttention's edge pass (or flushed at the end of backward when
+    there is no such pass) against launching them inside the block's own backward: same numbers up to summation order."""
+    B, N, D, L, H = 3, 64, 128, 2, 4
+    sd = O.init_stack_params(D, L, H, seed=51)
+    x, e1, e2, adj = O.synth_docs(B, N, D, seed=52)
+    hops = gcgcn_amd.GraphHops(D, L, H).to(gpu_device).eval()
+    hops.load_state_dict(sd, strict=True)
+    res = []
+    try:
+        for defer in (True, False):
+            F_.defer_weight_grads = defer
+            xs = [dev_leaf(t, gpu_device) for t in (x, e1, e2)]
+            out = hops(xs[0], [xs[1], xs[2]])[-1]
+            out.sum().backward()
+            assert _lib.lib().gcgcn_deferred_count() == 0 and not F_._parked
+            res.append([xs[0].grad, xs[1].grad] + [p.grad.clone() for p in hops.parameters() if p.grad is not None])
+            hops.zero_grad()
+        # a MAGGC block on its own: nothing carries the parked products, the end-of-backward callback launches them
+        conv = hops.graphcnn[1]
+        a = torch.softmax(torch.randn(B, H, N, N, generator=torch.Generator().manual_seed(5)), -1).to(gpu_device)
+        for defer in (True, False):
+            F_.defer_weight_grads = defer
+            xs = dev_leaf(x, gpu_device)
+            conv(xs, e2.to(gpu_device), a).sum().backward()
+            assert _lib.lib().gcgcn_deferred_count() == 0 and not F_._parked
+            res[0 if defer else 1].append(conv.flat.grad.clone())
+            conv.zero_grad()
+        # gradient accumulation: the second backward finds .grad set, so nothing may be parked (autograd adds at once)
+        F_.defer_weight_grads = True
+        xs = dev_leaf(x, gpu_device)
+        conv(xs, e2.to(gpu_device), a).sum().backward()
+        conv(xs, e2.to(gpu_device), a).sum().backward()
+        torch.testing.assert_close(conv.flat.grad, 2.0 * res[1][-1], rtol=2e-5, atol=2e-5)
+        conv.zero_grad()
+    finally:
+        F_.defer_weight_grads = True
+    assert len(res[0]) == len(res[1])
+    for a_, b_ in zip(*res):
+        torch.testing.assert_close(a_, b_, rtol=2e-5, atol=2e-5)
