@@ -49,7 +49,7 @@ SIGNATURES = {
     "gcgcn_mha_layout": (I, [I, P]),
     "gcgcn_mha_scratch": (L, [I, I, I]),
     "gcgcn_mha_fwd": (I, [I, I, I, I, P, P, P, P, F, P, P, P, P, P]),
-    "gcgcn_mha_bwd": (I, [I, I, I, I, P, P, P, F, P, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_mha_bwd": (I, [I, I, I, I, P, P, P, F, P, P, P, P, P, P, P, P, P, I, P]),
     "gcgcn_gcn_layout": (I, [I, I, I, P]),
     "gcgcn_gcn_scratch": (L, [I, I, I, I]),
     "gcgcn_gcn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, F, P, P, P, P, P, P, P, P, P]),

@@ -351,7 +351,7 @@ int64_t gcgcn_mha_scratch(int B, int N, int D) { return scratch_elems(B, N, D, 1
 
 int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat, const void* rng_snap, float p,
                   const float* Q, const float* P, const float* dA, const float* dX_in, float* dX, float* dflat, float* dS,
-                  float* dQ, float* scratch, void* stream) {
+                  float* dQ, float* scratch, int defer_weight_grads, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("mha_bwd", B, N, D, 1, H));
   const long wse = scratch ? gemm_scratch_elems(B, N, D, 1) : 0;
@@ -389,12 +389,13 @@ int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat,
     gs[1].B = X, gs[1].ldb = D, gs[1].b_kc = 0;
     gs[1].C = dflat, gs[1].ldc = D;
     gs[1].M = D, gs[1].N = D, gs[1].K = (int)M;
+    const int ng = (defer_weight_grads && gemm_defer(gs[1])) ? 1 : 2;  // dWq parked (see gcgcn_gcn_bwd)
     if (scratch) {  // dbq = column sums of dQ ride in the same two launches
       ColRide cr;
       cr.X = dQ, cr.out = dflat + (long)D * D, cr.part = scratch + wse, cr.R = M, cr.ld = D, cr.C = D;
-      GC_TRY(gemm_group(gs, 2, st, &cr));
+      GC_TRY(gemm_group(gs, ng, st, &cr));
     } else {
-      GC_TRY(gemm_group(gs, 2, st));
+      GC_TRY(gemm_group(gs, ng, st));
       GC_TRY(colsum(dQ, nullptr, dflat + (long)D * D, M, D, D, 1, 0, 0, 0, 0, scratch, st));
     }
   }

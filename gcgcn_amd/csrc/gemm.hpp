@@ -77,7 +77,7 @@ struct ColRide {
 
 // Up to MAXP independent problems carried by one launch (gemm_group).
 struct GemmGroup {
-  static constexpr int MAXP = 6;
+  static constexpr int MAXP = 9;
   GemmArgs p[MAXP];
   int tile_begin[MAXP + 1];  // first workgroup of each problem, a multiple of 8 (see gemm_group_kernel)
   int tile_count[MAXP];

@@ -195,6 +195,7 @@ class MhaFn(torch.autograd.Function):
              _p(scratch), _stream())
         ctx.save_for_backward(x, flat, Q, P)
         ctx.H, ctx.p, ctx.snap = H, float(p), snap
+        ctx.flat_leaf = flat if flat.is_leaf else None
         return (P if A is None else A), x.view_as(x)
 
     @staticmethod
@@ -209,8 +210,13 @@ class MhaFn(torch.autograd.Function):
         dS = torch.empty(B, H, N, N, device=dev)
         dQ = torch.empty(B, N, D, device=dev)
         scratch = torch.empty(max(_lib.lib().gcgcn_mha_scratch(B, N, D), 1), device=dev)
+        # dWq could be parked too (defer_mha_weight_grads); measured neutral at cfg 2 -- the carrying edge pass is already the
+        # longer side with the two convolutions' products (0.652 vs 0.648 ms) -- so it stays with its own group launch
+        defer = _can_park(ctx.flat_leaf, ctx.needs_input_grad[1]) if defer_mha_weight_grads else 0
         call("gcgcn_mha_bwd", B, N, D, H, _p(x), _p(flat), _p(ctx.snap), ctx.p, _p(Q), _p(P), _p(dA), _p(dXin), _p(dX),
-             _p(dflat), _p(dS), _p(dQ), _p(scratch), _stream())
+             _p(dflat), _p(dS), _p(dQ), _p(scratch), defer, _stream())
+        if defer:
+            _park_until_flush(x, dQ, dflat.untyped_storage())
         return dX, dflat, None, None, None, None
 
 
@@ -220,6 +226,7 @@ class MhaFn(torch.autograd.Function):
 # them (include/gcgcn.h); gcgcn_gat_bwd carries them as extra workgroups of that pass; a callback at the end of the
 # backward pass launches whatever is still parked (e.g. no GATAttention in the graph) and releases the operands.
 defer_weight_grads = os.environ.get("GCGCN_DEFER", "1") != "0"      # GCGCN_DEFER=0: A/B knob
+defer_mha_weight_grads = False
 _parked = []
 
 
@@ -229,6 +236,13 @@ def _flush_deferred():
             call("gcgcn_flush_deferred", _stream())
     finally:
         _parked.clear()
+
+
+def _can_park(leaf, needs_grad) -> int:
+    """Parking is sound only if autograd will INSTALL the gradient tensor as .grad: a leaf without a gradient yet and without
+    hooks that read it at once.  An existing .grad would be added to immediately, before the parked products have run."""
+    return 1 if (defer_weight_grads and needs_grad and leaf is not None and leaf.grad is None
+                 and not leaf._post_accumulate_grad_hooks and not leaf._backward_hooks) else 0
 
 
 def _park_until_flush(*tensors):
@@ -298,11 +312,7 @@ class GcnFn(torch.autograd.Function):
             debar_next = debar_next.contiguous()
             dE_next = torch.empty(ctx.next_shape, device=dev)
             ride, ride_p = _ride(debar_next, ctx.n_valid, dE_next, *debar_next.shape)
-        # parking is sound only if autograd will INSTALL dflat as .grad (a leaf without a gradient yet and without hooks
-        # that read it at once); an existing .grad would be added to now, before the parked products have run
-        leaf = ctx.flat_leaf
-        defer = 1 if (defer_weight_grads and H > 1 and ctx.needs_input_grad[3] and leaf is not None and leaf.grad is None
-                      and not leaf._post_accumulate_grad_hooks and not leaf._backward_hooks) else 0
+        defer = _can_park(ctx.flat_leaf, ctx.needs_input_grad[3])
         call("gcgcn_gcn_bwd", B, N, D, L, H, _p(x), _p(ebar), _p(adj), _p(ctx.n_valid), _p(flat), _p(ctx.snap),
              ctx.p, _p(ctx.out_snap), ctx.out_p, _p(Pn), _p(Y), _p(HO), _p(rinv), _p(dout), _p(dX), _p(dEbar), _p(dA),
              _p(dflat), _p(W1), _p(W2), _p(W3), _p(drow), _p(dXres), _p(dout_m), _p(scratch), ride_p, defer, _stream())

@@ -108,10 +108,11 @@ int64_t gcgcn_mha_scratch(int B, int N, int D);
 int gcgcn_mha_fwd(int B, int N, int D, int H, const float* X, const int32_t* n_valid, const float* flat,
                   const void* rng_snap, float p, float* Q, float* P, float* A, float* scratch, void* stream);
 /* backward.  dX_in[B,N,D] (NULL = zero) as in gcgcn_gat_bwd.  Workspace: dS[B,H,N,N], dQ[B,N,D],
- * scratch[gcgcn_mha_scratch]. */
+ * scratch[gcgcn_mha_scratch].  defer_weight_grads: dWq is parked as described at gcgcn_gcn_bwd (keep X, dQ and dflat
+ * alive until the flush). */
 int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat, const void* rng_snap, float p,
                   const float* Q, const float* P, const float* dA, const float* dX_in, float* dX, float* dflat,
-                  float* dS, float* dQ, float* scratch, void* stream);
+                  float* dS, float* dQ, float* scratch, int defer_weight_grads, void* stream);
 
 /* ---- GraphConvolution (H = 1) / MultiGraphConvolution  GCGCN_glove.py:52-120 --------------- */
 /* flat = [WnX D x H*D | We D x H*D | Wd | Wlin D x H*D | blin D]
