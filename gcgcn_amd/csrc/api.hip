@@ -566,7 +566,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
     }
     c.ride = er;
     if (use_chain()) {
-      GC_TRY(gcn_chain_bwd(c, st));
+      GC_TRY(gcn_chain_bwd(c, st, true));  // + parked weight gradients of earlier blocks where the chain leaves room
     } else {
       for (int l = L - 1; l >= 0; --l) {
         GC_TRY(relu_norm_bwd(dYa, Y, rinv, dM, drow, M, N, H, L, gh, l, l == L - 1, st));

@@ -91,12 +91,19 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_fwd_kernel(const GcnCtx c) 
   }
 }
 
+// cg: parked weight-gradient products (gemm.hpp) carried by a chain launch that leaves most compute units idle -- its
+// workgroups follow the chain workgroups in dispatch order, two 64x64 tiles each.
 template <bool ALIGNED>
-__global__ __launch_bounds__(64 * CW) void gcn_chain_bwd_kernel(const GcnCtx c) {
+__global__ __launch_bounds__(64 * CW) void gcn_chain_bwd_kernel(const GcnCtx c, const GemmGroup4 cg) {
   __shared__ __attribute__((aligned(16))) float lds[CHAIN_LDS];
-  if (blockIdx.x >= c.B * c.H) {  // passenger workgroup: one entity row of the riding dE broadcast
-    const EdgeRide& r = c.ride;
-    edge_bcast_row<4, CW>(r.in, r.n_valid, r.out, r.N, r.D, 0, blockIdx.x - c.B * c.H);
+  if (blockIdx.x >= c.B * c.H) {
+    const int pb = blockIdx.x - c.B * c.H, ng = cg.tile_begin[cg.nprob];
+    if (pb < ng) {  // passenger workgroup: two tiles of a parked product
+      gemm_group_pair_block(cg, pb, lds, TEAM_LDS);
+      return;
+    }
+    const EdgeRide& r = c.ride;  // passenger workgroup: one entity row of the riding dE broadcast
+    edge_bcast_row<4, CW>(r.in, r.n_valid, r.out, r.N, r.D, 0, pb - ng);
     return;
   }
   const int z = blockIdx.x;
@@ -183,14 +190,29 @@ int gcn_chain_fwd(const GcnCtx& c, hipStream_t st) {
   return check_launch("gcn_chain_fwd");
 }
 
-int gcn_chain_bwd(const GcnCtx& c, hipStream_t st) {
+int gcn_chain_bwd(const GcnCtx& c, hipStream_t st, bool carry_deferred) {
   GC_REQUIRE(c.ride.kind == 0 || (c.ride.kind == 2 && chain_can_carry(c.ride)), "gcn_chain_bwd: bad passenger");
-  dim3 grid(chain_grid(c, 2)), block(64 * CW);
   double fl = 0;
   for (int l = 0; l < c.L; ++l) fl += 4.0 * c.N * c.gh * c.N + 2.0 * c.N * c.gh * (double)l * c.gh;
-  ProfScope ps("gcn_chain_bwd", st, fl * c.B * c.H);
-  if (chain_aligned(c, true)) hipLaunchKernelGGL(gcn_chain_bwd_kernel<true>, grid, block, 0, st, c);
-  else hipLaunchKernelGGL(gcn_chain_bwd_kernel<false>, grid, block, 0, st, c);
+  fl *= (double)c.B * c.H;
+  GemmGroup4 cg;
+  cg.nprob = 0, cg.tile_begin[0] = 0;
+  // Parked products ride only where the chain leaves the chip mostly empty (few (doc, head) pairs) AND runs long enough:
+  // a passenger workgroup (two unsplit tiles) is matrix-pipe-bound at ~0.85 us per 32-deep k-step and occupies its
+  // compute unit alone (register footprint of this kernel), so it only hides behind a chain of several such times.
+  // The chain itself costs ~8 us per dependent product and tile pass (measured, cfg 2 / cfg 3).
+  int ng = 0;
+  if (carry_deferred && (long)c.B * c.H <= 64) {
+    const int passes = (((c.N + 63) / 64) * ((c.gh + 63) / 64) + 1) / 2;
+    const double t_chain = 8.0 * (4 * c.L - 1) * passes;                  // us
+    const double t_wg = 0.85 * ((double)c.B * c.N / 32.0);                // us: weight gradients have K = B N
+    const long rounds = t_wg > 0 ? (long)((t_chain - t_wg) / t_wg) : 0;
+    if (rounds > 0) ng = gemm_take_deferred_pairs(cg, &fl, rounds * (256 - (long)c.B * c.H));
+  }
+  dim3 grid(chain_grid(c, 2) + (unsigned)ng), block(64 * CW);
+  ProfScope ps("gcn_chain_bwd", st, fl);
+  if (chain_aligned(c, true)) hipLaunchKernelGGL(gcn_chain_bwd_kernel<true>, grid, block, 0, st, c, cg);
+  else hipLaunchKernelGGL(gcn_chain_bwd_kernel<false>, grid, block, 0, st, c, cg);
   return check_launch("gcn_chain_bwd");
 }
 

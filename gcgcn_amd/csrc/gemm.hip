@@ -342,32 +342,48 @@ bool gemm_defer(const GemmArgs& g_in) {
 
 int gemm_deferred_count() { return g_nparked; }
 
-int gemm_take_deferred(GemmGroup& gg, double* flops) {
-  gg.nprob = 0;
-  if (g_nparked == 0) return 0;
-  // longest K first (they run the longest: start them first), then by size
+static void sort_parked() {  // longest K first (they run the longest: start them first)
   for (int i = 1; i < g_nparked; ++i)
     for (int j = i; j > 0 && g_parked[j].K > g_parked[j - 1].K; --j) {
       const GemmArgs t = g_parked[j];
       g_parked[j] = g_parked[j - 1], g_parked[j - 1] = t;
     }
-  const int take = g_nparked < GemmGroup::MAXP ? g_nparked : GemmGroup::MAXP;
-  int tiles = 0;
+}
+
+static double flops_of(const GemmArgs& g) { return 2.0 * g.M * g.N * g.K * g.batch1 * g.batch2; }
+
+template <class G>
+static int take_parked(G& gg, double* flops, int tiles_per_wg, long max_wgs) {
+  gg.nprob = 0;
+  gg.tile_begin[0] = 0;
+  if (g_nparked == 0) return 0;
+  sort_parked();
+  int take = 0;
+  for (long got = 0; take < g_nparked && take < G::MAXP; ++take) {
+    const GemmArgs& g = g_parked[take];
+    got += ((long)(g.M >> 6) * (g.N >> 6) * g.batch1 * g.batch2 + tiles_per_wg - 1) / tiles_per_wg;
+    if (got > max_wgs) break;
+  }
+  if (take == 0) return 0;
+  int wgs = 0;
   for (int i = 0; i < take; ++i) {
     const GemmArgs& g = g_parked[i];
     const int own = (g.M >> 6) * (g.N >> 6) * g.batch1 * g.batch2;
-    tiles = (tiles + 7) & ~7;
-    gg.tile_begin[i] = tiles, gg.tile_count[i] = own, gg.red_begin[i] = 0;
-    tiles += own;
+    wgs = (wgs + 7) & ~7;
+    gg.tile_begin[i] = wgs, gg.tile_count[i] = own, gg.red_begin[i] = 0;
+    wgs += (own + tiles_per_wg - 1) / tiles_per_wg;
     gg.p[i] = g;
-    if (flops) *flops += 2.0 * g.M * g.N * g.K * g.batch1 * g.batch2;
+    if (flops) *flops += flops_of(g);
   }
   gg.nprob = take;
-  gg.tile_begin[take] = tiles, gg.red_begin[take] = 0;
+  gg.tile_begin[take] = wgs, gg.red_begin[take] = 0;
   for (int i = take; i < g_nparked; ++i) g_parked[i - take] = g_parked[i];
   g_nparked -= take;
-  return tiles;
+  return wgs;
 }
+
+int gemm_take_deferred(GemmGroup& gg, double* flops) { return take_parked(gg, flops, 1, 1L << 40); }
+int gemm_take_deferred_pairs(GemmGroup4& gg, double* flops, long max_wgs) { return take_parked(gg, flops, 2, max_wgs); }
 
 int gemm_flush_deferred(hipStream_t stream) {
   while (g_nparked > 0) {

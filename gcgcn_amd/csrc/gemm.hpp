@@ -75,16 +75,19 @@ struct ColRide {
   int C = 0;
 };
 
-// Up to MAXP independent problems carried by one launch (gemm_group).
-struct GemmGroup {
-  static constexpr int MAXP = 9;
-  GemmArgs p[MAXP];
-  int tile_begin[MAXP + 1];  // first workgroup of each problem, a multiple of 8 (see gemm_group_kernel)
-  int tile_count[MAXP];
-  int red_begin[MAXP + 1];
+// Up to NP independent problems carried by one launch.
+template <int NP>
+struct GemmGroupT {
+  static constexpr int MAXP = NP;
+  GemmArgs p[NP];
+  int tile_begin[NP + 1];  // first workgroup of each problem, a multiple of 8 (see gemm_group_kernel)
+  int tile_count[NP];      // 64x64 tiles of each problem
+  int red_begin[NP + 1];
   int nprob;
   ColRide col;  // col.X == nullptr: nothing rides
 };
+using GemmGroup = GemmGroupT<9>;   // gemm_group launches and the edge pass carrying parked problems
+using GemmGroup4 = GemmGroupT<4>;  // passengers of a chain launch (kernel arguments stay small)
 int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* col = nullptr);
 
 // ---- deferred problems ------------------------------------------------------------------------------------------
@@ -99,6 +102,9 @@ int gemm_deferred_count();
 // Move up to MAXP parked problems into gg (longest K first, per-problem XCD-aligned tile ranges); returns the number
 // of workgroups (0: nothing parked).  flops (optional) accumulates 2MNK of the taken problems.
 int gemm_take_deferred(GemmGroup& gg, double* flops);
+// Same for a chain launch: workgroups of 512 threads run TWO tiles each (tile_begin counts workgroups).
+// Takes parked problems (longest first) only while their workgroups fit into `max_wgs`; the rest waits for a later carrier.
+int gemm_take_deferred_pairs(GemmGroup4& gg, double* flops, long max_wgs);
 // Launch whatever is still parked as ordinary group launches (end of backward without a carrying launch).
 int gemm_flush_deferred(hipStream_t stream);
 

@@ -349,7 +349,8 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 // Workgroup hb of a multi-problem launch (GemmGroup): find its problem by the prefix sums of (8-aligned) tile ranges,
 // remap inside the problem, run one interior 64x64 tile.  Shared by gemm_group_kernel and by kernels that carry
 // deferred problems as passengers (edge.hip).
-__device__ __forceinline__ void gemm_group_block(const GemmGroup& gg, int hb, float* __restrict__ lds) {
+template <class G>
+__device__ __forceinline__ void gemm_group_block(const G& gg, int hb, float* __restrict__ lds) {
   int i = 0;
   while (i + 1 < gg.nprob && hb >= gg.tile_begin[i + 1]) ++i;
   int b = hb - gg.tile_begin[i];
@@ -364,6 +365,33 @@ __device__ __forceinline__ void gemm_group_block(const GemmGroup& gg, int hb, fl
   } else {
     if (g.b_kc) gemm_body<1, 1, false, true, true>(g, lds, bx, by, zs);
     else gemm_body<1, 1, false, false, true>(g, lds, bx, by, zs);
+  }
+}
+
+// The same for a 512-thread workgroup of two tile teams (chain kernels): workgroup hb runs tiles 2p and 2p + 1 of its
+// problem side by side; with an odd tile count the last workgroup's second team recomputes the last tile without
+// storing it, so both teams pass the same barriers.
+template <class G>
+__device__ __forceinline__ void gemm_group_pair_block(const G& gg, int hb, float* __restrict__ lds, int team_lds) {
+  int i = 0;
+  while (i + 1 < gg.nprob && hb >= gg.tile_begin[i + 1]) ++i;
+  const int p = hb - gg.tile_begin[i];
+  const int cnt = gg.tile_count[i];
+  if (2 * p >= cnt) return;  // padding workgroup (uniform over the workgroup)
+  const int team = threadIdx.x >> 8, t = threadIdx.x & 255;
+  int q = 2 * p + team;
+  const bool live = q < cnt;
+  if (!live) q = cnt - 1;
+  const GemmArgs& g = gg.p[i];
+  const int tn = g.N >> 6, tm = g.M >> 6;
+  const int bx = q % tn, by = (q / tn) % tm, zs = q / (tn * tm);
+  float* tl = lds + team * team_lds;
+  if (g.a_kc) {
+    if (g.b_kc) gemm_body<1, 1, true, true, true>(g, tl, bx, by, zs, t, live);
+    else gemm_body<1, 1, true, false, true>(g, tl, bx, by, zs, t, live);
+  } else {
+    if (g.b_kc) gemm_body<1, 1, false, true, true>(g, tl, bx, by, zs, t, live);
+    else gemm_body<1, 1, false, false, true>(g, tl, bx, by, zs, t, live);
   }
 }
 
