@@ -156,14 +156,14 @@ __global__ __launch_bounds__(64 * EW) void edge_bwd_carry_kernel(const float* __
                                                                  const float* __restrict__ dEbar, float* __restrict__ dE,
                                                                  float* __restrict__ dvpart, int N, int D, int nt,
                                                                  const GemmGroup gg) {
+  // one LDS image for both kinds of workgroup (the rows need N + EW * D floats of it): a fourth workgroup fits per CU
   __shared__ __attribute__((aligned(16))) float tile_lds[lds_floats<1, 1, true, true>()];
-  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int ntile = gg.tile_begin[gg.nprob];
   if ((int)blockIdx.x < ntile) {
     gemm_group_block(gg, blockIdx.x, tile_lds);
     return;
   }
-  edge_bwd_row<VEC, NTL>(E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D, nt, blockIdx.x - ntile, sm);
+  edge_bwd_row<VEC, NTL>(E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D, nt, blockIdx.x - ntile, tile_lds);
 }
 
 template <int VEC>
@@ -232,7 +232,7 @@ int edge_bwd(const float* E, const float* v, const int* n_valid, const float* dl
   dim3 block(64 * EW);
   GemmGroup gg;
   double gflops = 0;
-  const int ntile = (carry_deferred && vec && lds + sizeof(float) * lds_floats<1, 1, true, true>() <= 64 * 1024)
+  const int ntile = (carry_deferred && vec && lds <= sizeof(float) * lds_floats<1, 1, true, true>())
                         ? gemm_take_deferred(gg, &gflops)
                         : 0;
   if (ntile > 0) {  // parked weight-gradient products ride along
@@ -240,10 +240,10 @@ int edge_bwd(const float* E, const float* v, const int* n_valid, const float* dl
     {
       ProfScope ps("edge_bwd", st, (dE ? 8.0 : 4.0) * B * N * N * D);
       if (nt_e1())
-        hipLaunchKernelGGL((edge_bwd_carry_kernel<4, true>), grid, block, lds, st, E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D,
+        hipLaunchKernelGGL((edge_bwd_carry_kernel<4, true>), grid, block, 0, st, E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D,
                            nt_store(), gg);
       else
-        hipLaunchKernelGGL((edge_bwd_carry_kernel<4, false>), grid, block, lds, st, E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D,
+        hipLaunchKernelGGL((edge_bwd_carry_kernel<4, false>), grid, block, 0, st, E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D,
                            nt_store(), gg);
     }
     return check_launch("edge_bwd_carry");
