@@ -532,6 +532,8 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
     GC_TRY(mask_rows(dout, dout_m, M, D, N, n_valid, odrop, st));
     dout = dout_m;
   }
+  ColRide cr;
+  bool col_later = false;
   {  // one launch: dHO = dout Wlin  and  dWlin = dout^T HO
     GemmArgs gs[2];
     gs[0].ws = gs[1].ws = scratch, gs[0].ws_elems = gs[1].ws_elems = wse;
@@ -545,16 +547,15 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
     gs[1].M = D, gs[1].N = (int)HD, gs[1].K = (int)M;
     // a weight gradient nobody needs before the end of backward: parked for a later launch with idle matrix pipes
     const int ng1 = (defer_weight_grads && gemm_defer(gs[1])) ? 1 : 2;
-    if (scratch) {  // dblin = column sums of dout ride in the same two launches
-      ColRide cr;
+    if (scratch) {  // dblin = column sums of dout ride in this launch (stage 1) and in its reduce or the next kernel (stage 2)
       cr.X = dout, cr.out = dflat + y.oblin, cr.part = scratch + wse, cr.R = M, cr.ld = D, cr.C = D;
-      GC_TRY(gemm_group(gs, ng1, st, &cr));
+      GC_TRY(gemm_group(gs, ng1, st, &cr, &col_later));
     } else {
       GC_TRY(gemm_group(gs, ng1, st));
       GC_TRY(colsum(dout, nullptr, dflat + y.oblin, M, D, D, 1, 0, 0, 0, 0, scratch, st));
     }
   }
-  GC_TRY(head_sum_drop_bwd(dYa, dYa, dXres, M, H, D, drop, st));  // residual + dropout backward
+  GC_TRY(head_sum_drop_bwd(dYa, dYa, dXres, M, H, D, drop, st, col_later ? &cr : nullptr));  // residual + dropout backward
 
   {  // the dependent per-(doc, head) sequence, last sub-layer first
     GcnCtx c = make_ctx(B, N, D, L, H, y, X, A, flat, n_valid, drop);

@@ -220,7 +220,8 @@ int gemm(const GemmArgs& g_in, hipStream_t stream, int tile, int splits) {
 
 // Independent problems in one launch (plus at most one reduce launch).  Problems that are not interior
 // 64x64 shapes fall back to their own launches.
-int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* col) {
+int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* col, bool* col_later) {
+  if (col_later) *col_later = false;
   GemmGroup gg;
   gg.nprob = 0;
   long work = 0;  // tile-k-steps of the whole launch
@@ -316,6 +317,10 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* 
     hipLaunchKernelGGL(gemm_group_kernel, dim3(tiles + col1), dim3(256), 0, stream, gg);
   }
   if (int e = check_launch("gemm_group")) return e;
+  if (ride && !any_split && col_later) {  // nothing to reduce: the caller folds stage 2 into a kernel of its own
+    *col_later = true;
+    return 0;
+  }
   if (any_split || ride) {
     ProfScope ps("gemm_splitk_reduce", stream);
     hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(reds + col2), dim3(256), 0, stream, gg);

@@ -88,7 +88,9 @@ struct GemmGroupT {
 };
 using GemmGroup = GemmGroupT<9>;   // gemm_group launches and the edge pass carrying parked problems
 using GemmGroup4 = GemmGroupT<4>;  // passengers of a chain launch (kernel arguments stay small)
-int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* col = nullptr);
+// col_later (optional): if the launch needs no split-K reduce, stage 2 of the riding column sum is NOT launched on its own;
+// *col_later is set and the caller finishes it inside a later kernel of its own (col_ride_stage2_block).
+int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* col = nullptr, bool* col_later = nullptr);
 
 // ---- deferred problems ------------------------------------------------------------------------------------------
 // Weight-gradient products are needed by nobody before the end of backward, while later launches of the same

@@ -2,6 +2,7 @@
 // adjacency row normaliser, relu/normaliser backward, dropout, column reductions, the folded
 // GAT projection, and the device-side dropout RNG state.  All are launch-latency sized; the
 // big terms live in edge.hip (HBM) and gemm.hip (MFMA).
+#include "gemm.hpp"
 #include "rowops.hpp"
 
 namespace gc {
@@ -131,8 +132,21 @@ __global__ __launch_bounds__(64 * RW) void relu_norm_bwd_kernel(const float* __r
 //   dY[m, h, c] = dropout_bwd(dHO[m, h, c])   (may alias dHO)
 //   dXres[m, c] = sum_h dHO[m, h, c]
 // ---------------------------------------------------------------------------------------------
+// Trailing workgroups (blockIdx >= main) finish a riding column sum (gemm.hpp ColRide, stage 2): out[c] = sum of the
+// COL_RIDE_SLICES row-slice partials, in slice order.
 __global__ __launch_bounds__(256) void head_sum_drop_bwd_kernel(const float* dHO, float* dY, float* __restrict__ dXres,
-                                                                long M, int H, int D, Drop drop) {
+                                                                long M, int H, int D, Drop drop, int main_blocks,
+                                                                const float* __restrict__ cpart, float* __restrict__ cout,
+                                                                int cC) {
+  if ((int)blockIdx.x >= main_blocks) {
+    const int c = (blockIdx.x - main_blocks) * 256 + threadIdx.x;
+    if (c < cC) {
+      float s = 0.f;
+      for (int q = 0; q < COL_RIDE_SLICES; ++q) s += cpart[(long)q * cC + c];
+      cout[c] = s;
+    }
+    return;
+  }
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= M * D) return;
   const long m = e / D;
@@ -522,9 +536,12 @@ int relu_norm_bwd(const float* dY, const float* Y, const float* rinv, float* dM,
                      rows_m, N, H, L, gh, l, first, relu);
   return check_launch("relu_norm_bwd");
 }
-int head_sum_drop_bwd(const float* dHO, float* dY, float* dXres, long M, int H, int D, Drop drop, hipStream_t st) {
+int head_sum_drop_bwd(const float* dHO, float* dY, float* dXres, long M, int H, int D, Drop drop, hipStream_t st,
+                      const ColRide* finish) {
   ProfScope ps("head_sum_drop_bwd", st);
-  hipLaunchKernelGGL(head_sum_drop_bwd_kernel, dim3(cdiv(M * D, 256)), dim3(256), 0, st, dHO, dY, dXres, M, H, D, drop);
+  const int main_blocks = cdiv(M * D, 256), extra = finish ? cdiv(finish->C, 256) : 0;
+  hipLaunchKernelGGL(head_sum_drop_bwd_kernel, dim3(main_blocks + extra), dim3(256), 0, st, dHO, dY, dXres, M, H, D, drop,
+                     main_blocks, finish ? finish->part : nullptr, finish ? finish->out : nullptr, finish ? finish->C : 0);
   return check_launch("head_sum_drop_bwd");
 }
 int dropout(const float* x, float* y, long n, Drop drop, hipStream_t st) {

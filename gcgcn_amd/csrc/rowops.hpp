@@ -10,7 +10,9 @@ int softmax_bwd(const float* P, const float* dA, float* dS, long rows, int N, Dr
 int rowsum_inv(const float* A, float* rinv, long rows, int N, hipStream_t st);
 int relu_norm_bwd(const float* dY, const float* Y, const float* rinv, float* dM, float* drow, long rows_m, int N, int H,
                   int L, int gh, int l, int first, hipStream_t st, int relu = 1);
-int head_sum_drop_bwd(const float* dHO, float* dY, float* dXres, long M, int H, int D, Drop drop, hipStream_t st);
+struct ColRide;
+int head_sum_drop_bwd(const float* dHO, float* dY, float* dXres, long M, int H, int D, Drop drop, hipStream_t st,
+                      const ColRide* finish = nullptr);
 int dropout(const float* x, float* y, long n, Drop drop, hipStream_t st);
 int dropout_keep(unsigned char* keep, long n, Drop drop, hipStream_t st);
 int rng_next(void* state, void* snaps, int count, hipStream_t st);
