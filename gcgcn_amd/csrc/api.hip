@@ -240,14 +240,16 @@ int gcgcn_gat_layout(int D, int64_t* o) {
 }
 
 int gcgcn_gat_fwd(int B, int N, int D, const float* X, const float* E, const int32_t* n_valid, const float* flat,
-                  const void* rng_snap, float p, float* uvc, float* s, float* P, float* A, float* Ebar, void* stream) {
+                  const void* rng_snap, float p, float* uvc, float* s, float* P, float* A, float* Ebar, void* rng_state,
+                  void* rng_snaps, int rng_count, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("gat_fwd", B, N, D, 1, 1));
   GC_REQUIRE(X && E && flat && uvc && s && P && Ebar, "gat_fwd: null pointer");
   const Drop drop = make_drop(rng_snap, GCGCN_SALT_GAT, p);
   GC_REQUIRE(!drop.snap || A, "gat_fwd: dropout on but A is NULL");
   const long M = (long)B * N;
-  GC_TRY(gat_fold_fwd(flat, uvc, D, st));
+  GC_REQUIRE(!rng_state || (rng_snaps && rng_count > 0), "gat_fwd: rng_state given without snapshots to fill");
+  GC_TRY(gat_fold_fwd(flat, uvc, D, st, rng_state, rng_snaps, rng_count));  // + gcgcn_rng_next, if asked to
   GC_TRY(node_score_fwd(X, uvc, s, M, D, st));
   GC_TRY(edge_fwd(E, uvc + D, n_valid, Ebar, s, P, A, drop, B, N, D, st));  // + row softmax + dropout
   return 0;

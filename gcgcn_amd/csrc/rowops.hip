@@ -298,9 +298,17 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(const ColJobs j, floa
 // uvc output: [u D | v D | c 1]
 // ---------------------------------------------------------------------------------------------
 constexpr int FW = 16;  // waves per workgroup of the fold: all D/FW rows of a wave are in flight at once
-__global__ __launch_bounds__(64 * FW) void gat_fold_fwd_kernel(const float* __restrict__ flat, float* __restrict__ uvc, int D) {
+// rng_state != NULL: workgroup 0 also advances the dropout generator (what rng_next_kernel does), so the first kernel
+// of a hop loop serves every dropout site of the step without a launch of its own.
+__global__ __launch_bounds__(64 * FW) void gat_fold_fwd_kernel(const float* __restrict__ flat, float* __restrict__ uvc, int D,
+                                                               uint64_t* rng_state, uint64_t* rng_snaps, int rng_count) {
   __shared__ float red[2][FW][64];
   __shared__ float redc[FW];
+  if (rng_state && blockIdx.x == 0 && threadIdx.x < 64) {  // one wave: reads of the state precede its update in program order
+    const uint64_t seed = rng_state[0], ctr = rng_state[1];
+    for (int i = threadIdx.x; i < rng_count; i += 64) rng_snaps[2 * i] = seed, rng_snaps[2 * i + 1] = ctr + (uint64_t)i;
+    if (threadIdx.x == 0) rng_state[1] = ctr + (uint64_t)rng_count;
+  }
   const long DD = (long)D * D;
   const float* Wh = flat;
   const float* bh = Wh + DD;
@@ -633,9 +641,10 @@ int colsum3(const float* X0, const float* w0, float* o0, long R0, int C0, long l
   return check_launch("colsum3/2");
 }
 
-int gat_fold_fwd(const float* flat, float* uvc, int D, hipStream_t st) {
+int gat_fold_fwd(const float* flat, float* uvc, int D, hipStream_t st, void* rng_state, void* rng_snaps, int rng_count) {
   ProfScope ps("gat_fold_fwd", st);
-  hipLaunchKernelGGL(gat_fold_fwd_kernel, dim3(cdiv(D, 64)), dim3(64 * FW), 0, st, flat, uvc, D);
+  hipLaunchKernelGGL(gat_fold_fwd_kernel, dim3(cdiv(D, 64)), dim3(64 * FW), 0, st, flat, uvc, D, (uint64_t*)rng_state,
+                     (uint64_t*)rng_snaps, rng_count);
   return check_launch("gat_fold_fwd");
 }
 int gat_fold_bwd(const float* flat, const float* duvc, float* dflat, int D, hipStream_t st, const float* part,

@@ -22,7 +22,8 @@ int colsum(const float* X, const float* w, float* out, long R, int C, long ld, i
 int colsum3(const float* X0, const float* w0, float* o0, long R0, int C0, long ld0, const float* X1, const float* w1,
             float* o1, long R1, int C1, long ld1, const float* X2, const float* w2, float* o2, long R2, int C2, long ld2,
             float* scratch, hipStream_t st, bool stage2 = true, long* part_off = nullptr, int* ns_out = nullptr);
-int gat_fold_fwd(const float* flat, float* uvc, int D, hipStream_t st);
+int gat_fold_fwd(const float* flat, float* uvc, int D, hipStream_t st, void* rng_state = nullptr, void* rng_snaps = nullptr,
+                 int rng_count = 0);
 int gat_fold_bwd(const float* flat, const float* duvc, float* dflat, int D, hipStream_t st, const float* part = nullptr,
                  const long* part_off = nullptr, int ns = 0);
 bool gat_dlogit_ok(int N);

@@ -65,21 +65,27 @@ def manual_seed(seed: int, device=None):
     _rng_state[dev.index or 0] = torch.tensor([seed, 0], dtype=torch.int64, device=dev)
 
 
-_scope = None  # [snaps tensor [count, 2], next index] while a rng_scope is active
+_scope = None  # [snaps tensor [count, 2], next index, pending] while a rng_scope is active
 
 
-def _new_snaps(dev: torch.device, count: int) -> Tensor:
+def _state(dev: torch.device) -> Tensor:
     idx = dev.index or 0
     if idx not in _rng_state:
         manual_seed(torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, dev)
+    return _rng_state[idx]
+
+
+def _new_snaps(dev: torch.device, count: int) -> Tensor:
     snaps = torch.empty(count, 2, dtype=torch.int64, device=dev)
-    call("gcgcn_rng_next", _p(_rng_state[idx]), _p(snaps), count, _stream())
+    call("gcgcn_rng_next", _p(_state(dev)), _p(snaps), count, _stream())
     return snaps
 
 
 class rng_scope:
-    """Draw the {seed, counter} snapshots of up to `count` dropout-using forwards with ONE tiny launch
-    (GraphHops uses it for a whole hop loop); outside a scope every forward launches its own."""
+    """Draw the {seed, counter} snapshots of up to `count` dropout-using forwards at once (GraphHops uses it for a whole
+    hop loop); outside a scope every forward launches its own tiny kernel.  The draw itself is LAZY: the scope only
+    allocates the snapshot buffer; GATAttention's forward -- the first kernel of a hop loop -- fills it inside its own
+    first launch (gcgcn_gat_fwd's rng_state argument), and any other consumer that comes first launches gcgcn_rng_next."""
 
     def __init__(self, dev: torch.device, count: int, enabled: bool = True):
         self.dev, self.count, self.enabled = dev, count, enabled
@@ -88,7 +94,7 @@ class rng_scope:
         global _scope
         self.prev = _scope
         if self.enabled:
-            _scope = [_new_snaps(self.dev, self.count), 0]
+            _scope = [torch.empty(self.count, 2, dtype=torch.int64, device=self.dev), 0, True]
         return self
 
     def __exit__(self, *exc):
@@ -97,11 +103,24 @@ class rng_scope:
         return False
 
 
-def rng_snapshot(dev: torch.device) -> Tensor:
+def _take_pending_rng(dev: torch.device):
+    """(state, snaps, count) of the active scope if its snapshots have not been drawn yet -- the caller promises to draw
+    them in its next launch, before anything reads a snapshot -- else None."""
+    if _scope is not None and _scope[2] and _scope[0].device == dev:
+        _scope[2] = False
+        return _state(dev), _scope[0], _scope[0].shape[0]
+    return None
+
+
+def rng_snapshot(dev: torch.device, lazy: bool = False) -> Tensor:
     """Device-side {seed, counter} for one dropout-using forward; the counter advances on the GPU, so a
-    captured hipGraph draws a fresh mask at every replay."""
+    captured hipGraph draws a fresh mask at every replay.  lazy=True: the caller will take the pending draw itself
+    (_take_pending_rng) in the launch that reads this snapshot."""
     global _scope
     if _scope is not None and _scope[1] < _scope[0].shape[0] and _scope[0].device == dev:
+        if _scope[2] and not lazy:                      # somebody other than GATAttention comes first: draw now
+            _scope[2] = False
+            call("gcgcn_rng_next", _p(_state(dev)), _p(_scope[0]), _scope[0].shape[0], _stream())
         snap = _scope[0][_scope[1]]
         _scope[1] += 1
         return snap
@@ -122,16 +141,17 @@ class GatFn(torch.autograd.Function):
     here, where the attention's own dX kernel adds it -- instead of autograd summing the two with one more launch."""
 
     @staticmethod
-    def forward(ctx, x, e, flat, n_valid, p, snap):
+    def forward(ctx, x, e, flat, n_valid, p, snap, pending):
         B, N, D = x.shape
         dev = x.device
+        st, sn, cnt = pending if pending is not None else (None, None, 0)
         uvc = torch.empty(2 * D + 1, device=dev)
         s = torch.empty(B, N, device=dev)
         P = torch.empty(B, N, N, device=dev)
         A = torch.empty(B, N, N, device=dev) if snap is not None else None
         ebar = torch.empty(B, N, D, device=dev)
         call("gcgcn_gat_fwd", B, N, D, _p(x), _p(e), _p(n_valid), _p(flat), _p(snap), float(p), _p(uvc), _p(s),
-             _p(P), _p(A), _p(ebar), _stream())
+             _p(P), _p(A), _p(ebar), _p(st), _p(sn), cnt, _stream())
         ctx.save_for_backward(x, e, flat, uvc, P)
         ctx.n_valid, ctx.p, ctx.snap = n_valid, float(p), snap
         return (P if A is None else A), ebar, x.view_as(x)
@@ -156,7 +176,7 @@ class GatFn(torch.autograd.Function):
         call("gcgcn_gat_bwd", B, N, D, _p(x), _p(e), _p(ctx.n_valid), _p(flat), _p(ctx.snap), ctx.p, _p(uvc), _p(P),
              _p(dA), _p(dEbar), _p(dXin), _p(dX), _p(dE), _p(dflat), _p(dlogit), _p(ds), _p(dvpart), _p(duvc),
              _p(scratch), _stream())
-        return dX, dE, dflat, None, None, None
+        return dX, dE, dflat, None, None, None, None
 
 
 class EdgeMeanFn(torch.autograd.Function):
@@ -414,7 +434,8 @@ def gat_attention(x, e, flat, n_valid=None, p=0.1, training=False):
     if e.shape != (B, N, N, D):
         raise ValueError(f"edge_feat: expected {(B, N, N, D)}, got {tuple(e.shape)}")
     nv = _nv(n_valid, B, N, x.device)
-    return GatFn.apply(x, e, _chk(flat, "flat"), nv, p, _snap_for(training, p, x.device))   # (A, Ebar, alias of x)
+    snap = rng_snapshot(x.device, lazy=True) if (training and p > 0.0) else None
+    return GatFn.apply(x, e, _chk(flat, "flat"), nv, p, snap, _take_pending_rng(x.device))   # (A, Ebar, alias of x)
 
 
 def edge_mean(e, n_valid=None):

@@ -79,8 +79,12 @@ int gcgcn_gat_layout(int D, int64_t* out9);
  *   Ebar[B,N,D] mean_j E[b,i,j,:]  -- by-product of the single pass over E, consumed by the
  *               GraphConvolution that follows (GCGCN_glove.py:40-41 commuted)
  *   uvc[2D+1], s[B,N]  folded projection and node scores (saved for backward) */
+/* rng_state / rng_snaps / rng_count: optional (NULL, NULL, 0).  When given, the call also performs
+ * gcgcn_rng_next(rng_state, rng_snaps, rng_count) inside its first kernel, BEFORE anything reads rng_snap (which may
+ * point into rng_snaps): a hop loop draws the snapshots of all its dropout sites without a launch of its own. */
 int gcgcn_gat_fwd(int B, int N, int D, const float* X, const float* E, const int32_t* n_valid, const float* flat,
-                  const void* rng_snap, float p, float* uvc, float* s, float* P, float* A, float* Ebar, void* stream);
+                  const void* rng_snap, float p, float* uvc, float* s, float* P, float* A, float* Ebar, void* rng_state,
+                  void* rng_snaps, int rng_count, void* stream);
 
 /* backward.  dA[B,N,N], dEbar[B,N,D] (NULL = zero), dX_in[B,N,D] (NULL = zero: gradient node_feat has
  * already collected from its other consumers -- the convolution of the same hop -- added here instead of

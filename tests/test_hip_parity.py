@@ -343,8 +343,8 @@ def test_train_mode_matches_oracle_with_replayed_masks(gpu_device):
     snaps = []
     orig = F_.rng_snapshot
 
-    def spy(dev):
-        s = orig(dev)
+    def spy(dev, lazy=False):
+        s = orig(dev, lazy)
         snaps.append(s)
         return s
     F_.rng_snapshot = spy
