@@ -293,7 +293,7 @@ def main():
                 m = re.search(r"gc::(edge_\w+)_kernel<\d+(?:, (true|false))?", k)
                 if not m:
                     continue
-                name = m.group(1) + ({"true": "_att", "false": "_mean"}[m.group(2)] if m.group(1) == "edge_fwd" else "")
+                name = m.group(1).replace("_carry", "") + ({"true": "_att", "false": "_mean"}[m.group(2)] if m.group(1) == "edge_fwd" else "")
                 if name == fam:
                     r["traffic"] = v["hbm_bytes_per_launch_corrected"]
         return r
@@ -303,6 +303,19 @@ def main():
     roofline_hbm = None
     if use_prof and rank == 0 and dominant != "edge_bwd":
         roofline_hbm = roof("edge_bwd", *profile("edge_bwd", 5), "5 steps after the timed region")
+        from gcgcn_amd import functional as F_
+        if roofline_hbm and F_.defer_weight_grads and N % 64 == 0 and D % 64 == 0 and (D // L) % 64 == 0:
+            # The launch also carries the convolutions' parked weight-gradient products: their flops run on
+            # the matrix pipes under the HBM stream, so the launch is judged against both roofs.  (With a short CAGGC chain,
+            # cfg 1/2, all of them ride here; a long one, cfg 3, takes a share itself.)
+            M, gh = B * N, D // L
+            carried = sum(3 * 2.0 * D * (h * D) * M + sum(2.0 * (l * gh) * gh * M * h for l in range(1, L)) for h in (1, H))
+            us = roofline_hbm["avg_launch_us"]
+            roofline_hbm["carried_mfma"] = {"flops_per_launch": carried, "TFLOP/s": round(carried / us / 1e6, 2),
+                                            "frac_of_f32_mfma_peak": round(carried / (us * 1e-6) / MFMA_F32_PEAK, 4),
+                                            "note": "upper bound when a long CAGGC chain launch takes some of them; the PMC "
+                                                    "traffic of this launch includes the carried products' operand reads "
+                                                    "(edge stream alone: 1.02 x algorithmic, profiles/r01_c2_eager_kernel_stats_v5 era)"}
 
     if rank == 0:
         docs = B * world * args.steps
