@@ -358,7 +358,10 @@ __device__ __forceinline__ void gemm_group_block(const G& gg, int hb, float* __r
   b = xcd_remap(b, gg.tile_count[i]);
   const GemmArgs& g = gg.p[i];
   const int tn = g.N >> 6, tm = g.M >> 6;
-  const int bx = b % tn, by = (b / tn) % tm, zs = b / (tn * tm);
+  // walk the short side fastest: the tiles that are neighbours in the list (and therefore on one XCD) then share BOTH
+  // operand panels (weight gradients are [D x H*D] with K = B*N: 4 x 32 tiles, each reading two 512 KiB panels)
+  const int zs = b / (tn * tm), r = b - zs * (tn * tm);
+  const int bx = (tm < tn) ? r / tm : r % tn, by = (tm < tn) ? r % tm : r / tn;
   if (g.a_kc) {
     if (g.b_kc) gemm_body<1, 1, true, true, true>(g, lds, bx, by, zs);
     else gemm_body<1, 1, true, false, true>(g, lds, bx, by, zs);
