@@ -56,6 +56,7 @@ SIGNATURES = {
     "gcgcn_gcn_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, P]),
     "gcgcn_deferred_count": (I, []),
     "gcgcn_flush_deferred": (I, [P]),
+    "gcgcn_reset_deferred": (I, []),
     "gcgcn_graphconv_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_graphconv_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_pair_bce_fwd": (I, [I, I, I, P, P, P, P, P, P]),

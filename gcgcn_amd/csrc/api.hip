@@ -406,6 +406,10 @@ int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat,
 
 int gcgcn_deferred_count(void) { return gemm_deferred_count(); }
 int gcgcn_flush_deferred(void* stream) { return gemm_flush_deferred((hipStream_t)stream); }
+int gcgcn_reset_deferred(void) {
+  gemm_reset_deferred();
+  return 0;
+}
 
 // ---------------------------------------------------------------------------------------------
 // trainer loss

@@ -346,6 +346,7 @@ bool gemm_defer(const GemmArgs& g_in) {
 }
 
 int gemm_deferred_count() { return g_nparked; }
+void gemm_reset_deferred() { g_nparked = 0; }
 
 static void sort_parked() {  // longest K first (they run the longest: start them first)
   for (int i = 1; i < g_nparked; ++i)

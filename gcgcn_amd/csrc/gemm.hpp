@@ -109,6 +109,8 @@ int gemm_take_deferred(GemmGroup& gg, double* flops);
 int gemm_take_deferred_pairs(GemmGroup4& gg, double* flops, long max_wgs);
 // Launch whatever is still parked as ordinary group launches (end of backward without a carrying launch).
 int gemm_flush_deferred(hipStream_t stream);
+// Forget whatever is parked without launching it (a backward pass that failed half-way left operands that no longer exist).
+void gemm_reset_deferred();
 
 // Floats of split-K workspace that lets every GEMM of a [rows x cols]-sized problem split freely.
 inline long gemm_ws_elems(long rows, long cols) {

@@ -258,6 +258,13 @@ def _flush_deferred():
         _parked.clear()
 
 
+def _drop_stale_parked():
+    """A previous backward pass that raised half-way may have left parked products whose operands are gone: forget them
+    (called before the first parking of a pass, i.e. while this module's keep-alive list is empty)."""
+    if not _parked and _lib.lib().gcgcn_deferred_count() > 0:
+        call("gcgcn_reset_deferred")
+
+
 def _can_park(leaf, needs_grad) -> int:
     """Parking is sound only if autograd will INSTALL the gradient tensor as .grad: a leaf without a gradient yet and without
     hooks that read it at once.  An existing .grad would be added to immediately, before the parked products have run."""
@@ -332,6 +339,7 @@ class GcnFn(torch.autograd.Function):
             debar_next = debar_next.contiguous()
             dE_next = torch.empty(ctx.next_shape, device=dev)
             ride, ride_p = _ride(debar_next, ctx.n_valid, dE_next, *debar_next.shape)
+        _drop_stale_parked()
         defer = _can_park(ctx.flat_leaf, ctx.needs_input_grad[3])
         call("gcgcn_gcn_bwd", B, N, D, L, H, _p(x), _p(ebar), _p(adj), _p(ctx.n_valid), _p(flat), _p(ctx.snap),
              ctx.p, _p(ctx.out_snap), ctx.out_p, _p(Pn), _p(Y), _p(HO), _p(rinv), _p(dout), _p(dX), _p(dEbar), _p(dA),

@@ -166,6 +166,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
  * The parked parts of dflat are complete only after that. */
 int gcgcn_deferred_count(void);
 int gcgcn_flush_deferred(void* stream);
+int gcgcn_reset_deferred(void); /* forget parked products without launching them (after a backward pass that failed) */
 
 /* ---- GraphConv, the leaf layer  GCGCN_glove.py:18-50 ------------------------------------------ */
 /* forward(inputs X[B,N,Din], mean edge feature Ebar[B,N,De], adjacency A[B,N,N]):
