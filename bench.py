@@ -247,7 +247,7 @@ def main():
     # the dominant family is sampled on every 10th timed step only; edge_bwd-sized families (1 launch) always.
     # In graph mode the sampled steps are the ones issued eagerly (same kernels on the same data; the rest replay).
     if graph is not None:
-        sample_every = max(2, min(25, args.steps // 2))        # an eager step costs host time on top of the events
+        sample_every = max(2, min(25, args.steps))             # an eager step costs host time on top of the events
     else:
         sample_every = 1 if shares.get(dominant, {}).get("launches_per_step", 99) <= 2 else 10
     if use_prof:
