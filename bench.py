@@ -209,13 +209,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    FAMILIES = {  # kernel-name prefix -> (bound, peak, unit of work)
-        "gemm": ("mfma", MFMA_F32_PEAK), "gcn_chain": ("mfma", MFMA_F32_PEAK),
+    FAMILIES = {  # timer tag (= one kernel) -> (bound, peak)
+        "gemm_group": ("mfma", MFMA_F32_PEAK), "gemm_single": ("mfma", MFMA_F32_PEAK),
+        "gcn_chain_fwd": ("mfma", MFMA_F32_PEAK), "gcn_chain_bwd": ("mfma", MFMA_F32_PEAK),
         "edge_bwd": ("hbm", HBM_PEAK), "edge_fwd_att": ("hbm", HBM_PEAK), "edge_fwd_mean": ("hbm", HBM_PEAK),
         "edge_bcast": ("hbm", HBM_PEAK),
     }
-    SMALL = ("softmax", "mha_core", "head_sum", "dropout", "gat_fold", "node_score", "colsum", "mask_rows", "rowsum",
-             "relu_norm")
+    SMALL = ("gemm_splitk_reduce", "softmax", "mha_core", "head_sum", "dropout", "gat_fold", "gat_dlogit", "node_score",
+             "colsum", "mask_rows", "rowsum", "relu_norm")
+
+    KERNEL_NAMES = {"gemm_group": "gc::gemm_group_kernel", "gemm_single": "gc::gemm_kernel<...>",
+                    "gcn_chain_fwd": "gc::gcn_chain_fwd_kernel", "gcn_chain_bwd": "gc::gcn_chain_bwd_kernel",
+                    "edge_bwd": "gc::edge_bwd_carry_kernel / gc::edge_bwd_kernel", "edge_fwd_att": "gc::edge_fwd_kernel<4,true,*>"}
 
     def profile(prefix, nsteps):
         """HIP-event time of every launch whose kernel name starts with `prefix` over nsteps steps."""
@@ -281,7 +286,7 @@ def main():
         if n == 0 or ms <= 0:
             return None
         ach = work / (ms * 1e-3)                           # work/s over the time those launches were running
-        r = {"bound": bound, "kernel": fam + "*", "achieved": round(ach / (1e9 if bound == "hbm" else 1e12), 2),
+        r = {"bound": bound, "kernel": KERNEL_NAMES.get(fam, fam + "*"), "achieved": round(ach / (1e9 if bound == "hbm" else 1e12), 2),
              "peak": peak / (1e9 if bound == "hbm" else 1e12), "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
              "frac": round(ach / peak, 4), "traffic": None, "avg_launch_us": round(ms / n * 1e3, 2),
              "launches": n, "work_per_launch": work / n, "sampled_steps": samp,

@@ -49,7 +49,7 @@ struct GemmArgs {
   // z1 * nv_zdoc + r / nv_rows and is a padding row iff r % nv_rows >= n_valid[doc].
   const int* n_valid = nullptr;
   int nv_rows = 1, nv_zdoc = 0;
-  const char* tag = "gemm";  // name seen by the per-kernel timer
+  const char* tag = "gemm_single";  // name seen by the per-kernel timer (gemm_kernel launches; groups: "gemm_group")
   // split-K workspace (optional): partial sums [splits][batch][M][N]
   float* ws = nullptr;
   long ws_elems = 0;
