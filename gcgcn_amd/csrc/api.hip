@@ -52,6 +52,14 @@ ProfScope::ProfScope(const char* tag, hipStream_t s, double work) : slot(-1), st
 ProfScope::~ProfScope() {
   if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
 }
+bool prof_events(const char* tag, double work, hipEvent_t* start, hipEvent_t* stop) {
+  if (!g_prof.on || strncmp(tag, g_prof.filter, strlen(g_prof.filter)) != 0) return false;
+  if (2 * (g_prof.used + 1) > (int)g_prof.ev.size()) return false;  // ring full: stop recording
+  const int slot = g_prof.used++;
+  g_prof.work += work;
+  *start = g_prof.ev[2 * slot], *stop = g_prof.ev[2 * slot + 1];
+  return true;
+}
 
 #define GC_TRY(expr)            \
   do {                          \

@@ -184,9 +184,8 @@ int gcn_chain_fwd(const GcnCtx& c, hipStream_t st) {
   dim3 grid(chain_grid(c, 1)), block(64 * CW);
   double fl = 0;
   for (int l = 0; l < c.L; ++l) fl += 2.0 * c.N * c.gh * (c.N + (double)l * c.gh);
-  ProfScope ps("gcn_chain_fwd", st, fl * c.B * c.H);
-  if (chain_aligned(c, false)) hipLaunchKernelGGL(gcn_chain_fwd_kernel<true>, grid, block, 0, st, c);
-  else hipLaunchKernelGGL(gcn_chain_fwd_kernel<false>, grid, block, 0, st, c);
+  if (chain_aligned(c, false)) GC_LAUNCH_TIMED("gcn_chain_fwd", fl * c.B * c.H, gcn_chain_fwd_kernel<true>, grid, block, 0, st, c);
+  else GC_LAUNCH_TIMED("gcn_chain_fwd", fl * c.B * c.H, gcn_chain_fwd_kernel<false>, grid, block, 0, st, c);
   return check_launch("gcn_chain_fwd");
 }
 
@@ -210,9 +209,8 @@ int gcn_chain_bwd(const GcnCtx& c, hipStream_t st, bool carry_deferred) {
     if (rounds > 0) ng = gemm_take_deferred_pairs(cg, &fl, rounds * (256 - (long)c.B * c.H));
   }
   dim3 grid(chain_grid(c, 2) + (unsigned)ng), block(64 * CW);
-  ProfScope ps("gcn_chain_bwd", st, fl);
-  if (chain_aligned(c, true)) hipLaunchKernelGGL(gcn_chain_bwd_kernel<true>, grid, block, 0, st, c, cg);
-  else hipLaunchKernelGGL(gcn_chain_bwd_kernel<false>, grid, block, 0, st, c, cg);
+  if (chain_aligned(c, true)) GC_LAUNCH_TIMED("gcn_chain_bwd", fl, gcn_chain_bwd_kernel<true>, grid, block, 0, st, c, cg);
+  else GC_LAUNCH_TIMED("gcn_chain_bwd", fl, gcn_chain_bwd_kernel<false>, grid, block, 0, st, c, cg);
   return check_launch("gcn_chain_bwd");
 }
 

@@ -2,6 +2,7 @@
 // wave = 64 lanes everywhere; no other target is supported.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -107,6 +108,19 @@ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // While a filter is active, every launcher whose tag starts with the filter brackets its launch
 // with two hipEvents on the launch stream; bench.py reads the summed duration.  Off by default
 // (one predictable branch per launch); must stay off while a hipGraph is being captured.
+// For the kernels that dominate the step: reserve an event pair for a launch tagged `tag` (false: not being timed) and
+// pass it to hipExtLaunchKernelGGL, which stamps the kernel's own begin and end -- the same interval rocprofv3 reports.
+// (An event recorded before / after a launch, as ProfScope does, also includes the dispatch gap: +3-4 us per launch.)
+bool prof_events(const char* tag, double work, hipEvent_t* start, hipEvent_t* stop);
+#define GC_LAUNCH_TIMED(tag, work, kernel, grid, block, lds, st, ...)                                     \
+  do {                                                                                                    \
+    hipEvent_t _e0, _e1;                                                                                  \
+    if (gc::prof_events(tag, work, &_e0, &_e1))                                                           \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, st, _e0, _e1, 0, __VA_ARGS__);                      \
+    else                                                                                                  \
+      hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                      \
+  } while (0)
+
 struct ProfScope {
   ProfScope(const char* tag, hipStream_t st, double work = 0.0);  // work: flops (GEMM) or algorithmic bytes (edge)
   ~ProfScope();

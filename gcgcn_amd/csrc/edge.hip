@@ -206,12 +206,13 @@ int edge_fwd(const float* E, const float* v, const int* n_valid, float* Ebar, co
   const size_t lds = ((size_t)EW * D + (att ? (size_t)N : 0)) * sizeof(float);
   GC_REQUIRE(lds <= 160 * 1024, "edge_fwd: N=%d D=%d needs %zu B of LDS", N, D, lds);
   dim3 grid((unsigned)((long)B * N)), block(64 * EW);
-  ProfScope ps(att ? "edge_fwd_att" : "edge_fwd_mean", st, 4.0 * B * N * N * D);
+  const char* tag = att ? "edge_fwd_att" : "edge_fwd_mean";
+  const double bytes = 4.0 * B * N * N * D;
   // the mean-only pass reads E once per step: always non-temporal.  The attention pass over E1 keeps ordinary
   // loads by default (part of E1 is still in the Infinity Cache from the previous backward); GCGCN_NT_E1=1 streams it too.
   const bool ntl = !att || nt_e1();
 #define GC_EDGE_FWD(V, AT, NT) \
-  hipLaunchKernelGGL((edge_fwd_kernel<V, AT, NT>), grid, block, lds, st, E, v, n_valid, Ebar, coladd, P, A, drop, N, D)
+  GC_LAUNCH_TIMED(tag, bytes, (edge_fwd_kernel<V, AT, NT>), grid, block, lds, st, E, v, n_valid, Ebar, coladd, P, A, drop, N, D)
   if (vec) {
     if (att) { if (ntl) GC_EDGE_FWD(4, true, true); else GC_EDGE_FWD(4, true, false); }
     else GC_EDGE_FWD(4, false, true);
@@ -237,21 +238,20 @@ int edge_bwd(const float* E, const float* v, const int* n_valid, const float* dl
                         : 0;
   if (ntile > 0) {  // parked weight-gradient products ride along
     dim3 grid((unsigned)((long)B * N + ntile));
-    {
-      ProfScope ps("edge_bwd", st, (dE ? 8.0 : 4.0) * B * N * N * D);
-      if (nt_e1())
-        hipLaunchKernelGGL((edge_bwd_carry_kernel<4, true>), grid, block, 0, st, E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D,
-                           nt_store(), gg);
-      else
-        hipLaunchKernelGGL((edge_bwd_carry_kernel<4, false>), grid, block, 0, st, E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D,
-                           nt_store(), gg);
-    }
+    const double bytes = (dE ? 8.0 : 4.0) * B * N * N * D;
+    if (nt_e1())
+      GC_LAUNCH_TIMED("edge_bwd", bytes, (edge_bwd_carry_kernel<4, true>), grid, block, 0, st, E, v, n_valid, dlogit, dEbar, dE,
+                      dvpart, N, D, nt_store(), gg);
+    else
+      GC_LAUNCH_TIMED("edge_bwd", bytes, (edge_bwd_carry_kernel<4, false>), grid, block, 0, st, E, v, n_valid, dlogit, dEbar, dE,
+                      dvpart, N, D, nt_store(), gg);
     return check_launch("edge_bwd_carry");
   }
   dim3 grid((unsigned)((long)B * N));
-  ProfScope ps("edge_bwd", st, (dE ? 8.0 : 4.0) * B * N * N * D);
-#define GC_EDGE_BWD(V, NT) \
-  hipLaunchKernelGGL((edge_bwd_kernel<V, NT>), grid, block, lds, st, E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D, nt_store())
+  const double bytes = (dE ? 8.0 : 4.0) * B * N * N * D;
+#define GC_EDGE_BWD(V, NT)                                                                                                 \
+  GC_LAUNCH_TIMED("edge_bwd", bytes, (edge_bwd_kernel<V, NT>), grid, block, lds, st, E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D, \
+                  nt_store())
   if (vec) { if (nt_e1()) GC_EDGE_BWD(4, true); else GC_EDGE_BWD(4, false); }
   else { if (nt_e1()) GC_EDGE_BWD(1, true); else GC_EDGE_BWD(1, false); }
 #undef GC_EDGE_BWD

@@ -140,17 +140,11 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 template <int TM, int TN, bool ALIGNED>
 static int launch(const GemmArgs& g, hipStream_t stream) {
   dim3 grid(cdiv(g.N, 64 * TN), cdiv(g.M, 64 * TM), g.batch1 * g.batch2 * g.splits), block(256);
-  {
-    ProfScope ps(g.tag, stream, 2.0 * g.M * g.N * g.K * g.batch1 * g.batch2);
-    if (g.a_kc && !g.b_kc)
-      hipLaunchKernelGGL((gemm_kernel<TM, TN, true, false, ALIGNED>), grid, block, 0, stream, g);
-    else if (g.a_kc && g.b_kc)
-      hipLaunchKernelGGL((gemm_kernel<TM, TN, true, true, ALIGNED>), grid, block, 0, stream, g);
-    else if (!g.a_kc && !g.b_kc)
-      hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false, ALIGNED>), grid, block, 0, stream, g);
-    else
-      hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true, ALIGNED>), grid, block, 0, stream, g);
-  }
+  const double flops = 2.0 * g.M * g.N * g.K * g.batch1 * g.batch2;
+  if (g.a_kc && !g.b_kc) GC_LAUNCH_TIMED(g.tag, flops, (gemm_kernel<TM, TN, true, false, ALIGNED>), grid, block, 0, stream, g);
+  else if (g.a_kc && g.b_kc) GC_LAUNCH_TIMED(g.tag, flops, (gemm_kernel<TM, TN, true, true, ALIGNED>), grid, block, 0, stream, g);
+  else if (!g.a_kc && !g.b_kc) GC_LAUNCH_TIMED(g.tag, flops, (gemm_kernel<TM, TN, false, false, ALIGNED>), grid, block, 0, stream, g);
+  else GC_LAUNCH_TIMED(g.tag, flops, (gemm_kernel<TM, TN, false, true, ALIGNED>), grid, block, 0, stream, g);
   if (int e = check_launch("gemm")) return e;
   if (g.splits > 1) {
     ProfScope ps("gemm_splitk_reduce", stream);
@@ -312,10 +306,7 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* 
     gg.col = *col;
     col1 = cdiv(col->C, 64) * COL_RIDE_SLICES, col2 = cdiv(col->C, 256);
   }
-  {
-    ProfScope ps("gemm_group", stream, flops);
-    hipLaunchKernelGGL(gemm_group_kernel, dim3(tiles + col1), dim3(256), 0, stream, gg);
-  }
+  GC_LAUNCH_TIMED("gemm_group", flops, gemm_group_kernel, dim3(tiles + col1), dim3(256), 0, stream, gg);
   if (int e = check_launch("gemm_group")) return e;
   if (ride && !any_split && col_later) {  // nothing to reduce: the caller folds stage 2 into a kernel of its own
     *col_later = true;
