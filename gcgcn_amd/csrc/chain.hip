@@ -47,6 +47,32 @@ __device__ __forceinline__ void run_product(GemmArgs g, float* lds, int z) {
   }
 }
 
+// Two INDEPENDENT products side by side: team 0 runs every tile of g1, team 1 every tile of g2 (dPn_l = A^T dM_l and
+// dA += dM_l Pn_l^T both wait only for dM_l).  A tile of the GEMM body passes 1 + ceil(K / 32) workgroup barriers; the
+// team with fewer of them in total pads the difference, so both teams arrive at every barrier.
+template <bool AKC1, bool BKC1, int MK1, int RTA, bool AKC2, bool BKC2, int MK2, int RTB, bool ALIGNED>
+__device__ __forceinline__ void run_two_products(GemmArgs g1, GemmArgs g2, float* lds, int z) {
+  auto prep = [](GemmArgs& g) {
+    g.ksplit = g.K, g.splits = 1;
+    if (!ALIGNED) {
+      g.vecA = dev_al16(g.A) && g.lda % 4 == 0 && g.sA1 % 4 == 0 && g.sA2 % 4 == 0;
+      g.vecB = dev_al16(g.B) && g.ldb % 4 == 0 && g.sB1 % 4 == 0 && g.sB2 % 4 == 0;
+    }
+  };
+  prep(g1), prep(g2);
+  const int team = threadIdx.x >> 8, t = threadIdx.x & 255;
+  float* tl = lds + team * TEAM_LDS;
+  const int tn1 = (g1.N + 63) >> 6, tiles1 = ((g1.M + 63) >> 6) * tn1, b1 = tiles1 * (1 + (g1.K + 31) / 32);
+  const int tn2 = (g2.N + 63) >> 6, tiles2 = ((g2.M + 63) >> 6) * tn2, b2 = tiles2 * (1 + (g2.K + 31) / 32);
+  if (team == 0) {
+    for (int q = 0; q < tiles1; ++q) gemm_body<1, 1, AKC1, BKC1, ALIGNED, 16, MK1, RTA>(g1, tl, q % tn1, q / tn1, z, t, true);
+    for (int i = b1; i < b2; ++i) __syncthreads();
+  } else {
+    for (int q = 0; q < tiles2; ++q) gemm_body<1, 1, AKC2, BKC2, ALIGNED, 16, MK2, RTB>(g2, tl, q % tn2, q / tn2, z, t, true);
+    for (int i = b2; i < b1; ++i) __syncthreads();
+  }
+}
+
 template <bool ALIGNED>
 __global__ __launch_bounds__(64 * CW) void gcn_chain_fwd_kernel(const GcnCtx c) {
   __shared__ __attribute__((aligned(16))) float lds[CHAIN_LDS];
@@ -149,8 +175,7 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_bwd_kernel(const GcnCtx c, 
       }
     }
     __syncthreads();
-    run_product<false, false, ALIGNED, 0, 0>(plan_bwd_dP(c, l), lds, z);
-    run_product<true, true, ALIGNED, 0, EPI_ACCUM | EPI_ROWADD>(plan_bwd_dA(c, l), lds, z);
+    run_two_products<false, false, 0, 0, true, true, 0, EPI_ACCUM | EPI_ROWADD, ALIGNED>(plan_bwd_dP(c, l), plan_bwd_dA(c, l), lds, z);
     __syncthreads();
     if (l > 0) {
       run_product<true, true, ALIGNED, EPI_ACCUM, 0>(plan_bwd_dY(c, l), lds, z);
