@@ -26,7 +26,7 @@ __device__ __forceinline__ bool dev_al16(const void* p) { return (((uintptr_t)p)
 constexpr int TEAM_LDS = lds_floats<1, 1, true, true>();
 constexpr int CHAIN_LDS = 2 * TEAM_LDS;
 constexpr int CW = 8;   // waves per chain workgroup
-constexpr int RB = 4;   // rows a wave keeps in flight in the row-wise phases
+constexpr int RB = 8;   // rows a wave keeps in flight in the row-wise phases (8 waves x 8 rows: a 64-node graph in one pass)
 
 template <bool AKC, bool BKC, bool ALIGNED, int MASK, int RT>
 __device__ __forceinline__ void run_product(GemmArgs g, float* lds, int z) {
