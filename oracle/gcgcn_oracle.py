@@ -285,3 +285,89 @@ def pair_bce_loss_grad(logits: Tensor, labels: Tensor, n_valid: Optional[int] = 
     d = (p - y) / q.clamp_min(1e-12) * q / (r * (n * n - n))
     g[:n, :n] = d * (1.0 - torch.eye(n)).unsqueeze(-1)
     return g
+
+
+# --------------------------------------------------------------------------------------
+# SURVEY 8 row f1 (groundwork for the next round): the edge-feature producer
+#   WordAttention glove:171-190, SentenceAttention glove:193-214, call sites glove:314-327
+# --------------------------------------------------------------------------------------
+def word_attention(pad: Tensor, ctx_exp: Tensor, dis_emb: Tensor, sd: Params) -> Tensor:
+    """pad [N,N,S,T,1] bool (True = not a token of that sentence), ctx_exp [N,N,S,T,Hd] (the token states broadcast),
+    dis_emb [N,N,S,T,P] -> [N,N,S,Hd]."""
+    sent = ctx_exp @ sd["attention_sent.weight"].t() + sd["attention_sent.bias"]                  # :178
+    dis = dis_emb @ sd["attention_pos.weight"].t() + sd["attention_pos.bias"]                     # :179
+    score = torch.tanh(sent + dis) @ sd["attention_all.weight"].t() + sd["attention_all.bias"]   # :182
+    score = score.masked_fill(pad.expand_as(score), -100000.0)                                    # :184-185
+    att = torch.softmax(score, dim=3)                                                             # :186
+    return (att * ctx_exp).sum(dim=3)                                                             # :187
+
+
+def sentence_attention(pad: Tensor, cwa: Tensor, node_emb: Tensor, sd: Params) -> Tensor:
+    """pad [N,N,S,1] bool, cwa [N,N,S,Hd], node_emb [N,N,S,Hd] -> [N,N,Hd].  Reproduces the reference as written:
+    the divisor is the number of PADDED sentence slots (``pad.sum``, :205) plus 1e-10, and the weights are relu(score)."""
+    sent = cwa @ sd["attention_sent.weight"].t() + sd["attention_sent.bias"]                      # :201
+    dis = node_emb @ sd["attention_pos.weight"].t() + sd["attention_pos.bias"]                    # :202
+    score = torch.tanh(sent + dis) @ sd["attention_all.weight"].t() + sd["attention_all.bias"]   # :203
+    sent_num = pad.sum(dim=2)                                                                     # :205
+    score = score.masked_fill(pad, -100000.0)                                                     # :208
+    att = torch.relu(score)                                                                       # :211
+    return (att * cwa).sum(dim=2) / (sent_num + 1e-10)                                            # :212
+
+
+def edge_features(ctx: Tensor, sen_matrix: Tensor, pos_h: Tensor, pos_t: Tensor, node_feat: Tensor, dis_table: Tensor,
+                  sd: Params, hop: int) -> Tensor:
+    """E = context_sent_att [N,N,Hd] of hop ``hop`` exactly as the model's forward builds it (glove:300-327): ctx [T,Hd]
+    token states, sen_matrix [N,N,S,T] bool, pos_h / pos_t [N,N,S,T] distance ids, node_feat [N,Hd], dis_table [21,P]
+    (``dis_embed.weight``); sd holds ``word_attention.{hop}.*``, ``linear_word_att.{hop}.*``, ``sentence_attention.{hop}.*``,
+    ``linear_sentence_att.{hop}.*``."""
+    n, _, s, t = sen_matrix.shape
+    wpad = ~sen_matrix.unsqueeze(4)                                                               # :302
+    ctx_exp = ctx.unsqueeze(0).unsqueeze(0).unsqueeze(0).expand(n, n, s, -1, -1)                  # :303 (ctx is [1,T,Hd] there)
+    spad = ~sen_matrix[:, :, :, 0:1]                                                              # :305
+    wa = sub(sd, f"word_attention.{hop}")
+    cw_h = word_attention(wpad, ctx_exp, dis_table[pos_h], wa)                                    # :307, 317
+    cw_t = word_attention(wpad, ctx_exp, dis_table[pos_t], wa)                                    # :308, 318
+    lw = sub(sd, f"linear_word_att.{hop}")
+    cwa = torch.cat([cw_h, cw_t], 3) @ lw["weight"].t() + lw["bias"]                              # :320-321
+    sa = sub(sd, f"sentence_attention.{hop}")
+    ne_h = node_feat.unsqueeze(0).unsqueeze(2).expand_as(cwa)                                     # :324
+    ne_t = node_feat.unsqueeze(1).unsqueeze(2).expand_as(cwa)                                     # :325
+    cs_h = sentence_attention(spad, cwa, ne_h, sa)                                                # :327
+    cs_t = sentence_attention(spad, cwa, ne_t, sa)                                                # :328
+    ls = sub(sd, f"linear_sentence_att.{hop}")
+    return torch.cat([cs_h, cs_t], 2) @ ls["weight"].t() + ls["bias"]                             # :329-330
+
+
+def edge_features_folded(ctx: Tensor, sen_matrix: Tensor, pos_h: Tensor, pos_t: Tensor, node_feat: Tensor,
+                         dis_table: Tensor, sd: Params, hop: int) -> Tensor:
+    """The same E without ever materialising [N,N,S,T,Hd]: the word score depends only on (token t,
+    distance id k), so it is a [21, T] table gathered by the position matrices; the attended word context is then a
+    [N*N*S, T] x [T, Hd] product, and the node terms of the sentence score are per-entity vectors.  This is the
+    algorithm a kernel would implement; it is pinned against :func:`edge_features`."""
+    n, _, s, t = sen_matrix.shape
+    wa = sub(sd, f"word_attention.{hop}")
+    sent = ctx @ wa["attention_sent.weight"].t() + wa["attention_sent.bias"]                       # [T,Hd]
+    dis = dis_table @ wa["attention_pos.weight"].t() + wa["attention_pos.bias"]                    # [21,Hd]
+    table = (torch.tanh(sent.unsqueeze(0) + dis.unsqueeze(1)) @ wa["attention_all.weight"].t()
+             + wa["attention_all.bias"]).squeeze(-1)                                              # [21,T]
+    tt = torch.arange(t).expand(n, n, s, t)
+
+    def word(pos):
+        score = table[pos, tt].masked_fill(~sen_matrix, -100000.0)                                # [N,N,S,T]
+        return (torch.softmax(score, dim=3).reshape(-1, t) @ ctx).view(n, n, s, -1)               # [N,N,S,Hd]
+    lw = sub(sd, f"linear_word_att.{hop}")
+    cwa = torch.cat([word(pos_h), word(pos_t)], 3) @ lw["weight"].t() + lw["bias"]
+    sa = sub(sd, f"sentence_attention.{hop}")
+    sfeat = cwa @ sa["attention_sent.weight"].t() + sa["attention_sent.bias"]                      # [N,N,S,Hd]
+    nterm = node_feat @ sa["attention_pos.weight"].t() + sa["attention_pos.bias"]                  # [N,Hd]
+    spad = ~sen_matrix[:, :, :, 0]                                                                # [N,N,S]
+    div = spad.sum(dim=2, keepdim=True) + 1e-10                                                   # padded slots, as the reference
+
+    def sentence(node_term):                                                                      # node_term [N,N,1,Hd]
+        score = (torch.tanh(sfeat + node_term) @ sa["attention_all.weight"].t() + sa["attention_all.bias"]).squeeze(-1)
+        att = torch.relu(score.masked_fill(spad, -100000.0))
+        return (att.unsqueeze(-1) * cwa).sum(dim=2) / div
+    cs_h = sentence(nterm.view(1, n, 1, -1))                                                       # head side: indexed by j
+    cs_t = sentence(nterm.view(n, 1, 1, -1))                                                       # tail side: indexed by i
+    ls = sub(sd, f"linear_sentence_att.{hop}")
+    return torch.cat([cs_h, cs_t], 2) @ ls["weight"].t() + ls["bias"]

@@ -234,6 +234,46 @@ def full_model_case(ref, docs=8, n=16, t=40, s=3, vocab=200):
     return "model_c1", pk
 
 
+def producer_cases(ref):
+    """SURVEY 8 row f1 (groundwork): the edge-feature producer run with the reference's own WordAttention /
+    SentenceAttention classes in the order of the model's forward (glove:300-330).  Inputs, parameters (under the model's
+    key names for hop 0), E and the gradients of sum(E * cot) w.r.t. the token states, the node features, the distance
+    table and every parameter."""
+    for (n, s, t, hd, p, seed) in ((5, 3, 11, 16, 6, 1), (4, 2, 7, 8, 4, 2)):
+        torch.manual_seed(seed)
+        wa = ref.WordAttention(hd, hd, position_dim=p)
+        sa = ref.SentenceAttention(hd, hd)
+        lw, ls = torch.nn.Linear(2 * hd, hd), torch.nn.Linear(2 * hd, hd)
+        g = torch.Generator().manual_seed(seed)
+        table = (torch.randn(21, p, generator=g) * 0.5).requires_grad_()
+        ctx = torch.tanh(torch.randn(1, t, hd, generator=g)).requires_grad_()
+        node = torch.randn(n, hd, generator=g).requires_grad_()
+        sen = torch.rand(n, n, s, t, generator=g) < 0.4
+        sen[:, :, 0, 0] = True                       # first sentence slot is real everywhere
+        sen[:, :, s - 1, :] = False                  # last slot is padding ...
+        sen[0, 1, s - 1, 0] = True                   # ... except for one pair: no padded slot -> division by 1e-10 (glove:212)
+        ph = torch.randint(0, 21, (n, n, s, t), generator=g)
+        pt = torch.randint(0, 21, (n, n, s, t), generator=g)
+        wpad = ~sen.unsqueeze(4)                                                               # glove:302
+        ctxe = ctx.unsqueeze(0).unsqueeze(0).expand(n, n, s, -1, -1)                           # glove:303
+        spad = ~sen[:, :, :, 0:1]                                                              # glove:305
+        cw = torch.cat([wa(wpad, ctxe, table[ph]), wa(wpad, ctxe, table[pt])], 3)              # glove:317-320
+        cwa = lw(cw)                                                                           # glove:321
+        nh = node.unsqueeze(0).unsqueeze(2).expand_as(cwa)                                     # glove:324
+        nt = node.unsqueeze(1).unsqueeze(2).expand_as(cwa)                                     # glove:325
+        e = ls(torch.cat([sa(spad, cwa, nh), sa(spad, cwa, nt)], 2))                           # glove:327-330
+        cot = torch.randn(e.shape, generator=g) * (e.abs() < 1e3).float()                      # keep the 1e10-scaled pair out of the loss
+        (e * cot).sum().backward()
+        d = {"ctx": _np(ctx[0]), "node": _np(node), "table": _np(table), "sen": _np(sen), "pos_h": _np(ph), "pos_t": _np(pt),
+             "out": _np(e), "cot": _np(cot), "grad.ctx": _np(ctx.grad[0]), "grad.node": _np(node.grad), "grad.table": _np(table.grad)}
+        for pre, m in (("word_attention.0", wa), ("sentence_attention.0", sa), ("linear_word_att.0", lw), ("linear_sentence_att.0", ls)):
+            for k, v in m.state_dict().items():
+                d[f"sd.{pre}.{k}"] = _np(v)
+            for k, v in m.named_parameters():
+                d[f"grad.sd.{pre}.{k}"] = _np(v.grad)
+        yield f"producer_n{n}_s{s}_t{t}_h{hd}", d
+
+
 def loss_cases():
     """SURVEY 8 row f2.  config/Config.py cannot be imported here (it needs torch_geometric), and the loss is not a
     function there but a loop inside ``train`` (:355-366).  The fixtures are produced by that loop's own operations --
@@ -256,9 +296,11 @@ def main():
     total = 0
     if "--loss-only" in sys.argv:
         cases = list(loss_cases())
+    elif "--producer-only" in sys.argv:
+        cases = list(producer_cases(load_reference()))
     else:
         ref = load_reference()
-        cases = list(block_cases(ref)) + [full_model_case(ref)] + list(loss_cases())
+        cases = list(block_cases(ref)) + [full_model_case(ref)] + list(loss_cases()) + list(producer_cases(ref))
     for name, pk in cases:
         path = os.path.join(OUT_DIR, name + ".npz")
         np.savez_compressed(path, **pk)

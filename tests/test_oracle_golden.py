@@ -148,3 +148,28 @@ def test_pair_bce_loss_loop_and_ragged():
     torch.testing.assert_close(O.pair_bce_loss(x.detach(), y, n_valid=4), sub, rtol=1e-6, atol=1e-6)
     gr = O.pair_bce_loss_grad(x.detach(), y, n_valid=4)
     assert gr[4:].abs().sum() == 0 and gr[:, 4:].abs().sum() == 0
+
+
+@pytest.mark.parametrize("path", golden_files("producer"), ids=ids(golden_files("producer")))
+def test_edge_feature_producer(path):
+    """SURVEY 8 f1 groundwork: the restatement of WordAttention + SentenceAttention + the two Linear layers (glove:300-330)
+    and the FOLDED algorithm a kernel would run ([21, T] score table, no [N,N,S,T,Hd] tensor) against the reference's own
+    classes, forward and gradients -- including the pair whose divisor is 1e-10 (no padded sentence slot, glove:205,212)."""
+    g = load_golden(path)
+    r = g["raw"]
+    sd = g["sd"]
+    for fn in (O.edge_features, O.edge_features_folded):
+        ctx = torch.from_numpy(r["ctx"]).requires_grad_()
+        node = torch.from_numpy(r["node"]).requires_grad_()
+        table = torch.from_numpy(r["table"]).requires_grad_()
+        sdl = {k: v.clone().requires_grad_() for k, v in sd.items()}
+        e = fn(ctx, torch.from_numpy(r["sen"]), torch.from_numpy(r["pos_h"]), torch.from_numpy(r["pos_t"]), node, table, sdl, 0)
+        ref = g["out"]
+        assert ((~torch.from_numpy(r["sen"])[:, :, :, 0]).sum(2) == 0).any()   # a pair without any padded slot is in the fixture
+        torch.testing.assert_close(e, ref, rtol=2e-5, atol=1e-6)
+        (e * g["cot"]).sum().backward()
+        torch.testing.assert_close(ctx.grad, torch.from_numpy(r["grad.ctx"]), rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(node.grad, torch.from_numpy(r["grad.node"]), rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(table.grad, torch.from_numpy(r["grad.table"]), rtol=1e-4, atol=1e-6)
+        for k, ref_g in g["grad_sd"].items():
+            torch.testing.assert_close(sdl[k].grad, ref_g, rtol=1e-4, atol=1e-6, msg=lambda m: f"grad {k}: {m}")
