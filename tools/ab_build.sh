@@ -1,6 +1,6 @@
 #!/bin/bash
 # Build the library of another git revision next to the working tree's, for same-session A/B timing:
-#   tools/ab_build.sh <rev>   ->  gpurun_ab_old.so     (then: GCGCN_LIB=$PWD/gpurun_ab_old.so python bench.py ...)
+#   tools/ab_build.sh <rev>   ->  build/ab_old.so     (then: GCGCN_LIB=$PWD/build/ab_old.so python bench.py ...)
 # Only meaningful while both revisions speak the same C ABI (include/gcgcn.h).
 set -e
 rev=${1:-HEAD}
@@ -18,5 +18,6 @@ for f in *.hip; do
   objs="$objs ${f%.hip}.o"
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /root/repo/gpurun_ab_old.so $objs
-ls -la /root/repo/gpurun_ab_old.so
+mkdir -p /root/repo/build
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /root/repo/build/ab_old.so $objs
+ls -la /root/repo/build/ab_old.so

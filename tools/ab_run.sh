@@ -1,5 +1,5 @@
 run() { # label lib args
-  if [ "$1" = old ]; then export GCGCN_LIB=$PWD/gpurun_ab_old.so; else unset GCGCN_LIB; fi
+  if [ "$1" = old ]; then export GCGCN_LIB=$PWD/build/ab_old.so; else unset GCGCN_LIB; fi
   shift
   timeout -k 10 120 python bench.py --no-cpu-baseline --steps 200 --prof-kernel edge_bwd "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], end=' ')"
 }
