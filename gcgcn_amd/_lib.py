@@ -13,6 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GCGCN_LIB=<path> loads another build of the same ABI (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("GCGCN_LIB") or os.path.join(_HERE, "lib", "libgcgcn_hip.so")
 
+ABI_VERSION = 2
+
 SALT_GAT = 0x47415431
 SALT_MHA = 0x4D484131
 SALT_GCN = 0x47434E31
@@ -40,23 +42,24 @@ SIGNATURES = {
     "gcgcn_rng_next": (I, [P, P, I, P]),
     "gcgcn_dropout_keep": (I, [P, L, P, c_uint64, F, P]),
     "gcgcn_dropout": (I, [P, P, L, P, c_uint64, F, P]),
-    "gcgcn_gat_layout": (I, [I, P]),
-    "gcgcn_gat_fwd": (I, [I, I, I, P, P, P, P, P, F, P, P, P, P, P, P, P, I, P]),
+    "gcgcn_gat_layout": (I, [I, I, P]),
+    "gcgcn_gat_fwd": (I, [I, I, I, I, P, P, P, P, P, F, P, P, P, P, P, P, P, I, P, P]),
     "gcgcn_gat_bwd_scratch": (L, [I, I, I]),
-    "gcgcn_gat_bwd": (I, [I, I, I, P, P, P, P, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_gat_bwd": (I, [I, I, I, I, P, P, P, P, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_edge_mean_fwd": (I, [I, I, I, P, P, P, P]),
     "gcgcn_edge_mean_bwd": (I, [I, I, I, P, P, P, P]),
     "gcgcn_mha_layout": (I, [I, P]),
     "gcgcn_mha_scratch": (L, [I, I, I]),
     "gcgcn_mha_fwd": (I, [I, I, I, I, P, P, P, P, F, P, P, P, P, P]),
-    "gcgcn_mha_bwd": (I, [I, I, I, I, P, P, P, F, P, P, P, P, P, P, P, P, P, I, P]),
+    "gcgcn_mha_bwd": (I, [I, I, I, I, P, P, P, F, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_gcn_layout": (I, [I, I, I, P]),
     "gcgcn_gcn_scratch": (L, [I, I, I, I]),
     "gcgcn_gcn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, F, P, P, P, P, P, P, P, P, P]),
-    "gcgcn_gcn_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, P]),
-    "gcgcn_deferred_count": (I, []),
-    "gcgcn_flush_deferred": (I, [P]),
-    "gcgcn_reset_deferred": (I, []),
+    "gcgcn_gcn_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_defer_create": (P, []),
+    "gcgcn_defer_destroy": (None, [P]),
+    "gcgcn_defer_count": (I, [P]),
+    "gcgcn_defer_flush": (I, [P, P]),
     "gcgcn_graphconv_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_graphconv_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_pair_bce_fwd": (I, [I, I, I, P, P, P, P, P, P]),
@@ -80,8 +83,8 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if handle.gcgcn_version() != 1:
-            raise RuntimeError(f"gcgcn_amd: ABI version {handle.gcgcn_version()} != 1")
+        if handle.gcgcn_version() != ABI_VERSION:
+            raise RuntimeError(f"gcgcn_amd: ABI version {handle.gcgcn_version()} != {ABI_VERSION}")
         _lib = handle
     return _lib
 

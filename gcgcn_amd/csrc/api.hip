@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <new>
 #include <vector>
 
 #include <stdlib.h>
@@ -152,7 +153,7 @@ using namespace gc;
 
 extern "C" {
 
-int gcgcn_version(void) { return 1; }
+int gcgcn_version(void) { return 2; }
 const char* gcgcn_last_error(void) { return g_err; }
 
 int gcgcn_set_option(const char* name, int value) {
@@ -232,34 +233,35 @@ int gcgcn_dropout(const float* x, float* y, int64_t n, const void* rng_snap, uin
 // ---------------------------------------------------------------------------------------------
 // GATAttention
 // ---------------------------------------------------------------------------------------------
-int gcgcn_gat_layout(int D, int64_t* o) {
-  GC_REQUIRE(D > 0 && o, "gat_layout: bad arguments");
-  const long DD = (long)D * D;
-  o[0] = 0;             // W_h
-  o[1] = DD;            // b_h
-  o[2] = o[1] + D;      // W_t
-  o[3] = o[2] + DD;     // b_t
-  o[4] = o[3] + D;      // W_r
-  o[5] = o[4] + DD;     // b_r
-  o[6] = o[5] + D;      // wt
-  o[7] = o[6] + 3 * D;  // wt bias
+int gcgcn_gat_layout(int D, int Dh, int64_t* o) {
+  GC_REQUIRE(D > 0 && Dh > 0 && o, "gat_layout: bad arguments");
+  const long DD = (long)Dh * D;
+  o[0] = 0;              // W_h [Dh, D]
+  o[1] = DD;             // b_h
+  o[2] = o[1] + Dh;      // W_t
+  o[3] = o[2] + DD;      // b_t
+  o[4] = o[3] + Dh;      // W_r
+  o[5] = o[4] + DD;      // b_r
+  o[6] = o[5] + Dh;      // wt
+  o[7] = o[6] + 3 * Dh;  // wt bias
   o[8] = o[7] + 1;
   return 0;
 }
 
-int gcgcn_gat_fwd(int B, int N, int D, const float* X, const float* E, const int32_t* n_valid, const float* flat,
+int gcgcn_gat_fwd(int B, int N, int D, int Dh, const float* X, const float* E, const int32_t* n_valid, const float* flat,
                   const void* rng_snap, float p, float* uvc, float* s, float* P, float* A, float* Ebar, void* rng_state,
-                  void* rng_snaps, int rng_count, void* stream) {
+                  void* rng_snaps, int rng_count, const uint8_t* mask, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("gat_fwd", B, N, D, 1, 1));
+  GC_REQUIRE(Dh > 0, "gat_fwd: hidden_dim=%d", Dh);
   GC_REQUIRE(X && E && flat && uvc && s && P && Ebar, "gat_fwd: null pointer");
   const Drop drop = make_drop(rng_snap, GCGCN_SALT_GAT, p);
   GC_REQUIRE(!drop.snap || A, "gat_fwd: dropout on but A is NULL");
   const long M = (long)B * N;
   GC_REQUIRE(!rng_state || (rng_snaps && rng_count > 0), "gat_fwd: rng_state given without snapshots to fill");
-  GC_TRY(gat_fold_fwd(flat, uvc, D, st, rng_state, rng_snaps, rng_count));  // + gcgcn_rng_next, if asked to
+  GC_TRY(gat_fold_fwd(flat, uvc, D, Dh, st, rng_state, rng_snaps, rng_count));  // + gcgcn_rng_next, if asked to
   GC_TRY(node_score_fwd(X, uvc, s, M, D, st));
-  GC_TRY(edge_fwd(E, uvc + D, n_valid, Ebar, s, P, A, drop, B, N, D, st));  // + row softmax + dropout
+  GC_TRY(edge_fwd(E, uvc + D, n_valid, Ebar, s, P, A, drop, B, N, D, st, mask));  // + row softmax + dropout
   return 0;
 }
 
@@ -268,12 +270,13 @@ int64_t gcgcn_gat_bwd_scratch(int B, int N, int D) {
   return a > b ? a : b;
 }
 
-int gcgcn_gat_bwd(int B, int N, int D, const float* X, const float* E, const int32_t* n_valid, const float* flat,
+int gcgcn_gat_bwd(int B, int N, int D, int Dh, const float* X, const float* E, const int32_t* n_valid, const float* flat,
                   const void* rng_snap, float p, const float* uvc, const float* P, const float* dA, const float* dEbar,
                   const float* dX_in, float* dX, float* dE, float* dflat, float* dlogit, float* ds, float* dvpart,
-                  float* duvc, float* scratch, void* stream) {
+                  float* duvc, float* scratch, void* defer_queue, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("gat_bwd", B, N, D, 1, 1));
+  GC_REQUIRE(Dh > 0, "gat_bwd: hidden_dim=%d", Dh);
   GC_REQUIRE(X && E && flat && uvc && P && dA && dX && dflat && dlogit && ds && dvpart && duvc,
              "gat_bwd: null pointer");
   const Drop drop = make_drop(rng_snap, GCGCN_SALT_GAT, p);
@@ -288,14 +291,14 @@ int gcgcn_gat_bwd(int B, int N, int D, const float* X, const float* E, const int
     GC_TRY(colsum(dlogit, nullptr, ds, N, N, N, B, (long)N * N, 0, N, 0, nullptr, st));
     GC_TRY(node_score_bwd(ds, uvc, dX_in, dX, M, D, st));
   }
-  GC_TRY(edge_bwd(E, uvc + D, n_valid, dlogit, dEbar, dE, dvpart, B, N, D, st, true));  // + parked weight gradients
+  GC_TRY(edge_bwd(E, uvc + D, n_valid, dlogit, dEbar, dE, dvpart, B, N, D, st, (DeferQueue*)defer_queue));  // + parked weight gradients
   // du = sum_m ds[m] X[m,:],  dv = sum partials,  dc = sum_m ds[m]: row-slice partials in one launch; the fold's
   // backward sums the slices itself (duvc stays unused)
   long part_off[3];
   int ns = 0;
   GC_TRY(colsum3(X, ds, duvc, M, D, D, dvpart, nullptr, duvc + D, M, D, D, ds, nullptr, duvc + 2 * D, M, 1, 1, scratch,
                  st, false, part_off, &ns));
-  GC_TRY(gat_fold_bwd(flat, duvc, dflat, D, st, scratch, part_off, ns));
+  GC_TRY(gat_fold_bwd(flat, duvc, dflat, D, Dh, st, scratch, part_off, ns));
   return 0;
 }
 
@@ -361,7 +364,7 @@ int64_t gcgcn_mha_scratch(int B, int N, int D) { return scratch_elems(B, N, D, 1
 
 int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat, const void* rng_snap, float p,
                   const float* Q, const float* P, const float* dA, const float* dX_in, float* dX, float* dflat, float* dS,
-                  float* dQ, float* scratch, int defer_weight_grads, void* stream) {
+                  float* dQ, float* scratch, void* defer_queue, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("mha_bwd", B, N, D, 1, H));
   const long wse = scratch ? gemm_scratch_elems(B, N, D, 1) : 0;
@@ -399,7 +402,7 @@ int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat,
     gs[1].B = X, gs[1].ldb = D, gs[1].b_kc = 0;
     gs[1].C = dflat, gs[1].ldc = D;
     gs[1].M = D, gs[1].N = D, gs[1].K = (int)M;
-    const int ng = (defer_weight_grads && gemm_defer(gs[1])) ? 1 : 2;  // dWq parked (see gcgcn_gcn_bwd)
+    const int ng = gemm_defer((DeferQueue*)defer_queue, gs[1]) ? 1 : 2;  // dWq parked (see gcgcn_gcn_bwd)
     if (scratch) {  // dbq = column sums of dQ ride in the same two launches
       ColRide cr;
       cr.X = dQ, cr.out = dflat + (long)D * D, cr.part = scratch + wse, cr.R = M, cr.ld = D, cr.C = D;
@@ -412,12 +415,10 @@ int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat,
   return 0;
 }
 
-int gcgcn_deferred_count(void) { return gemm_deferred_count(); }
-int gcgcn_flush_deferred(void* stream) { return gemm_flush_deferred((hipStream_t)stream); }
-int gcgcn_reset_deferred(void) {
-  gemm_reset_deferred();
-  return 0;
-}
+void* gcgcn_defer_create(void) { return new (std::nothrow) DeferQueue(); }
+void gcgcn_defer_destroy(void* queue) { delete (DeferQueue*)queue; }
+int gcgcn_defer_count(const void* queue) { return queue ? ((const DeferQueue*)queue)->n : 0; }
+int gcgcn_defer_flush(void* queue, void* stream) { return gemm_flush_deferred((DeferQueue*)queue, (hipStream_t)stream); }
 
 // ---------------------------------------------------------------------------------------------
 // trainer loss
@@ -522,7 +523,8 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
                   float out_p, const float* Pn, const float* Y, const float* HO, const float* rinv, const float* dout,
                   float* dX, float* dEbar,
                   float* dA, float* dflat, float* W1, float* W2, float* W3, float* drow, float* dXres, float* dout_m,
-                  float* scratch, const gcgcn_edge_ride* ride, int defer_weight_grads, void* stream) {
+                  float* scratch, const gcgcn_edge_ride* ride, void* defer_queue, void* stream) {
+  DeferQueue* dq = (DeferQueue*)defer_queue;
   const Drop odrop = make_drop(out_rng_snap, GCGCN_SALT_GLUE, out_p);
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("gcn_bwd", B, N, D, L, H));
@@ -560,7 +562,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
     gs[1].C = dflat + y.oWlin, gs[1].ldc = HD;
     gs[1].M = D, gs[1].N = (int)HD, gs[1].K = (int)M;
     // a weight gradient nobody needs before the end of backward: parked for a later launch with idle matrix pipes
-    const int ng1 = (defer_weight_grads && gemm_defer(gs[1])) ? 1 : 2;
+    const int ng1 = gemm_defer(dq, gs[1]) ? 1 : 2;
     if (scratch) {  // dblin = column sums of dout ride in this launch (stage 1) and in its reduce or the next kernel (stage 2)
       cr.X = dout, cr.out = dflat + y.oblin, cr.part = scratch + wse, cr.R = M, cr.ld = D, cr.C = D;
       GC_TRY(gemm_group(gs, ng1, st, &cr, &col_later));
@@ -581,7 +583,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
     }
     c.ride = er;
     if (use_chain()) {
-      GC_TRY(gcn_chain_bwd(c, st, true));  // + parked weight gradients of earlier blocks where the chain leaves room
+      GC_TRY(gcn_chain_bwd(c, st, dq));  // + parked weight gradients of earlier blocks where the chain leaves room
     } else {
       for (int l = L - 1; l >= 0; --l) {
         GC_TRY(relu_norm_bwd(dYa, Y, rinv, dM, drow, M, N, H, L, gh, l, l == L - 1, st));
@@ -594,7 +596,8 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
   {  // one launch for every product that only needs the finished dPn / dM:
      //   dWnX = X^T dPn, dWe = Ebar^T dM, dX = dPn WnX^T + sum_h dHO_h, dEbar = dM We^T,
      //   dWd_{h,l} = [Y_0 .. Y_{l-1}]_h^T dPn_{h,l}  (l >= 1, batched over heads)
-    GemmArgs gs[16];
+    constexpr int GMAX = 16;
+    GemmArgs gs[GMAX];
     int n = 0;
     auto next = [&]() -> GemmArgs& {
       GemmArgs& g = gs[n++];
@@ -603,7 +606,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
       return g;
     };
     auto park = [&]() {  // the problem just described is a weight gradient: park it if asked to (and possible)
-      if (defer_weight_grads && gemm_defer(gs[n - 1])) --n;
+      if (gemm_defer(dq, gs[n - 1])) --n;
     };
     {
       GemmArgs& g = next();
@@ -636,7 +639,11 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
       g.C = dEbar, g.ldc = D;
       g.M = (int)M, g.N = D, g.K = (int)HD;
     }
-    for (int l = 1; l < L && n < 16; ++l) {
+    for (int l = 1; l < L; ++l) {
+      if (n == GMAX) {  // many sub-layers and nothing parked: launch what has been described so far
+        GC_TRY(gemm_group(gs, n, st));
+        n = 0;
+      }
       GemmArgs& g = next();
       g.A = Y, g.lda = HD, g.a_kc = 0, g.sA2 = (long)L * gh;
       g.B = dP + (long)l * gh, g.ldb = HD, g.b_kc = 0, g.sB2 = (long)L * gh;

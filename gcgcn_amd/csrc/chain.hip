@@ -214,7 +214,7 @@ int gcn_chain_fwd(const GcnCtx& c, hipStream_t st) {
   return check_launch("gcn_chain_fwd");
 }
 
-int gcn_chain_bwd(const GcnCtx& c, hipStream_t st, bool carry_deferred) {
+int gcn_chain_bwd(const GcnCtx& c, hipStream_t st, DeferQueue* carry) {
   GC_REQUIRE(c.ride.kind == 0 || (c.ride.kind == 2 && chain_can_carry(c.ride)), "gcn_chain_bwd: bad passenger");
   double fl = 0;
   for (int l = 0; l < c.L; ++l) fl += 4.0 * c.N * c.gh * c.N + 2.0 * c.N * c.gh * (double)l * c.gh;
@@ -226,12 +226,12 @@ int gcn_chain_bwd(const GcnCtx& c, hipStream_t st, bool carry_deferred) {
   // compute unit alone (register footprint of this kernel), so it only hides behind a chain of several such times.
   // The chain itself costs ~8 us per dependent product and tile pass (measured, cfg 2 / cfg 3).
   int ng = 0;
-  if (carry_deferred && (long)c.B * c.H <= 64) {
+  if (carry && carry->n > 0 && (long)c.B * c.H <= 64) {
     const int passes = (((c.N + 63) / 64) * ((c.gh + 63) / 64) + 1) / 2;
     const double t_chain = 8.0 * (4 * c.L - 1) * passes;                  // us
     const double t_wg = 0.85 * ((double)c.B * c.N / 32.0);                // us: weight gradients have K = B N
     const long rounds = t_wg > 0 ? (long)((t_chain - t_wg) / t_wg) : 0;
-    if (rounds > 0) ng = gemm_take_deferred_pairs(cg, &fl, rounds * (256 - (long)c.B * c.H));
+    if (rounds > 0) ng = gemm_take_deferred_pairs(carry, cg, &fl, rounds * (256 - (long)c.B * c.H));
   }
   dim3 grid(chain_grid(c, 2) + (unsigned)ng), block(64 * CW);
   if (chain_aligned(c, true)) GC_LAUNCH_TIMED("gcn_chain_bwd", fl, gcn_chain_bwd_kernel<true>, grid, block, 0, st, c, cg);

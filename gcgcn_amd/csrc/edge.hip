@@ -27,9 +27,10 @@ template <int VEC, bool ATT, bool NTL>
 __global__ __launch_bounds__(64 * EW) void edge_fwd_kernel(const float* __restrict__ E, const float* __restrict__ v,
                                                            const int* __restrict__ n_valid, float* __restrict__ Ebar,
                                                            const float* __restrict__ coladd, float* __restrict__ P,
-                                                           float* __restrict__ Aout, Drop drop, int N, int D) {
+                                                           float* __restrict__ Aout, Drop drop, int N, int D,
+                                                           const unsigned char* __restrict__ mask) {
   extern __shared__ __attribute__((aligned(16))) float cs[];  // [EW][D] per-wave column sums, then [N] logits
-  edge_fwd_row<VEC, ATT, NTL, EW>(E, v, n_valid, Ebar, coladd, P, Aout, drop, N, D, blockIdx.x, cs);
+  edge_fwd_row<VEC, ATT, NTL, EW>(E, v, n_valid, Ebar, coladd, P, Aout, drop, N, D, blockIdx.x, cs, mask);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -197,7 +198,7 @@ static int nt_store() {
 }
 
 int edge_fwd(const float* E, const float* v, const int* n_valid, float* Ebar, const float* coladd, float* P, float* A,
-             Drop drop, int B, int N, int D, hipStream_t st) {
+             Drop drop, int B, int N, int D, hipStream_t st, const unsigned char* mask) {
   GC_REQUIRE(E && Ebar, "edge_fwd: null pointer");
   GC_REQUIRE(B > 0 && N > 0 && D > 0, "edge_fwd: bad shape B=%d N=%d D=%d", B, N, D);
   const bool att = P != nullptr;
@@ -212,7 +213,7 @@ int edge_fwd(const float* E, const float* v, const int* n_valid, float* Ebar, co
   // loads by default (part of E1 is still in the Infinity Cache from the previous backward); GCGCN_NT_E1=1 streams it too.
   const bool ntl = !att || nt_e1();
 #define GC_EDGE_FWD(V, AT, NT) \
-  GC_LAUNCH_TIMED(tag, bytes, (edge_fwd_kernel<V, AT, NT>), grid, block, lds, st, E, v, n_valid, Ebar, coladd, P, A, drop, N, D)
+  GC_LAUNCH_TIMED(tag, bytes, (edge_fwd_kernel<V, AT, NT>), grid, block, lds, st, E, v, n_valid, Ebar, coladd, P, A, drop, N, D, mask)
   if (vec) {
     if (att) { if (ntl) GC_EDGE_FWD(4, true, true); else GC_EDGE_FWD(4, true, false); }
     else GC_EDGE_FWD(4, false, true);
@@ -225,7 +226,7 @@ int edge_fwd(const float* E, const float* v, const int* n_valid, float* Ebar, co
 }
 
 int edge_bwd(const float* E, const float* v, const int* n_valid, const float* dlogit, const float* dEbar, float* dE,
-             float* dvpart, int B, int N, int D, hipStream_t st, bool carry_deferred) {
+             float* dvpart, int B, int N, int D, hipStream_t st, DeferQueue* carry) {
   GC_REQUIRE(E && v && dlogit && dvpart, "edge_bwd: null pointer");
   const bool vec = (D % 4 == 0) && al16(E) && al16(v) && (!dE || al16(dE)) && (!dEbar || al16(dEbar));
   const size_t lds = ((size_t)((N + 3) & ~3) + (size_t)EW * D) * sizeof(float);
@@ -233,8 +234,8 @@ int edge_bwd(const float* E, const float* v, const int* n_valid, const float* dl
   dim3 block(64 * EW);
   GemmGroup gg;
   double gflops = 0;
-  const int ntile = (carry_deferred && vec && lds <= sizeof(float) * lds_floats<1, 1, true, true>())
-                        ? gemm_take_deferred(gg, &gflops)
+  const int ntile = (carry && carry->n > 0 && vec && lds <= sizeof(float) * lds_floats<1, 1, true, true>())
+                        ? gemm_take_deferred(carry, gg, &gflops)
                         : 0;
   if (ntile > 0) {  // parked weight-gradient products ride along
     dim3 grid((unsigned)((long)B * N + ntile));

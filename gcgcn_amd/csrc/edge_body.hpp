@@ -65,7 +65,7 @@ __device__ __forceinline__ void edge_fwd_row(const float* __restrict__ E, const 
                                              const int* __restrict__ n_valid, float* __restrict__ Ebar,
                                              const float* __restrict__ coladd, float* __restrict__ P,
                                              float* __restrict__ Aout, const Drop& drop, int N, int D, int bi,
-                                             float* __restrict__ cs) {
+                                             float* __restrict__ cs, const unsigned char* __restrict__ mask = nullptr) {
   const int b = bi / N, i = bi - b * N;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
@@ -149,18 +149,20 @@ __device__ __forceinline__ void edge_fwd_row(const float* __restrict__ E, const 
   }
   if (ATT && wave == 0) {  // row softmax over the nv real columns
     const float* ca = coladd + (long)b * N;
+    // energies; opt-in, paper-faithful mask: energy.masked_fill(mask, -100000.0) (the in-place form glove:163-164 meant)
+    for (int j = lane; j < nv; j += 64) lg[j] = (mask && mask[(long)bi * N + j]) ? -100000.0f : lg[j] + ca[j];
     float m = -INFINITY;
-    for (int j = lane; j < nv; j += 64) m = fmaxf(m, lg[j] + ca[j]);
+    for (int j = lane; j < nv; j += 64) m = fmaxf(m, lg[j]);
     m = wave_max(m);
     float sum = 0.f;
-    for (int j = lane; j < nv; j += 64) sum += expf(lg[j] + ca[j] - m);
+    for (int j = lane; j < nv; j += 64) sum += expf(lg[j] - m);
     sum = wave_sum(sum);
     const float isum = 1.f / sum;
     const bool dd = Aout && drop.snap;
     const uint64_t key = dd ? drop_key(drop) : 0;
     for (int j = lane; j < N; j += 64) {
       float pv = 0.f;
-      if (j < nv) pv = expf(lg[j] + ca[j] - m) * isum;
+      if (j < nv) pv = expf(lg[j] - m) * isum;
       const long o = (long)bi * N + j;
       P[o] = pv;
       if (Aout) {

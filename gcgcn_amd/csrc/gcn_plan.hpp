@@ -127,6 +127,6 @@ __host__ __device__ inline GemmArgs plan_bwd_dY(const GcnCtx& c, int l) {
 // chain.hip
 bool chain_can_carry(const EdgeRide& r);
 int gcn_chain_fwd(const GcnCtx& c, hipStream_t st);
-int gcn_chain_bwd(const GcnCtx& c, hipStream_t st, bool carry_deferred = false);
+int gcn_chain_bwd(const GcnCtx& c, hipStream_t st, DeferQueue* carry = nullptr);
 
 }  // namespace gc

@@ -321,50 +321,46 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* 
 }
 
 // ---- deferred problems ------------------------------------------------------------------------------------------
-// Process-wide, not thread-local: autograd runs the blocks' backward on its device thread and the end-of-backward
-// callback (the flush) on the thread that called backward().  One backward pass at a time may park problems.
-static GemmArgs g_parked[16];
-static int g_nparked = 0;
-
-bool gemm_defer(const GemmArgs& g_in) {
+// One DeferQueue per backward pass (owned by the host side, gcgcn_defer_create / _destroy): no process-wide state, so
+// two passes -- other models, other devices, other threads -- never see each other's problems, and a pass that fails
+// half-way simply drops its queue.
+bool gemm_defer(DeferQueue* q, const GemmArgs& g_in) {
+  if (!q) return false;
   GemmArgs g = g_in;
-  if (g_nparked >= 16 || g.M == 0 || g.N == 0) return false;
+  if (q->n >= DeferQueue::CAP || g.M == 0 || g.N == 0) return false;
   if (prepare(g, 1, 1, 0) < 0) return false;
   if (!(g.vecA && g.vecB && g.M % 64 == 0 && g.N % 64 == 0 && g.K % BK == 0)) return false;
   g.ws = nullptr, g.ws_elems = 0;  // unsplit: the whole K inside one workgroup
-  g_parked[g_nparked++] = g;
+  q->p[q->n++] = g;
   return true;
 }
 
-int gemm_deferred_count() { return g_nparked; }
-void gemm_reset_deferred() { g_nparked = 0; }
-
-static void sort_parked() {  // longest K first (they run the longest: start them first)
-  for (int i = 1; i < g_nparked; ++i)
-    for (int j = i; j > 0 && g_parked[j].K > g_parked[j - 1].K; --j) {
-      const GemmArgs t = g_parked[j];
-      g_parked[j] = g_parked[j - 1], g_parked[j - 1] = t;
+static void sort_parked(DeferQueue* q) {  // longest K first (they run the longest: start them first)
+  for (int i = 1; i < q->n; ++i)
+    for (int j = i; j > 0 && q->p[j].K > q->p[j - 1].K; --j) {
+      const GemmArgs t = q->p[j];
+      q->p[j] = q->p[j - 1], q->p[j - 1] = t;
     }
 }
 
 static double flops_of(const GemmArgs& g) { return 2.0 * g.M * g.N * g.K * g.batch1 * g.batch2; }
 
 template <class G>
-static int take_parked(G& gg, double* flops, int tiles_per_wg, long max_wgs) {
+static int take_parked(DeferQueue* q, G& gg, double* flops, int tiles_per_wg, long max_wgs) {
   gg.nprob = 0;
   gg.tile_begin[0] = 0;
-  if (g_nparked == 0) return 0;
-  sort_parked();
+  if (!q || q->n == 0) return 0;
+  sort_parked(q);
   int take = 0;
-  for (long got = 0; take < g_nparked && take < G::MAXP; ++take) {
-    const GemmArgs& g = g_parked[take];
+  for (long got = 0; take < q->n && take < G::MAXP; ++take) {
+    const GemmArgs& g = q->p[take];
     got += ((long)(g.M >> 6) * (g.N >> 6) * g.batch1 * g.batch2 + tiles_per_wg - 1) / tiles_per_wg;
     if (got > max_wgs) break;
   }
   if (take == 0) return 0;
   int wgs = 0;
   for (int i = 0; i < take; ++i) {
-    const GemmArgs& g = g_parked[i];
+    const GemmArgs& g = q->p[i];
     const int own = (g.M >> 6) * (g.N >> 6) * g.batch1 * g.batch2;
     wgs = (wgs + 7) & ~7;
     gg.tile_begin[i] = wgs, gg.tile_count[i] = own, gg.red_begin[i] = 0;
@@ -374,20 +370,22 @@ static int take_parked(G& gg, double* flops, int tiles_per_wg, long max_wgs) {
   }
   gg.nprob = take;
   gg.tile_begin[take] = wgs, gg.red_begin[take] = 0;
-  for (int i = take; i < g_nparked; ++i) g_parked[i - take] = g_parked[i];
-  g_nparked -= take;
+  for (int i = take; i < q->n; ++i) q->p[i - take] = q->p[i];
+  q->n -= take;
   return wgs;
 }
 
-int gemm_take_deferred(GemmGroup& gg, double* flops) { return take_parked(gg, flops, 1, 1L << 40); }
-int gemm_take_deferred_pairs(GemmGroup4& gg, double* flops, long max_wgs) { return take_parked(gg, flops, 2, max_wgs); }
+int gemm_take_deferred(DeferQueue* q, GemmGroup& gg, double* flops) { return take_parked(q, gg, flops, 1, 1L << 40); }
+int gemm_take_deferred_pairs(DeferQueue* q, GemmGroup4& gg, double* flops, long max_wgs) {
+  return take_parked(q, gg, flops, 2, max_wgs);
+}
 
-int gemm_flush_deferred(hipStream_t stream) {
-  while (g_nparked > 0) {
+int gemm_flush_deferred(DeferQueue* q, hipStream_t stream) {
+  while (q && q->n > 0) {
     GemmArgs probs[GemmGroup::MAXP];
-    const int n = g_nparked < GemmGroup::MAXP ? g_nparked : GemmGroup::MAXP;
-    for (int i = 0; i < n; ++i) probs[i] = g_parked[g_nparked - n + i];
-    g_nparked -= n;
+    const int n = q->n < GemmGroup::MAXP ? q->n : GemmGroup::MAXP;
+    for (int i = 0; i < n; ++i) probs[i] = q->p[q->n - n + i];
+    q->n -= n;
     if (int e = gemm_group(probs, n, stream)) return e;
   }
   return 0;

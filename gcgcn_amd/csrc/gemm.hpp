@@ -95,22 +95,25 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* 
 // ---- deferred problems ------------------------------------------------------------------------------------------
 // Weight-gradient products are needed by nobody before the end of backward, while later launches of the same
 // backward leave the matrix pipes idle (the edge-tensor stream of GATAttention's backward is HBM-bound).  A block can
-// park such a product here (host-side, one queue per process); the next launch that can carry passengers takes them along as
-// extra workgroups, unsplit (their full K runs inside one workgroup: no reduce launch).  Whoever parks a problem must
-// keep its operands alive until gemm_flush_deferred() or a carrying launch has been enqueued.
+// park such a product in the DeferQueue of its backward pass (host memory, owned by the caller: one queue per pass, no
+// process-wide state); the next launch that can carry passengers takes them along as extra workgroups, unsplit (their
+// full K runs inside one workgroup: no reduce launch).  Whoever parks a problem must keep its operands alive until
+// gemm_flush_deferred() or a carrying launch has been enqueued.
 // Only interior, 16-byte aligned shapes are parked (gemm_defer returns false otherwise: launch it now).
-bool gemm_defer(const GemmArgs& g);
-int gemm_deferred_count();
+struct DeferQueue {
+  static constexpr int CAP = 32;
+  GemmArgs p[CAP];
+  int n = 0;
+};
+bool gemm_defer(DeferQueue* q, const GemmArgs& g);  // q == nullptr: never parks
 // Move up to MAXP parked problems into gg (longest K first, per-problem XCD-aligned tile ranges); returns the number
 // of workgroups (0: nothing parked).  flops (optional) accumulates 2MNK of the taken problems.
-int gemm_take_deferred(GemmGroup& gg, double* flops);
+int gemm_take_deferred(DeferQueue* q, GemmGroup& gg, double* flops);
 // Same for a chain launch: workgroups of 512 threads run TWO tiles each (tile_begin counts workgroups).
 // Takes parked problems (longest first) only while their workgroups fit into `max_wgs`; the rest waits for a later carrier.
-int gemm_take_deferred_pairs(GemmGroup4& gg, double* flops, long max_wgs);
+int gemm_take_deferred_pairs(DeferQueue* q, GemmGroup4& gg, double* flops, long max_wgs);
 // Launch whatever is still parked as ordinary group launches (end of backward without a carrying launch).
-int gemm_flush_deferred(hipStream_t stream);
-// Forget whatever is parked without launching it (a backward pass that failed half-way left operands that no longer exist).
-void gemm_reset_deferred();
+int gemm_flush_deferred(DeferQueue* q, hipStream_t stream);
 
 // Floats of split-K workspace that lets every GEMM of a [rows x cols]-sized problem split freely.
 inline long gemm_ws_elems(long rows, long cols) {

@@ -294,14 +294,16 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(const ColJobs j, floa
 // GATAttention folded (glove:156-162 has no non-linearity between the three
 // Linear(D,D) and wt):  energy[i,j] = u.x_j + v.e_ij + c
 //   u = W_h^T wt_h + W_t^T wt_t,  v = W_r^T wt_r,  c = wt_h.b_h + wt_t.b_t + wt_r.b_r + b
-// flat parameter layout: [W_h D*D | b_h D | W_t D*D | b_t D | W_r D*D | b_r D | wt 3D | wtb 1]
+// D = att_input_dim (width of x and e), Dh = hidden_dim (rows of the three Linear layers, glove:148-151).
+// flat parameter layout: [W_h Dh*D | b_h Dh | W_t Dh*D | b_t Dh | W_r Dh*D | b_r Dh | wt 3Dh | wtb 1]
 // uvc output: [u D | v D | c 1]
 // ---------------------------------------------------------------------------------------------
 constexpr int FW = 16;  // waves per workgroup of the fold: all D/FW rows of a wave are in flight at once
 // rng_state != NULL: workgroup 0 also advances the dropout generator (what rng_next_kernel does), so the first kernel
 // of a hop loop serves every dropout site of the step without a launch of its own.
 __global__ __launch_bounds__(64 * FW) void gat_fold_fwd_kernel(const float* __restrict__ flat, float* __restrict__ uvc, int D,
-                                                               uint64_t* rng_state, uint64_t* rng_snaps, int rng_count) {
+                                                               int Dh, uint64_t* rng_state, uint64_t* rng_snaps,
+                                                               int rng_count) {
   __shared__ float red[2][FW][64];
   __shared__ float redc[FW];
   if (rng_state && blockIdx.x == 0 && threadIdx.x < 64) {  // one wave: reads of the state precede its update in program order
@@ -309,23 +311,23 @@ __global__ __launch_bounds__(64 * FW) void gat_fold_fwd_kernel(const float* __re
     for (int i = threadIdx.x; i < rng_count; i += 64) rng_snaps[2 * i] = seed, rng_snaps[2 * i + 1] = ctr + (uint64_t)i;
     if (threadIdx.x == 0) rng_state[1] = ctr + (uint64_t)rng_count;
   }
-  const long DD = (long)D * D;
+  const long DD = (long)Dh * D;
   const float* Wh = flat;
   const float* bh = Wh + DD;
-  const float* Wt = bh + D;
+  const float* Wt = bh + Dh;
   const float* bt = Wt + DD;
-  const float* Wr = bt + D;
+  const float* Wr = bt + Dh;
   const float* br = Wr + DD;
-  const float* wt = br + D;
+  const float* wt = br + Dh;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = blockIdx.x * 64 + lane;
   float au = 0.f, av = 0.f;
   if (k < D) {
 #pragma unroll 8
-    for (int d = wave; d < D; d += FW) {
+    for (int d = wave; d < Dh; d += FW) {
       au = fmaf(Wh[(long)d * D + k], wt[d], au);
-      au = fmaf(Wt[(long)d * D + k], wt[D + d], au);
-      av = fmaf(Wr[(long)d * D + k], wt[2 * D + d], av);
+      au = fmaf(Wt[(long)d * D + k], wt[Dh + d], au);
+      av = fmaf(Wr[(long)d * D + k], wt[2 * Dh + d], av);
     }
   }
   red[0][wave][lane] = au;
@@ -339,12 +341,12 @@ __global__ __launch_bounds__(64 * FW) void gat_fold_fwd_kernel(const float* __re
   }
   if (blockIdx.x == 0) {
     float c = 0.f;
-    for (int d = threadIdx.x; d < D; d += 64 * FW) c += wt[d] * bh[d] + wt[D + d] * bt[d] + wt[2 * D + d] * br[d];
+    for (int d = threadIdx.x; d < Dh; d += 64 * FW) c += wt[d] * bh[d] + wt[Dh + d] * bt[d] + wt[2 * Dh + d] * br[d];
     c = wave_sum(c);
     if (lane == 0) redc[wave] = c;
     __syncthreads();
     if (threadIdx.x == 0) {
-      float tot = wt[3 * D];
+      float tot = wt[3 * Dh];
       for (int w = 0; w < FW; ++w) tot += redc[w];
       uvc[2 * D] = tot;
     }
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(64 * FW) void gat_fold_fwd_kernel(const float* __re
 // ns > 0: duvc is not final yet -- `part` holds ns row-slice partials of du, dv, dc (colsum3 stage 1, jobs at
 // part_off[0..2]); every workgroup first sums them in slice order into LDS, which replaces the second-stage launch.
 __global__ __launch_bounds__(64 * RW) void gat_fold_bwd_kernel(const float* __restrict__ flat, const float* __restrict__ duvc,
-                                                               float* __restrict__ dflat, int D,
+                                                               float* __restrict__ dflat, int D, int Dh,
                                                                const float* __restrict__ part, long off_dv, long off_dc,
                                                                int ns) {
   extern __shared__ float sduvc[];  // [2 D + 1] when ns > 0
@@ -379,14 +381,14 @@ __global__ __launch_bounds__(64 * RW) void gat_fold_bwd_kernel(const float* __re
     duvc = sduvc;
   }
   const int d = blockIdx.x * RW + (threadIdx.x >> 6);
-  if (d >= D) return;
+  if (d >= Dh) return;
   const int lane = threadIdx.x & 63;
-  const long DD = (long)D * D;
-  const long oWh = 0, obh = DD, oWt = obh + D, obt = oWt + DD, oWr = obt + D, obr = oWr + DD, owt = obr + D;
+  const long DD = (long)Dh * D;
+  const long oWh = 0, obh = DD, oWt = obh + Dh, obt = oWt + DD, oWr = obt + Dh, obr = oWr + DD, owt = obr + Dh;
   const float* du = duvc;
   const float* dv = duvc + D;
   const float dc = duvc[2 * D];
-  const float wh = flat[owt + d], wtt = flat[owt + D + d], wr = flat[owt + 2 * D + d];
+  const float wh = flat[owt + d], wtt = flat[owt + Dh + d], wr = flat[owt + 2 * Dh + d];
   float ah = 0.f, at = 0.f, ar = 0.f;
   for (int k = lane; k < D; k += 64) {
     const float u = du[k], v = dv[k];
@@ -403,9 +405,9 @@ __global__ __launch_bounds__(64 * RW) void gat_fold_bwd_kernel(const float* __re
     dflat[obt + d] = wtt * dc;
     dflat[obr + d] = wr * dc;
     dflat[owt + d] = ah + flat[obh + d] * dc;
-    dflat[owt + D + d] = at + flat[obt + d] * dc;
-    dflat[owt + 2 * D + d] = ar + flat[obr + d] * dc;
-    if (d == 0) dflat[owt + 3 * D] = dc;
+    dflat[owt + Dh + d] = at + flat[obt + d] * dc;
+    dflat[owt + 2 * Dh + d] = ar + flat[obr + d] * dc;
+    if (d == 0) dflat[owt + 3 * Dh] = dc;
   }
 }
 
@@ -641,17 +643,18 @@ int colsum3(const float* X0, const float* w0, float* o0, long R0, int C0, long l
   return check_launch("colsum3/2");
 }
 
-int gat_fold_fwd(const float* flat, float* uvc, int D, hipStream_t st, void* rng_state, void* rng_snaps, int rng_count) {
+int gat_fold_fwd(const float* flat, float* uvc, int D, int Dh, hipStream_t st, void* rng_state, void* rng_snaps,
+                 int rng_count) {
   ProfScope ps("gat_fold_fwd", st);
-  hipLaunchKernelGGL(gat_fold_fwd_kernel, dim3(cdiv(D, 64)), dim3(64 * FW), 0, st, flat, uvc, D, (uint64_t*)rng_state,
+  hipLaunchKernelGGL(gat_fold_fwd_kernel, dim3(cdiv(D, 64)), dim3(64 * FW), 0, st, flat, uvc, D, Dh, (uint64_t*)rng_state,
                      (uint64_t*)rng_snaps, rng_count);
   return check_launch("gat_fold_fwd");
 }
-int gat_fold_bwd(const float* flat, const float* duvc, float* dflat, int D, hipStream_t st, const float* part,
+int gat_fold_bwd(const float* flat, const float* duvc, float* dflat, int D, int Dh, hipStream_t st, const float* part,
                  const long* part_off, int ns) {
   ProfScope ps("gat_fold_bwd", st);
   const size_t lds = ns > 0 ? sizeof(float) * (2 * (size_t)D + 1) : 0;
-  hipLaunchKernelGGL(gat_fold_bwd_kernel, dim3(cdiv(D, RW)), dim3(64 * RW), lds, st, flat, duvc, dflat, D, part,
+  hipLaunchKernelGGL(gat_fold_bwd_kernel, dim3(cdiv(Dh, RW)), dim3(64 * RW), lds, st, flat, duvc, dflat, D, Dh, part,
                      ns > 0 ? part_off[1] : 0L, ns > 0 ? part_off[2] : 0L, ns);
   return check_launch("gat_fold_bwd");
 }

@@ -11,6 +11,7 @@ int rowsum_inv(const float* A, float* rinv, long rows, int N, hipStream_t st);
 int relu_norm_bwd(const float* dY, const float* Y, const float* rinv, float* dM, float* drow, long rows_m, int N, int H,
                   int L, int gh, int l, int first, hipStream_t st, int relu = 1);
 struct ColRide;
+struct DeferQueue;
 int head_sum_drop_bwd(const float* dHO, float* dY, float* dXres, long M, int H, int D, Drop drop, hipStream_t st,
                       const ColRide* finish = nullptr);
 int dropout(const float* x, float* y, long n, Drop drop, hipStream_t st);
@@ -22,10 +23,10 @@ int colsum(const float* X, const float* w, float* out, long R, int C, long ld, i
 int colsum3(const float* X0, const float* w0, float* o0, long R0, int C0, long ld0, const float* X1, const float* w1,
             float* o1, long R1, int C1, long ld1, const float* X2, const float* w2, float* o2, long R2, int C2, long ld2,
             float* scratch, hipStream_t st, bool stage2 = true, long* part_off = nullptr, int* ns_out = nullptr);
-int gat_fold_fwd(const float* flat, float* uvc, int D, hipStream_t st, void* rng_state = nullptr, void* rng_snaps = nullptr,
-                 int rng_count = 0);
-int gat_fold_bwd(const float* flat, const float* duvc, float* dflat, int D, hipStream_t st, const float* part = nullptr,
-                 const long* part_off = nullptr, int ns = 0);
+int gat_fold_fwd(const float* flat, float* uvc, int D, int Dh, hipStream_t st, void* rng_state = nullptr,
+                 void* rng_snaps = nullptr, int rng_count = 0);
+int gat_fold_bwd(const float* flat, const float* duvc, float* dflat, int D, int Dh, hipStream_t st,
+                 const float* part = nullptr, const long* part_off = nullptr, int ns = 0);
 bool gat_dlogit_ok(int N);
 int gat_dlogit(const float* P, const float* dA, const float* uvc, const float* dXin, float* dlogit, float* ds, float* dX,
                int B, int N, int D, Drop drop, hipStream_t st);
@@ -34,9 +35,9 @@ int node_score_bwd(const float* ds, const float* uvc, const float* dXin, float* 
 int mask_rows(const float* x, float* y, long M, int D, int N, const int* n_valid, Drop drop, hipStream_t st);
 
 int edge_fwd(const float* E, const float* v, const int* n_valid, float* Ebar, const float* coladd, float* P, float* A,
-             Drop drop, int B, int N, int D, hipStream_t st);
+             Drop drop, int B, int N, int D, hipStream_t st, const unsigned char* mask = nullptr);
 int edge_bwd(const float* E, const float* v, const int* n_valid, const float* dlogit, const float* dEbar, float* dE,
-             float* dvpart, int B, int N, int D, hipStream_t st, bool carry_deferred = false);
+             float* dvpart, int B, int N, int D, hipStream_t st, DeferQueue* carry = nullptr);
 int edge_bcast(const float* dEbar, const int* n_valid, float* dE, int B, int N, int D, hipStream_t st);
 
 // mha_core.hip: fused attention core of MultiHeadAttention for N <= 64

@@ -23,7 +23,17 @@ step), and
   (reverse-topological) order, as RCCL requires.  For much longer steps (large N, large D).
 
 ``linears_k.*`` never receive gradients (reference quirk) and are skipped on every rank
-alike.
+alike.  Every OTHER bucketed parameter takes part in every step's collective on every rank: a rank whose shard
+produced no gradient for a block contributes zeros (a per-rank skip would issue a different collective sequence
+and hang RCCL).
+
+Which mode at 8 GPUs (model, not yet measured -- DESIGN.md section 7): the cfg-2 bucket is 9 MB; a ring all-reduce
+over xGMI moves 2 * 7/8 * 9 MB per link at ~153 GB/s/link = ~0.10 ms (+ ~0.03 ms launch/latency) against a 0.6 ms
+step.  Exposed (overlap=False) that is a ~18 % scaling loss at most; overlap=True can hide the MAGGC block's share
+(80 % of the bytes) behind the ~0.25 ms of MHA / CAGGC / GAT backward that follows it, but it needs tensor hooks,
+which switch deferred weight gradients off for the hooked parameters (functional._pass_for_parking): +0.03 ms of
+compute, and +0.29 ms of stream fork/join was measured for four async collectives on one rank.  So: overlap=False
+with deferral stays the default; ``bench.py --overlap-grads`` flips it for the driver's scaling run to compare.
 """
 from __future__ import annotations
 
@@ -61,7 +71,7 @@ class FlatGradBucket:
         if not grads:
             return
         cm = getattr(dist, "_coalescing_manager", None)
-        if cm is not None and grads[0].is_cuda and len(grads) > 1:
+        if cm is not None and grads[0].is_cuda and len(grads) > 1 and dist.get_backend(self.pg) == "nccl":
             try:
                 with cm(group=self.pg, device=grads[0].device, async_ops=False):
                     for g in grads:
@@ -83,7 +93,13 @@ class FlatGradBucket:
         total_loss / batch_size)."""
         if self._distributed():
             if not self.overlap:
-                self._all_reduce_coalesced([p.grad for p in self.params if p.grad is not None])
+                for p in self.params:               # same collective sequence on every rank, whatever its shard produced
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
+                self._all_reduce_coalesced([p.grad for p in self.params])
+            elif len(self._pending) != len(self.params):
+                raise RuntimeError(f"FlatGradBucket(overlap=True): {len(self._pending)} of {len(self.params)} gradient "
+                                   "hooks fired on this rank; every rank must produce every block's gradient each step")
             for w in self._pending:
                 w.wait()
         self._pending.clear()

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 import weakref
 from typing import Optional
 
@@ -65,7 +66,12 @@ def manual_seed(seed: int, device=None):
     _rng_state[dev.index or 0] = torch.tensor([seed, 0], dtype=torch.int64, device=dev)
 
 
-_scope = None  # [snaps tensor [count, 2], next index, pending] while a rng_scope is active
+_tls = threading.local()   # .scope: [snaps tensor [count, 2], next index, pending] while a rng_scope is active on this
+                           # thread; .handoff: the edge means parked on this thread (no process-global mutable state)
+
+
+def _get_scope():
+    return getattr(_tls, "scope", None)
 
 
 def _state(dev: torch.device) -> Tensor:
@@ -91,24 +97,23 @@ class rng_scope:
         self.dev, self.count, self.enabled = dev, count, enabled
 
     def __enter__(self):
-        global _scope
-        self.prev = _scope
+        self.prev = _get_scope()
         if self.enabled:
-            _scope = [torch.empty(self.count, 2, dtype=torch.int64, device=self.dev), 0, True]
+            _tls.scope = [torch.empty(self.count, 2, dtype=torch.int64, device=self.dev), 0, True]
         return self
 
     def __exit__(self, *exc):
-        global _scope
-        _scope = self.prev
+        _tls.scope = self.prev
         return False
 
 
 def _take_pending_rng(dev: torch.device):
     """(state, snaps, count) of the active scope if its snapshots have not been drawn yet -- the caller promises to draw
     them in its next launch, before anything reads a snapshot -- else None."""
-    if _scope is not None and _scope[2] and _scope[0].device == dev:
-        _scope[2] = False
-        return _state(dev), _scope[0], _scope[0].shape[0]
+    sc = _get_scope()
+    if sc is not None and sc[2] and sc[0].device == dev:
+        sc[2] = False
+        return _state(dev), sc[0], sc[0].shape[0]
     return None
 
 
@@ -116,13 +121,13 @@ def rng_snapshot(dev: torch.device, lazy: bool = False) -> Tensor:
     """Device-side {seed, counter} for one dropout-using forward; the counter advances on the GPU, so a
     captured hipGraph draws a fresh mask at every replay.  lazy=True: the caller will take the pending draw itself
     (_take_pending_rng) in the launch that reads this snapshot."""
-    global _scope
-    if _scope is not None and _scope[1] < _scope[0].shape[0] and _scope[0].device == dev:
-        if _scope[2] and not lazy:                      # somebody other than GATAttention comes first: draw now
-            _scope[2] = False
-            call("gcgcn_rng_next", _p(_state(dev)), _p(_scope[0]), _scope[0].shape[0], _stream())
-        snap = _scope[0][_scope[1]]
-        _scope[1] += 1
+    sc = _get_scope()
+    if sc is not None and sc[1] < sc[0].shape[0] and sc[0].device == dev:
+        if sc[2] and not lazy:                          # somebody other than GATAttention comes first: draw now
+            sc[2] = False
+            call("gcgcn_rng_next", _p(_state(dev)), _p(sc[0]), sc[0].shape[0], _stream())
+        snap = sc[0][sc[1]]
+        sc[1] += 1
         return snap
     return _new_snaps(dev, 1)[0]
 
@@ -141,7 +146,7 @@ class GatFn(torch.autograd.Function):
     here, where the attention's own dX kernel adds it -- instead of autograd summing the two with one more launch."""
 
     @staticmethod
-    def forward(ctx, x, e, flat, n_valid, p, snap, pending):
+    def forward(ctx, x, e, flat, n_valid, p, snap, pending, Dh, mask):
         B, N, D = x.shape
         dev = x.device
         st, sn, cnt = pending if pending is not None else (None, None, 0)
@@ -150,10 +155,10 @@ class GatFn(torch.autograd.Function):
         P = torch.empty(B, N, N, device=dev)
         A = torch.empty(B, N, N, device=dev) if snap is not None else None
         ebar = torch.empty(B, N, D, device=dev)
-        call("gcgcn_gat_fwd", B, N, D, _p(x), _p(e), _p(n_valid), _p(flat), _p(snap), float(p), _p(uvc), _p(s),
-             _p(P), _p(A), _p(ebar), _p(st), _p(sn), cnt, _stream())
+        call("gcgcn_gat_fwd", B, N, D, Dh, _p(x), _p(e), _p(n_valid), _p(flat), _p(snap), float(p), _p(uvc), _p(s),
+             _p(P), _p(A), _p(ebar), _p(st), _p(sn), cnt, _p(mask), _stream())
         ctx.save_for_backward(x, e, flat, uvc, P)
-        ctx.n_valid, ctx.p, ctx.snap = n_valid, float(p), snap
+        ctx.n_valid, ctx.p, ctx.snap, ctx.Dh = n_valid, float(p), snap, Dh
         return (P if A is None else A), ebar, x.view_as(x)
 
     @staticmethod
@@ -173,10 +178,11 @@ class GatFn(torch.autograd.Function):
         duvc = torch.empty(2 * D + 1, device=dev)
         nscr = _lib.lib().gcgcn_gat_bwd_scratch(B, N, D)
         scratch = torch.empty(max(nscr, 1), device=dev)
-        call("gcgcn_gat_bwd", B, N, D, _p(x), _p(e), _p(ctx.n_valid), _p(flat), _p(ctx.snap), ctx.p, _p(uvc), _p(P),
+        bp = _current_pass()                     # weight gradients parked earlier in this backward pass ride in the edge pass
+        call("gcgcn_gat_bwd", B, N, D, ctx.Dh, _p(x), _p(e), _p(ctx.n_valid), _p(flat), _p(ctx.snap), ctx.p, _p(uvc), _p(P),
              _p(dA), _p(dEbar), _p(dXin), _p(dX), _p(dE), _p(dflat), _p(dlogit), _p(ds), _p(dvpart), _p(duvc),
-             _p(scratch), _stream())
-        return dX, dE, dflat, None, None, None, None
+             _p(scratch), None if bp is None else bp.queue, _stream())
+        return dX, dE, dflat, None, None, None, None, None, None
 
 
 class EdgeMeanFn(torch.autograd.Function):
@@ -232,50 +238,115 @@ class MhaFn(torch.autograd.Function):
         scratch = torch.empty(max(_lib.lib().gcgcn_mha_scratch(B, N, D), 1), device=dev)
         # dWq could be parked too (defer_mha_weight_grads); measured neutral at cfg 2 -- the carrying edge pass is already the
         # longer side with the two convolutions' products (0.652 vs 0.648 ms) -- so it stays with its own group launch
-        defer = _can_park(ctx.flat_leaf, ctx.needs_input_grad[1]) if defer_mha_weight_grads else 0
+        bp = _pass_for_parking(ctx, 1) if defer_mha_weight_grads else None
         call("gcgcn_mha_bwd", B, N, D, H, _p(x), _p(flat), _p(ctx.snap), ctx.p, _p(Q), _p(P), _p(dA), _p(dXin), _p(dX),
-             _p(dflat), _p(dS), _p(dQ), _p(scratch), defer, _stream())
-        if defer:
-            _park_until_flush(x, dQ, dflat.untyped_storage())
+             _p(dflat), _p(dS), _p(dQ), _p(scratch), None if bp is None else bp.queue, _stream())
+        if bp is not None:
+            bp.park(ctx.flat_leaf, dflat, (x, dQ))
+            dflat = None                                # installed as .grad by the pass's end-of-backward callback
         return dX, dflat, None, None, None, None
 
 
 # ---- deferred weight gradients ---------------------------------------------------------------------------------
-# A MAGGC block's weight-gradient products (7 GFLOP at cfg 2) are needed by nobody before the end of backward, and the
+# A block's weight-gradient products (7 GFLOP for MAGGC at cfg 2) are needed by nobody before the end of backward, and the
 # last big kernel of backward -- GATAttention's pass over E -- is HBM-bound with idle matrix pipes.  gcgcn_gcn_bwd parks
-# them (include/gcgcn.h); gcgcn_gat_bwd carries them as extra workgroups of that pass; a callback at the end of the
-# backward pass launches whatever is still parked (e.g. no GATAttention in the graph) and releases the operands.
+# them in the queue of the running backward pass (include/gcgcn.h); gcgcn_gat_bwd carries them as extra workgroups of its
+# edge pass; the pass's end-of-backward callback launches whatever is still parked and hands the gradients over.
+#
+# Soundness.  A parked gradient is NOT returned to autograd (the function returns None for it): autograd would add or
+# clone the tensor -- e.g. when one module is called twice inside one backward pass, the reference trainer's own pattern,
+# config/Config.py:340-372 -- before the parked products have written it.  Instead the callback, which runs after every
+# node of the pass, installs each finished buffer as ``.grad`` (or adds it to a ``.grad`` that exists by then: gradient
+# accumulation, other consumers of the parameter).  Parking is refused -- the products then run inside the block's own
+# backward and the gradient takes autograd's normal route -- unless this is a ``.backward()`` pass that will reach the
+# parameter's AccumulateGrad node (not ``autograd.grad``, not ``inputs=[...]`` without it) and the parameter has no hooks.
+# Node-level hooks on AccumulateGrad (torch DistributedDataParallel) cannot be seen from here: under DDP set
+# GCGCN_DEFER=0 (gcgcn_amd.dist.FlatGradBucket needs nothing: it reduces after backward, or uses tensor hooks).
+#
+# State.  One _BackwardPass per autograd graph task, registered under the task's id and owned by the engine through the
+# queued callback: a pass that raises half-way is destroyed with its graph task -- parked operands, queue and all --
+# and leaves nothing behind; passes of other models, devices or threads never share a queue.
 defer_weight_grads = os.environ.get("GCGCN_DEFER", "1") != "0"      # GCGCN_DEFER=0: A/B knob
 defer_mha_weight_grads = False
-_parked = []
+_passes = {}            # graph task id -> weakref to its _BackwardPass
+_passes_lock = threading.Lock()
 
 
-def _flush_deferred():
+class _BackwardPass:
+    def __init__(self, task_id: int):
+        self.task_id = task_id
+        self.queue = _lib.lib().gcgcn_defer_create()
+        if not self.queue:
+            raise MemoryError("gcgcn_defer_create failed")
+        self.keep = []          # operands of parked products
+        self.installs = []      # (leaf parameter, its finished flat gradient)
+
+    def park(self, leaf, dflat, operands):
+        self.keep.append(operands)
+        self.installs.append((leaf, dflat))
+
+    def __call__(self):         # end of the backward pass (autograd final callback; runs on the caller's stream)
+        with _passes_lock:
+            _passes.pop(self.task_id, None)
+        try:
+            if _lib.lib().gcgcn_defer_count(self.queue) > 0:
+                call("gcgcn_defer_flush", self.queue, _stream())
+            with torch.no_grad():
+                for leaf, dflat in self.installs:
+                    if leaf.grad is None:
+                        leaf.grad = dflat
+                    else:
+                        leaf.grad.add_(dflat)
+        finally:
+            self.keep.clear()
+            self.installs.clear()
+
+    def __del__(self):          # also the only thing that happens to the pass of a backward that raised
+        q, self.queue = self.queue, None
+        if q:
+            try:
+                _lib.lib().gcgcn_defer_destroy(q)
+            except Exception:   # interpreter shutdown
+                pass
+
+
+def _current_pass() -> Optional[_BackwardPass]:
+    """The pass object of the graph task this thread is executing, if a block has parked something in it."""
+    tid = torch._C._current_graph_task_id()
+    if tid < 0:
+        return None
+    ref = _passes.get(tid)
+    return None if ref is None else ref()
+
+
+def _pass_for_parking(ctx, idx: int) -> Optional[_BackwardPass]:
+    """The running backward pass if input ``idx`` of this function (a flat parameter) may be parked, else None."""
+    if not (defer_weight_grads and ctx.needs_input_grad[idx]):
+        return None
+    leaf = ctx.flat_leaf
+    if leaf is None or leaf._post_accumulate_grad_hooks or leaf._backward_hooks:
+        return None
+    tid = torch._C._current_graph_task_id()
+    if tid < 0:
+        return None
     try:
-        if _lib.lib().gcgcn_deferred_count() > 0:
-            call("gcgcn_flush_deferred", _stream())
-    finally:
-        _parked.clear()
-
-
-def _drop_stale_parked():
-    """A previous backward pass that raised half-way may have left parked products whose operands are gone: forget them
-    (called before the first parking of a pass, i.e. while this module's keep-alive list is empty)."""
-    if not _parked and _lib.lib().gcgcn_deferred_count() > 0:
-        call("gcgcn_reset_deferred")
-
-
-def _can_park(leaf, needs_grad) -> int:
-    """Parking is sound only if autograd will INSTALL the gradient tensor as .grad: a leaf without a gradient yet and without
-    hooks that read it at once.  An existing .grad would be added to immediately, before the parked products have run."""
-    return 1 if (defer_weight_grads and needs_grad and leaf is not None and leaf.grad is None
-                 and not leaf._post_accumulate_grad_hooks and not leaf._backward_hooks) else 0
-
-
-def _park_until_flush(*tensors):
-    if not _parked:                                    # first parking of this backward pass: flush when it ends
-        torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)
-    _parked.append(tensors)
+        acc = ctx.next_functions[idx][0]         # the parameter's AccumulateGrad node
+        if acc is None or getattr(acc, "variable", None) is not leaf or torch._C._will_engine_execute_node(acc) is not True:
+            return None
+    except RuntimeError:                          # autograd.grad(): the gradient is captured, not accumulated
+        return None
+    with _passes_lock:
+        ref = _passes.get(tid)
+        bp = None if ref is None else ref()
+        if bp is None:
+            # (a dead entry under this id belongs to an earlier process-lifetime task that failed: ids are not reused
+            # while a task lives)
+            bp = _BackwardPass(tid)
+            _passes[tid] = weakref.ref(bp)
+            torch.autograd.Variable._execution_engine.queue_callback(bp)     # the engine owns the pass from here on
+            for k in [k for k, r in _passes.items() if r() is None]:
+                del _passes[k]
+    return bp
 
 
 def _ride(inp, n_valid, out, B, N, D):
@@ -339,17 +410,15 @@ class GcnFn(torch.autograd.Function):
             debar_next = debar_next.contiguous()
             dE_next = torch.empty(ctx.next_shape, device=dev)
             ride, ride_p = _ride(debar_next, ctx.n_valid, dE_next, *debar_next.shape)
-        _drop_stale_parked()
-        defer = _can_park(ctx.flat_leaf, ctx.needs_input_grad[3])
+        bp = _pass_for_parking(ctx, 3)
         call("gcgcn_gcn_bwd", B, N, D, L, H, _p(x), _p(ebar), _p(adj), _p(ctx.n_valid), _p(flat), _p(ctx.snap),
              ctx.p, _p(ctx.out_snap), ctx.out_p, _p(Pn), _p(Y), _p(HO), _p(rinv), _p(dout), _p(dX), _p(dEbar), _p(dA),
-             _p(dflat), _p(W1), _p(W2), _p(W3), _p(drow), _p(dXres), _p(dout_m), _p(scratch), ride_p, defer, _stream())
+             _p(dflat), _p(W1), _p(W2), _p(W3), _p(drow), _p(dXres), _p(dout_m), _p(scratch), ride_p,
+             None if bp is None else bp.queue, _stream())
         del ride
-        if defer:
-            # dflat is held through its STORAGE: the memory stays alive, but the tensor autograd receives keeps a use
-            # count of one, so AccumulateGrad installs it as .grad instead of cloning it now (before the parked products
-            # ran; a view would reference the tensor itself as its base)
-            _park_until_flush(x, ebar, Y, HO, dout, dout_m, W2, W3, dflat.untyped_storage())
+        if bp is not None:
+            bp.park(ctx.flat_leaf, dflat, (x, ebar, Y, HO, dout, dout_m, W2, W3))
+            dflat = None                                # installed as .grad by the pass's end-of-backward callback
         return dX, dEbar, dA, dflat, None, None, None, None, None, dE_next, None, None
 
 
@@ -436,14 +505,20 @@ def _snap_for(training: bool, p: float, dev) -> Optional[Tensor]:
     return rng_snapshot(dev) if (training and p > 0.0) else None
 
 
-def gat_attention(x, e, flat, n_valid=None, p=0.1, training=False):
+def gat_attention(x, e, flat, n_valid=None, p=0.1, training=False, hidden_dim=None, mask=None):
+    """``mask`` (bool/uint8 ``[B,N,N]``, True = fill with -100000): the paper-faithful opt-in; None = the reference."""
     x, e = _chk(x, "node_feat", 3), _chk(e, "edge_feat", 4)
     B, N, D = x.shape
     if e.shape != (B, N, N, D):
         raise ValueError(f"edge_feat: expected {(B, N, N, D)}, got {tuple(e.shape)}")
     nv = _nv(n_valid, B, N, x.device)
     snap = rng_snapshot(x.device, lazy=True) if (training and p > 0.0) else None
-    return GatFn.apply(x, e, _chk(flat, "flat"), nv, p, snap, _take_pending_rng(x.device))   # (A, Ebar, alias of x)
+    if mask is not None:
+        if not mask.is_cuda or tuple(mask.shape) != (B, N, N):
+            raise ValueError(f"mask: expected a GPU tensor of shape {(B, N, N)}, got {tuple(mask.shape)} on {mask.device}")
+        mask = (mask != 0).to(torch.uint8).contiguous()
+    return GatFn.apply(x, e, _chk(flat, "flat"), nv, p, snap, _take_pending_rng(x.device),
+                       D if hidden_dim is None else int(hidden_dim), mask)                    # (A, Ebar, alias of x)
 
 
 def edge_mean(e, n_valid=None):
@@ -490,24 +565,36 @@ def dropout(x, p=0.2, training=False, salt=SALT_GLUE):
     return DropoutFn.apply(x, p, rng_snapshot(x.device), salt)
 
 
-# ---- one-slot hand-off of the edge mean from GATAttention to the GraphConvolution that follows ------
+# ---- hand-off of the edge mean from GATAttention to the GraphConvolution that follows ---------------
 # The reference calls gat(X, E, mask) and then graphcnn[0](X, E, A) with the SAME E (glove:332-333).
 # GATAttention's single pass over E also yields mean_j E; it is parked here so the convolution does
-# not stream E from HBM a second time.  One slot, consumed on use, replaced by the next GAT call.
-_handoff = None
+# not stream E from HBM a second time.  Per thread, keyed by the edge tensor's identity (a few entries: interleaved
+# models keep theirs), consumed on use, dropped when the tensor dies or changes (version counter).
+_HANDOFF_SLOTS = 4
+
+
+def _handoffs() -> dict:
+    h = getattr(_tls, "handoff", None)
+    if h is None:
+        h = _tls.handoff = {}
+    return h
 
 
 def park_edge_mean(e: Tensor, n_valid, ebar: Tensor):
-    global _handoff
-    _handoff = (weakref.ref(e), e._version, n_valid, ebar)
+    h = _handoffs()
+    for k in [k for k, v in h.items() if v[0]() is None]:
+        del h[k]
+    h.pop(id(e), None)
+    while len(h) >= _HANDOFF_SLOTS:
+        del h[next(iter(h))]                       # oldest first
+    h[id(e)] = (weakref.ref(e), e._version, n_valid, ebar)
 
 
 def take_edge_mean(e: Tensor, n_valid) -> Optional[Tensor]:
-    global _handoff
-    h, _handoff = _handoff, None
-    if h is None:
+    ent = _handoffs().pop(id(e), None)
+    if ent is None:
         return None
-    ref, ver, nvp, ebar = h
+    ref, ver, nvp, ebar = ent
     if ref() is e and e._version == ver and nvp is n_valid:
         return ebar
     return None

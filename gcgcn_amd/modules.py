@@ -72,10 +72,14 @@ class _FlatBlock(nn.Module):
             for key in state_dict.keys():
                 if key.startswith(prefix) and key[len(prefix):] not in shapes:
                     unexpected_keys.append(key)
-        if len(got) == len(shapes):
+        if got:
             with torch.no_grad():
                 dev = self.flat.device
-                self._load_ref({k: v.to(device=dev, dtype=torch.float32) for k, v in got.items()})
+                full = {k: v.to(device=dev, dtype=torch.float32) for k, v in got.items()}
+                if len(got) < len(shapes):      # partial checkpoint (strict=False): nn.Module loads whatever matches
+                    cur = self._ref_tensors()
+                    full = {k: full.get(k, cur[k]) for k in shapes}
+                self._load_ref(full)
 
 
 def _batched(x: Tensor, nd: int):
@@ -92,39 +96,44 @@ class GATAttention(_FlatBlock):
     """CAGGC adjacency (GCGCN_glove.py:144-168): A = dropout(softmax_j(wt.[W_h x_j; W_t x_j; W_r e_ij])).
 
     ``mask`` is accepted and ignored exactly like the reference (its masked_fill result is discarded,
-    glove:163-164).  The one pass over ``edge_feat`` also produces ``mean_j edge_feat`` which is parked
-    for the ``GraphConvolution`` call that follows with the same tensor (functional.park_edge_mean).
+    glove:163-164).  ``apply_mask=True`` (extension, off by default) is the paper-faithful variant: masked
+    pairs get energy -100000 before the softmax, i.e. the partially connected adjacency the in-place
+    ``masked_fill_`` would have produced.  The one pass over ``edge_feat`` also produces ``mean_j edge_feat``
+    which is parked for the ``GraphConvolution`` call that follows with the same tensor
+    (functional.park_edge_mean).
     """
 
-    def __init__(self, att_input_dim: int, hidden_dim: int, dropout: float = 0.1):
+    def __init__(self, att_input_dim: int, hidden_dim: int, dropout: float = 0.1, apply_mask: bool = False):
         super().__init__()
-        if att_input_dim != hidden_dim:
-            # the reference only ever builds GATAttention(hidden, hidden) (glove:254); the fold of the three
-            # Linear layers into (u, v, c) holds for any hidden_dim, the flat layout assumes a square W.
-            raise ValueError("GATAttention: att_input_dim must equal hidden_dim")
-        self.dim = att_input_dim
+        self.dim = att_input_dim                 # width of node_feat / edge_feat
+        self.hidden_dim = hidden_dim             # rows of the three nn.Linear(att_input_dim, hidden_dim), glove:148-150
+        self.apply_mask = bool(apply_mask)
         self.p = float(dropout) if dropout is not None else 0.0
-        self.flat = nn.Parameter(torch.empty(P_.gat_layout(self.dim)[-1]))
+        self.flat = nn.Parameter(torch.empty(P_.gat_layout(self.dim, hidden_dim)[-1]))
         with torch.no_grad():
-            P_.pack_gat(P_.init_gat(self.dim), self.dim, self.flat)
+            P_.pack_gat(P_.init_gat(self.dim, hidden_dim), self.dim, self.flat, hidden_dim)
 
     def _ref_shapes(self):
-        return P_.gat_shapes(self.dim)
+        return P_.gat_shapes(self.dim, self.hidden_dim)
 
     def _ref_tensors(self):
-        return P_.unpack_gat(self.flat.detach(), self.dim)
+        return P_.unpack_gat(self.flat.detach(), self.dim, self.hidden_dim)
 
     def _load_ref(self, sd):
-        P_.pack_gat(sd, self.dim, self.flat)
+        P_.pack_gat(sd, self.dim, self.flat, self.hidden_dim)
 
     def named_grads(self):
-        return P_.unpack_gat(self.flat.grad, self.dim) if self.flat.grad is not None else {}
+        return P_.unpack_gat(self.flat.grad, self.dim, self.hidden_dim) if self.flat.grad is not None else {}
 
     def forward(self, node_feat: Tensor, edge_feat: Tensor, mask: Optional[Tensor] = None,
                 n_valid: Optional[Tensor] = None, return_input_alias: bool = False) -> Tensor:
         x, batched = _batched(node_feat, 2)
         e, _ = _batched(edge_feat, 3)
-        a, ebar, xa = F_.gat_attention(x, e, self.flat, n_valid, self.p, self.training)
+        mk = None
+        if self.apply_mask and mask is not None:
+            mk, _ = _batched(mask, 2)
+        a, ebar, xa = F_.gat_attention(x, e, self.flat, n_valid, self.p, self.training, hidden_dim=self.hidden_dim,
+                                       mask=mk)
         F_.park_edge_mean(edge_feat, n_valid, ebar)
         a = a if batched else a.squeeze(0)
         # extension: (A, alias of node_feat).  Feeding the alias to the convolution of the same hop routes the
@@ -337,10 +346,10 @@ class GraphHops(nn.Module):
     """
 
     def __init__(self, hidden_size: int = 128, layer_num: int = 2, head_num: int = 8, graph_hop: int = 2,
-                 alpha: float = 1.0, dropout: float = 0.2):
+                 alpha: float = 1.0, dropout: float = 0.2, apply_mask: bool = False):
         super().__init__()
         self.graph_hop, self.alpha, self.p = graph_hop, float(alpha), float(dropout)
-        self.get_weighted_adj_matrix = GATAttention(hidden_size, hidden_size)
+        self.get_weighted_adj_matrix = GATAttention(hidden_size, hidden_size, apply_mask=apply_mask)
         self.get_adj_matrix = nn.ModuleList([MultiHeadAttention(head_num, hidden_size) for _ in range(graph_hop - 1)])
         self.graphcnn = nn.ModuleList()
         for i in range(graph_hop):
@@ -397,8 +406,12 @@ class GraphHops(nn.Module):
             e = edge_feats[i]
             if i < 1:
                 # glove:330 builds mask = eq(adj_matrix, 0) and glove:163-164 then discards it; the mask is
-                # not even materialised here (adj_matrix is accepted for signature compatibility only)
-                a, xa = self.get_weighted_adj_matrix(x, e, None, n_valid=n_valid, return_input_alias=True)  # glove:332
+                # not even materialised here (adj_matrix is accepted for signature compatibility only) unless the
+                # paper-faithful opt-in asks for it
+                mask = None
+                if self.get_weighted_adj_matrix.apply_mask and adj_matrix is not None:
+                    mask = torch.eq(adj_matrix, 0)                                                          # glove:330
+                a, xa = self.get_weighted_adj_matrix(x, e, mask, n_valid=n_valid, return_input_alias=True)  # glove:332
                 if x.is_cuda and self.graph_hop > 1 and self.overlap_edge_mean:
                     fork_edge_means()
                 new = self.graphcnn[i](xa, e, a, n_valid=n_valid, ride_edge=ride(i), out_dropout=odrop)  # glove:333

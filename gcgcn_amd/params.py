@@ -18,9 +18,11 @@ Tensor = torch.Tensor
 
 
 # ---- layouts (mirrors of gcgcn_*_layout in csrc/api.hip; checked against the library in tests)
-def gat_layout(D: int):
-    DD = D * D
-    o = [0, DD, DD + D, 2 * DD + D, 2 * DD + 2 * D, 3 * DD + 2 * D, 3 * DD + 3 * D, 3 * DD + 6 * D]
+def gat_layout(D: int, Dh: int = None):
+    """D = att_input_dim, Dh = hidden_dim (defaults to D, the only shape the reference model builds, glove:254)."""
+    Dh = D if Dh is None else Dh
+    DD = Dh * D
+    o = [0, DD, DD + Dh, 2 * DD + Dh, 2 * DD + 2 * Dh, 3 * DD + 2 * Dh, 3 * DD + 3 * Dh, 3 * DD + 6 * Dh]
     return o + [o[-1] + 1]
 
 
@@ -49,21 +51,22 @@ GAT_KEYS = ("linear_node_h.weight", "linear_node_h.bias", "linear_node_t.weight"
             "linear_edge_r.weight", "linear_edge_r.bias", "wt.weight", "wt.bias")
 
 
-def gat_shapes(D: int) -> Dict[str, tuple]:
-    return {"linear_node_h.weight": (D, D), "linear_node_h.bias": (D,),
-            "linear_node_t.weight": (D, D), "linear_node_t.bias": (D,),
-            "linear_edge_r.weight": (D, D), "linear_edge_r.bias": (D,),
-            "wt.weight": (1, 3 * D), "wt.bias": (1,)}
+def gat_shapes(D: int, Dh: int = None) -> Dict[str, tuple]:
+    Dh = D if Dh is None else Dh
+    return {"linear_node_h.weight": (Dh, D), "linear_node_h.bias": (Dh,),
+            "linear_node_t.weight": (Dh, D), "linear_node_t.bias": (Dh,),
+            "linear_edge_r.weight": (Dh, D), "linear_edge_r.bias": (Dh,),
+            "wt.weight": (1, 3 * Dh), "wt.bias": (1,)}
 
 
-def unpack_gat(flat: Tensor, D: int) -> Dict[str, Tensor]:
-    o = gat_layout(D)
-    shp = gat_shapes(D)
+def unpack_gat(flat: Tensor, D: int, Dh: int = None) -> Dict[str, Tensor]:
+    o = gat_layout(D, Dh)
+    shp = gat_shapes(D, Dh)
     return {k: flat[o[i]:o[i + 1]].view(shp[k]) for i, k in enumerate(GAT_KEYS)}
 
 
-def pack_gat(sd: Dict[str, Tensor], D: int, out: Tensor) -> Tensor:
-    o = gat_layout(D)
+def pack_gat(sd: Dict[str, Tensor], D: int, out: Tensor, Dh: int = None) -> Tensor:
+    o = gat_layout(D, Dh)
     for i, k in enumerate(GAT_KEYS):
         out[o[i]:o[i + 1]].copy_(sd[k].reshape(-1))
     return out
@@ -169,8 +172,8 @@ def _linear_init(weight: Tensor, bias: Tensor):
     torch.nn.init.uniform_(bias, -bound, bound)
 
 
-def init_gat(D: int) -> Dict[str, Tensor]:
-    sd = {k: torch.empty(s) for k, s in gat_shapes(D).items()}
+def init_gat(D: int, Dh: int = None) -> Dict[str, Tensor]:
+    sd = {k: torch.empty(s) for k, s in gat_shapes(D, Dh).items()}
     for nm in ("linear_node_h", "linear_node_t", "linear_edge_r", "wt"):
         _linear_init(sd[nm + ".weight"], sd[nm + ".bias"])
     return sd

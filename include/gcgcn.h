@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-int gcgcn_version(void);            /* ABI version, currently 1 */
+int gcgcn_version(void);            /* ABI version, currently 2 */
 const char* gcgcn_last_error(void); /* message of the last failing call on this thread */
 
 /* Run-time switches for A/B tests.  "chain": 1 (default) = the per-(doc, head) products of a conv run inside the
@@ -69,9 +69,11 @@ int gcgcn_dropout(const float* x, float* y, int64_t n, const void* rng_snap, uin
 #define GCGCN_SALT_GLUE 0x474c5531ull
 
 /* ---- GATAttention (CAGGC adjacency)  GCGCN_glove.py:144-168 -------------------------------- */
-/* flat = [W_h D*D | b_h D | W_t D*D | b_t D | W_r D*D | b_r D | wt 3D | wt_bias 1]
+/* D = att_input_dim (width of node_feat and edge_feat), Dh = hidden_dim (rows of the three nn.Linear(att_input_dim,
+ * hidden_dim), glove:148-150; wt = nn.Linear(3 * hidden_dim, 1), glove:151).
+ * flat = [W_h Dh*D | b_h Dh | W_t Dh*D | b_t Dh | W_r Dh*D | b_r Dh | wt 3Dh | wt_bias 1]
  * out[0..7] = offsets of those eight pieces, out[8] = total floats. */
-int gcgcn_gat_layout(int D, int64_t* out9);
+int gcgcn_gat_layout(int D, int Dh, int64_t* out9);
 
 /* forward(node_feat X[B,N,D], edge_feat E[B,N,N,D], mask ignored as in the reference):
  *   P[B,N,N]    softmax_j(u.x_j + v.e_ij + c)            (saved for backward)
@@ -81,20 +83,26 @@ int gcgcn_gat_layout(int D, int64_t* out9);
  *   uvc[2D+1], s[B,N]  folded projection and node scores (saved for backward) */
 /* rng_state / rng_snaps / rng_count: optional (NULL, NULL, 0).  When given, the call also performs
  * gcgcn_rng_next(rng_state, rng_snaps, rng_count) inside its first kernel, BEFORE anything reads rng_snap (which may
- * point into rng_snaps): a hop loop draws the snapshots of all its dropout sites without a launch of its own. */
-int gcgcn_gat_fwd(int B, int N, int D, const float* X, const float* E, const int32_t* n_valid, const float* flat,
+ * point into rng_snaps): a hop loop draws the snapshots of all its dropout sites without a launch of its own.
+ * mask: NULL (default: the reference DISCARDS its masked_fill result, glove:163-164, so its mask is a no-op), or a
+ * uint8/bool [B,N,N] whose non-zero entries get energy -100000 before the softmax: the paper-faithful partially
+ * connected adjacency, an explicit opt-in (GATAttention(apply_mask=True)).  The backward needs no mask: masked entries
+ * have P == 0 exactly, hence a zero logit gradient. */
+int gcgcn_gat_fwd(int B, int N, int D, int Dh, const float* X, const float* E, const int32_t* n_valid, const float* flat,
                   const void* rng_snap, float p, float* uvc, float* s, float* P, float* A, float* Ebar, void* rng_state,
-                  void* rng_snaps, int rng_count, void* stream);
+                  void* rng_snaps, int rng_count, const uint8_t* mask, void* stream);
 
 /* backward.  dA[B,N,N], dEbar[B,N,D] (NULL = zero), dX_in[B,N,D] (NULL = zero: gradient node_feat has
  * already collected from its other consumers -- the convolution of the same hop -- added here instead of
  * by a separate kernel) -> dX[B,N,D], dE[B,N,N,D] (NULL = not wanted), dflat.  Workspace: dlogit[B,N,N], ds[B,N], dvpart[B*N*D], duvc[2D+1],
  * scratch[gcgcn_gat_bwd_scratch(B,N,D)]. */
 int64_t gcgcn_gat_bwd_scratch(int B, int N, int D);
-int gcgcn_gat_bwd(int B, int N, int D, const float* X, const float* E, const int32_t* n_valid, const float* flat,
+/* defer_queue: NULL, or the gcgcn_defer queue of this backward pass (below): weight-gradient products parked in it by
+ * gcgcn_gcn_bwd / gcgcn_mha_bwd calls that ran earlier in the pass ride in this call's HBM-bound edge pass. */
+int gcgcn_gat_bwd(int B, int N, int D, int Dh, const float* X, const float* E, const int32_t* n_valid, const float* flat,
                   const void* rng_snap, float p, const float* uvc, const float* P, const float* dA, const float* dEbar,
                   const float* dX_in, float* dX, float* dE, float* dflat, float* dlogit, float* ds, float* dvpart,
-                  float* duvc, float* scratch, void* stream);
+                  float* duvc, float* scratch, void* defer_queue, void* stream);
 
 /* ---- edge mean alone (MAGGC hop: E enters only through GraphConv's mean, glove:40-41) ------ */
 int gcgcn_edge_mean_fwd(int B, int N, int D, const float* E, const int32_t* n_valid, float* Ebar, void* stream);
@@ -112,11 +120,11 @@ int64_t gcgcn_mha_scratch(int B, int N, int D);
 int gcgcn_mha_fwd(int B, int N, int D, int H, const float* X, const int32_t* n_valid, const float* flat,
                   const void* rng_snap, float p, float* Q, float* P, float* A, float* scratch, void* stream);
 /* backward.  dX_in[B,N,D] (NULL = zero) as in gcgcn_gat_bwd.  Workspace: dS[B,H,N,N], dQ[B,N,D],
- * scratch[gcgcn_mha_scratch].  defer_weight_grads: dWq is parked as described at gcgcn_gcn_bwd (keep X, dQ and dflat
- * alive until the flush). */
+ * scratch[gcgcn_mha_scratch].  defer_queue (may be NULL): dWq is parked as described at gcgcn_gcn_bwd (keep X, dQ and
+ * dflat alive until the flush). */
 int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat, const void* rng_snap, float p,
                   const float* Q, const float* P, const float* dA, const float* dX_in, float* dX, float* dflat,
-                  float* dS, float* dQ, float* scratch, int defer_weight_grads, void* stream);
+                  float* dS, float* dQ, float* scratch, void* defer_queue, void* stream);
 
 /* ---- GraphConvolution (H = 1) / MultiGraphConvolution  GCGCN_glove.py:52-120 --------------- */
 /* flat = [WnX D x H*D | We D x H*D | Wd | Wlin D x H*D | blin D]
@@ -157,16 +165,19 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
                   float out_p, const float* Pn, const float* Y, const float* HO, const float* rinv, const float* dout,
                   float* dX, float* dEbar,
                   float* dA, float* dflat, float* W1, float* W2, float* W3, float* drow, float* dXres, float* dout_m,
-                  float* scratch, const gcgcn_edge_ride* ride, int defer_weight_grads, void* stream);
-/* defer_weight_grads != 0: the block's weight-gradient products (dWlin, dWnX, dWe, dWd: nobody needs them before the
- * end of backward) are not launched by this call but parked (host side, one queue per process: one backward pass at a time); the
- * next gcgcn_gat_bwd carries them as extra workgroups of its HBM-bound edge pass, where the matrix pipes are idle.  Until then the
- * caller must keep X, Ebar, Y, HO, dout (dout_m), W2, W3 and dflat of this call alive, and must call
- * gcgcn_flush_deferred(stream) at the end of backward (it launches what is still parked; no-op otherwise).
- * The parked parts of dflat are complete only after that. */
-int gcgcn_deferred_count(void);
-int gcgcn_flush_deferred(void* stream);
-int gcgcn_reset_deferred(void); /* forget parked products without launching them (after a backward pass that failed) */
+                  float* scratch, const gcgcn_edge_ride* ride, void* defer_queue, void* stream);
+/* defer_queue != NULL: the block's weight-gradient products (dWlin, dWnX, dWe, dWd: nobody needs them before the end
+ * of backward) are not launched by this call but parked in that queue -- a small host-side object the caller creates
+ * per backward pass (no process-wide state: concurrent passes, models and devices never share one).  A later
+ * gcgcn_gat_bwd (or a long gcgcn_gcn_bwd chain launch) given the same queue carries them as extra workgroups of a launch
+ * whose matrix pipes are idle.  Until then the caller must keep X, Ebar, Y, HO, dout (dout_m), W2, W3 and dflat of this
+ * call alive, and must call gcgcn_defer_flush(queue, stream) at the end of the pass (it launches what is still parked;
+ * no-op otherwise).  The parked parts of dflat are complete only after that.  Destroying a queue forgets what is
+ * parked in it without launching anything (a pass that failed half-way). */
+void* gcgcn_defer_create(void);
+void gcgcn_defer_destroy(void* queue);
+int gcgcn_defer_count(const void* queue);
+int gcgcn_defer_flush(void* queue, void* stream);
 
 /* ---- GraphConv, the leaf layer  GCGCN_glove.py:18-50 ------------------------------------------ */
 /* forward(inputs X[B,N,Din], mean edge feature Ebar[B,N,De], adjacency A[B,N,N]):

@@ -18,8 +18,10 @@ import types
 
 import numpy as np
 import torch
+from torch import nn
 
-REF_FILE = "/root/reference/models/GCGCN_glove.py"
+REF_ROOT = "/root/reference"
+REF_FILE = REF_ROOT + "/models/GCGCN_glove.py"
 OUT_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 
 
@@ -274,18 +276,37 @@ def producer_cases(ref):
         yield f"producer_n{n}_s{s}_t{t}_h{hd}", d
 
 
+def trainer_loss_lines():
+    """The trainer's own loss statements, read as text from /root/reference/config/Config.py at generation time (the module
+    itself is not importable: it needs torch_geometric, and the loss is a loop inside ``train``, not a function):
+    line 302 (``BCE = nn.BCELoss(reduction='mean')``) and lines 355-364 (sigmoid, the double loop of BCE calls, the
+    division by N^2 - N), dedented, with the literal ``.cuda()`` calls removed (no GPU in the build container).  Returns
+    source text to ``exec``; nothing of it is written to the repo."""
+    import textwrap
+    lines = open(os.path.join(REF_ROOT, "config", "Config.py"), encoding="utf-8").read().split("\n")
+    bce = lines[301]
+    assert bce.strip() == "BCE = nn.BCELoss(reduction='mean')", bce
+    body = lines[354:364]
+    assert body[0].strip() == "predict_re = torch.sigmoid(predict_re)", body[0]
+    assert body[-1].strip() == "temp_loss = temp_loss/(node_num*node_num-node_num)", body[-1]
+    return textwrap.dedent(bce) + "\n" + textwrap.dedent("\n".join(body)).replace(".cuda()", "") + "\n"
+
+
 def loss_cases():
-    """SURVEY 8 row f2.  config/Config.py cannot be imported here (it needs torch_geometric), and the loss is not a
-    function there but a loop inside ``train`` (:355-366).  The fixtures are produced by that loop's own operations --
-    ``torch.sigmoid``, ``nn.BCELoss(reduction='mean')`` per ordered pair, sum, division by N^2 - N -- as transcribed in
-    ``gcgcn_oracle.pair_bce_loss_loop``, with autograd through ATen's BCE for the gradient."""
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-    from oracle import gcgcn_oracle as O
+    """SURVEY 8 row f2, pinned on the reference's own lines: ``config/Config.py:302, 355-364`` are executed verbatim
+    (``trainer_loss_lines``) on synthetic ``predict_re`` / ``label_matrix``; loss and autograd gradient become the fixture.
+    The oracle's transcription (``gcgcn_oracle.pair_bce_loss_loop``) and its vectorised restatement are checked against
+    these files by tests/test_oracle_golden.py."""
+    from torch.autograd import Variable
+    src = trainer_loss_lines()
+    code = compile(src, "Config.py:302,355-364", "exec")
     for n, scale, seed in ((2, 1.0, 0), (5, 3.0, 1), (16, 1.0, 1337), (9, 40.0, 2)):   # scale 40: saturated sigmoids
         g = torch.Generator().manual_seed(seed)
         logits = (torch.randn(n, n, 97, generator=g) * scale).requires_grad_()
         labels = (torch.rand(n, n, 97, generator=g) < 0.04).float()
-        loss = O.pair_bce_loss_loop(logits, labels)
+        ns = {"torch": torch, "nn": nn, "Variable": Variable, "predict_re": logits, "label_matrix": labels}
+        exec(code, ns)                                                                  # the trainer's statements
+        loss = ns["temp_loss"].squeeze(0)
         grad, = torch.autograd.grad(loss, logits)
         yield f"pair_bce_n{n}_s{int(scale)}", {"logits": _np(logits), "labels": _np(labels), "loss": _np(loss),
                                               "dlogits": _np(grad)}

@@ -1,7 +1,9 @@
 """SURVEY 8(e) check on the real kernels: the gradients of a global batch sharded over two ranks and summed by
-FlatGradBucket equal the gradients one process computes on the whole batch (dropout off).  Two processes share the one
-GPU of the test box; the collective travels over gloo (RCCL needs one GPU per rank), which exercises the same
-FlatGradBucket / shard_batch code the N-GPU bench uses."""
+``FlatGradBucket.all_reduce()`` equal the gradients one process computes on the whole batch (dropout off).  Two processes
+share the one GPU of the test box; the collective travels over gloo on the DEVICE tensors (RCCL needs one GPU per rank), so
+shard_batch, the flat per-block gradients written by the HIP backward, the deferred-weight-gradient hand-over and the
+bucket's collective code are all the ones the N-GPU bench uses.  Modes: one collective after backward (default, weight
+gradients deferred) and per-block collectives from tensor hooks (overlap=True; parking must then be refused)."""
 import os
 import socket
 
@@ -26,6 +28,7 @@ def _worker(rank, world, port, out):
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         import gcgcn_amd
+        from gcgcn_amd import functional as F_
         from gcgcn_amd.dist import FlatGradBucket, shard_batch
         from oracle import gcgcn_oracle as O
         dev = torch.device("cuda:0")
@@ -34,27 +37,56 @@ def _worker(rank, world, port, out):
         sd = O.init_stack_params(D, L, H, seed=7)
         x, e1, e2, _ = O.synth_docs(B, N, D, seed=8)
         cot = torch.randn(B, N, D, generator=torch.Generator().manual_seed(9))
+        assert F_.defer_weight_grads                                            # GCGCN_DEFER=1, the default
+        msgs = []
+        for overlap in (False, True):
+            hops = gcgcn_amd.GraphHops(D, L, H).to(dev).eval()
+            hops.load_state_dict(sd, strict=True)
+            plain = FlatGradBucket(hops)                                        # no hooks: for the single-process reference
+            parked = []
+            orig = F_._BackwardPass.park
+
+            def spy(self, leaf, dflat, operands, _orig=orig, _parked=parked):
+                _parked.append(leaf)
+                return _orig(self, leaf, dflat, operands)
+            F_._BackwardPass.park = spy
+
+            def grads(bucket, xs, a, b, c):
+                bucket.zero_grad()
+                o = hops(xs.to(dev), [a.to(dev), b.to(dev)])[-1]
+                torch.autograd.backward(o, c.to(dev))
+
+            grads(plain, x, e1, e2, cot)                                        # one process, the global batch
+            whole = [p.grad.clone() for p in plain.params]
+            assert len(parked) == 2                                             # both convolutions parked their products
+            bucket = FlatGradBucket(hops, overlap=overlap)
+            del parked[:]
+            xs, a, b, c = shard_batch([x, e1, e2, cot], rank, world)            # this rank's documents
+            grads(bucket, xs, a, b, c)
+            if overlap:
+                assert not parked, "hooked parameters must not be parked"       # _pass_for_parking refuses: hooks present
+                assert len(bucket._pending) == len(bucket.params)
+            else:
+                assert len(parked) == 2
+            bucket.all_reduce()                                                 # the collective itself, on device tensors
+            F_._BackwardPass.park = orig
+            err = max(((p.grad - w).abs().max() / w.abs().max().clamp_min(1e-12)).item()
+                      for p, w in zip(bucket.params, whole))
+            msgs.append("ok" if err < 1e-5 else f"overlap={overlap}: relative gradient error {err:.3e}")
+        # a rank without a gradient for some block still joins the collective (zeros), instead of hanging the others
         hops = gcgcn_amd.GraphHops(D, L, H).to(dev).eval()
-        hops.load_state_dict(sd, strict=True)
         bucket = FlatGradBucket(hops)
-
-        def grads(xs, a, b, c):
-            bucket.zero_grad()
-            out = hops(xs.to(dev), [a.to(dev), b.to(dev)])[-1]
-            torch.autograd.backward(out, c.to(dev))
-            return [p.grad for p in bucket.params]
-
-        whole = [g.clone().cpu() for g in grads(x, e1, e2, cot)]              # one process, the global batch
-        xs, a, b, c = shard_batch([x, e1, e2, cot], rank, world)              # this rank's documents
-        grads(xs, a, b, c)
-        for p in bucket.params:                                               # gloo sums host copies of the flat buffers
-            host = p.grad.cpu()
-            dist.all_reduce(host)
-            p.grad.copy_(host)
-        err = max(((p.grad.cpu() - w).abs().max() / w.abs().max().clamp_min(1e-12)).item() for p, w in zip(bucket.params, whole))
-        out.put((rank, "ok" if err < 1e-5 else f"relative gradient error {err:.3e}"))
+        bucket.zero_grad()
+        if rank == 0:
+            for p in bucket.params:
+                p.grad = torch.ones_like(p)
+        bucket.all_reduce()
+        ok = all(torch.equal(p.grad, torch.ones_like(p)) for p in bucket.params)
+        msgs.append("ok" if ok else "zero-fill collective gave a wrong sum")
+        out.put((rank, "ok" if all(m == "ok" for m in msgs) else "; ".join(msgs)))
     except Exception as e:  # noqa: BLE001
-        out.put((rank, repr(e)))
+        import traceback
+        out.put((rank, repr(e) + traceback.format_exc()[-600:]))
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()

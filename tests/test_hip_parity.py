@@ -271,6 +271,19 @@ def _oracle_stack(x, e1, e2, adj, sd, L, H, nv=None, keeps=None):
     return outs, gx, ge1, ge2, sdl
 
 
+def _check_stack_param_grads(hops, sdl, rtol=1e-3, atol=2e-4):
+    """Every parameter gradient of the four blocks against the oracle's (sums over B*N rows: fp32 summation-order slack)."""
+    ref_grads = {k: v.grad for k, v in sdl.items() if v.grad is not None}
+    seen = 0
+    for mod, pre in ((hops.get_weighted_adj_matrix, "get_weighted_adj_matrix."), (hops.graphcnn[0], "graphcnn.0."),
+                     (hops.get_adj_matrix[0], "get_adj_matrix.0."), (hops.graphcnn[1], "graphcnn.1.")):
+        for k, gk in mod.named_grads().items():
+            torch.testing.assert_close(gk.cpu(), ref_grads[pre + k], rtol=rtol, atol=atol,
+                                       msg=lambda m: f"grad {pre + k}: {m}")
+            seen += 1
+    assert seen == len(ref_grads), (seen, len(ref_grads))       # nothing the reference differentiates is missing
+
+
 @pytest.mark.parametrize("B,N,D,L,H", [(3, 64, 256, 2, 8), (2, 24, 96, 4, 4), (2, 70, 64, 2, 2),
                                        (1, 64, 768, 4, 4),      # cfg 3 (bert) document shape
                                        (1, 256, 512, 2, 8)])    # cfg 5 (stress) document shape
@@ -292,13 +305,7 @@ def test_batched_matches_per_doc_oracle(gpu_device, B, N, D, L, H):
         close(xg.grad[b], gx[b].grad, f"dX[{b}]")
         close(e1g.grad[b], ge1[b].grad, f"dE1[{b}]")
         close(e2g.grad[b], ge2[b].grad, f"dE2[{b}]")
-    ref_grads = {k: v.grad for k, v in sdl.items() if v.grad is not None}
-    # parameter gradients are sums over B*N rows: allow the fp32 summation-order slack
-    for mod, pre in ((hops.get_weighted_adj_matrix, "get_weighted_adj_matrix."), (hops.graphcnn[0], "graphcnn.0."),
-                     (hops.get_adj_matrix[0], "get_adj_matrix.0."), (hops.graphcnn[1], "graphcnn.1.")):
-        for k, gk in mod.named_grads().items():
-            torch.testing.assert_close(gk.cpu(), ref_grads[pre + k], rtol=1e-3, atol=2e-4,
-                                       msg=lambda m: f"grad {pre + k}: {m}")
+    _check_stack_param_grads(hops, sdl)
 
 
 def test_ragged_batch_matches_truncated_docs(gpu_device):
@@ -332,9 +339,12 @@ def test_ragged_batch_matches_truncated_docs(gpu_device):
         torch.testing.assert_close(gk.cpu(), ref_grads["graphcnn.1." + k], rtol=1e-3, atol=2e-4)
 
 
-def test_train_mode_matches_oracle_with_replayed_masks(gpu_device):
-    """Dropout on (4 sites): replay the kernel's keep-masks in the CPU oracle; results must agree."""
-    B, N, D, L, H = 2, 16, 32, 2, 4
+@pytest.mark.parametrize("B,N,D,L,H", [(2, 16, 32, 2, 4),        # guarded (ragged-shape) kernel instantiations
+                                       (2, 64, 256, 2, 8),       # cfg 2 document shape: the ALIGNED chain / GEMM dropout
+                                       (1, 64, 768, 4, 4)])      # epilogues the bench runs; cfg 3 (bert) document shape
+def test_train_mode_matches_oracle_with_replayed_masks(gpu_device, B, N, D, L, H):
+    """Dropout on (6 sites, glove:59/74, 111, 131, 152, 341): replay the kernels' keep-masks in the CPU oracle; outputs,
+    dX, dE1, dE2 and every parameter gradient of the four blocks must agree."""
     sd = O.init_stack_params(D, L, H, seed=21)
     x, e1, e2, adj = O.synth_docs(B, N, D, seed=22)
     hops = gcgcn_amd.GraphHops(D, L, H).to(gpu_device).train()
@@ -373,9 +383,12 @@ def test_train_mode_matches_oracle_with_replayed_masks(gpu_device):
     outs, gx, ge1, ge2, sdl = _oracle_stack(x, e1, e2, adj, sd, L, H, keeps=keeps)
     sum(outs[b][2].sum() for b in range(B)).backward()
     for b in range(B):
+        close(feats[1][b], outs[b][1], f"x1[{b}]")
         close(feats[2][b], outs[b][2], f"x2[{b}]")
         close(xg.grad[b], gx[b].grad, f"dX[{b}]")
         close(e1g.grad[b], ge1[b].grad, f"dE1[{b}]")
+        close(e2g.grad[b], ge2[b].grad, f"dE2[{b}]")
+    _check_stack_param_grads(hops, sdl)
     # a second forward draws different masks
     f2 = hops(xg.detach(), [e1g.detach(), e2g.detach()], adj.to(gpu_device))
     assert not torch.equal(f2[2], feats[2])
@@ -384,38 +397,87 @@ def test_train_mode_matches_oracle_with_replayed_masks(gpu_device):
 # ------------------------------------------------------------------------------------------------------
 # full-size properties (cfg 2: B=32, N=64, D=256, L=2, H=8)
 # ------------------------------------------------------------------------------------------------------
-def test_full_size_properties(gpu_device):
-    B, N, D, L, H = 32, 64, 256, 2, 8
+@pytest.mark.parametrize("cfg,B,N,D,L,H", [("c2", 32, 64, 256, 2, 8), ("c3", 32, 64, 768, 4, 4), ("c5", 32, 256, 512, 2, 8)])
+def test_full_size_properties(gpu_device, cfg, B, N, D, L, H):
+    """BASELINE.json's full batch sizes (cfg 2, cfg 3 = bert shape, cfg 5 = stress shape): the code paths only a full
+    batch takes (split-K factors, group-launch overflow peeling, weight gradients carried by the CAGGC chain launch and
+    the edge pass) checked through size-independent properties + one document against the CPU oracle."""
     sd = O.init_stack_params(D, L, H, seed=1337)
-    x, e1, e2, adj = O.synth_docs(B, N, D, seed=1337)
+    g = torch.Generator(device=gpu_device).manual_seed(1337)
+    x = torch.rand(B, N, D, generator=g, device=gpu_device) * 2 - 1
+    adj = (torch.rand(B, N, N, generator=g, device=gpu_device) < 0.3).float() * (1 - torch.eye(N, device=gpu_device))
+    e1 = torch.randn(B, N, N, D, generator=g, device=gpu_device) * 0.5 * adj.unsqueeze(-1)
+    e2 = torch.randn(B, N, N, D, generator=g, device=gpu_device) * 0.5
     hops = gcgcn_amd.GraphHops(D, L, H).to(gpu_device).eval()
     hops.load_state_dict(sd, strict=True)
 
     def run(xs, e1s, e2s):
-        xg, a, b = dev_leaf(xs, gpu_device), dev_leaf(e1s, gpu_device), dev_leaf(e2s, gpu_device)
-        hops.zero_grad()        # same state for every run: with a .grad in place the weight gradients are not parked, and the
-        f = hops(xg, [a, b])    # data-gradient GEMMs they would have shared a launch with pick another split-K factor
+        xg, a, b = (t.clone().requires_grad_() for t in (xs, e1s, e2s))
+        hops.zero_grad()        # same state for every run
+        f = hops(xg, [a, b])
         f[2].sum().backward()
-        return f, xg.grad, a.grad, b.grad
+        return f, xg.grad, a.grad, b.grad, [p.grad.clone() for p in hops.parameters() if p.grad is not None]
 
-    f, dx, de1, de2 = run(x, e1, e2)
-    f_again, dx2, de1_2, _ = run(x, e1, e2)
+    f, dx, de1, de2, pg = run(x, e1, e2)
+    f_again, dx2, de1_2, de2_2, pg2 = run(x, e1, e2)
     assert torch.equal(f[2], f_again[2]) and torch.equal(dx, dx2) and torch.equal(de1, de1_2)   # deterministic
+    assert torch.equal(de2, de2_2) and all(torch.equal(a, b) for a, b in zip(pg, pg2))
+    del f_again, dx2, de1_2, de2_2, pg2
     # batch independence: a document alone (B=1, the reference's call shape) == the same document in the batch
-    # (not bitwise: the GEMMs pick a different split-K factor for M = 64 rows than for M = 2048)
-    f1, dx1, de1_1, de2_1 = run(x[5:6], e1[5:6], e2[5:6])
+    # (not bitwise: the GEMMs pick a different split-K factor for M = N rows than for M = B N)
+    f1, dx1, de1_1, de2_1, _ = run(x[5:6], e1[5:6], e2[5:6])
     for a, b in ((f1[2][0], f[2][5]), (dx1[0], dx[5]), (de1_1[0], de1[5]), (de2_1[0], de2[5])):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=2e-5)
     # attention rows are distributions; dE2 is constant along j (SURVEY 2.2-4)
-    a0 = hops.get_weighted_adj_matrix(x.to(gpu_device), e1.to(gpu_device))
+    with torch.no_grad():
+        a0 = hops.get_weighted_adj_matrix(x, e1)
     torch.testing.assert_close(a0.sum(-1), torch.ones(B, N, device=gpu_device), rtol=1e-5, atol=1e-5)
     assert torch.equal(de2[:, :, 0, :], de2[:, :, N - 1, :])
+    # linearity of the parameter gradients in the batch: grad(all docs) == grad(first half) + grad(second half)
+    h = B // 2
+    _, _, _, _, pa = run(x[:h], e1[:h], e2[:h])
+    _, _, _, _, pb = run(x[h:], e1[h:], e2[h:])
+    for whole, a, b in zip(pg, pa, pb):
+        torch.testing.assert_close(whole, a + b, rtol=1e-4, atol=1e-4 * max(1.0, whole.abs().max().item()))
     # one document of the full batch against the CPU oracle
-    xr = x[31].clone().requires_grad_()
-    ref = O.hop_stack(xr, [e1[31], e2[31]], None, sd, L, H)
+    d = B - 1
+    xr = x[d].cpu().requires_grad_()
+    e1r, e2r = e1[d].cpu().requires_grad_(), e2[d].cpu().requires_grad_()
+    ref = O.hop_stack(xr, [e1r, e2r], None, sd, L, H)
     ref[2].sum().backward()
-    close(f[2][31], ref[2], "x2[31]")
-    close(dx[31], xr.grad, "dX[31]")
+    close(f[1][d], ref[1], f"{cfg} x1[{d}]")
+    close(f[2][d], ref[2], f"{cfg} x2[{d}]")
+    close(dx[d], xr.grad, f"{cfg} dX[{d}]")
+    close(de1[d], e1r.grad, f"{cfg} dE1[{d}]")
+    close(de2[d], e2r.grad, f"{cfg} dE2[{d}]")
+
+
+@pytest.mark.parametrize("B,N,D,L,H", [(16, 64, 768, 4, 4),     # cfg 3 shape: B H <= 64 and a long chain -- the CAGGC chain
+                                       (4, 64, 256, 2, 8)])    # launch takes parked products as two-tile passengers
+def test_deferred_and_immediate_weight_gradients_agree_at_batch(gpu_device, B, N, D, L, H):
+    """The weight gradients parked by the convolutions and carried by a later launch (gemm_take_deferred_pairs in the
+    chain launch, gemm_take_deferred in GATAttention's edge pass) against the same products launched at once, and both
+    against the per-document CPU oracle summed over the batch."""
+    sd = O.init_stack_params(D, L, H, seed=61)
+    x, e1, e2, adj = O.synth_docs(B, N, D, seed=62)
+    hops = gcgcn_amd.GraphHops(D, L, H).to(gpu_device).eval()
+    hops.load_state_dict(sd, strict=True)
+    res = {}
+    try:
+        for defer in (True, False):
+            F_.defer_weight_grads = defer
+            xs = [dev_leaf(t, gpu_device) for t in (x, e1, e2)]
+            hops.zero_grad()
+            hops(xs[0], [xs[1], xs[2]])[-1].sum().backward()
+            assert not F_._passes
+            res[defer] = [p.grad.clone() for p in hops.parameters() if p.grad is not None]
+    finally:
+        F_.defer_weight_grads = True
+    for a_, b_ in zip(res[True], res[False]):
+        torch.testing.assert_close(a_, b_, rtol=2e-5, atol=2e-5 * max(1.0, b_.abs().max().item()))
+    outs, gx, ge1, ge2, sdl = _oracle_stack(x, e1, e2, adj, sd, L, H)
+    sum(o[2].sum() for o in outs).backward()
+    _check_stack_param_grads(hops, sdl)
 
 
 def test_edge_mean_handoff_is_used_and_safe(gpu_device):
@@ -427,9 +489,9 @@ def test_edge_mean_handoff_is_used_and_safe(gpu_device):
     e = torch.randn(6, 6, D, device=gpu_device)
     with torch.no_grad():
         a = gat(x, e)
-        assert F_._handoff is not None
+        assert id(e) in F_._handoffs()
         y1 = conv(x, e, a)
-        assert F_._handoff is None                      # consumed
+        assert id(e) not in F_._handoffs()              # consumed
         y2 = conv(x, e, a)                              # recomputed from E
         a = gat(x, e)
         e2 = e.clone()
@@ -642,7 +704,7 @@ def test_deferred_weight_gradients_equal_immediate_ones(gpu_device):
             xs = [dev_leaf(t, gpu_device) for t in (x, e1, e2)]
             out = hops(xs[0], [xs[1], xs[2]])[-1]
             out.sum().backward()
-            assert _lib.lib().gcgcn_deferred_count() == 0 and not F_._parked
+            assert not F_._passes                       # the pass object lives exactly as long as its backward
             res.append([xs[0].grad, xs[1].grad] + [p.grad.clone() for p in hops.parameters() if p.grad is not None])
             hops.zero_grad()
         # a MAGGC block on its own: nothing carries the parked products, the end-of-backward callback launches them
@@ -652,10 +714,10 @@ def test_deferred_weight_gradients_equal_immediate_ones(gpu_device):
             F_.defer_weight_grads = defer
             xs = dev_leaf(x, gpu_device)
             conv(xs, e2.to(gpu_device), a).sum().backward()
-            assert _lib.lib().gcgcn_deferred_count() == 0 and not F_._parked
+            assert not F_._passes
             res[0 if defer else 1].append(conv.flat.grad.clone())
             conv.zero_grad()
-        # gradient accumulation: the second backward finds .grad set, so nothing may be parked (autograd adds at once)
+        # gradient accumulation: the second backward finds .grad set; the end-of-backward hand-over adds to it
         F_.defer_weight_grads = True
         xs = dev_leaf(x, gpu_device)
         conv(xs, e2.to(gpu_device), a).sum().backward()
@@ -667,3 +729,93 @@ def test_deferred_weight_gradients_equal_immediate_ones(gpu_device):
     assert len(res[0]) == len(res[1])
     for a_, b_ in zip(*res):
         torch.testing.assert_close(a_, b_, rtol=2e-5, atol=2e-5)
+
+
+# ---- API width: what the reference's constructors accept beyond the one shape its model builds -------------------
+@pytest.mark.parametrize("B,N,Din,Dh", [(2, 9, 12, 20), (1, 64, 256, 128), (3, 17, 40, 8)])
+def test_gat_rectangular_projection(gpu_device, B, N, Din, Dh):
+    """GATAttention(att_input_dim, hidden_dim) with att_input_dim != hidden_dim (nn.Linear(att_input_dim, hidden_dim),
+    glove:148-150): output and all gradients against the op-for-op oracle."""
+    g = torch.Generator().manual_seed(Din * 31 + Dh)
+    m = gcgcn_amd.GATAttention(Din, Dh).to(gpu_device).eval()
+    sd = {k: v.cpu().clone().requires_grad_() for k, v in m.state_dict().items()}
+    x = torch.rand(B, N, Din, generator=g) * 2 - 1
+    e = torch.randn(B, N, N, Din, generator=g) * 0.5
+    cot = torch.randn(B, N, N, generator=g)
+    xg, eg = dev_leaf(x, gpu_device), dev_leaf(e, gpu_device)
+    a = m(xg, eg)
+    a.backward(cot.to(gpu_device))
+    xr, er = x.clone().requires_grad_(), e.clone().requires_grad_()
+    ref = torch.stack([O.gat_attention(xr[b], er[b], sd) for b in range(B)])
+    ref.backward(cot)
+    close(a, ref, "A")
+    close(xg.grad, xr.grad, "dX")
+    close(eg.grad, er.grad, "dE")
+    for k, gk in m.named_grads().items():
+        torch.testing.assert_close(gk.cpu(), sd[k].grad, rtol=1e-3, atol=1e-4, msg=lambda s: f"grad {k}: {s}")
+
+
+@pytest.mark.parametrize("B,N,D", [(2, 16, 32), (2, 64, 256)])
+def test_gat_masked_opt_in(gpu_device, B, N, D):
+    """apply_mask=True: the paper-faithful partially connected adjacency (energy -100000 where mask, i.e. what the
+    reference's discarded masked_fill, glove:163-164, would have done in place).  Default stays the reference's no-op;
+    a fully masked row falls back to the uniform distribution like torch's softmax over equal energies."""
+    sd = O.sub(O.init_stack_params(D, 2, 4, seed=3), "get_weighted_adj_matrix")
+    x, e1, _, adj = O.synth_docs(B, N, D, seed=4)
+    adj[0, 3] = 0                                          # a fully masked row
+    mask = torch.eq(adj, 0)
+    outs = {}
+    for flag in (True, False):
+        m = gcgcn_amd.GATAttention(D, D, apply_mask=flag).to(gpu_device).eval()
+        m.load_state_dict(sd)
+        xg, eg = dev_leaf(x, gpu_device), dev_leaf(e1, gpu_device)
+        a = m(xg, eg, mask.to(gpu_device))
+        a.square().sum().backward()
+        xr, er = x.clone().requires_grad_(), e1.clone().requires_grad_()
+        sdl = {k: v.clone().requires_grad_() for k, v in sd.items()}
+        ref = torch.stack([O.gat_attention(xr[b], er[b], sdl, mask[b], apply_mask=flag) for b in range(B)])
+        ref.square().sum().backward()
+        close(a, ref, f"A (apply_mask={flag})")
+        close(xg.grad, xr.grad, "dX")
+        close(eg.grad, er.grad, "dE")
+        for k, gk in m.named_grads().items():
+            torch.testing.assert_close(gk.cpu(), sdl[k].grad, rtol=1e-3, atol=1e-4)
+        outs[flag] = a.detach()
+    part = (mask & ~mask.all(-1, keepdim=True)).to(gpu_device)
+    assert part.any() and (outs[True][part] == 0).all()                         # masked pairs carry no weight ...
+    torch.testing.assert_close(outs[True][0, 3], torch.full((N,), 1.0 / N, device=gpu_device))   # ... unless all are masked
+    assert not torch.allclose(outs[True], outs[False])
+    # through the hop loop: GraphHops(apply_mask=True) builds mask = eq(adj, 0) itself (glove:330)
+    full = O.init_stack_params(D, 2, 4, seed=3)
+    hops = gcgcn_amd.GraphHops(D, 2, 4, apply_mask=True).to(gpu_device).eval()
+    hops.load_state_dict(full, strict=True)
+    _, _, e2, _ = O.synth_docs(B, N, D, seed=4)
+    f = hops(x.to(gpu_device), [e1.to(gpu_device), e2.to(gpu_device)], adj.to(gpu_device))
+    a_ref = O.gat_attention(x[1], e1[1], sd, mask[1], apply_mask=True)
+    x1_ref = O.graph_convolution(x[1], e1[1], a_ref, O.sub(full, "graphcnn.0"), 2)
+    close(f[1][1], x1_ref, "x1 through the masked hop")
+
+
+def test_many_sublayers(gpu_device):
+    """layer_num = 16: more weight-gradient products than one group launch describes (the dWd loop used to stop
+    silently at 16 problems when nothing was parked) -- with and without deferral, against the oracle."""
+    B, N, D, L, H = 2, 10, 64, 16, 2
+    sd = O.init_stack_params(D, L, H, seed=81)
+    x, e1, e2, adj = O.synth_docs(B, N, D, seed=82)
+    hops = gcgcn_amd.GraphHops(D, L, H).to(gpu_device).eval()
+    hops.load_state_dict(sd, strict=True)
+    outs, gx, ge1, ge2, sdl = _oracle_stack(x, e1, e2, adj, sd, L, H)
+    sum(o[2].sum() for o in outs).backward()
+    try:
+        for defer in (False, True):
+            F_.defer_weight_grads = defer
+            hops.zero_grad()
+            xs = [dev_leaf(t, gpu_device) for t in (x, e1, e2)]
+            f = hops(xs[0], [xs[1], xs[2]])
+            f[2].sum().backward()
+            for b in range(B):
+                close(f[2][b], outs[b][2], f"x2[{b}]")
+                close(xs[0].grad[b], gx[b].grad, f"dX[{b}]")
+            _check_stack_param_grads(hops, sdl)
+    finally:
+        F_.defer_weight_grads = True

@@ -20,12 +20,13 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in gcgcn.h but missing from libgcgcn_hip.so"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.gcgcn_version() == 1
+    assert lib.gcgcn_version() == _lib.ABI_VERSION == 2
 
 
 @pytest.mark.parametrize("D,L,H", [(8, 2, 2), (128, 2, 8), (768, 4, 4), (512, 2, 8), (12, 4, 4)])
 def test_layouts_match_library(D, L, H):
-    assert P.gat_layout(D) == _lib.layout("gat", D)
+    assert P.gat_layout(D) == _lib.layout("gat", D, D)
+    assert P.gat_layout(D, 2 * D + 3) == _lib.layout("gat", D, 2 * D + 3)          # att_input_dim != hidden_dim
     assert P.mha_layout(D) == _lib.layout("mha", D)
     assert P.gcn_layout(D, L, H) == _lib.layout("gcn", D, L, H)
 
@@ -62,6 +63,34 @@ def test_strict_load_reports_missing_and_unexpected():
     bad["graphcnn.0.linear_layer.weight"] = torch.zeros(3, 3)
     with pytest.raises(RuntimeError, match="size mismatch"):
         hops.load_state_dict(bad)
+
+
+def test_partial_checkpoint_loads_what_matches():
+    """strict=False with some keys of a block missing: nn.Module semantics (which the reference follows) load the keys
+    that are present and report the others."""
+    torch.manual_seed(1)
+    hops = gcgcn_amd.GraphHops(8, 2, 2)
+    before = {k: v.clone() for k, v in hops.state_dict().items()}
+    sd = {"graphcnn.1.graphconv.3.weights_node": torch.full((12, 4), 0.5),
+          "get_weighted_adj_matrix.wt.bias": torch.tensor([7.0])}
+    res = hops.load_state_dict(sd, strict=False)
+    after = hops.state_dict()
+    assert "graphcnn.1.linear_layer.bias" in res.missing_keys and not res.unexpected_keys
+    for k in before:
+        want = sd.get(k, before[k])
+        assert torch.equal(after[k], want), k
+
+
+def test_gat_rectangular_projection_state_dict():
+    """GATAttention(att_input_dim, hidden_dim) with att_input_dim != hidden_dim: the reference's shapes (glove:148-151)."""
+    m = gcgcn_amd.GATAttention(12, 20)
+    sd = m.state_dict()
+    assert sd["linear_node_h.weight"].shape == (20, 12) and sd["linear_edge_r.bias"].shape == (20,)
+    assert sd["wt.weight"].shape == (1, 60)
+    ref = torch.nn.Linear(12, 20)
+    sd["linear_node_t.weight"] = ref.weight.detach().clone()
+    m.load_state_dict(sd, strict=True)
+    assert torch.equal(m.state_dict()["linear_node_t.weight"], ref.weight.detach())
 
 
 def test_constructor_contract():

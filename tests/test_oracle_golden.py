@@ -127,12 +127,18 @@ def test_dropout_mask_convention():
 
 @pytest.mark.parametrize("path", golden_files("pair_bce"), ids=ids(golden_files("pair_bce")))
 def test_pair_bce_loss(path):
-    """the vectorised restatement (value and ATen-faithful gradient) against the trainer's loop of
-    nn.BCELoss calls (fixtures from oracle/make_golden.py::loss_cases), including saturated sigmoids."""
+    """the oracle's transcription of the trainer's loop and its vectorised restatement (value and
+    ATen-faithful gradient) against fixtures produced by EXECUTING the reference's own statements, config/Config.py:302 and
+    :355-364 (oracle/make_golden.py::loss_cases), including saturated sigmoids."""
     r = load_golden(path)["raw"]
     logits, labels = torch.from_numpy(r["logits"]), torch.from_numpy(r["labels"])
     torch.testing.assert_close(O.pair_bce_loss(logits, labels), torch.from_numpy(r["loss"]), rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(O.pair_bce_loss_grad(logits, labels), torch.from_numpy(r["dlogits"]), rtol=1e-5, atol=1e-9)
+    x = logits.clone().requires_grad_()
+    loop = O.pair_bce_loss_loop(x, labels)
+    gl, = torch.autograd.grad(loop, x)
+    torch.testing.assert_close(loop.detach(), torch.from_numpy(r["loss"]), rtol=0, atol=0)      # same ops, same order: bitwise
+    torch.testing.assert_close(gl, torch.from_numpy(r["dlogits"]), rtol=0, atol=0)
 
 
 def test_pair_bce_loss_loop_and_ragged():
