@@ -111,6 +111,10 @@ def main():
     ap.add_argument("--prof-kernel", default="auto",
                     help="kernel family timed with HIP events inside the timed region (auto = the one with the largest time share)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--input-sets", type=int, default=3,
+                    help="resident synthetic batches rotated through the steps (default 3: 3 x (E1 + E2) = 805 MB at cfg 2, "
+                         "more than the 256 MiB Infinity Cache, so no step finds its inputs cached by the step before -- as in "
+                         "a training loop that feeds new documents every step).  1 = replay one batch (cache-warm)")
     ap.add_argument("--ragged", action="store_true",
                     help="secondary run (SURVEY 8d): DocRED-like entity counts n_valid ~ clip(round(N(19.5, 6^2)), 2, 42) padded to N")
     ap.add_argument("--early-mean", action="store_true", help="issue the E2 mean before GATAttention (A/B; default off)")
@@ -158,49 +162,61 @@ def main():
     hops.early_edge_mean = args.early_mean
     gcgcn_amd.manual_seed(1337 + rank, dev)
     bucket = FlatGradBucket(hops, overlap=args.overlap_grads)   # default: one coalesced all-reduce after backward
-    x, e1, e2, adj = synth(cfg, 1337 + rank, dev)
-    for t in (x, e1, e2):
-        t.requires_grad_()
-    cot = torch.ones(B, N, D, device=dev)         # d(sum(out))/d(out)
     n_valid = None
     if args.ragged:
         g = torch.Generator().manual_seed(4242 + rank)
         n_valid = torch.clamp(torch.round(torch.randn(B, generator=g) * 6.0 + 19.5), 2, min(42, N)).to(torch.int32).to(dev)
-        with torch.no_grad():                      # padding rows of X must be zero (include/gcgcn.h)
-            x.mul_((torch.arange(N, device=dev)[None, :] < n_valid[:, None]).unsqueeze(-1).float())
+    nsets = max(1, args.input_sets)
+    sets = []                                     # resident batches, rotated: step i runs on sets[i % nsets]
+    for k in range(nsets):
+        x, e1, e2, adj = synth(cfg, 1337 + rank + 1000 * k, dev)
+        if n_valid is not None:
+            with torch.no_grad():                  # padding rows of X must be zero (include/gcgcn.h)
+                x.mul_((torch.arange(N, device=dev)[None, :] < n_valid[:, None]).unsqueeze(-1).float())
+        for t in (x, e1, e2):
+            t.requires_grad_()
+        sets.append((x, e1, e2, adj))
+    cot = torch.ones(B, N, D, device=dev)         # d(sum(out))/d(out)
 
-    def fwd_bwd():
+    def fwd_bwd(k):
+        x, e1, e2, adj = sets[k]
         x.grad = e1.grad = e2.grad = None
         bucket.zero_grad()
         out = hops(x, [e1, e2], adj, n_valid=n_valid)[-1]
         torch.autograd.backward(out, cot)
 
-    graph, graph_grads = None, []
-    if args.mode == "graph":                      # capture the launch-bound step in one hipGraph
+    graphs, graph_grads = [], []
+    if args.mode == "graph":                      # capture the launch-bound step in one hipGraph per resident batch
         try:
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
-                for _ in range(3):
-                    fwd_bwd()
+                for k in range(nsets):
+                    fwd_bwd(k)
             torch.cuda.current_stream().wait_stream(s)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                fwd_bwd()
-            graph_grads = [(p, p.grad) for p in bucket.params]     # the tensors the replays write the gradients into
+            for k in range(nsets):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    fwd_bwd(k)
+                graphs.append(g)
+                graph_grads.append([(p, p.grad) for p in bucket.params])   # the tensors that graph's replays write the gradients into
         except Exception as ex:                   # never lose the measurement to a capture problem: issue the steps eagerly
             print(f"bench.py: hipGraph capture failed ({ex!r}); running --mode eager", file=sys.stderr)
-            graph, graph_grads = None, []
+            graphs, graph_grads = [], []
             args.mode = "eager"
             torch.cuda.synchronize()
+    counter = [0]
 
-    def step(eager=False):
-        if graph is not None and not eager:
-            graph.replay()
-            for p, g in graph_grads:                           # an eager (profiled) step in between re-pointed .grad
+    def step(eager=False, k=None):
+        if k is None:
+            k = counter[0] % nsets
+            counter[0] += 1
+        if graphs and not eager:
+            graphs[k].replay()
+            for p, g in graph_grads[k]:                        # .grad = what this replay wrote
                 p.grad = g
         else:
-            fwd_bwd()
+            fwd_bwd(k)
         if world > 1 or force_dist:
             bucket.all_reduce()
 
@@ -248,26 +264,29 @@ def main():
         sync()
 
     # ---- the timed region: exactly K steps, the dominant family's launches bracketed by HIP events ----------
-    # Two HIP events per launch stall the queue enough to matter (19 GEMM launches a step cost +20 %), so
-    # the dominant family is sampled on every 10th timed step only; edge_bwd-sized families (1 launch) always.
-    # In graph mode the sampled steps are the ones issued eagerly (same kernels on the same data; the rest replay).
-    if graph is not None:
-        sample_every = max(2, min(25, args.steps))             # an eager step costs host time on top of the events
+    # Two HIP events per launch stall the queue enough to matter (19 GEMM launches a step cost +20 %), so the dominant
+    # family is sampled on a few timed steps only.  In graph mode those are issued eagerly (events cannot be recorded inside
+    # a replay; same kernels, same rotating data) and they are the LAST steps of the region: the host has by then queued
+    # the replays far ahead of the GPU, so the ~1 ms of Python per eager step hides behind the backlog instead of starving
+    # the GPU.  Eager mode samples every 10th step (every step for a one-launch family).
+    if graphs:
+        nsamp = max(1, min(5, args.steps // 4))
+        sampled_steps = set(range(args.steps - nsamp, args.steps))
     else:
-        sample_every = 1 if shares.get(dominant, {}).get("launches_per_step", 99) <= 2 else 10
+        every = 1 if shares.get(dominant, {}).get("launches_per_step", 99) <= 2 else 10
+        sampled_steps = set(i for i in range(args.steps) if i % every == every // 2)
     if use_prof:
         _lib.call("gcgcn_prof_start", dominant.encode(), args.steps * 64 + 64)
         _lib.call("gcgcn_prof_enable", 0)
     import gc
     gc.collect()
     gc.disable()                                               # no collector pauses inside the timed region
+    counter[0] = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
-        sampled = (i % sample_every == sample_every // 2) if sample_every > 1 else True
-        if use_prof and sample_every > 1:
+        sampled = i in sampled_steps
+        if use_prof:
             _lib.call("gcgcn_prof_enable", 1 if sampled else 0)
-        elif use_prof and i == 0:
-            _lib.call("gcgcn_prof_enable", 1)
         step(eager=sampled)
     sync()
     dt = time.perf_counter() - t0
@@ -291,10 +310,12 @@ def main():
              "frac": round(ach / peak, 4), "traffic": None, "avg_launch_us": round(ms / n * 1e3, 2),
              "launches": n, "work_per_launch": work / n, "sampled_steps": samp,
              "work": "executed fp32 flops (2MNK)" if bound == "mfma" else "algorithmic HBM bytes"}
-        pmc = os.path.join(ROOT, "profiles", "r01_c2_pmc_hbm.json")
-        if bound == "hbm" and args.config == "c2" and os.path.exists(pmc):   # PMC passes are offline (rocprofv3 --pmc)
+        import glob
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c2_pmc_hbm.json")))   # latest round's PMC passes
+        if bound == "hbm" and args.config == "c2" and pmcs:    # (offline: rocprofv3 --pmc, tools/pmc_hbm.sh)
             import re
-            for k, v in json.load(open(pmc))["kernels"].items():
+            r["traffic_source"] = os.path.relpath(pmcs[-1], ROOT)
+            for k, v in json.load(open(pmcs[-1]))["kernels"].items():
                 m = re.search(r"gc::(edge_\w+)_kernel<\d+(?:, (true|false))?", k)
                 if not m:
                     continue
@@ -303,11 +324,28 @@ def main():
                     r["traffic"] = v["hbm_bytes_per_launch_corrected"]
         return r
 
-    nsamp = args.steps if sample_every == 1 else len([i for i in range(args.steps) if i % sample_every == sample_every // 2])
-    roofline = roof(dominant, kms.value, kn.value, kw.value, f"{nsamp} of the {args.steps} timed steps" + (" (the eagerly issued ones; the others replay the hipGraph)" if graph is not None else ""))
+    roofline = roof(dominant, kms.value, kn.value, kw.value,
+                    len(sampled_steps))
+    if roofline is not None:
+        roofline["sampled_on"] = (f"the last {len(sampled_steps)} of the {args.steps} timed steps (issued eagerly so that HIP events "
+                                  "bracket the launches; the others replay the hipGraphs)" if graphs else
+                                  f"{len(sampled_steps)} of the {args.steps} timed steps")
+    # the cache-warm figure (one batch replayed back to back, E1 partly served from the Infinity Cache) for comparison
+    warm = None
+    if nsets > 1 and rank == 0 and world == 1 and not force_dist:
+        for _ in range(3):
+            step(k=0)
+        torch.cuda.synchronize()
+        tw = time.perf_counter()
+        for _ in range(args.steps):
+            step(k=0)
+        torch.cuda.synchronize()
+        warm = (time.perf_counter() - tw) / args.steps
     roofline_hbm = None
     if use_prof and rank == 0 and dominant != "edge_bwd":
-        roofline_hbm = roof("edge_bwd", *profile("edge_bwd", 5), "5 steps after the timed region")
+        roofline_hbm = roof("edge_bwd", *profile("edge_bwd", 5), 5)
+        if roofline_hbm:
+            roofline_hbm["sampled_on"] = "5 eager steps after the timed region (rotating inputs)"
         from gcgcn_amd import functional as F_
         if roofline_hbm and F_.defer_weight_grads and N % 64 == 0 and D % 64 == 0 and (D // L) % 64 == 0:
             # The launch also carries the convolutions' parked weight-gradient products: their flops run on
@@ -333,9 +371,12 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: GraphHops fwd+bwd, B={B}/GPU N={N} D={D} L={L} H={H}, train mode, "
                                    f"E1/E2/X/params require grad" + (", ragged n_valid (mean %.1f)" % n_valid.float().mean().item()
-                                                                      if n_valid is not None else ""),
-                       "global_batch": B * world, "mode": args.mode,
-                       "parallelism": f"dp{world}"},
+                                                                      if n_valid is not None else "")
+                                   + (f", rotating inputs: {nsets} resident batches ({nsets * 8 * N * N * D * B / 1e6:.0f} MB of E "
+                                      "per GPU), step i runs on batch i mod " + str(nsets) if nsets > 1 else ", one batch replayed (cache-warm)"),
+                       "global_batch": B * world, "mode": args.mode, "input_sets": nsets,
+                       "parallelism": f"dp{world}", "grad_allreduce": ("per-block, overlapped with backward (tensor hooks)"
+                                                                       if args.overlap_grads else "one coalesced collective after backward")},
             "roofline": roofline,
             "roofline_hbm": roofline_hbm,
             "whole_step": {"hbm_frac": round(value / world * 20 * N * N * D / HBM_PEAK, 4),
@@ -343,6 +384,10 @@ def main():
                            "algorithmic_bytes_per_doc": 20 * N * N * D, "algorithmic_flops_per_doc": flops},
             "time_shares_ms_per_step": {k: v for k, v in shares.items() if v["launches_per_step"]},
         }
+        if warm is not None:
+            line["extra"] = {"warm_replay_ms_per_step": round(warm * 1e3, 4), "warm_replay_docs_per_s": round(B / warm, 2),
+                             "note": "one resident batch replayed back to back (the round-1 bench): its E1 is partly served from "
+                                     "the 256 MiB Infinity Cache; `value` above is the rotating-input (cold) figure"}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg)
         real_stdout.write(json.dumps(line) + "\n")

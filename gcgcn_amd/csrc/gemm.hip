@@ -320,6 +320,102 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* 
   return 0;
 }
 
+// ---- one dimension known only on the device (gemm.hpp) --------------------------------------------------------
+template <bool AKC, bool BKC, bool ALIGNED>
+__global__ __launch_bounds__(256, 4) void gemm_dyn_kernel(GemmArgs g, const int* __restrict__ cnt, int dyn, int splits) {
+  __shared__ __attribute__((aligned(16))) float lds[lds_floats<1, 1, AKC, BKC>()];
+  const int c = *cnt;
+  const int cr = ALIGNED ? (c + 63) & ~63 : c;
+  if (dyn == 1) {
+    g.M = cr, g.splits = 1, g.ksplit = g.K;
+    const int tn = (g.N + 63) >> 6, tiles = ((cr + 63) >> 6) * tn;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+      gemm_body<1, 1, AKC, BKC, ALIGNED>(g, lds, tile % tn, tile / tn, 0);
+      __syncthreads();  // the next tile restages LDS
+    }
+    return;
+  }
+  g.K = cr, g.splits = splits;
+  g.ksplit = ((((cr + splits - 1) / splits) + BK - 1) / BK) * BK;
+  if (g.ksplit < BK) g.ksplit = BK;
+  const int tn = (g.N + 63) >> 6, tm = (g.M + 63) >> 6, tiles = tm * tn * splits;
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int sp = tile % splits, r = tile / splits;
+    const int bx = r % tn, by = r / tn;
+    if (sp * g.ksplit >= cr) {  // this K slice is empty
+      if (splits > 1) {         // its partial tile is zero
+        float* __restrict__ W = g.ws + (long)sp * g.M * g.N;
+        for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+          const int row = by * 64 + (e >> 6), col = bx * 64 + (e & 63);
+          if (row < g.M && col < g.N) W[(long)row * g.N + col] = 0.f;
+        }
+      } else if (cr == 0) {  // no rows at all: C = epilogue(0) is produced by the body over zero k-steps -- not reachable
+      }                      // (ksplit >= BK, sp == 0, cr == 0 handled below)
+      continue;
+    }
+    gemm_body<1, 1, AKC, BKC, ALIGNED>(g, lds, bx, by, sp);
+    __syncthreads();
+  }
+}
+
+// *cnt == 0 with dyn == 2: every slice is empty; C must still be defined (zeros).
+__global__ __launch_bounds__(256) void gemm_dyn_zero_kernel(GemmArgs g, const int* __restrict__ cnt) {
+  if (*cnt != 0) return;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)g.M * g.N) return;
+  const int row = (int)(e / g.N), col = (int)(e - (long)row * g.N);
+  if (!g.accumulate) g.C[(long)row * g.ldc + col] = 0.f;
+}
+
+int gemm_dyn(const GemmArgs& g_in, const int* cnt, int dyn, long cap, hipStream_t st) {
+  GemmArgs g = g_in;
+  GC_REQUIRE(cnt && (dyn == 1 || dyn == 2) && cap >= 0, "gemm_dyn: bad arguments");
+  GC_REQUIRE(g.batch1 == 1 && g.batch2 == 1, "gemm_dyn: batched problems are not supported");
+  if (cap == 0) cap = 1;
+  if (dyn == 1) g.M = (int)((cap + 63) & ~63L); else g.K = (int)((cap + 63) & ~63L);
+  if (prepare(g, 1, 1, 0) < 0) return 1;
+  const bool al = g.vecA && g.vecB && g.N % 64 == 0 && (dyn == 1 ? g.K % BK == 0 : g.M % 64 == 0);
+  int splits = 1;
+  if (dyn == 2) {
+    // enough K slices to fill the chip with the few output tiles of a weight gradient; each slice >= 8 k-steps
+    const long tiles = (long)cdiv(g.M, 64) * cdiv(g.N, 64);
+    long want = (1024 + tiles - 1) / tiles, most = cap / (8 * BK);
+    if (most < 1) most = 1;
+    splits = (int)(want < most ? want : most);
+    if (splits > 64) splits = 64;
+    if (splits > 1 && (!g.ws || (long)splits * g.M * g.N > g.ws_elems || g.N % 4 != 0 || (((uintptr_t)g.ws) & 15) != 0)) splits = 1;
+    if (splits == 1) {
+      dim3 zg(cdiv((long)g.M * g.N, 256));
+      hipLaunchKernelGGL(gemm_dyn_zero_kernel, zg, dim3(256), 0, st, g, cnt);
+    }
+  }
+  g.splits = splits;
+  const long tiles_cap = dyn == 1 ? (long)cdiv(cap, 64) * cdiv(g.N, 64) : (long)cdiv(g.M, 64) * cdiv(g.N, 64) * splits;
+  const unsigned grid = (unsigned)(tiles_cap < 1024 ? (tiles_cap > 0 ? tiles_cap : 1) : 1024);
+  const double flops = 0.0;  // data-dependent: not counted by the host-side timer
+#define GC_DYN(AK, BKc, AL) GC_LAUNCH_TIMED("gemm_dyn", flops, (gemm_dyn_kernel<AK, BKc, AL>), dim3(grid), dim3(256), 0, st, g, cnt, dyn, splits)
+  if (al) {
+    if (g.a_kc && !g.b_kc) GC_DYN(true, false, true);
+    else if (g.a_kc && g.b_kc) GC_DYN(true, true, true);
+    else if (!g.a_kc && !g.b_kc) GC_DYN(false, false, true);
+    else GC_DYN(false, true, true);
+  } else {
+    if (g.a_kc && !g.b_kc) GC_DYN(true, false, false);
+    else if (g.a_kc && g.b_kc) GC_DYN(true, true, false);
+    else if (!g.a_kc && !g.b_kc) GC_DYN(false, false, false);
+    else GC_DYN(false, true, false);
+  }
+#undef GC_DYN
+  if (int e = check_launch("gemm_dyn")) return e;
+  if (splits > 1) {  // sums `splits` partial slabs (empty slices wrote zeros) and runs the epilogue
+    ProfScope ps("gemm_splitk_reduce", st);
+    dim3 rgrid(cdiv((long)g.M * g.N / 4, 256), 1);
+    hipLaunchKernelGGL(splitk_reduce_kernel, rgrid, dim3(256), 0, st, g);
+    return check_launch("gemm_dyn_reduce");
+  }
+  return 0;
+}
+
 // ---- deferred problems ------------------------------------------------------------------------------------------
 // One DeferQueue per backward pass (owned by the host side, gcgcn_defer_create / _destroy): no process-wide state, so
 // two passes -- other models, other devices, other threads -- never see each other's problems, and a pass that fails

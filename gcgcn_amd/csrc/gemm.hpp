@@ -115,6 +115,19 @@ int gemm_take_deferred_pairs(DeferQueue* q, GemmGroup4& gg, double* flops, long 
 // Launch whatever is still parked as ordinary group launches (end of backward without a carrying launch).
 int gemm_flush_deferred(DeferQueue* q, hipStream_t stream);
 
+// ---- one dimension known only on the device ------------------------------------------------------------------
+// Products over a data-dependent selection of rows (the live sentence slots / entity pairs of the edge-feature producer,
+// producer.hip): the row count lives in device memory, the host only knows an upper bound `cap`.  A fixed grid of
+// persistent workgroups walks the tile list computed from *cnt, so no host synchronisation and no worst-case grid.
+//   dyn = 1: M = *cnt  (rows of A and of C; g.M is ignored)
+//   dyn = 2: K = *cnt  (rows of both operands -- weight gradients; g.K is ignored); split-K over a factor chosen from
+//            `cap`, partials through g.ws + the deterministic reduce.
+// Interior shapes (N, and M or K, multiples of 64 / 32; 16-byte aligned) take the unguarded tile body with the count
+// rounded UP to a multiple of 64: operand buffers must be readable that far, C writable that far (dyn = 1), and for
+// dyn = 2 at least one operand's rows in [*cnt, roundup64(*cnt)) must be zero.  Other shapes take the guarded body
+// with the exact count.
+int gemm_dyn(const GemmArgs& g, const int* cnt, int dyn, long cap, hipStream_t st);
+
 // Floats of split-K workspace that lets every GEMM of a [rows x cols]-sized problem split freely.
 inline long gemm_ws_elems(long rows, long cols) {
   long need = 16 * rows * cols;

@@ -1,0 +1,836 @@
+// Edge-feature producer: WordAttention + SentenceAttention + the two Linear layers that build
+// E = context_sent_att[N, N, Hd] for one hop (GCGCN_glove.py:171-214 and the call sequence :300-330).
+//
+// The reference materialises [N, N, S, T, Hd] tensors (token states broadcast over every entity pair and sentence
+// slot): 2.3 GB per document at N = 42, S = 5, T = 512, Hd = 128 -- the reason its batch size is 1.  Nothing of that
+// size exists here:
+//   * the word score tanh(W_s ctx_t + W_p dis_k) . w_a depends only on (token t, distance id k): a [ND, T] table per
+//     document, gathered by the position matrices;
+//   * a sentence slot contributes to E iff token 0 belongs to it (sent_att_padding_matrix = ~sen_matrix[..., 0:1],
+//     glove:305: every other slot is filled with -100000 and relu'd to exactly zero, glove:208-211, forward and
+//     backward) -- only those LIVE slots are computed.  They are compacted into rows (deterministic order); all
+//     per-slot products are GEMMs over the compact rows whose count stays on the device (gemm_dyn);
+//   * the attended word context of a live slot is a softmax-weighted sum of the token states over the slot's token
+//     range only (masked tokens have weight exp(-100000 - max) == 0 exactly).
+// The reference's divisor quirk is kept: the sentence-level sum is divided by the number of PADDED slots + 1e-10
+// (glove:205, 212).
+//
+// Per-slot / per-pair arithmetic runs in wave-per-row kernels (lanes over the Hd feature columns, token states read
+// from L2); backward scatter-adds (token-state, score-table and node-term gradients, shared by many slots) use fp32
+// atomics, so those gradients are reproducible only up to summation order.
+#include "gemm.hpp"
+#include "rowops.hpp"
+
+namespace gc {
+
+constexpr int PW = 4;      // waves per workgroup of the row kernels
+constexpr int PGRID = 2048;  // persistent grid of the row kernels (8 workgroups per CU)
+constexpr int HCMAX = 8;   // Hd <= 64 * HCMAX
+
+struct ProdIdx {           // compact index of the live slots / pairs (device memory, int32)
+  int* doc_counts;         // [B][2] live slots, live pairs per document
+  int* pair_bits;          // [B*N*N] bit s set: slot s of the pair is live
+  int* pair_row0;          // [B*N*N] first compact row of the pair (its live slots are consecutive rows)
+  int* pair_prow;          // [B*N*N] compact pair index, -1: no live slot
+  float* pair_div;         // [B*N*N] padded slots + 1e-10 (glove:205, 212); 0 for padding entities
+  int* row_slot;           // [cap_rows] flat slot index ((b*N + i)*N + j)*S + s of a compact row
+  int* prow_pair;          // [cap_pairs] flat pair index of a compact pair
+  int* counts;             // [4] rows, pairs, overflow flag, unused
+};
+
+__device__ __forceinline__ int pos_at(const void* pos, int pos_bytes, long idx) {
+  return pos_bytes == 8 ? (int)((const long long*)pos)[idx] : (pos_bytes == 4 ? ((const int*)pos)[idx] : (int)((const unsigned char*)pos)[idx]);
+}
+
+// ---- index: pass A, one workgroup per document -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prod_index_a_kernel(const unsigned char* __restrict__ sen, const int* __restrict__ n_valid,
+                                                           ProdIdx ix, int N, int S, int T) {
+  __shared__ int sc[256], sp[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
+  const int NN = N * N;
+  int run_s = 0, run_p = 0;
+  for (int base = 0; base < NN; base += 256) {
+    const int p = base + tid;
+    int bits = 0;
+    if (p < NN) {
+      const int i = p / N, j = p - i * N;
+      if (i < nv && j < nv) {
+        const long s0 = ((long)b * NN + p) * S;
+        for (int s = 0; s < S; ++s)
+          if (sen[(s0 + s) * T] != 0) bits |= 1 << s;
+      }
+    }
+    const int c = __popc(bits), live = c > 0;
+    sc[tid] = c, sp[tid] = live;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {  // inclusive Hillis-Steele scan of both counters
+      const int a = tid >= d ? sc[tid - d] : 0, q = tid >= d ? sp[tid - d] : 0;
+      __syncthreads();
+      sc[tid] += a, sp[tid] += q;
+      __syncthreads();
+    }
+    if (p < NN) {
+      const long pp = (long)b * NN + p;
+      ix.pair_bits[pp] = bits;
+      ix.pair_row0[pp] = run_s + sc[tid] - c;         // local to the document; pass B adds the document's offset
+      ix.pair_prow[pp] = live ? run_p + sp[tid] - 1 : -1;
+    }
+    run_s += sc[255], run_p += sp[255];
+    __syncthreads();
+  }
+  if (tid == 0) ix.doc_counts[2 * b] = run_s, ix.doc_counts[2 * b + 1] = run_p;
+}
+
+// ---- index: pass B, grid (ceil(N*N / 256), B): global rows + inverse maps ------------------------------------------
+__global__ __launch_bounds__(256) void prod_index_b_kernel(const int* __restrict__ n_valid, ProdIdx ix, int B, int N, int S,
+                                                           int cap_rows, int cap_pairs) {
+  __shared__ int off[2], red[2][256];
+  const int b = blockIdx.y, tid = threadIdx.x, NN = N * N;
+  int a = 0, q = 0, ta = 0, tq = 0;
+  for (int d = tid; d < B; d += 256) {
+    const int cs = ix.doc_counts[2 * d], cp = ix.doc_counts[2 * d + 1];
+    if (d < b) a += cs, q += cp;
+    ta += cs, tq += cp;
+  }
+  red[0][tid] = a, red[1][tid] = q;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if (tid < d) red[0][tid] += red[0][tid + d], red[1][tid] += red[1][tid + d];
+    __syncthreads();
+  }
+  if (tid == 0) off[0] = red[0][0], off[1] = red[1][0];
+  __syncthreads();
+  if (blockIdx.x == 0 && b == 0) {  // totals (every thread holds a strided share)
+    __syncthreads();
+    red[0][tid] = ta, red[1][tid] = tq;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+      if (tid < d) red[0][tid] += red[0][tid + d], red[1][tid] += red[1][tid + d];
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const int over = red[0][0] > cap_rows || red[1][0] > cap_pairs;
+      ix.counts[0] = min(red[0][0], cap_rows), ix.counts[1] = min(red[1][0], cap_pairs), ix.counts[2] = over, ix.counts[3] = 0;
+    }
+  }
+  const int p = blockIdx.x * 256 + tid;
+  if (p >= NN) return;
+  const long pp = (long)b * NN + p;
+  const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
+  const int i = p / N, j = p - i * N;
+  const int bits = ix.pair_bits[pp];
+  const int row0 = off[0] + ix.pair_row0[pp];
+  int prow = ix.pair_prow[pp];
+  if (prow >= 0) prow += off[1];
+  const int n = __popc(bits);
+  if (row0 + n > cap_rows || prow >= cap_pairs) {  // over capacity: the pair is dropped (counts[2] reports it)
+    ix.pair_bits[pp] = 0, ix.pair_prow[pp] = -1, ix.pair_row0[pp] = 0;
+    ix.pair_div[pp] = (i < nv && j < nv) ? (float)S + 1e-10f : 0.f;
+    return;
+  }
+  ix.pair_row0[pp] = row0;
+  ix.pair_prow[pp] = prow;
+  ix.pair_div[pp] = (i < nv && j < nv) ? (float)(S - n) + 1e-10f : 0.f;
+  if (prow >= 0) ix.prow_pair[prow] = (int)pp;
+  int k = 0;
+  for (int s = 0; s < S; ++s)
+    if (bits >> s & 1) ix.row_slot[row0 + k++] = (int)(pp * S + s);
+}
+
+// ---- word score table: table[b, k, t] = w_a . tanh(sentF[b, t, :] + disF[k, :]) + b_a   (glove:178-182 folded) ------
+__global__ __launch_bounds__(64 * PW) void prod_table_fwd_kernel(const float* __restrict__ sentF, const float* __restrict__ disF,
+                                                                 const float* __restrict__ wa, float ba_unused,
+                                                                 const float* __restrict__ ba, float* __restrict__ table,
+                                                                 long BT, int T, int Hd, int ND) {
+  const long bt = (long)blockIdx.x * PW + (threadIdx.x >> 6);
+  if (bt >= BT) return;
+  const int lane = threadIdx.x & 63;
+  const long b = bt / T;
+  const int t = (int)(bt - b * T);
+  float sf[HCMAX], w[HCMAX];
+#pragma unroll
+  for (int cc = 0; cc < HCMAX; ++cc) {
+    const int c = lane + 64 * cc;
+    sf[cc] = c < Hd ? sentF[bt * Hd + c] : 0.f;
+    w[cc] = c < Hd ? wa[c] : 0.f;
+  }
+  const float bias = ba[0];
+  for (int k = 0; k < ND; ++k) {
+    float a = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < HCMAX; ++cc) {
+      const int c = lane + 64 * cc;
+      if (c < Hd) a = fmaf(w[cc], tanhf(sf[cc] + disF[(long)k * Hd + c]), a);
+    }
+    a = wave_sum(a);
+    if (lane == 0) table[(b * ND + k) * T + t] = a + bias;
+  }
+}
+
+// ---- word attention of the live slots (glove:184-187): CW[row, side*Hd + c] = sum_t softmax_t(score)[t] ctx[b, t, c] -
+// dynamic LDS: PW * T floats (the un-normalised weights of the wave's slot)
+__global__ __launch_bounds__(64 * PW) void prod_word_fwd_kernel(const float* __restrict__ ctx, const unsigned char* __restrict__ sen,
+                                                                const void* __restrict__ pos_h, const void* __restrict__ pos_t,
+                                                                int pos_bytes, const float* __restrict__ table, ProdIdx ix,
+                                                                float* __restrict__ CW, float* __restrict__ stats, int N, int S,
+                                                                int T, int Hd, int ND) {
+  extern __shared__ float wsm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* ev = wsm + (long)wave * T;
+  const int nrows = ix.counts[0], total = 2 * nrows;
+  const long slots_per_doc = (long)N * N * S;
+  for (int r0 = blockIdx.x * PW; r0 < total; r0 += gridDim.x * PW) {
+    const int r = r0 + wave;
+    const bool on = r < total;
+    int t0 = T, t1 = 0;
+    float inv = 0.f;
+    long b = 0;
+    if (on) {
+      const int row = r >> 1, side = r & 1;
+      const long slot = ix.row_slot[row];
+      b = slot / slots_per_doc;
+      const unsigned char* m = sen + slot * T;
+      const void* pos = side ? pos_t : pos_h;
+      const float* tab = table + b * ND * T;
+      float mx = -INFINITY;
+      for (int t = lane; t < T; t += 64) {
+        float sc = -INFINITY;
+        if (m[t]) {
+          const int k = min(max(pos_at(pos, pos_bytes, slot * T + t), 0), ND - 1);
+          sc = tab[(long)k * T + t];
+          t0 = min(t0, t), t1 = max(t1, t + 1);
+        }
+        ev[t] = sc;
+        mx = fmaxf(mx, sc);
+      }
+      mx = wave_max(mx);
+      t0 = -(int)wave_max((float)-t0), t1 = (int)wave_max((float)t1);   // exact for |t| < 2^24
+      float sum = 0.f;
+      for (int t = lane; t < T; t += 64) {
+        const float e = ev[t] == -INFINITY ? 0.f : expf(ev[t] - mx);   // masked tokens: exp(-100000 - max) == 0 in fp32
+        ev[t] = e;
+        sum += e;
+      }
+      sum = wave_sum(sum);
+      inv = 1.f / sum;
+      if (lane == 0) stats[2 * (long)r] = mx, stats[2 * (long)r + 1] = inv;
+    }
+    __syncthreads();  // ev[] written lane-wise, read by every lane below (uniform trip count: every wave gets here)
+    if (on) {
+      const int row = r >> 1, side = r & 1;
+      const float* cb = ctx + b * T * Hd;
+      for (int c0 = 0; c0 < Hd; c0 += 256) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        int t = t0;
+        for (; t + 3 < t1; t += 4) {  // four token rows in flight
+          float x[4][4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+              const int c = c0 + lane + 64 * cc;
+              x[u][cc] = c < Hd ? cb[(long)(t + u) * Hd + c] : 0.f;
+            }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float e = ev[t + u];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) acc[cc] = fmaf(e, x[u][cc], acc[cc]);
+          }
+        }
+        for (; t < t1; ++t) {
+          const float e = ev[t];
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            const int c = c0 + lane + 64 * cc;
+            if (c < Hd) acc[cc] = fmaf(e, cb[(long)t * Hd + c], acc[cc]);
+          }
+        }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int c = c0 + lane + 64 * cc;
+          if (c < Hd) CW[(long)row * 2 * Hd + side * Hd + c] = acc[cc] * inv;
+        }
+      }
+    }
+    __syncthreads();  // before the next slot overwrites ev[]
+  }
+  // rows [nrows, roundup64(nrows)) feed the K-dynamic GEMMs as zeros
+  if (blockIdx.x == 0) {
+    const int hi = (nrows + 63) & ~63;
+    for (long e = (long)nrows * 2 * Hd + threadIdx.x; e < (long)hi * 2 * Hd; e += 64 * PW) CW[e] = 0.f;
+  }
+}
+
+// ---- sentence attention of the live pairs (glove:201-212) ----------------------------------------------------------
+//   score_h[s] = w . tanh(sfeat[row] + nterm[b, j]) + c,  score_t[s] uses nterm[b, i];  att = relu(score)
+//   CS[prow] = [ sum_s att_h[s] cwa[row] / div | sum_s att_t[s] cwa[row] / div ]
+__global__ __launch_bounds__(64 * PW) void prod_sent_fwd_kernel(const float* __restrict__ sfeat, const float* __restrict__ cwa,
+                                                                const float* __restrict__ nterm, const float* __restrict__ wsa,
+                                                                const float* __restrict__ bsa, ProdIdx ix,
+                                                                float* __restrict__ CS, float* __restrict__ score, int N, int Hd) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int npairs = ix.counts[1];
+  const long NN = (long)N * N;
+  float w[HCMAX];
+#pragma unroll
+  for (int cc = 0; cc < HCMAX; ++cc) w[cc] = (lane + 64 * cc) < Hd ? wsa[lane + 64 * cc] : 0.f;
+  const float bias = bsa[0];
+  for (int prow = blockIdx.x * PW + wave; prow < npairs; prow += gridDim.x * PW) {
+    const long pair = ix.prow_pair[prow];
+    const long b = pair / NN;
+    const int ij = (int)(pair - b * NN), i = ij / N, j = ij - i * N;
+    const int row0 = ix.pair_row0[pair], n = __popc(ix.pair_bits[pair]);
+    const float div = ix.pair_div[pair];
+    const float* nj = nterm + (b * N + j) * Hd;   // head side: node_feat.unsqueeze(0) -> indexed by the column entity
+    const float* ni = nterm + (b * N + i) * Hd;   // tail side: node_feat.unsqueeze(1) -> indexed by the row entity
+    float nh[HCMAX], nt[HCMAX], ch[HCMAX], ct[HCMAX];
+#pragma unroll
+    for (int cc = 0; cc < HCMAX; ++cc) {
+      const int c = lane + 64 * cc;
+      nh[cc] = c < Hd ? nj[c] : 0.f, nt[cc] = c < Hd ? ni[c] : 0.f, ch[cc] = 0.f, ct[cc] = 0.f;
+    }
+    for (int k = 0; k < n; ++k) {
+      const long row = row0 + k;
+      float ph = 0.f, pt = 0.f, cw[HCMAX];
+#pragma unroll
+      for (int cc = 0; cc < HCMAX; ++cc) {
+        const int c = lane + 64 * cc;
+        cw[cc] = 0.f;
+        if (c < Hd) {
+          const float sf = sfeat[row * Hd + c];
+          cw[cc] = cwa[row * Hd + c];
+          ph = fmaf(w[cc], tanhf(sf + nh[cc]), ph);
+          pt = fmaf(w[cc], tanhf(sf + nt[cc]), pt);
+        }
+      }
+      const float sh = wave_sum(ph) + bias, st = wave_sum(pt) + bias;
+      if (lane == 0) score[2 * row] = sh, score[2 * row + 1] = st;
+      const float ah = fmaxf(sh, 0.f), at = fmaxf(st, 0.f);
+#pragma unroll
+      for (int cc = 0; cc < HCMAX; ++cc) ch[cc] = fmaf(ah, cw[cc], ch[cc]), ct[cc] = fmaf(at, cw[cc], ct[cc]);
+    }
+#pragma unroll
+    for (int cc = 0; cc < HCMAX; ++cc) {
+      const int c = lane + 64 * cc;
+      if (c < Hd) CS[(long)prow * 2 * Hd + c] = ch[cc] / div, CS[(long)prow * 2 * Hd + Hd + c] = ct[cc] / div;
+    }
+  }
+  if (blockIdx.x == 0) {
+    const int hi = (npairs + 63) & ~63;
+    for (long e = (long)npairs * 2 * Hd + threadIdx.x; e < (long)hi * 2 * Hd; e += 64 * PW) CS[e] = 0.f;
+  }
+}
+
+// ---- E[b, i, j, :] = Ec[prow] for pairs with a live slot, the bias of linear_sentence_att for the others (their
+// sentence sums are exactly zero), 0 for padding entities.  One workgroup per entity row (b, i).
+__global__ __launch_bounds__(256) void prod_expand_kernel(const float* __restrict__ Ec, const float* __restrict__ bls,
+                                                          const int* __restrict__ n_valid, const int* __restrict__ pair_prow,
+                                                          float* __restrict__ E, int N, int Hd) {
+  const long bi = blockIdx.x;
+  const long b = bi / N;
+  const int i = (int)(bi - b * N);
+  const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
+  const long tot = (long)N * Hd;
+  for (long e = threadIdx.x; e < tot; e += 256) {
+    const int j = (int)(e / Hd), c = (int)(e - (long)j * Hd);
+    float v = 0.f;
+    if (i < nv && j < nv) {
+      const int prow = pair_prow[bi * N + j];
+      v = prow >= 0 ? Ec[(long)prow * Hd + c] : bls[c];
+    }
+    E[bi * tot + e] = v;
+  }
+}
+
+// ---- backward: dEc[prow] = dE[pair];  wpair[pair] = 1 for real pairs (weights of the bias-gradient column sum) -----
+__global__ __launch_bounds__(64 * PW) void prod_gather_kernel(const float* __restrict__ dE, ProdIdx ix, float* __restrict__ dEc,
+                                                              int Hd) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int npairs = ix.counts[1];
+  for (int prow = blockIdx.x * PW + wave; prow < npairs; prow += gridDim.x * PW) {
+    const long pair = ix.prow_pair[prow];
+    for (int c = lane; c < Hd; c += 64) dEc[(long)prow * Hd + c] = dE[pair * Hd + c];
+  }
+  if (blockIdx.x == 0) {
+    const int hi = (npairs + 63) & ~63;
+    for (long e = (long)npairs * Hd + threadIdx.x; e < (long)hi * Hd; e += 64 * PW) dEc[e] = 0.f;
+  }
+}
+
+// ---- backward of the sentence attention ------------------------------------------------------------------------------
+//   in : dCS[prow] = [dcs_h | dcs_t];  out: dcwa[row] (attention-weighted part), dsfeat[row], dnterm += (atomics),
+//        dwb[0..Hd) += d w, dwb[Hd] += d c (atomics, once per workgroup).  dynamic LDS: (Hd + 1) floats.
+__global__ __launch_bounds__(64 * PW) void prod_sent_bwd_kernel(const float* __restrict__ sfeat, const float* __restrict__ cwa,
+                                                                const float* __restrict__ nterm, const float* __restrict__ wsa,
+                                                                const float* __restrict__ score, const float* __restrict__ dCS,
+                                                                ProdIdx ix, float* __restrict__ dcwa, float* __restrict__ dsfeat,
+                                                                float* __restrict__ dnterm, float* __restrict__ dwb, int N, int Hd) {
+  extern __shared__ float sacc[];  // [Hd + 1]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = threadIdx.x; c <= Hd; c += 64 * PW) sacc[c] = 0.f;
+  __syncthreads();
+  const int npairs = ix.counts[1], nrows = ix.counts[0];
+  const long NN = (long)N * N;
+  float w[HCMAX], dw[HCMAX];
+#pragma unroll
+  for (int cc = 0; cc < HCMAX; ++cc) w[cc] = (lane + 64 * cc) < Hd ? wsa[lane + 64 * cc] : 0.f, dw[cc] = 0.f;
+  float dbias = 0.f;
+  for (int prow = blockIdx.x * PW + wave; prow < npairs; prow += gridDim.x * PW) {
+    const long pair = ix.prow_pair[prow];
+    const long b = pair / NN;
+    const int ij = (int)(pair - b * NN), i = ij / N, j = ij - i * N;
+    const int row0 = ix.pair_row0[pair], n = __popc(ix.pair_bits[pair]);
+    const float div = ix.pair_div[pair];
+    const long oj = (b * N + j) * Hd, oi = (b * N + i) * Hd;
+    float nh[HCMAX], nt[HCMAX], gh[HCMAX], gt[HCMAX], dnh[HCMAX], dnt[HCMAX];
+#pragma unroll
+    for (int cc = 0; cc < HCMAX; ++cc) {
+      const int c = lane + 64 * cc;
+      nh[cc] = c < Hd ? nterm[oj + c] : 0.f, nt[cc] = c < Hd ? nterm[oi + c] : 0.f;
+      gh[cc] = c < Hd ? dCS[(long)prow * 2 * Hd + c] / div : 0.f;          // d(sum_s att_h cwa)
+      gt[cc] = c < Hd ? dCS[(long)prow * 2 * Hd + Hd + c] / div : 0.f;
+      dnh[cc] = 0.f, dnt[cc] = 0.f;
+    }
+    for (int k = 0; k < n; ++k) {
+      const long row = row0 + k;
+      const float sh = score[2 * row], st = score[2 * row + 1];
+      const float ah = fmaxf(sh, 0.f), at = fmaxf(st, 0.f);
+      float cw[HCMAX], zh[HCMAX], zt[HCMAX], ph = 0.f, pt = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < HCMAX; ++cc) {
+        const int c = lane + 64 * cc;
+        cw[cc] = 0.f, zh[cc] = 0.f, zt[cc] = 0.f;
+        if (c < Hd) {
+          const float sf = sfeat[row * Hd + c];
+          cw[cc] = cwa[row * Hd + c];
+          zh[cc] = tanhf(sf + nh[cc]), zt[cc] = tanhf(sf + nt[cc]);
+          ph = fmaf(gh[cc], cw[cc], ph), pt = fmaf(gt[cc], cw[cc], pt);
+        }
+      }
+      // d att -> d score through relu (score <= 0: zero gradient, as torch.relu)
+      const float dsh = sh > 0.f ? wave_sum(ph) : 0.f, dst = st > 0.f ? wave_sum(pt) : 0.f;
+      dbias += dsh + dst;
+#pragma unroll
+      for (int cc = 0; cc < HCMAX; ++cc) {
+        const int c = lane + 64 * cc;
+        if (c < Hd) {
+          const float dzh = dsh * w[cc] * (1.f - zh[cc] * zh[cc]), dzt = dst * w[cc] * (1.f - zt[cc] * zt[cc]);
+          dcwa[row * Hd + c] = ah * gh[cc] + at * gt[cc];
+          dsfeat[row * Hd + c] = dzh + dzt;
+          dnh[cc] += dzh, dnt[cc] += dzt;
+          dw[cc] = fmaf(dsh, zh[cc], fmaf(dst, zt[cc], dw[cc]));
+        }
+      }
+    }
+#pragma unroll
+    for (int cc = 0; cc < HCMAX; ++cc) {
+      const int c = lane + 64 * cc;
+      if (c < Hd) {
+        atomicAdd(dnterm + oj + c, dnh[cc]);
+        atomicAdd(dnterm + oi + c, dnt[cc]);
+      }
+    }
+  }
+#pragma unroll
+  for (int cc = 0; cc < HCMAX; ++cc)
+    if ((lane + 64 * cc) < Hd) atomicAdd(&sacc[lane + 64 * cc], dw[cc]);
+  if (lane == 0) atomicAdd(&sacc[Hd], dbias);   // every lane holds the same dbias
+  __syncthreads();
+  for (int c = threadIdx.x; c <= Hd; c += 64 * PW)
+    if (sacc[c] != 0.f) atomicAdd(dwb + c, sacc[c]);
+  if (blockIdx.x == 0) {
+    const int hi = (nrows + 63) & ~63;
+    for (long e = (long)nrows * Hd + threadIdx.x; e < (long)hi * Hd; e += 64 * PW) dcwa[e] = 0.f, dsfeat[e] = 0.f;
+  }
+}
+
+// ---- backward of the word attention --------------------------------------------------------------------------------
+//   dcw = dCW[row, side]: g[t] = dcw . ctx[t];  dscore[t] = att[t] (g[t] - sum_t att g);  dtable[b, pos[t], t] += dscore
+//   dctx[b, t, :] += att[t] dcw          (atomics: many slots share a token / a table entry)
+// dynamic LDS: PW * 2 * T floats (weights, then g)
+__global__ __launch_bounds__(64 * PW) void prod_word_bwd_kernel(const float* __restrict__ ctx, const unsigned char* __restrict__ sen,
+                                                                const void* __restrict__ pos_h, const void* __restrict__ pos_t,
+                                                                int pos_bytes, const float* __restrict__ table,
+                                                                const float* __restrict__ stats, const float* __restrict__ dCW,
+                                                                ProdIdx ix, float* __restrict__ dtable, float* __restrict__ dctx,
+                                                                int N, int S, int T, int Hd, int ND) {
+  extern __shared__ float wsm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* av = wsm + (long)wave * 2 * T;  // att[t]
+  float* gv = av + T;                    // g[t]
+  const int nrows = ix.counts[0], total = 2 * nrows;
+  const long slots_per_doc = (long)N * N * S;
+  for (int r0 = blockIdx.x * PW; r0 < total; r0 += gridDim.x * PW) {
+    const int r = r0 + wave;
+    const bool on = r < total;
+    int t0 = T, t1 = 0;
+    long b = 0, slot = 0;
+    const void* pos = pos_h;
+    if (on) {
+      const int row = r >> 1, side = r & 1;
+      slot = ix.row_slot[row];
+      b = slot / slots_per_doc;
+      pos = side ? pos_t : pos_h;
+      const unsigned char* m = sen + slot * T;
+      const float* tab = table + b * ND * T;
+      const float mx = stats[2 * (long)r], inv = stats[2 * (long)r + 1];
+      for (int t = lane; t < T; t += 64) {
+        float a = 0.f;
+        if (m[t]) {
+          const int k = min(max(pos_at(pos, pos_bytes, slot * T + t), 0), ND - 1);
+          a = expf(tab[(long)k * T + t] - mx) * inv;
+          t0 = min(t0, t), t1 = max(t1, t + 1);
+        }
+        av[t] = a;
+      }
+      t0 = -(int)wave_max((float)-t0), t1 = (int)wave_max((float)t1);
+    }
+    __syncthreads();
+    float dotsum = 0.f;
+    if (on) {
+      const int row = r >> 1, side = r & 1;
+      const float* cb = ctx + b * T * Hd;
+      float* db = dctx + b * T * Hd;
+      float dcw[HCMAX];
+#pragma unroll
+      for (int cc = 0; cc < HCMAX; ++cc) dcw[cc] = (lane + 64 * cc) < Hd ? dCW[(long)row * 2 * Hd + side * Hd + lane + 64 * cc] : 0.f;
+      for (int t = t0; t < t1; t += 4) {  // four tokens at a time: independent loads, interleaved reductions
+        float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int tt = min(t + u, t1 - 1);
+#pragma unroll
+          for (int cc = 0; cc < HCMAX; ++cc) {
+            const int c = lane + 64 * cc;
+            if (c < Hd) p[u] = fmaf(dcw[cc], cb[(long)tt * Hd + c], p[u]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float g = wave_sum(p[u]);
+          if (t + u < t1) {
+            const float a = av[t + u];
+            if (lane == 0) gv[t + u] = g;
+            dotsum = fmaf(a, g, dotsum);
+            if (a != 0.f) {
+#pragma unroll
+              for (int cc = 0; cc < HCMAX; ++cc) {
+                const int c = lane + 64 * cc;
+                if (c < Hd) atomicAdd(db + (long)(t + u) * Hd + c, a * dcw[cc]);
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (on) {
+      float* dt = dtable + b * ND * T;
+      for (int t = t0 + lane; t < t1; t += 64) {
+        const float a = av[t];
+        if (a != 0.f) {
+          const int k = min(max(pos_at(pos, pos_bytes, slot * T + t), 0), ND - 1);
+          atomicAdd(dt + (long)k * T + t, a * (gv[t] - dotsum));
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- backward of the score table ------------------------------------------------------------------------------------
+//   dsentF[b, t, c] = sum_k dtable[b,k,t] w_a[c] (1 - z^2),  ddisF[k, c] += (same, summed over b, t),  dwab[c] += dtable z,
+//   dwab[Hd] += dtable          z = tanh(sentF[b,t,c] + disF[k,c]).   dynamic LDS: (ND * Hd + Hd + 1) floats.
+__global__ __launch_bounds__(64 * PW) void prod_table_bwd_kernel(const float* __restrict__ sentF, const float* __restrict__ disF,
+                                                                 const float* __restrict__ wa, const float* __restrict__ dtable,
+                                                                 float* __restrict__ dsentF, float* __restrict__ ddisF,
+                                                                 float* __restrict__ dwab, long BT, int T, int Hd, int ND) {
+  extern __shared__ float sacc[];  // [ND][Hd] ddisF partial | [Hd] dwa | [1] dba
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tot = ND * Hd + Hd + 1;
+  for (int e = threadIdx.x; e < tot; e += 64 * PW) sacc[e] = 0.f;
+  __syncthreads();
+  float w[HCMAX], dw[HCMAX];
+#pragma unroll
+  for (int cc = 0; cc < HCMAX; ++cc) w[cc] = (lane + 64 * cc) < Hd ? wa[lane + 64 * cc] : 0.f, dw[cc] = 0.f;
+  float dbias = 0.f;
+  for (long bt = (long)blockIdx.x * PW + wave; bt < BT; bt += (long)gridDim.x * PW) {
+    const long b = bt / T;
+    const int t = (int)(bt - b * T);
+    float sf[HCMAX], ds[HCMAX];
+#pragma unroll
+    for (int cc = 0; cc < HCMAX; ++cc) sf[cc] = (lane + 64 * cc) < Hd ? sentF[bt * Hd + lane + 64 * cc] : 0.f, ds[cc] = 0.f;
+    for (int k = 0; k < ND; ++k) {
+      const float g = dtable[(b * ND + k) * T + t];   // uniform over the wave
+      if (g == 0.f) continue;
+      dbias += g;
+#pragma unroll
+      for (int cc = 0; cc < HCMAX; ++cc) {
+        const int c = lane + 64 * cc;
+        if (c < Hd) {
+          const float z = tanhf(sf[cc] + disF[(long)k * Hd + c]);
+          const float d = g * w[cc] * (1.f - z * z);
+          ds[cc] += d;
+          atomicAdd(&sacc[k * Hd + c], d);
+          dw[cc] = fmaf(g, z, dw[cc]);
+        }
+      }
+    }
+#pragma unroll
+    for (int cc = 0; cc < HCMAX; ++cc)
+      if ((lane + 64 * cc) < Hd) dsentF[bt * Hd + lane + 64 * cc] = ds[cc];
+  }
+#pragma unroll
+  for (int cc = 0; cc < HCMAX; ++cc)
+    if ((lane + 64 * cc) < Hd) atomicAdd(&sacc[ND * Hd + lane + 64 * cc], dw[cc]);
+  if (lane == 0) atomicAdd(&sacc[ND * Hd + Hd], dbias);
+  __syncthreads();
+  for (int e = threadIdx.x; e < ND * Hd; e += 64 * PW)
+    if (sacc[e] != 0.f) atomicAdd(ddisF + e, sacc[e]);
+  for (int e = threadIdx.x; e <= Hd; e += 64 * PW)
+    if (sacc[ND * Hd + e] != 0.f) atomicAdd(dwab + e, sacc[ND * Hd + e]);
+}
+
+// ---- column sums over the compact rows (bias gradients): part[slice][C], then out[c] = sum of the slices in order ----
+constexpr int DCS = 64;
+__global__ __launch_bounds__(256) void prod_colsum_dyn_kernel(const float* __restrict__ X, const int* __restrict__ cnt, int C,
+                                                              float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane, sp = blockIdx.y;
+  const long R = *cnt, rps = (R + DCS - 1) / DCS;
+  const long r0 = sp * rps, r1 = min(R, r0 + rps);
+  float acc = 0.f;
+  if (c < C)
+    for (long r = r0 + wave; r < r1; r += 4) acc += X[r * C + c];
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && c < C) part[(long)sp * C + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+__global__ __launch_bounds__(256) void prod_colsum_fin_kernel(const float* __restrict__ part, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int q = 0; q < DCS; ++q) s += part[(long)q * C + c];
+  out[c] = s;
+}
+
+// =====================================================================================================================
+// host side
+// =====================================================================================================================
+struct ProdLayout {  // offsets (floats) inside the block's flat parameter buffer; reference tensors keep their [out, in] layout
+  long Ws, bs, Wp, bp, wa, ba;           // word_attention.{attention_sent, attention_pos, attention_all}
+  long Wlw, blw;                         // linear_word_att            [Hd, 2Hd]
+  long Wss, bss, Wsp, bsp, wsa, bsa;     // sentence_attention.{attention_sent, attention_pos, attention_all}
+  long Wls, bls;                         // linear_sentence_att        [Hd, 2Hd]
+  long total;
+};
+ProdLayout prod_layout(int Hd, int P) {
+  ProdLayout y;
+  long o = 0;
+  auto take = [&](long n) { const long at = o; o += n; return at; };
+  y.Ws = take((long)Hd * Hd), y.bs = take(Hd), y.Wp = take((long)Hd * P), y.bp = take(Hd), y.wa = take(Hd), y.ba = take(1);
+  y.Wlw = take(2L * Hd * Hd), y.blw = take(Hd);
+  y.Wss = take((long)Hd * Hd), y.bss = take(Hd), y.Wsp = take((long)Hd * Hd), y.bsp = take(Hd), y.wsa = take(Hd), y.bsa = take(1);
+  y.Wls = take(2L * Hd * Hd), y.bls = take(Hd);
+  y.total = o;
+  return y;
+}
+
+static long up64(long v) { return (v + 63) & ~63L; }
+
+int prod_index(const unsigned char* sen, const int* n_valid, ProdIdx ix, int B, int N, int S, int T, long cap_rows, long cap_pairs,
+               hipStream_t st) {
+  GC_REQUIRE(S >= 1 && S <= 31, "producer: %d sentence slots per pair (1..31 supported)", S);
+  GC_REQUIRE((long)B * N * N * S < (1L << 31), "producer: B*N*N*S exceeds 32-bit slot indices");
+  ProfScope ps("prod_index", st);
+  hipLaunchKernelGGL(prod_index_a_kernel, dim3(B), dim3(256), 0, st, sen, n_valid, ix, N, S, T);
+  if (int e = check_launch("prod_index_a")) return e;
+  hipLaunchKernelGGL(prod_index_b_kernel, dim3(cdiv((long)N * N, 256), B), dim3(256), 0, st, n_valid, ix, B, N, S, (int)cap_rows,
+                     (int)cap_pairs);
+  return check_launch("prod_index_b");
+}
+
+static int linear_fwd(const float* X, long M, int K, const float* W, const float* bias, int Nout, float* Y, float* ws, long wse,
+                      hipStream_t st, const int* cnt = nullptr, long cap = 0) {  // Y = X W^T + b, W stored [Nout, K]
+  GemmArgs g;
+  g.A = X, g.lda = K, g.a_kc = 1;
+  g.B = W, g.ldb = K, g.b_kc = 1;
+  g.C = Y, g.ldc = Nout;
+  g.M = (int)M, g.N = Nout, g.K = K;
+  g.bias = bias;
+  g.ws = ws, g.ws_elems = wse;
+  g.tag = "prod_gemm";
+  return cnt ? gemm_dyn(g, cnt, 1, cap, st) : gemm(g, st);
+}
+// dX (+)= dY W          (W stored [Nout, K]: the "N" form with k = Nout)
+static int linear_bwd_x(const float* dY, long M, int Nout, const float* W, int K, float* dX, int accumulate, float* ws, long wse,
+                        hipStream_t st, const int* cnt = nullptr, long cap = 0) {
+  GemmArgs g;
+  g.A = dY, g.lda = Nout, g.a_kc = 1;
+  g.B = W, g.ldb = K, g.b_kc = 0;
+  g.C = dX, g.ldc = K;
+  g.M = (int)M, g.N = K, g.K = Nout;
+  g.accumulate = accumulate;
+  g.ws = ws, g.ws_elems = wse;
+  g.tag = "prod_gemm";
+  return cnt ? gemm_dyn(g, cnt, 1, cap, st) : gemm(g, st);
+}
+// dW[Nout, K] = dY^T X   (rows = the reduction dimension)
+static int linear_bwd_w(const float* dY, const float* X, long M, int Nout, int K, float* dW, float* ws, long wse, hipStream_t st,
+                        const int* cnt = nullptr, long cap = 0) {
+  GemmArgs g;
+  g.A = dY, g.lda = Nout, g.a_kc = 0;
+  g.B = X, g.ldb = K, g.b_kc = 0;
+  g.C = dW, g.ldc = K;
+  g.M = Nout, g.N = K, g.K = (int)M;
+  g.ws = ws, g.ws_elems = wse;
+  g.tag = "prod_gemm";
+  return cnt ? gemm_dyn(g, cnt, 2, cap, st) : gemm(g, st);
+}
+
+struct ProdBufs {  // caller-owned device memory (include/gcgcn.h lists the sizes)
+  float *sentF, *disF, *table, *CW, *stats, *cwa, *sfeat, *nterm, *score, *CS, *Ec;
+};
+
+int prod_fwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx, const unsigned char* sen, const void* pos_h,
+             const void* pos_t, int pos_bytes, const float* node, const float* dis_table, const int* n_valid, const float* flat,
+             ProdIdx ix, long cap_rows, long cap_pairs, ProdBufs w, float* E, float* ws, long wse, hipStream_t st) {
+  GC_REQUIRE(Hd >= 1 && Hd <= 64 * HCMAX, "producer: hidden width %d (1..%d supported)", Hd, 64 * HCMAX);
+  GC_REQUIRE(pos_bytes == 8 || pos_bytes == 4 || pos_bytes == 1, "producer: position ids must be int64, int32 or uint8");
+  GC_REQUIRE((size_t)PW * 2 * T * sizeof(float) <= 64 * 1024, "producer: T=%d tokens exceed the LDS budget", T);
+  const ProdLayout y = prod_layout(Hd, P);
+  const long BT = (long)B * T;
+  GC_TRY(linear_fwd(ctx, BT, Hd, flat + y.Ws, flat + y.bs, Hd, w.sentF, ws, wse, st));          // glove:178
+  GC_TRY(linear_fwd(dis_table, ND, P, flat + y.Wp, flat + y.bp, Hd, w.disF, ws, wse, st));      // glove:179 on the 21 ids
+  {
+    ProfScope ps("prod_table", st);
+    hipLaunchKernelGGL(prod_table_fwd_kernel, dim3(cdiv(BT, PW)), dim3(64 * PW), 0, st, w.sentF, w.disF, flat + y.wa, 0.f,
+                       flat + y.ba, w.table, BT, T, Hd, ND);
+    GC_TRY(check_launch("prod_table_fwd"));
+  }
+  GC_TRY(prod_index(sen, n_valid, ix, B, N, S, T, cap_rows, cap_pairs, st));
+  {
+    ProfScope ps("prod_word", st);
+    hipLaunchKernelGGL(prod_word_fwd_kernel, dim3(PGRID), dim3(64 * PW), (size_t)PW * T * sizeof(float), st, ctx, sen, pos_h, pos_t,
+                       pos_bytes, w.table, ix, w.CW, w.stats, N, S, T, Hd, ND);
+    GC_TRY(check_launch("prod_word_fwd"));
+  }
+  GC_TRY(linear_fwd(w.CW, 0, 2 * Hd, flat + y.Wlw, flat + y.blw, Hd, w.cwa, ws, wse, st, ix.counts, cap_rows));       // :320-321
+  GC_TRY(linear_fwd(w.cwa, 0, Hd, flat + y.Wss, flat + y.bss, Hd, w.sfeat, ws, wse, st, ix.counts, cap_rows));        // :201
+  GC_TRY(linear_fwd(node, (long)B * N, Hd, flat + y.Wsp, flat + y.bsp, Hd, w.nterm, ws, wse, st));                    // :202 per entity
+  {
+    ProfScope ps("prod_sent", st);
+    hipLaunchKernelGGL(prod_sent_fwd_kernel, dim3(PGRID), dim3(64 * PW), 0, st, w.sfeat, w.cwa, w.nterm, flat + y.wsa, flat + y.bsa,
+                       ix, w.CS, w.score, N, Hd);
+    GC_TRY(check_launch("prod_sent_fwd"));
+  }
+  GC_TRY(linear_fwd(w.CS, 0, 2 * Hd, flat + y.Wls, flat + y.bls, Hd, w.Ec, ws, wse, st, ix.counts + 1, cap_pairs));   // :329-330
+  {
+    ProfScope ps("prod_expand", st, 4.0 * B * N * N * Hd);
+    hipLaunchKernelGGL(prod_expand_kernel, dim3((unsigned)((long)B * N)), dim3(256), 0, st, w.Ec, flat + y.bls, n_valid, ix.pair_prow,
+                       E, N, Hd);
+    GC_TRY(check_launch("prod_expand"));
+  }
+  return 0;
+}
+
+struct ProdGrads {  // caller-owned workspace of the backward pass
+  float *dEc, *dCS, *dcwa, *dsfeat, *dnterm, *dCW, *dtable, *dsentF, *ddisF, *dwb, *part, *wpair;
+};
+
+static int colsum_dyn(const float* X, const int* cnt, int C, float* part, float* out, hipStream_t st) {
+  ProfScope ps("prod_colsum", st);
+  hipLaunchKernelGGL(prod_colsum_dyn_kernel, dim3(cdiv(C, 64), DCS), dim3(256), 0, st, X, cnt, C, part);
+  if (int e = check_launch("prod_colsum_dyn")) return e;
+  hipLaunchKernelGGL(prod_colsum_fin_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, C, out);
+  return check_launch("prod_colsum_fin");
+}
+
+int prod_bwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx, const unsigned char* sen, const void* pos_h,
+             const void* pos_t, int pos_bytes, const float* node, const float* dis_table, const int* n_valid, const float* flat,
+             ProdIdx ix, long cap_rows, long cap_pairs, ProdBufs w, const float* dE, ProdGrads g, float* dctx, float* dnode,
+             float* ddis_table, float* dflat, float* ws, long wse, hipStream_t st) {
+  const ProdLayout y = prod_layout(Hd, P);
+  const long BT = (long)B * T, BN = (long)B * N, BNN = BN * N;
+  const int* nrows = ix.counts;
+  const int* npairs = ix.counts + 1;
+  // zero the atomics' targets
+  GC_REQUIRE(hipMemsetAsync(dctx, 0, sizeof(float) * BT * Hd, st) == hipSuccess, "producer: memset failed");
+  GC_REQUIRE(hipMemsetAsync(g.dnterm, 0, sizeof(float) * BN * Hd, st) == hipSuccess, "producer: memset failed");
+  GC_REQUIRE(hipMemsetAsync(g.dtable, 0, sizeof(float) * B * ND * T, st) == hipSuccess, "producer: memset failed");
+  GC_REQUIRE(hipMemsetAsync(g.ddisF, 0, sizeof(float) * ND * Hd, st) == hipSuccess, "producer: memset failed");
+  GC_REQUIRE(hipMemsetAsync(g.dwb, 0, sizeof(float) * 2 * (Hd + 1), st) == hipSuccess, "producer: memset failed");
+  // linear_sentence_att: E = CS W_ls^T + b_ls on live pairs, b_ls on every other real pair
+  {
+    ProfScope ps("prod_gather", st);
+    hipLaunchKernelGGL(prod_gather_kernel, dim3(PGRID), dim3(64 * PW), 0, st, dE, ix, g.dEc, Hd);
+    GC_TRY(check_launch("prod_gather"));
+  }
+  // d b_ls = sum over real pairs of dE (padding pairs hold a constant 0: their gradient is ignored)
+  GC_TRY(colsum(dE, n_valid ? g.wpair : nullptr, dflat + y.bls, BNN, Hd, Hd, 1, 0, 0, 0, 0, ws, st));
+  GC_TRY(linear_bwd_w(g.dEc, w.CS, 0, Hd, 2 * Hd, dflat + y.Wls, ws, wse, st, npairs, cap_pairs));
+  GC_TRY(linear_bwd_x(g.dEc, 0, Hd, flat + y.Wls, 2 * Hd, g.dCS, 0, ws, wse, st, npairs, cap_pairs));
+  {
+    ProfScope ps("prod_sent", st);
+    hipLaunchKernelGGL(prod_sent_bwd_kernel, dim3(PGRID), dim3(64 * PW), sizeof(float) * (Hd + 1), st, w.sfeat, w.cwa, w.nterm,
+                       flat + y.wsa, w.score, g.dCS, ix, g.dcwa, g.dsfeat, g.dnterm, g.dwb, N, Hd);
+    GC_TRY(check_launch("prod_sent_bwd"));
+  }
+  GC_REQUIRE(hipMemcpyAsync(dflat + y.wsa, g.dwb, sizeof(float) * (Hd + 1), hipMemcpyDeviceToDevice, st) == hipSuccess,
+             "producer: copy failed");   // wsa | bsa are adjacent in the layout
+  // sentence_attention.attention_sent / attention_pos
+  GC_TRY(linear_bwd_w(g.dsfeat, w.cwa, 0, Hd, Hd, dflat + y.Wss, ws, wse, st, nrows, cap_rows));
+  GC_TRY(colsum_dyn(g.dsfeat, nrows, Hd, g.part, dflat + y.bss, st));
+  GC_TRY(linear_bwd_x(g.dsfeat, 0, Hd, flat + y.Wss, Hd, g.dcwa, 1, ws, wse, st, nrows, cap_rows));   // dcwa += dsfeat W_ss
+  GC_TRY(linear_bwd_w(g.dnterm, node, BN, Hd, Hd, dflat + y.Wsp, ws, wse, st));
+  GC_TRY(colsum(g.dnterm, nullptr, dflat + y.bsp, BN, Hd, Hd, 1, 0, 0, 0, 0, ws, st));
+  GC_TRY(linear_bwd_x(g.dnterm, BN, Hd, flat + y.Wsp, Hd, dnode, 0, ws, wse, st));
+  // linear_word_att
+  GC_TRY(linear_bwd_w(g.dcwa, w.CW, 0, Hd, 2 * Hd, dflat + y.Wlw, ws, wse, st, nrows, cap_rows));
+  GC_TRY(colsum_dyn(g.dcwa, nrows, Hd, g.part, dflat + y.blw, st));
+  GC_TRY(linear_bwd_x(g.dcwa, 0, Hd, flat + y.Wlw, 2 * Hd, g.dCW, 0, ws, wse, st, nrows, cap_rows));
+  // word attention -> score table and token states
+  {
+    ProfScope ps("prod_word", st);
+    hipLaunchKernelGGL(prod_word_bwd_kernel, dim3(PGRID), dim3(64 * PW), (size_t)PW * 2 * T * sizeof(float), st, ctx, sen, pos_h,
+                       pos_t, pos_bytes, w.table, w.stats, g.dCW, ix, g.dtable, dctx, N, S, T, Hd, ND);
+    GC_TRY(check_launch("prod_word_bwd"));
+  }
+  {
+    ProfScope ps("prod_table", st);
+    const int grid = (int)(cdiv(BT, PW) < 1024 ? cdiv(BT, PW) : 1024);
+    hipLaunchKernelGGL(prod_table_bwd_kernel, dim3(grid), dim3(64 * PW), sizeof(float) * ((size_t)ND * Hd + Hd + 1), st, w.sentF,
+                       w.disF, flat + y.wa, g.dtable, g.dsentF, g.ddisF, g.dwb + Hd + 1, BT, T, Hd, ND);
+    GC_TRY(check_launch("prod_table_bwd"));
+  }
+  GC_REQUIRE(hipMemcpyAsync(dflat + y.wa, g.dwb + Hd + 1, sizeof(float) * (Hd + 1), hipMemcpyDeviceToDevice, st) == hipSuccess,
+             "producer: copy failed");   // wa | ba adjacent
+  // word_attention.attention_sent / attention_pos
+  GC_TRY(linear_bwd_w(g.dsentF, ctx, BT, Hd, Hd, dflat + y.Ws, ws, wse, st));
+  GC_TRY(colsum(g.dsentF, nullptr, dflat + y.bs, BT, Hd, Hd, 1, 0, 0, 0, 0, ws, st));
+  GC_TRY(linear_bwd_x(g.dsentF, BT, Hd, flat + y.Ws, Hd, dctx, 1, ws, wse, st));                     // dctx += dsentF W_s
+  GC_TRY(linear_bwd_w(g.ddisF, dis_table, ND, Hd, P, dflat + y.Wp, ws, wse, st));
+  GC_TRY(colsum(g.ddisF, nullptr, dflat + y.bp, ND, Hd, Hd, 1, 0, 0, 0, 0, ws, st));
+  GC_TRY(linear_bwd_x(g.ddisF, ND, Hd, flat + y.Wp, P, ddis_table, 0, ws, wse, st));
+  return 0;
+}
+
+// wpair[pair] = 1 for pairs of real entities, 0 otherwise (ragged batches)
+__global__ void prod_wpair_kernel(const int* __restrict__ n_valid, float* __restrict__ wpair, int N, long BNN) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= BNN) return;
+  const long b = p / ((long)N * N);
+  const int ij = (int)(p - b * N * N), i = ij / N, j = ij - i * N;
+  const int nv = min(max(n_valid[b], 0), N);
+  wpair[p] = (i < nv && j < nv) ? 1.f : 0.f;
+}
+int prod_wpair(const int* n_valid, float* wpair, int B, int N, hipStream_t st) {
+  const long BNN = (long)B * N * N;
+  hipLaunchKernelGGL(prod_wpair_kernel, dim3(cdiv(BNN, 256)), dim3(256), 0, st, n_valid, wpair, N, BNN);
+  return check_launch("prod_wpair");
+}
+
+}  // namespace gc

@@ -278,7 +278,8 @@ def _check_stack_param_grads(hops, sdl, rtol=1e-3, atol=2e-4):
     for mod, pre in ((hops.get_weighted_adj_matrix, "get_weighted_adj_matrix."), (hops.graphcnn[0], "graphcnn.0."),
                      (hops.get_adj_matrix[0], "get_adj_matrix.0."), (hops.graphcnn[1], "graphcnn.1.")):
         for k, gk in mod.named_grads().items():
-            torch.testing.assert_close(gk.cpu(), ref_grads[pre + k], rtol=rtol, atol=atol,
+            ref = ref_grads[pre + k]        # absolute slack relative to the tensor's largest entry (long fp32 sums)
+            torch.testing.assert_close(gk.cpu(), ref, rtol=rtol, atol=atol * max(1.0, ref.abs().max().item()),
                                        msg=lambda m: f"grad {pre + k}: {m}")
             seen += 1
     assert seen == len(ref_grads), (seen, len(ref_grads))       # nothing the reference differentiates is missing
@@ -438,7 +439,8 @@ def test_full_size_properties(gpu_device, cfg, B, N, D, L, H):
     _, _, _, _, pa = run(x[:h], e1[:h], e2[:h])
     _, _, _, _, pb = run(x[h:], e1[h:], e2[h:])
     for whole, a, b in zip(pg, pa, pb):
-        torch.testing.assert_close(whole, a + b, rtol=1e-4, atol=1e-4 * max(1.0, whole.abs().max().item()))
+        # (sums of 2048+ fp32 products in different split-K orders on each side: slack relative to the largest entry)
+        torch.testing.assert_close(whole, a + b, rtol=1e-4, atol=5e-4 * max(1.0, whole.abs().max().item()))
     # one document of the full batch against the CPU oracle
     d = B - 1
     xr = x[d].cpu().requires_grad_()
