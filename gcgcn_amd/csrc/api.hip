@@ -62,11 +62,6 @@ bool prof_events(const char* tag, double work, hipEvent_t* start, hipEvent_t* st
   return true;
 }
 
-#define GC_TRY(expr)            \
-  do {                          \
-    if (int _e = (expr)) return _e; \
-  } while (0)
-
 struct GcnLayout {
   long oWnX, oWe, oWd, oWlin, oblin, total, wd_head;
   int gh;

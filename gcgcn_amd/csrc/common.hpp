@@ -24,6 +24,11 @@ int check_launch(const char* what);
     }                                              \
   } while (0)
 
+#define GC_TRY(expr)                \
+  do {                              \
+    if (int _e = (expr)) return _e; \
+  } while (0)
+
 // ---- wave-level reductions (64 lanes) -------------------------------------------------------------
 // DPP lane swizzles instead of ds_bpermute shuffles: four data-parallel-primitive moves fold each row of 16 lanes
 // (quad swap, quad-pair swap, half-row mirror, row mirror -- afterwards every lane holds its row's total), then

@@ -18,6 +18,8 @@
 // Per-slot / per-pair arithmetic runs in wave-per-row kernels (lanes over the Hd feature columns, token states read
 // from L2); backward scatter-adds (token-state, score-table and node-term gradients, shared by many slots) use fp32
 // atomics, so those gradients are reproducible only up to summation order.
+#include <string.h>
+
 #include "gemm.hpp"
 #include "rowops.hpp"
 
@@ -101,19 +103,17 @@ __global__ __launch_bounds__(256) void prod_index_b_kernel(const int* __restrict
   }
   if (tid == 0) off[0] = red[0][0], off[1] = red[1][0];
   __syncthreads();
-  if (blockIdx.x == 0 && b == 0) {  // totals (every thread holds a strided share)
+  red[0][tid] = ta, red[1][tid] = tq;   // totals of the batch (every thread holds a strided share)
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if (tid < d) red[0][tid] += red[0][tid + d], red[1][tid] += red[1][tid + d];
     __syncthreads();
-    red[0][tid] = ta, red[1][tid] = tq;
-    __syncthreads();
-    for (int d = 128; d > 0; d >>= 1) {
-      if (tid < d) red[0][tid] += red[0][tid + d], red[1][tid] += red[1][tid + d];
-      __syncthreads();
-    }
-    if (tid == 0) {
-      const int over = red[0][0] > cap_rows || red[1][0] > cap_pairs;
-      ix.counts[0] = min(red[0][0], cap_rows), ix.counts[1] = min(red[1][0], cap_pairs), ix.counts[2] = over, ix.counts[3] = 0;
-    }
   }
+  // Over capacity: nothing is computed at all (every pair counts as dead, E = bias) rather than a partly filled index,
+  // and the flag reports it.
+  const bool over = red[0][0] > cap_rows || red[1][0] > cap_pairs;
+  if (blockIdx.x == 0 && b == 0 && tid == 0)
+    ix.counts[0] = over ? 0 : red[0][0], ix.counts[1] = over ? 0 : red[1][0], ix.counts[2] = over, ix.counts[3] = 0;
   const int p = blockIdx.x * 256 + tid;
   if (p >= NN) return;
   const long pp = (long)b * NN + p;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void prod_index_b_kernel(const int* __restrict
   int prow = ix.pair_prow[pp];
   if (prow >= 0) prow += off[1];
   const int n = __popc(bits);
-  if (row0 + n > cap_rows || prow >= cap_pairs) {  // over capacity: the pair is dropped (counts[2] reports it)
+  if (over) {
     ix.pair_bits[pp] = 0, ix.pair_prow[pp] = -1, ix.pair_row0[pp] = 0;
     ix.pair_div[pp] = (i < nv && j < nv) ? (float)S + 1e-10f : 0.f;
     return;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void prod_index_b_kernel(const int* __restrict
 
 // ---- word score table: table[b, k, t] = w_a . tanh(sentF[b, t, :] + disF[k, :]) + b_a   (glove:178-182 folded) ------
 __global__ __launch_bounds__(64 * PW) void prod_table_fwd_kernel(const float* __restrict__ sentF, const float* __restrict__ disF,
-                                                                 const float* __restrict__ wa, float ba_unused,
+                                                                 const float* __restrict__ wa,
                                                                  const float* __restrict__ ba, float* __restrict__ table,
                                                                  long BT, int T, int Hd, int ND) {
   const long bt = (long)blockIdx.x * PW + (threadIdx.x >> 6);
@@ -707,7 +707,7 @@ int prod_fwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx
   GC_TRY(linear_fwd(dis_table, ND, P, flat + y.Wp, flat + y.bp, Hd, w.disF, ws, wse, st));      // glove:179 on the 21 ids
   {
     ProfScope ps("prod_table", st);
-    hipLaunchKernelGGL(prod_table_fwd_kernel, dim3(cdiv(BT, PW)), dim3(64 * PW), 0, st, w.sentF, w.disF, flat + y.wa, 0.f,
+    hipLaunchKernelGGL(prod_table_fwd_kernel, dim3(cdiv(BT, PW)), dim3(64 * PW), 0, st, w.sentF, w.disF, flat + y.wa,
                        flat + y.ba, w.table, BT, T, Hd, ND);
     GC_TRY(check_launch("prod_table_fwd"));
   }
@@ -834,3 +834,132 @@ int prod_wpair(const int* n_valid, float* wpair, int B, int N, hipStream_t st) {
 }
 
 }  // namespace gc
+
+// =====================================================================================================================
+// C ABI (include/gcgcn.h)
+// =====================================================================================================================
+#include "../../include/gcgcn.h"
+
+namespace gc {
+
+// live slots / live pairs of a batch (two integer atomics per workgroup: exact, order-independent)
+__global__ __launch_bounds__(256) void prod_count_kernel(const unsigned char* __restrict__ sen, const int* __restrict__ n_valid,
+                                                         int* __restrict__ counts, int N, int S, int T) {
+  __shared__ int red[2][4];
+  const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x, NN = N * N;
+  const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
+  int c = 0;
+  if (p < NN) {
+    const int i = p / N, j = p - i * N;
+    if (i < nv && j < nv) {
+      const long s0 = ((long)b * NN + p) * S;
+      for (int s = 0; s < S; ++s) c += sen[(s0 + s) * T] != 0;
+    }
+  }
+  const float cs = wave_sum((float)c), cp = wave_sum(c > 0 ? 1.f : 0.f);   // <= 64 * 31: exact in fp32
+  if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = (int)cs, red[1][threadIdx.x >> 6] = (int)cp;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(counts, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(counts + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+
+struct ProdBound { ProdIdx ix; ProdBufs w; ProdGrads g; float* scratch; long n_int, n_fwd, n_bwd; };
+// Carve the caller's three buffers (every piece starts 16-byte aligned); with null bases this only measures them.
+static ProdBound prod_bind(int32_t* ibuf, float* fwd, float* bwd, bool want_bwd, int B, int N, int S, int T, int Hd, int P, int ND,
+                           long cap_rows, long cap_pairs) {
+  const long R = up64(cap_rows), Q = up64(cap_pairs), BNN = (long)B * N * N;
+  ProdBound o;
+  memset(&o, 0, sizeof(o));
+  long at = 0;
+  auto ti = [&](long n) { int32_t* p = ibuf ? ibuf + at : nullptr; at += (n + 3) & ~3L; return p; };
+  o.ix.doc_counts = ti(2L * B), o.ix.pair_bits = ti(BNN), o.ix.pair_row0 = ti(BNN), o.ix.pair_prow = ti(BNN);
+  o.ix.pair_div = (float*)ti(BNN), o.ix.row_slot = ti(R), o.ix.prow_pair = ti(Q), o.ix.counts = ti(4);
+  o.n_int = at;
+  float* base = fwd;
+  at = 0;
+  auto tf = [&](long n) { float* p = base ? base + at : nullptr; at += (n + 3) & ~3L; return p; };
+  o.w.sentF = tf((long)B * T * Hd), o.w.disF = tf((long)ND * Hd), o.w.table = tf((long)B * ND * T), o.w.CW = tf(R * 2 * Hd);
+  o.w.stats = tf(4 * R), o.w.cwa = tf(R * Hd), o.w.sfeat = tf(R * Hd), o.w.nterm = tf((long)B * N * Hd), o.w.score = tf(2 * R);
+  o.w.CS = tf(Q * 2 * Hd), o.w.Ec = tf(Q * Hd);
+  o.n_fwd = at;
+  if (want_bwd) {
+    base = bwd, at = 0;
+    o.g.dEc = tf(Q * Hd), o.g.dCS = tf(Q * 2 * Hd), o.g.dcwa = tf(R * Hd), o.g.dsfeat = tf(R * Hd), o.g.dnterm = tf((long)B * N * Hd);
+    o.g.dCW = tf(R * 2 * Hd), o.g.dtable = tf((long)B * ND * T), o.g.dsentF = tf((long)B * T * Hd), o.g.ddisF = tf((long)ND * Hd);
+    o.g.dwb = tf(2 * (Hd + 1)), o.g.part = tf((long)DCS * 2 * Hd), o.g.wpair = tf(BNN);
+    o.scratch = base ? base + at : nullptr;
+    o.n_bwd = at;
+  }
+  (void)S, (void)P;
+  return o;
+}
+
+static long prod_scratch_elems(int B, int N, int T, int Hd) {
+  const long rows = (long)B * T > (long)B * N ? (long)B * T : (long)B * N;
+  long a = gemm_ws_elems(rows, 2L * Hd), b = 64L * Hd * 2 * Hd + 16;   // split-K partials of the K-dynamic weight gradients
+  long c = colsum_scratch_elems((long)B * N * N, Hd, 1);
+  long m = a > b ? a : b;
+  m = m > c ? m : c;
+  return (m + 3) & ~3L;
+}
+
+}  // namespace gc
+
+using namespace gc;
+
+extern "C" {
+
+int gcgcn_producer_layout(int Hd, int P, int64_t* o) {
+  GC_REQUIRE(Hd > 0 && P > 0 && o, "producer_layout: bad arguments");
+  const ProdLayout y = prod_layout(Hd, P);
+  const long v[17] = {y.Ws, y.bs, y.Wp, y.bp, y.wa, y.ba, y.Wlw, y.blw, y.Wss, y.bss, y.Wsp, y.bsp, y.wsa, y.bsa, y.Wls, y.bls, y.total};
+  for (int i = 0; i < 17; ++i) o[i] = v[i];
+  return 0;
+}
+
+int gcgcn_producer_count(int B, int N, int S, int T, const uint8_t* sen, const int32_t* n_valid, int32_t* counts2, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  GC_REQUIRE(B > 0 && N > 0 && S >= 1 && S <= 31 && T > 0 && sen && counts2, "producer_count: bad arguments");
+  GC_REQUIRE(hipMemsetAsync(counts2, 0, 2 * sizeof(int32_t), st) == hipSuccess, "producer_count: memset failed");
+  hipLaunchKernelGGL(prod_count_kernel, dim3(cdiv((long)N * N, 256), B), dim3(256), 0, st, sen, n_valid, counts2, N, S, T);
+  return check_launch("prod_count");
+}
+
+int gcgcn_producer_sizes(int B, int N, int S, int T, int Hd, int P, int ND, int64_t cap_rows, int64_t cap_pairs, int64_t* out3) {
+  GC_REQUIRE(B > 0 && N > 0 && S > 0 && T > 0 && Hd > 0 && P > 0 && ND > 0 && cap_rows >= 0 && cap_pairs >= 0 && out3,
+             "producer_sizes: bad arguments");
+  const ProdBound z = prod_bind(nullptr, nullptr, nullptr, true, B, N, S, T, Hd, P, ND, cap_rows, cap_pairs);
+  out3[0] = z.n_int, out3[1] = z.n_fwd, out3[2] = z.n_bwd + prod_scratch_elems(B, N, T, Hd);
+  return 0;
+}
+
+int gcgcn_producer_fwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx, const uint8_t* sen, const void* pos_h,
+                       const void* pos_t, int pos_bytes, const float* node, const float* dis_table, const int32_t* n_valid,
+                       const float* flat, int64_t cap_rows, int64_t cap_pairs, int32_t* ibuf, float* fbuf, float* scratch,
+                       int64_t scratch_elems, float* E, void* stream) {
+  GC_REQUIRE(B > 0 && N > 0 && T > 0 && Hd > 0 && P > 0 && ND > 0, "producer_fwd: bad shape");
+  GC_REQUIRE(ctx && sen && pos_h && pos_t && node && dis_table && flat && ibuf && fbuf && E, "producer_fwd: null pointer");
+  GC_REQUIRE(cap_rows >= 0 && cap_pairs >= 0 && cap_rows < (1L << 30) && cap_pairs < (1L << 30), "producer_fwd: bad capacities");
+  const ProdBound o = prod_bind(ibuf, fbuf, nullptr, false, B, N, S, T, Hd, P, ND, cap_rows, cap_pairs);
+  return prod_fwd(B, N, S, T, Hd, P, ND, ctx, sen, pos_h, pos_t, pos_bytes, node, dis_table, n_valid, flat, o.ix, cap_rows, cap_pairs,
+                  o.w, E, scratch, scratch ? scratch_elems : 0, (hipStream_t)stream);
+}
+
+int gcgcn_producer_bwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx, const uint8_t* sen, const void* pos_h,
+                       const void* pos_t, int pos_bytes, const float* node, const float* dis_table, const int32_t* n_valid,
+                       const float* flat, int64_t cap_rows, int64_t cap_pairs, int32_t* ibuf, float* fbuf, float* bbuf,
+                       const float* dE, float* dctx, float* dnode, float* ddis_table, float* dflat, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  GC_REQUIRE(B > 0 && N > 0 && T > 0 && Hd > 0 && P > 0 && ND > 0, "producer_bwd: bad shape");
+  GC_REQUIRE(ctx && sen && pos_h && pos_t && node && dis_table && flat && ibuf && fbuf && bbuf && dE && dctx && dnode && ddis_table &&
+                 dflat,
+             "producer_bwd: null pointer");
+  const ProdBound o = prod_bind(ibuf, fbuf, bbuf, true, B, N, S, T, Hd, P, ND, cap_rows, cap_pairs);
+  if (n_valid) GC_TRY(prod_wpair(n_valid, o.g.wpair, B, N, st));
+  return prod_bwd(B, N, S, T, Hd, P, ND, ctx, sen, pos_h, pos_t, pos_bytes, node, dis_table, n_valid, flat, o.ix, cap_rows, cap_pairs,
+                  o.w, dE, o.g, dctx, dnode, ddis_table, dflat, o.scratch, prod_scratch_elems(B, N, T, Hd), st);
+}
+
+}  // extern "C"

@@ -500,6 +500,90 @@ class PairBceFn(torch.autograd.Function):
         return dlogits, None, None
 
 
+class ProducerFn(torch.autograd.Function):
+    """(ctx[B,T,Hd], node[B,N,Hd], dis_table[ND,P], flat; sen, pos_h, pos_t) -> E[B,N,N,Hd].  The edge-feature producer of
+    one hop: WordAttention x2 + linear_word_att + SentenceAttention x2 + linear_sentence_att, GCGCN_glove.py:171-214 as
+    called at :300-330."""
+
+    @staticmethod
+    def forward(ctx_, tok, node, dis_table, flat, sen, pos_h, pos_t, n_valid, cap_rows, cap_pairs):
+        B, T, Hd = tok.shape
+        N, S = sen.shape[1], sen.shape[3]
+        ND, P = dis_table.shape
+        dev = tok.device
+        sizes = (ctypes.c_int64 * 3)()
+        call("gcgcn_producer_sizes", B, N, S, T, Hd, P, ND, cap_rows, cap_pairs, ctypes.cast(sizes, ctypes.c_void_p))
+        ibuf = torch.empty(sizes[0], dtype=torch.int32, device=dev)
+        fbuf = torch.empty(sizes[1], device=dev)
+        E = torch.empty(B, N, N, Hd, device=dev)
+        pb = pos_h.element_size()
+        call("gcgcn_producer_fwd", B, N, S, T, Hd, P, ND, _p(tok), _p(sen), _p(pos_h), _p(pos_t), pb, _p(node), _p(dis_table),
+             _p(n_valid), _p(flat), cap_rows, cap_pairs, _p(ibuf), _p(fbuf), None, 0, _p(E), _stream())
+        ctx_.save_for_backward(tok, node, dis_table, flat, sen, pos_h, pos_t, ibuf, fbuf)
+        ctx_.n_valid, ctx_.caps, ctx_.nbwd = n_valid, (cap_rows, cap_pairs), int(sizes[2])
+        return E
+
+    @staticmethod
+    def backward(ctx_, dE):
+        tok, node, dis_table, flat, sen, pos_h, pos_t, ibuf, fbuf = ctx_.saved_tensors
+        B, T, Hd = tok.shape
+        N, S = sen.shape[1], sen.shape[3]
+        ND, P = dis_table.shape
+        dev = tok.device
+        dE = dE.contiguous()
+        bbuf = torch.empty(ctx_.nbwd, device=dev)
+        dtok, dnode = torch.empty_like(tok), torch.empty_like(node)
+        dtab, dflat = torch.empty_like(dis_table), torch.empty_like(flat)
+        call("gcgcn_producer_bwd", B, N, S, T, Hd, P, ND, _p(tok), _p(sen), _p(pos_h), _p(pos_t), pos_h.element_size(), _p(node),
+             _p(dis_table), _p(ctx_.n_valid), _p(flat), ctx_.caps[0], ctx_.caps[1], _p(ibuf), _p(fbuf), _p(bbuf), _p(dE), _p(dtok),
+             _p(dnode), _p(dtab), _p(dflat), _stream())
+        return dtok, dnode, dtab, dflat, None, None, None, None, None, None
+
+
+def producer_live_counts(sen: Tensor, n_valid=None):
+    """(live sentence slots, entity pairs with a live slot) of a batch -- one small kernel and a device-to-host read.
+    A slot is live iff token 0 belongs to it: the reference's own padding test (``~sen_matrix[..., 0:1]``, glove:305)."""
+    B, N, _, S, T = sen.shape
+    counts = torch.empty(2, dtype=torch.int32, device=sen.device)
+    call("gcgcn_producer_count", B, N, S, T, _p(sen), _p(n_valid), _p(counts), _stream())
+    r, q = counts.tolist()
+    return r, q
+
+
+def edge_features(tok, sen, pos_h, pos_t, node, dis_table, flat, n_valid=None, max_live_slots=None, max_live_pairs=None):
+    """E[B,N,N,Hd] of one hop from token states tok[B,T,Hd], sentence masks sen[B,N,N,S,T] (bool / uint8), distance ids
+    pos_h / pos_t [B,N,N,S,T] (int64 as the reference passes them, or int32 / uint8), entity features node[B,N,Hd] and
+    the distance-embedding table dis_table[ND,P].  Without ``max_live_*`` the live slots are counted first (one host
+    synchronisation per call, as cheap as the reference's own ``.cuda()`` copies); with them nothing synchronises and the
+    call can be captured in a hipGraph."""
+    tok, node, dis_table = _chk(tok, "context_output", 3), _chk(node, "node_feat", 3), _chk(dis_table, "dis_embed.weight", 2)
+    B, T, Hd = tok.shape
+    if sen.dim() != 5 or sen.shape[0] != B or sen.shape[4] != T or sen.shape[1] != sen.shape[2]:
+        raise ValueError(f"sen_matrix: expected [B={B}, N, N, S, T={T}], got {tuple(sen.shape)}")
+    N, S = sen.shape[1], sen.shape[3]
+    if node.shape != (B, N, Hd):
+        raise ValueError(f"node_feat: expected {(B, N, Hd)}, got {tuple(node.shape)}")
+    if not sen.is_cuda:
+        raise RuntimeError("sen_matrix: gcgcn_amd runs on MI355X only (no CPU fallback)")
+    if sen.dtype == torch.bool:
+        sen = sen.view(torch.uint8)
+    elif sen.dtype != torch.uint8:
+        sen = (sen != 0).to(torch.uint8)
+    sen = sen.contiguous()
+    for nm, p in (("pos_matrix_h", pos_h), ("pos_matrix_t", pos_t)):
+        if tuple(p.shape) != tuple(sen.shape) or p.dtype not in (torch.int64, torch.int32, torch.uint8) or not p.is_cuda:
+            raise ValueError(f"{nm}: expected a GPU int64 / int32 / uint8 tensor of shape {tuple(sen.shape)}")
+    if pos_t.dtype != pos_h.dtype:
+        raise ValueError("pos_matrix_h and pos_matrix_t must have the same dtype")
+    nv = _nv(n_valid, B, N, tok.device)
+    if max_live_slots is None or max_live_pairs is None:
+        r, q = producer_live_counts(sen, nv)
+        max_live_slots = r if max_live_slots is None else max_live_slots
+        max_live_pairs = q if max_live_pairs is None else max_live_pairs
+    return ProducerFn.apply(tok, node, dis_table, _chk(flat, "flat"), sen, pos_h.contiguous(), pos_t.contiguous(), nv,
+                            int(max_live_slots), int(max_live_pairs))
+
+
 # ---- functional entry points -------------------------------------------------------------------------
 def _snap_for(training: bool, p: float, dev) -> Optional[Tensor]:
     return rng_snapshot(dev) if (training and p > 0.0) else None

@@ -335,6 +335,69 @@ class MultiGraphConvolution(_GcnBase):
 
 
 # ======================================================================================================
+class EdgeFeatureProducer(_FlatBlock):
+    """The edge-feature producer of ONE hop: what GCGCN_glove.forward does between glove:300 and
+    :330 -- ``word_attention[i]`` on the head and tail distance embeddings, ``linear_word_att[i]``,
+    ``sentence_attention[i]`` on the head and tail node embeddings, ``linear_sentence_att[i]`` -- as one call that
+    returns ``context_sent_att`` without ever building an ``[N, N, S, T, hidden]`` tensor.
+
+    ``state_dict()`` keys are the model's attribute paths without the hop index (``word_attention.attention_sent.weight``,
+    ``linear_word_att.weight``, ``sentence_attention.attention_pos.bias``, ``linear_sentence_att.weight``, ...);
+    :meth:`load_model_hop` takes a GCGCN_glove checkpoint and a hop number.  Reference behaviours kept on purpose: a
+    sentence slot counts only if token 0 belongs to it (``sent_att_padding_matrix = ~sen_matrix[:,:,:,0:1]``, glove:305),
+    the sentence sum is divided by the number of PADDED slots + 1e-10 (glove:205, 212), the attention weights are
+    ``relu`` of the scores (glove:211).
+    """
+
+    def __init__(self, hidden_size: int = 128, dis_size: int = 20):
+        super().__init__()
+        self.hidden, self.dis_size = hidden_size, dis_size
+        self.flat = nn.Parameter(torch.empty(P_.producer_layout(hidden_size, dis_size)[-1]))
+        with torch.no_grad():
+            P_.pack_producer(P_.init_producer(hidden_size, dis_size), hidden_size, dis_size, self.flat)
+
+    def _ref_shapes(self):
+        return P_.producer_shapes(self.hidden, self.dis_size)
+
+    def _ref_tensors(self):
+        return P_.unpack_producer(self.flat.detach(), self.hidden, self.dis_size)
+
+    def _load_ref(self, sd):
+        P_.pack_producer(sd, self.hidden, self.dis_size, self.flat)
+
+    def named_grads(self):
+        return P_.unpack_producer(self.flat.grad, self.hidden, self.dis_size) if self.flat.grad is not None else {}
+
+    def load_model_hop(self, model_state_dict: Dict[str, Tensor], hop: int, strict: bool = True):
+        """Load ``word_attention.{hop}.*``, ``linear_word_att.{hop}.*``, ``sentence_attention.{hop}.*`` and
+        ``linear_sentence_att.{hop}.*`` of a GCGCN_glove / GCGCN_bert checkpoint."""
+        sd = {}
+        for k in self._ref_shapes():
+            head, rest = k.split(".", 1)
+            src = f"{head}.{hop}.{rest}"
+            if src in model_state_dict:
+                sd[k] = model_state_dict[src]
+        return self.load_state_dict(sd, strict=strict)
+
+    def forward(self, context_output: Tensor, sen_matrix: Tensor, pos_matrix_h: Tensor, pos_matrix_t: Tensor,
+                node_feat: Tensor, dis_embed_weight: Tensor, n_valid: Optional[Tensor] = None,
+                max_live_slots: Optional[int] = None, max_live_pairs: Optional[int] = None) -> Tensor:
+        """context_output ``[T,H]`` / ``[1,T,H]`` (the reference's shapes, glove:292) or ``[B,T,H]``; sen_matrix / pos_matrix_*
+        ``[N,N,S,T]`` or ``[B,N,N,S,T]``; node_feat ``[N,H]`` / ``[B,N,H]``; dis_embed_weight = ``model.dis_embed.weight``.
+        Returns ``context_sent_att``: ``[N,N,H]`` or ``[B,N,N,H]``."""
+        batched = sen_matrix.dim() == 5
+        tok = context_output
+        if tok.dim() == 2:
+            tok = tok.unsqueeze(0)
+        if not batched:
+            sen_matrix, pos_matrix_h, pos_matrix_t = (t.unsqueeze(0) for t in (sen_matrix, pos_matrix_h, pos_matrix_t))
+            node_feat = node_feat.unsqueeze(0)
+        e = F_.edge_features(tok, sen_matrix, pos_matrix_h, pos_matrix_t, node_feat, dis_embed_weight, self.flat, n_valid,
+                             max_live_slots, max_live_pairs)
+        return e if batched else e.squeeze(0)
+
+
+# ======================================================================================================
 class GraphHops(nn.Module):
     """The model's hop loop restricted to the graph blocks (GCGCN_glove.py:254-262 construction,
     :329-341 forward): hop 0 = GATAttention + GraphConvolution (CAGGC), hop i >= 1 = MultiHeadAttention +

@@ -197,3 +197,47 @@ def init_gcn(D: int, L: int, H: int) -> Dict[str, Tensor]:
             torch.nn.init.xavier_uniform_(v)
     _linear_init(sd["linear_layer.weight"], sd["linear_layer.bias"])
     return sd
+
+
+# ---- edge-feature producer (one hop): WordAttention + linear_word_att + SentenceAttention + linear_sentence_att ----
+# (GCGCN_glove.py:171-214, constructed at :266-269).  Keys are the model's attribute paths without the hop index.
+def producer_shapes(Hd: int, P: int) -> Dict[str, tuple]:
+    return {"word_attention.attention_sent.weight": (Hd, Hd), "word_attention.attention_sent.bias": (Hd,),
+            "word_attention.attention_pos.weight": (Hd, P), "word_attention.attention_pos.bias": (Hd,),
+            "word_attention.attention_all.weight": (1, Hd), "word_attention.attention_all.bias": (1,),
+            "linear_word_att.weight": (Hd, 2 * Hd), "linear_word_att.bias": (Hd,),
+            "sentence_attention.attention_sent.weight": (Hd, Hd), "sentence_attention.attention_sent.bias": (Hd,),
+            "sentence_attention.attention_pos.weight": (Hd, Hd), "sentence_attention.attention_pos.bias": (Hd,),
+            "sentence_attention.attention_all.weight": (1, Hd), "sentence_attention.attention_all.bias": (1,),
+            "linear_sentence_att.weight": (Hd, 2 * Hd), "linear_sentence_att.bias": (Hd,)}
+
+
+def producer_layout(Hd: int, P: int):
+    o, at = [], 0
+    for shp in producer_shapes(Hd, P).values():
+        o.append(at)
+        n = 1
+        for v in shp:
+            n *= v
+        at += n
+    return o + [at]
+
+
+def unpack_producer(flat: Tensor, Hd: int, P: int) -> Dict[str, Tensor]:
+    o = producer_layout(Hd, P)
+    return {k: flat[o[i]:o[i + 1]].view(shp) for i, (k, shp) in enumerate(producer_shapes(Hd, P).items())}
+
+
+def pack_producer(sd: Dict[str, Tensor], Hd: int, P: int, out: Tensor) -> Tensor:
+    o = producer_layout(Hd, P)
+    for i, k in enumerate(producer_shapes(Hd, P)):
+        out[o[i]:o[i + 1]].copy_(sd[k].reshape(-1))
+    return out
+
+
+def init_producer(Hd: int, P: int) -> Dict[str, Tensor]:
+    sd = {k: torch.empty(s) for k, s in producer_shapes(Hd, P).items()}
+    for k in list(sd):
+        if k.endswith(".weight"):
+            _linear_init(sd[k], sd[k[:-6] + "bias"])
+    return sd

@@ -204,6 +204,39 @@ int gcgcn_pair_bce_fwd(int B, int N, int R, const float* logits, const float* la
 int gcgcn_pair_bce_bwd(int B, int N, int R, const float* logits, const float* labels, const int32_t* n_valid,
                        const float* dloss, float* dlogits, void* stream);
 
+/* ---- edge-feature producer  GCGCN_glove.py:171-214 and the call sequence :300-330 ------------ */
+/* Builds E = context_sent_att[B,N,N,Hd] -- the edge tensor the blocks above consume -- from the token states:
+ * WordAttention (glove:171-190) on the head- and tail-side distance embeddings, Linear(2Hd, Hd) (linear_word_att),
+ * SentenceAttention (glove:193-214) on the head- and tail-side node embeddings, Linear(2Hd, Hd) (linear_sentence_att).
+ *   ctx[B,T,Hd]        token states (context_output, glove:292)
+ *   sen[B,N,N,S,T]     uint8 / bool: token t belongs to sentence slot s of pair (i, j)   (sen_matrix)
+ *   pos_h, pos_t       [B,N,N,S,T] distance ids 0..ND-1 (pos_matrix_h / _t), element width pos_bytes in {8, 4, 1}
+ *   node[B,N,Hd]       entity features (node_feat);  dis_table[ND,P] = dis_embed.weight
+ * Nothing of size [N,N,S,T,Hd] is materialised (the reference's 2.3 GB per document): the word score is a [ND,T] table per
+ * document; only LIVE sentence slots -- those containing token 0, the only ones the reference's padding test
+ * ~sen_matrix[...,0:1] (glove:305) does not zero out, forward and backward -- are computed, compacted into rows whose
+ * count stays on the device.  The reference's divisor (number of PADDED slots + 1e-10, glove:205,212) is reproduced.
+ * flat = [word_attention.attention_sent W,b | .attention_pos W,b | .attention_all w,b | linear_word_att W,b |
+ *         sentence_attention.attention_sent W,b | .attention_pos W,b | .attention_all w,b | linear_sentence_att W,b],
+ * every matrix in the reference's [out, in] layout; out17 = the 16 offsets + total.
+ * Capacities: cap_rows >= live slots, cap_pairs >= pairs with a live slot (gcgcn_producer_count reports both; anything
+ * beyond a capacity is dropped and flagged in ibuf's counts[2]).  Buffers (caller-owned): ibuf int32[sizes[0]], fbuf
+ * float[sizes[1]] (written by forward, read by backward), bbuf float[sizes[2]] (backward workspace) from
+ * gcgcn_producer_sizes.  Gradients w.r.t. ctx, the score table and the per-entity node terms are scatter-added with
+ * fp32 atomics (reproducible up to summation order). */
+int gcgcn_producer_layout(int Hd, int P, int64_t* out17);
+int gcgcn_producer_count(int B, int N, int S, int T, const uint8_t* sen, const int32_t* n_valid, int32_t* counts2, void* stream);
+int gcgcn_producer_sizes(int B, int N, int S, int T, int Hd, int P, int ND, int64_t cap_rows, int64_t cap_pairs, int64_t* out3);
+int gcgcn_producer_fwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx, const uint8_t* sen, const void* pos_h,
+                       const void* pos_t, int pos_bytes, const float* node, const float* dis_table, const int32_t* n_valid,
+                       const float* flat, int64_t cap_rows, int64_t cap_pairs, int32_t* ibuf, float* fbuf, float* scratch,
+                       int64_t scratch_elems, float* E, void* stream);
+/* dE[B,N,N,Hd] -> dctx[B,T,Hd], dnode[B,N,Hd], ddis_table[ND,P], dflat (layout of flat). */
+int gcgcn_producer_bwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx, const uint8_t* sen, const void* pos_h,
+                       const void* pos_t, int pos_bytes, const float* node, const float* dis_table, const int32_t* n_valid,
+                       const float* flat, int64_t cap_rows, int64_t cap_pairs, int32_t* ibuf, float* fbuf, float* bbuf,
+                       const float* dE, float* dctx, float* dnode, float* ddis_table, float* dflat, void* stream);
+
 /* ---- raw batched GEMM (exposed for unit tests and benchmarks of the MFMA kernel) ----------- */
 /* C[z] = alpha * opA(A[z]) opB(B[z]);  a_kc: A stored [M][K] else [K][M];  b_kc: B stored [N][K]
  * else [K][N];  z < batch with element strides sA, sB, sC;  tile: 0 auto, 1 = 64x64, 2 = 128x128;

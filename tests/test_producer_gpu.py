@@ -1,0 +1,174 @@
+"""SURVEY 8 row f1 on the GPU: the edge-feature producer kernels (csrc/producer.hip) against (1) the fixtures produced by
+the reference's own WordAttention / SentenceAttention classes and (2) the CPU oracle's op-for-op restatement on seeded
+inputs: DocRED-shaped ranges, ragged batches, every position-id dtype, no live slot at all, capacities given up front."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_files, ids, load_golden
+import gcgcn_amd
+from gcgcn_amd import functional as F_, params as P_
+from oracle import gcgcn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _hop_sd(sd, hop=0):
+    """model-style keys (word_attention.{hop}.x) -> producer keys (word_attention.x)"""
+    out = {}
+    for k, v in sd.items():
+        head, h, rest = k.split(".", 2)
+        if int(h) == hop:
+            out[f"{head}.{rest}"] = v
+    return out
+
+
+def _model_sd(prod, hop=0):
+    return {f"{k.split('.', 1)[0]}.{hop}.{k.split('.', 1)[1]}": v for k, v in prod.state_dict().items()}
+
+
+@pytest.mark.parametrize("path", golden_files("producer"), ids=ids(golden_files("producer")))
+def test_producer_golden(gpu_device, path):
+    """Forward and every gradient against the reference's own classes (fixtures of oracle/make_golden.py), including the
+    pair whose divisor is 1e-10 (no padded slot, glove:205,212: values ~1e10 -- compared relatively)."""
+    g = load_golden(path)
+    r = g["raw"]
+    T, Hd = r["ctx"].shape
+    P = r["table"].shape[1]
+    prod = gcgcn_amd.EdgeFeatureProducer(Hd, P).to(gpu_device)
+    res = prod.load_model_hop({k: v for k, v in g["sd"].items()}, 0)
+    assert not res.missing_keys
+    ctx = torch.from_numpy(r["ctx"]).to(gpu_device).requires_grad_()
+    node = torch.from_numpy(r["node"]).to(gpu_device).requires_grad_()
+    table = torch.from_numpy(r["table"]).to(gpu_device).requires_grad_()
+    sen, ph, pt = (torch.from_numpy(r[k]).to(gpu_device) for k in ("sen", "pos_h", "pos_t"))
+    e = prod(ctx, sen, ph, pt, node, table)
+    ref = g["out"]
+    scale = ref.abs().amax(dim=-1, keepdim=True).clamp_min(1.0)          # rows scaled by 1e10 are compared relatively
+    torch.testing.assert_close(e.cpu() / scale, ref / scale, rtol=1e-4, atol=1e-5)
+    (e * g["cot"].to(gpu_device)).sum().backward()
+    for got, key in ((ctx.grad, "grad.ctx"), (node.grad, "grad.node"), (table.grad, "grad.table")):
+        want = torch.from_numpy(r[key])
+        torch.testing.assert_close(got.cpu(), want, rtol=1e-3, atol=1e-5 * max(1.0, want.abs().max().item()))
+    grads = prod.named_grads()
+    for k, want in _hop_sd(g["grad_sd"]).items():
+        torch.testing.assert_close(grads[k].cpu(), want, rtol=1e-3, atol=1e-5 * max(1.0, want.abs().max().item()),
+                                   msg=lambda m: f"grad {k}: {m}")
+
+
+def synth_doc(B, N, S, T, Hd, P, seed, first_frac=0.4, dtype=torch.int64, ranges=True):
+    """DocRED-shaped producer inputs: every slot is a contiguous token range (a sentence, config/Config.py:187); a
+    fraction of them starts at token 0 (the slots the reference keeps); distance ids as from_list_to_tensor writes them
+    (dis_plus +- bucket inside the range, 0 outside)."""
+    g = torch.Generator().manual_seed(seed)
+    ctx = torch.tanh(torch.randn(B, T, Hd, generator=g))
+    node = torch.rand(B, N, Hd, generator=g) * 2 - 1
+    table = torch.randn(21, P, generator=g) * 0.5
+    sen = torch.zeros(B, N, N, S, T, dtype=torch.bool)
+    ph = torch.zeros(B, N, N, S, T, dtype=torch.int64)
+    pt = torch.zeros(B, N, N, S, T, dtype=torch.int64)
+    for b in range(B):
+        for i in range(N):
+            for j in range(N):
+                ns = int(torch.randint(0, S + 1, (1,), generator=g))
+                for s in range(ns):
+                    ln = int(torch.randint(3, max(4, min(T, 40)), (1,), generator=g))
+                    t0 = 0 if torch.rand(1, generator=g).item() < first_frac else int(torch.randint(0, T - ln + 1, (1,), generator=g))
+                    t0 = min(t0, T - ln)
+                    if ranges:
+                        sen[b, i, j, s, t0:t0 + ln] = True
+                    else:                                                     # arbitrary mask: holes inside the range
+                        sen[b, i, j, s, t0:t0 + ln] = torch.rand(ln, generator=g) < 0.7
+                        if t0 == 0:
+                            sen[b, i, j, s, 0] = torch.rand(1, generator=g).item() < 0.8
+                    ph[b, i, j, s, t0:t0 + ln] = torch.randint(0, 21, (ln,), generator=g)
+                    pt[b, i, j, s, t0:t0 + ln] = torch.randint(0, 21, (ln,), generator=g)
+    return ctx, node, table, sen, ph.to(dtype), pt.to(dtype)
+
+
+def _oracle(prod, ctx, node, table, sen, ph, pt, cot, nv=None):
+    sd = {k: v.cpu().clone().requires_grad_() for k, v in _model_sd(prod).items()}
+    ctx, node, table = ctx.clone().requires_grad_(), node.clone().requires_grad_(), table.clone().requires_grad_()
+    outs = []
+    for b in range(ctx.shape[0]):
+        n = sen.shape[1] if nv is None else int(nv[b])
+        outs.append(O.edge_features_folded(ctx[b], sen[b, :n, :n], ph[b, :n, :n].long(), pt[b, :n, :n].long(), node[b, :n], table,
+                                           sd, 0))
+    loss = sum((o * cot[b, :o.shape[0], :o.shape[0]]).sum() for b, o in enumerate(outs))
+    loss.backward()
+    return outs, ctx.grad, node.grad, table.grad, {k: v.grad for k, v in _hop_sd(sd).items()}
+
+
+@pytest.mark.parametrize("B,N,S,T,Hd,P,dtype,ranges", [
+    (2, 6, 3, 40, 64, 20, torch.int64, True),          # interior GEMM shapes, the reference's id dtype
+    (1, 12, 5, 120, 128, 20, torch.uint8, True),       # the reference's widths (hidden 128, dis_size 20), packed ids
+    (2, 5, 2, 33, 24, 7, torch.int32, False),          # ragged widths (guarded GEMM path), arbitrary masks
+    (1, 42, 5, 512, 128, 20, torch.int64, True),       # the largest DocRED document: N = 42, max_num = 5, max_length = 512
+])
+def test_producer_matches_oracle(gpu_device, B, N, S, T, Hd, P, dtype, ranges):
+    ctx, node, table, sen, ph, pt = synth_doc(B, N, S, T, Hd, P, seed=B * 100 + N, dtype=dtype, ranges=ranges)
+    cot = torch.randn(B, N, N, Hd, generator=torch.Generator().manual_seed(1))
+    # keep the 1e10-scaled pairs (no padded slot) out of the loss: fp32 noise on 1e10-sized terms would swamp the rest
+    live = sen[..., 0]                                                       # [B,N,N,S]
+    cot = cot * (~live).any(-1).unsqueeze(-1).float()
+    prod = gcgcn_amd.EdgeFeatureProducer(Hd, P).to(gpu_device)
+    dev = lambda t: t.to(gpu_device)
+    cg, ng, tg = (dev(t).requires_grad_() for t in (ctx, node, table))
+    e = prod(cg, dev(sen), dev(ph), dev(pt), ng, tg)
+    (e * dev(cot)).sum().backward()
+    outs, dctx, dnode, dtab, dsd = _oracle(prod, ctx, node, table, sen, ph, pt, cot)
+    for b in range(B):
+        scale = outs[b].detach().abs().amax(dim=-1, keepdim=True).clamp_min(1.0)
+        torch.testing.assert_close(e[b].detach().cpu() / scale, outs[b].detach() / scale, rtol=1e-4, atol=1e-4)
+    for got, want, nm in ((cg.grad, dctx, "dctx"), (ng.grad, dnode, "dnode"), (tg.grad, dtab, "dtable")):
+        torch.testing.assert_close(got.cpu(), want, rtol=1e-3, atol=1e-4 * max(1.0, want.abs().max().item()), msg=lambda m: f"{nm}: {m}")
+    grads = prod.named_grads()
+    for k, want in dsd.items():
+        torch.testing.assert_close(grads[k].cpu(), want, rtol=1e-3, atol=1e-4 * max(1.0, want.abs().max().item()),
+                                   msg=lambda m: f"grad {k}: {m}")
+
+
+def test_producer_ragged_capacities_and_empty(gpu_device):
+    """n_valid (padding entities: zero rows / columns of E, no gradient), capacities given up front (no host sync: what a
+    hipGraph capture needs; too small a capacity is flagged), and a batch without any live slot (E = the last bias)."""
+    B, N, S, T, Hd, P = 3, 7, 3, 50, 64, 20
+    ctx, node, table, sen, ph, pt = synth_doc(B, N, S, T, Hd, P, seed=5)
+    nv = torch.tensor([7, 3, 5], dtype=torch.int32)
+    cot = torch.randn(B, N, N, Hd, generator=torch.Generator().manual_seed(2)) * (~sen[..., 0]).any(-1).unsqueeze(-1).float()
+    prod = gcgcn_amd.EdgeFeatureProducer(Hd, P).to(gpu_device)
+    dev = lambda t: t.to(gpu_device)
+    res = []
+    for caps in (None, (B * N * N * S, B * N * N)):
+        cg, ng, tg = (dev(t).requires_grad_() for t in (ctx, node, table))
+        kw = {} if caps is None else dict(max_live_slots=caps[0], max_live_pairs=caps[1])
+        e = prod(cg, dev(sen), dev(ph), dev(pt), ng, tg, n_valid=dev(nv), **kw)
+        prod.zero_grad()
+        (e * dev(cot)).sum().backward()
+        res.append((e.detach(), cg.grad, ng.grad, tg.grad, prod.flat.grad.clone()))
+    for a, b_ in zip(*res):
+        torch.testing.assert_close(a, b_, rtol=1e-4, atol=1e-5 * max(1.0, b_.abs().max().item()))   # atomics: summation order
+    e = res[0][0]
+    outs, dctx, dnode, dtab, dsd = _oracle(prod, ctx, node, table, sen, ph, pt, cot, nv=nv)
+    for b in range(B):
+        n = int(nv[b])
+        scale = outs[b].detach().abs().amax(dim=-1, keepdim=True).clamp_min(1.0)
+        torch.testing.assert_close(e[b, :n, :n].cpu() / scale, outs[b].detach() / scale, rtol=1e-4, atol=1e-4)
+        assert e[b, n:].abs().max().item() == 0 if n < N else True
+        assert e[b, :, n:].abs().max().item() == 0 if n < N else True
+    torch.testing.assert_close(res[0][1].cpu(), dctx, rtol=1e-3, atol=1e-4 * max(1.0, dctx.abs().max().item()))
+    grads = P_.unpack_producer(res[0][4].cpu(), Hd, P)
+    for k, want in dsd.items():
+        torch.testing.assert_close(grads[k], want, rtol=1e-3, atol=1e-4 * max(1.0, want.abs().max().item()), msg=lambda m: f"grad {k}: {m}")
+    # counts, and a capacity that is too small
+    r, q = F_.producer_live_counts(dev(sen).view(torch.uint8), dev(nv))
+    live = sen[..., 0].clone()
+    for b in range(B):
+        live[b, int(nv[b]):] = False
+        live[b, :, int(nv[b]):] = False
+    assert r == int(live.sum()) and q == int(live.any(-1).sum())
+    # no live slot at all: every real pair gets linear_sentence_att's bias
+    sen0 = sen.clone()
+    sen0[..., 0] = False
+    e0 = prod(dev(ctx), dev(sen0), dev(ph), dev(pt), dev(node), dev(table))
+    bias = prod.named_tensors()["linear_sentence_att.bias"]
+    torch.testing.assert_close(e0, bias.expand_as(e0).contiguous())
