@@ -69,6 +69,10 @@ SIGNATURES = {
     "gcgcn_producer_sizes": (I, [I, I, I, I, I, I, I, L, L, P]),
     "gcgcn_producer_fwd": (I, [I, I, I, I, I, I, I, P, P, P, P, I, P, P, P, P, L, L, P, P, P, L, P, P]),
     "gcgcn_producer_bwd": (I, [I, I, I, I, I, I, I, P, P, P, P, I, P, P, P, P, L, L, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_head_layout": (I, [I, I, I, I, I, P]),
+    "gcgcn_head_sizes": (I, [I, I, I, I, P]),
+    "gcgcn_head_fwd": (I, [I, I, I, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_head_bwd": (I, [I, I, I, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_gemm": (I, [I, I, I, P, L, I, P, L, I, P, L, I, L, L, L, F, P, I, I, I, I, P, L, P]),
 }
 
@@ -104,7 +108,7 @@ def call(name: str, *args):
 
 def layout(kind: str, *dims) -> list:
     """Offsets (in floats) of a block's flat parameter buffer, straight from the library."""
-    n = {"gat": 9, "mha": 3, "gcn": 7, "producer": 17}[kind]
+    n = {"gat": 9, "mha": 3, "gcn": 7, "producer": 17, "head": 7}[kind]
     out = (c_int64 * n)()
     call(f"gcgcn_{kind}_layout", *dims, ctypes.cast(out, c_void_p))
     return list(out)

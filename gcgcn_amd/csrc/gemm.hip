@@ -135,6 +135,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
   reduce4(g, blockIdx.y, (long)blockIdx.x * 256 + threadIdx.x);
 }
 
+int splitk_reduce(const GemmArgs& g, hipStream_t st) {
+  ProfScope ps("gemm_splitk_reduce", st);
+  dim3 rgrid(cdiv((long)g.M * g.N / 4, 256), g.batch1 * g.batch2);
+  hipLaunchKernelGGL(splitk_reduce_kernel, rgrid, dim3(256), 0, st, g);
+  return check_launch("gemm_splitk_reduce");
+}
+
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 template <int TM, int TN, bool ALIGNED>

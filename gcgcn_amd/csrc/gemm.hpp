@@ -115,6 +115,9 @@ int gemm_take_deferred_pairs(DeferQueue* q, GemmGroup4& gg, double* flops, long 
 // Launch whatever is still parked as ordinary group launches (end of backward without a carrying launch).
 int gemm_flush_deferred(DeferQueue* q, hipStream_t stream);
 
+// The deterministic reduce + epilogue over g.splits partial slabs in g.ws (for tile kernels defined outside gemm.hip).
+int splitk_reduce(const GemmArgs& g, hipStream_t st);
+
 // ---- one dimension known only on the device ------------------------------------------------------------------
 // Products over a data-dependent selection of rows (the live sentence slots / entity pairs of the edge-feature producer,
 // producer.hip): the row count lives in device memory, the host only knows an upper bound `cap`.  A fixed grid of

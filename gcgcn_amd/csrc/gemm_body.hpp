@@ -68,6 +68,21 @@ __device__ __forceinline__ void store_tile(const float (&r)[BMN / 32][4], float*
   }
 }
 
+// How a tile body obtains its operands.  PlainOperands reads g.A / g.B; other policies (head.hip: operands that are
+// per-row outer products, never materialised) generate the same register tile instead.  Same k-loop for all of them.
+struct PlainOperands {
+  template <int BMN, bool KC, bool ALIGNED>
+  __device__ __forceinline__ void load_a(float (&r)[BMN / 32][4], const GemmArgs& g, const float* __restrict__ A, int m0, int k0,
+                                                int kend, int t) const {
+    load_tile<BMN, KC, ALIGNED>(r, A, g.lda, m0, k0, g.M, kend, g.vecA, t);
+  }
+  template <int BMN, bool KC, bool ALIGNED>
+  __device__ __forceinline__ void load_b(float (&r)[BMN / 32][4], const GemmArgs& g, const float* __restrict__ B, int n0, int k0,
+                                                int kend, int t) const {
+    load_tile<BMN, KC, ALIGNED>(r, B, g.ldb, n0, k0, g.N, kend, g.vecB, t);
+  }
+};
+
 // Compile-time epilogue feature mask: a product that is known not to use a feature does not even compile
 // its branch (the chain kernels inline ten tile bodies; with every option live in each, they are
 // instruction-fetch bound).  EPI_ALL keeps every feature behind its run-time flag.
@@ -209,9 +224,10 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, const Epi& e, const 
   }
 }
 
-template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED, int EG = 4, int MASK = 0, int RT = EPI_ALL>
+template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED, int EG = 4, int MASK = 0, int RT = EPI_ALL, class OPS = PlainOperands>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__ lds, const int bx, const int by,
-                                          const int zs, const int t = threadIdx.x, const bool do_store = true) {
+                                          const int zs, const int t = threadIdx.x, const bool do_store = true,
+                                          const OPS& ops = OPS()) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int LDA = AKC ? BM + 1 : BM;
   constexpr int LDB = BKC ? BN + 1 : BN;
@@ -250,12 +266,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
   float ra0[BM / 32][4], rb0[BN / 32][4], ra1[BM / 32][4], rb1[BN / 32][4];
   const int nk = (kend - kbeg + BK - 1) / BK;
   auto kof = [&](int kt) { return kbeg + min(kt, nk - 1) * BK; };
-  load_tile<BM, AKC, ALIGNED>(ra0, A, g.lda, m0, kof(0), g.M, kend, g.vecA, t);
-  load_tile<BN, BKC, ALIGNED>(rb0, B, g.ldb, n0, kof(0), g.N, kend, g.vecB, t);
+  ops.template load_a<BM, AKC, ALIGNED>(ra0, g, A, m0, kof(0), kend, t);
+  ops.template load_b<BN, BKC, ALIGNED>(rb0, g, B, n0, kof(0), kend, t);
   store_tile<BM, AKC>(ra0, lds, t);
   store_tile<BN, BKC>(rb0, lds + OFFB, t);
-  load_tile<BM, AKC, ALIGNED>(ra0, A, g.lda, m0, kof(1), g.M, kend, g.vecA, t);
-  load_tile<BN, BKC, ALIGNED>(rb0, B, g.ldb, n0, kof(1), g.N, kend, g.vecB, t);
+  ops.template load_a<BM, AKC, ALIGNED>(ra0, g, A, m0, kof(1), kend, t);
+  ops.template load_b<BN, BKC, ALIGNED>(rb0, g, B, n0, kof(1), kend, t);
   __syncthreads();
 
   // One k-tile from LDS stage `cur`.  The operands of k-step kk+2 are read while the MFMAs of step kk
@@ -285,15 +301,15 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
     }
   };
   for (int kt = 0; kt < nk; kt += 2) {
-    load_tile<BM, AKC, ALIGNED>(ra1, A, g.lda, m0, kof(kt + 2), g.M, kend, g.vecA, t);
-    load_tile<BN, BKC, ALIGNED>(rb1, B, g.ldb, n0, kof(kt + 2), g.N, kend, g.vecB, t);
+    ops.template load_a<BM, AKC, ALIGNED>(ra1, g, A, m0, kof(kt + 2), kend, t);
+    ops.template load_b<BN, BKC, ALIGNED>(rb1, g, B, n0, kof(kt + 2), kend, t);
     compute(0);
     store_tile<BM, AKC>(ra0, lds + SA, t);
     store_tile<BN, BKC>(rb0, lds + OFFB + SB, t);
     __syncthreads();
     if (kt + 1 >= nk) break;
-    load_tile<BM, AKC, ALIGNED>(ra0, A, g.lda, m0, kof(kt + 3), g.M, kend, g.vecA, t);
-    load_tile<BN, BKC, ALIGNED>(rb0, B, g.ldb, n0, kof(kt + 3), g.N, kend, g.vecB, t);
+    ops.template load_a<BM, AKC, ALIGNED>(ra0, g, A, m0, kof(kt + 3), kend, t);
+    ops.template load_b<BN, BKC, ALIGNED>(rb0, g, B, n0, kof(kt + 3), kend, t);
     compute(1);
     store_tile<BM, AKC>(ra1, lds, t);
     store_tile<BN, BKC>(rb1, lds + OFFB, t);

@@ -1,0 +1,455 @@
+// Classifier head: GCGCN_glove.py:306-307 and 344-358.
+//
+//   feats = cat(node_feats..., ner_emb[node_type])                         [N, F]
+//   eh[i, j] = tanh(dense_layer(cat(feats[j], dis_embed[dis_plus + rel[i, j]])))        "head" side: column entity
+//   et[i, j] = tanh(dense_layer(cat(feats[i], dis_embed[dis_plus - rel[i, j]])))        "tail" side: row entity
+//   logits[i, j, :] = Bilinear(eh, et) + Linear(cat(eh, et))               [N, N, R]
+//
+// The dense layer is linear in its concatenated input, so it splits into a per-entity term U[n] = W_f feats[n] + b,
+// a 7-row table for the entity type and a 21-row table for the relative-position id; eh / et are one gather + tanh per
+// pair -- no [N, N, F + 20] tensor.  The bilinear form, 2 N^2 128^2 R flops per document (13 GFLOP at N = 64, more than
+// the whole graph path), runs on the exact-fp32 MFMA as ONE product per pass with K = 128 * 128 (+ 256 for the linear
+// part): the operand row of pair p is the outer product eh[p] (x) et[p], generated in registers while the tile is staged
+// (gemm_body's operand policy) -- the 8.6 GB a [pairs, 16384] operand would take at B = 32 never exists.  Backward: the
+// same trick three times (d eh: rows dout[p] (x) et[p] against W viewed [(r, b), a]; d et: dout[p] (x) eh[p] against
+// [(r, a), b]; d W: dout^T against the generated [pairs, 16384] operand).
+#include <string.h>
+
+#include "gemm_body.hpp"
+#include "rowops.hpp"
+
+namespace gc {
+
+constexpr int HW = 128;  // hidden width of eh / et (hidden_size is hard-coded to 128 in the reference, glove:234)
+
+struct HeadOps {
+  const float* P;   // [rows, ldp]: the factor indexed by k / 128
+  const float* Q;   // [rows, ldq]: the factor indexed by k % 128
+  const float* W2;  // forward: classification_layer_01.weight [R, 256] behind the bilinear weight
+  long ldp, ldq, ldw2;
+  int KB;           // K of the outer-product segment
+  int nmax;         // rows of the weight operand that exist (R); beyond: clamped (their outputs are never stored)
+  int rows;         // pairs
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// MODE 1 forward  : A gen [pairs, KB + 256] = [eh (x) et | eh | et],   B = W_b [R][16384] | W_c [R][256]   (k-contiguous rows)
+// MODE 2 d eh     : A gen [pairs, R * 128]  = dout (x) et,              B[n = a][k = (r, b)] = W_b[r][a][b]
+// MODE 3 d et     : A gen [pairs, R * 128]  = dout (x) eh,              B[k = (r, a)][n = b] = W_b[r][a][b]  (natural layout)
+// MODE 4 d W_b    : A = doutp [pairs][128] as [K][M],                   B gen [K = pairs][N = (a, b)] = eh (x) et
+template <int MODE>
+struct HeadOperands {
+  HeadOps o;
+  template <int BMN, bool KC, bool ALIGNED>
+  __device__ __forceinline__ void load_a(float (&r)[BMN / 32][4], const GemmArgs& g, const float* __restrict__ A, int m0, int k0,
+                                         int kend, int t) const {
+#pragma unroll
+    for (int q = 0; q < BMN / 32; ++q) {
+      const int f = t + 256 * q;
+      float4 v;
+      if (MODE != 4) {
+        const long row = min(m0 + (f >> 3), o.rows - 1);   // clamped: rows past the end are computed and never stored
+        const int kq = k0 + ((f & 7) << 2);
+        if (MODE == 1 && k0 >= o.KB) {
+          v = (k0 < o.KB + HW) ? ld4(o.P + row * o.ldp + (kq - o.KB)) : ld4(o.Q + row * o.ldq + (kq - o.KB - HW));
+        } else {
+          const float p = o.P[row * o.ldp + (k0 >> 7)];
+          v = ld4(o.Q + row * o.ldq + (kq & (HW - 1)));
+          v.x *= p, v.y *= p, v.z *= p, v.w *= p;
+        }
+      } else {
+        const int k = k0 + (f >> 4), col = m0 + ((f & 15) << 2);
+        v = ld4(A + (long)min(k, o.rows - 1) * g.lda + col);
+        if (k >= o.rows) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      r[q][0] = v.x, r[q][1] = v.y, r[q][2] = v.z, r[q][3] = v.w;
+    }
+  }
+  template <int BMN, bool KC, bool ALIGNED>
+  __device__ __forceinline__ void load_b(float (&r)[BMN / 32][4], const GemmArgs& g, const float* __restrict__ B, int n0, int k0,
+                                         int kend, int t) const {
+#pragma unroll
+    for (int q = 0; q < BMN / 32; ++q) {
+      const int f = t + 256 * q;
+      float4 v;
+      if (MODE == 1) {         // [N][K] rows of W_b, then of W_c
+        const long n = min(n0 + (f >> 3), o.nmax - 1);
+        const int kq = k0 + ((f & 7) << 2);
+        v = (k0 < o.KB) ? ld4(B + n * (long)o.KB + kq) : ld4(o.W2 + n * o.ldw2 + (kq - o.KB));
+      } else if (MODE == 2) {  // [N = a][K = (r, b)]: element at W_b + r * 16384 + a * 128 + b
+        const long n = n0 + (f >> 3);
+        const int kq = k0 + ((f & 7) << 2);
+        v = ld4(B + (long)(k0 >> 7) * (HW * HW) + n * HW + (kq & (HW - 1)));
+      } else if (MODE == 3) {  // [K = (r, a)][N = b]: the natural layout
+        const long k = k0 + (f >> 4);
+        v = ld4(B + k * HW + n0 + ((f & 15) << 2));
+      } else {                 // generated [K = pair][N = (a, b)]
+        const long k = min(k0 + (f >> 4), o.rows - 1);
+        const int n = n0 + ((f & 15) << 2);
+        const float p = o.P[k * o.ldp + (n >> 7)];
+        v = ld4(o.Q + k * o.ldq + (n & (HW - 1)));
+        v.x *= p, v.y *= p, v.z *= p, v.w *= p;
+      }
+      r[q][0] = v.x, r[q][1] = v.y, r[q][2] = v.z, r[q][3] = v.w;
+    }
+  }
+};
+
+template <int MODE, bool AKC, bool BKC>
+__global__ __launch_bounds__(256, 4) void head_gemm_kernel(const GemmArgs g, const HeadOps o) {
+  __shared__ __attribute__((aligned(16))) float lds[lds_floats<1, 1, AKC, BKC>()];
+  const int tn = (g.N + 63) >> 6, tm = (g.M + 63) >> 6;
+  const int nwg = tn * tm * g.splits;
+  const int b = xcd_remap(blockIdx.x, nwg);
+  // the short side fastest: neighbouring workgroups (one XCD) share the weight panel they stream
+  const int zs = b / (tn * tm), rr = b - zs * (tn * tm);
+  const int bx = (tm < tn) ? rr / tm : rr % tn, by = (tm < tn) ? rr % tm : rr / tn;
+  HeadOperands<MODE> ops;
+  ops.o = o;
+  gemm_body<1, 1, AKC, BKC, false, 4, 0, EPI_ALL, HeadOperands<MODE>>(g, lds, bx, by, zs, threadIdx.x, true, ops);
+}
+
+static int head_gemm(int mode, GemmArgs g, const HeadOps& o, hipStream_t st) {
+  const long tiles = (long)cdiv(g.M, 64) * cdiv(g.N, 64);
+  int splits = 1;
+  if (g.ws && tiles < 2048) {  // long-K weight gradient with few output tiles
+    const long iters = cdiv(g.K, BK);
+    while (splits < 8 && tiles * splits < 2048 && iters / (splits * 2) >= 64 && (long)(splits * 2) * g.M * g.N <= g.ws_elems) splits *= 2;
+  }
+  g.splits = splits;
+  g.ksplit = splits > 1 ? (int)(((cdiv(g.K, BK) + splits - 1) / splits) * BK) : g.K;
+  g.vecA = g.vecB = 1;
+  g.batch1 = g.batch2 = 1;
+  const dim3 grid((unsigned)(tiles * splits)), block(256);
+  const double flops = 2.0 * g.M * g.N * g.K;
+  switch (mode) {
+    case 1: GC_LAUNCH_TIMED("head_bilinear", flops, (head_gemm_kernel<1, true, true>), grid, block, 0, st, g, o); break;
+    case 2: GC_LAUNCH_TIMED("head_bilinear", flops, (head_gemm_kernel<2, true, true>), grid, block, 0, st, g, o); break;
+    case 3: GC_LAUNCH_TIMED("head_bilinear", flops, (head_gemm_kernel<3, true, false>), grid, block, 0, st, g, o); break;
+    default: GC_LAUNCH_TIMED("head_bilinear", flops, (head_gemm_kernel<4, false, false>), grid, block, 0, st, g, o); break;
+  }
+  if (int e = check_launch("head_gemm")) return e;
+  return splits > 1 ? splitk_reduce(g, st) : 0;
+}
+
+// ---- per-entity term + type table:  UT[b, n, :] = U[b, n, :] + Tt[type[b, n], :];  bsum = b_bilinear + b_linear -------
+__global__ __launch_bounds__(256) void head_node_kernel(const float* __restrict__ U, const float* __restrict__ Tt,
+                                                        const long long* __restrict__ type, float* __restrict__ UT, long BN,
+                                                        const float* __restrict__ bb, const float* __restrict__ bc,
+                                                        float* __restrict__ bsum, int R) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x == 0)
+    for (int r = threadIdx.x; r < R; r += 256) bsum[r] = bb[r] + bc[r];
+  if (e >= BN * HW) return;
+  const long n = e / HW;
+  const int c = (int)(e - n * HW);
+  const int ty = min(max((int)type[n], 0), 6);
+  UT[e] = U[e] + Tt[ty * HW + c];
+}
+
+// ---- eh[p] = tanh(UT[b, j] + Rt[dis_plus + rel[p]]),  et[p] = tanh(UT[b, i] + Rt[dis_plus - rel[p]])   (one wave per pair)
+__global__ __launch_bounds__(256) void head_feat_fwd_kernel(const float* __restrict__ UT, const float* __restrict__ Rt,
+                                                            const long long* __restrict__ rel, float* __restrict__ EH,
+                                                            float* __restrict__ ET, long pairs, int N, int dis_plus, int ND) {
+  const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= pairs) return;
+  const int lane = threadIdx.x & 63;
+  const long b = p / ((long)N * N);
+  const int ij = (int)(p - b * N * N), i = ij / N, j = ij - i * N;
+  const int d = (int)rel[p];
+  const int kh = min(max(dis_plus + d, 0), ND - 1), kt = min(max(dis_plus - d, 0), ND - 1);
+  const float2 uj = *reinterpret_cast<const float2*>(UT + (b * N + j) * HW + 2 * lane);
+  const float2 ui = *reinterpret_cast<const float2*>(UT + (b * N + i) * HW + 2 * lane);
+  const float2 rh = *reinterpret_cast<const float2*>(Rt + (long)kh * HW + 2 * lane);
+  const float2 rt = *reinterpret_cast<const float2*>(Rt + (long)kt * HW + 2 * lane);
+  *reinterpret_cast<float2*>(EH + p * HW + 2 * lane) = make_float2(tanhf(uj.x + rh.x), tanhf(uj.y + rh.y));
+  *reinterpret_cast<float2*>(ET + p * HW + 2 * lane) = make_float2(tanhf(ui.x + rt.x), tanhf(ui.y + rt.y));
+}
+
+// ---- doutp[p, 0..127] = dout[p, 0..R) (zero padding), pairs of padding entities zeroed ---------------------------------
+__global__ __launch_bounds__(256) void head_pad_kernel(const float* __restrict__ dout, const int* __restrict__ n_valid,
+                                                       float* __restrict__ doutp, long pairs, int N, int R) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= pairs * HW) return;
+  const long p = e / HW;
+  const int c = (int)(e - p * HW);
+  float v = 0.f;
+  if (c < R) {
+    bool ok = true;
+    if (n_valid) {
+      const long b = p / ((long)N * N);
+      const int ij = (int)(p - b * N * N), i = ij / N, j = ij - i * N, nv = n_valid[b];
+      ok = i < nv && j < nv;
+    }
+    if (ok) v = dout[p * R + c];
+  }
+  doutp[e] = v;
+}
+
+// ---- through the tanh, in place: dEH <- dEH (1 - eh^2), dET <- dET (1 - et^2) -----------------------------------------
+__global__ __launch_bounds__(256) void head_tanh_bwd_kernel(const float* __restrict__ EH, const float* __restrict__ ET,
+                                                            float* __restrict__ dEH, float* __restrict__ dET, long n4) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n4) return;
+  const float4 h = ld4(EH + 4 * e), t = ld4(ET + 4 * e);
+  float4 a = ld4(dEH + 4 * e), b = ld4(dET + 4 * e);
+  a.x *= 1.f - h.x * h.x, a.y *= 1.f - h.y * h.y, a.z *= 1.f - h.z * h.z, a.w *= 1.f - h.w * h.w;
+  b.x *= 1.f - t.x * t.x, b.y *= 1.f - t.y * t.y, b.z *= 1.f - t.z * t.z, b.w *= 1.f - t.w * t.w;
+  *reinterpret_cast<float4*>(dEH + 4 * e) = a;
+  *reinterpret_cast<float4*>(dET + 4 * e) = b;
+}
+
+// ---- dUT[b, n, :] = sum_i dEH[b, i, n, :] + sum_j dET[b, n, j, :]   (one workgroup per entity, rows in order) ----------
+__global__ __launch_bounds__(256) void head_node_bwd_kernel(const float* __restrict__ dEH, const float* __restrict__ dET,
+                                                            float* __restrict__ dUT, int N) {
+  __shared__ float red[2][HW];
+  const long bn = blockIdx.x;
+  const long b = bn / N;
+  const int n = (int)(bn - b * N);
+  const int c = threadIdx.x & (HW - 1), half = threadIdx.x >> 7;   // 2 x 128 threads: half 0 sums the head side, half 1 the tail side
+  float a = 0.f;
+  const long base = b * N * N;
+  if (half == 0) {
+    for (int i = 0; i < N; ++i) a += dEH[(base + (long)i * N + n) * HW + c];
+  } else {
+    for (int j = 0; j < N; ++j) a += dET[(base + (long)n * N + j) * HW + c];
+  }
+  red[half][c] = a;
+  __syncthreads();
+  if (half == 0) dUT[bn * HW + c] = red[0][c] + red[1][c];
+}
+
+// ---- partial gradient of a gathered table: part[b, k, :] = sum over the items of document b whose id == k --------------
+//   rel mode : items = pairs, two contributions per pair (dEH at dis_plus + rel, dET at dis_plus - rel); grid (B, ND)
+//   type mode: items = entities (X2 == nullptr), ids = type; grid (B, 7)
+__global__ __launch_bounds__(256) void head_table_bwd_kernel(const long long* __restrict__ ids, const float* __restrict__ X1,
+                                                             const float* __restrict__ X2, float* __restrict__ part, long per_doc,
+                                                             int dis_plus, int nk) {
+  __shared__ float red[2][HW];
+  const int b = blockIdx.x, k = blockIdx.y;
+  const int c = threadIdx.x & (HW - 1), half = threadIdx.x >> 7;
+  const float* X = half ? X2 : X1;
+  float a = 0.f;
+  if (X) {
+    const long base = (long)b * per_doc;
+    for (long q = 0; q < per_doc; ++q) {
+      const int d = (int)ids[base + q];
+      const int id = X2 ? (half ? dis_plus - d : dis_plus + d) : d;
+      if (min(max(id, 0), nk - 1) == k) a += X[(base + q) * HW + c];
+    }
+  }
+  red[half][c] = a;
+  __syncthreads();
+  if (half == 0) part[((long)b * nk + k) * HW + c] = red[0][c] + red[1][c];
+}
+__global__ __launch_bounds__(256) void head_table_fin_kernel(const float* __restrict__ part, float* __restrict__ out, int B, int n) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += part[(long)b * n + e];
+  out[e] = s;
+}
+
+// =====================================================================================================================
+struct HeadLayout { long Wd, bd, Wc, bc, bb, Wb, total; int Fin; };
+// flat = [dense_layer W [128, Fin] | b | classification_layer_01 W [R, 256] | b | bili b [R] | bili W [R, 128, 128]]
+// (the bilinear weight last: the padded linear products read up to 31 rows past W_c, which must stay inside the buffer)
+static HeadLayout head_layout(int Hd, int nf, int Pt, int Pr, int R) {
+  HeadLayout y;
+  y.Fin = Hd * nf + Pt + Pr;
+  long o = 0;
+  auto take = [&](long n) { const long at = o; o += (n + 3) & ~3L; return at; };
+  y.Wd = take((long)HW * y.Fin), y.bd = take(HW), y.Wc = take((long)R * 2 * HW), y.bc = take(R), y.bb = take(R);
+  y.Wb = take((long)R * HW * HW);
+  y.total = o;
+  return y;
+}
+
+struct HeadBufs {
+  float *U, *Tt, *Rt, *UT, *bsum, *EH, *ET;                                  // forward (EH / ET saved for backward)
+  float *doutp, *dEH, *dET, *dUT, *partR, *partT, *dRt, *dTt, *dW, *scratch;  // backward
+  long scratch_elems;
+};
+
+static int small_gemm(const float* A, long lda, int a_kc, const float* B, long ldb, int b_kc, float* C, long ldc, int M, int N, int K,
+                      const float* bias, int accumulate, float* ws, long wse, hipStream_t st) {
+  GemmArgs g;
+  g.A = A, g.lda = lda, g.a_kc = a_kc, g.B = B, g.ldb = ldb, g.b_kc = b_kc, g.C = C, g.ldc = ldc;
+  g.M = M, g.N = N, g.K = K, g.bias = bias, g.accumulate = accumulate, g.ws = ws, g.ws_elems = wse;
+  g.tag = "head_gemm";
+  return gemm(g, st);
+}
+
+int head_fwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int dis_plus, const float* const* feats, const long long* type,
+             const long long* rel, const float* ner_emb, const float* dis_table, const float* flat, HeadBufs w, float* logits,
+             hipStream_t st) {
+  const HeadLayout y = head_layout(Hd, nf, Pt, Pr, R);
+  const long BN = (long)B * N, pairs = BN * N;
+  GC_REQUIRE(pairs < (1L << 31) / 2 && R >= 1 && R <= HW, "head: %ld pairs / %d relations out of range", pairs, R);
+  for (int k = 0; k < nf; ++k)  // U = sum_k feats_k W_k^T + b           (glove:354-355, the entity part of the dense layer)
+    GC_TRY(small_gemm(feats[k], Hd, 1, flat + y.Wd + (long)k * Hd, y.Fin, 1, w.U, HW, (int)BN, HW, Hd, k == 0 ? flat + y.bd : nullptr,
+                      k > 0, nullptr, 0, st));
+  GC_TRY(small_gemm(ner_emb, Pt, 1, flat + y.Wd + (long)nf * Hd, y.Fin, 1, w.Tt, HW, 7, HW, Pt, nullptr, 0, nullptr, 0, st));
+  GC_TRY(small_gemm(dis_table, Pr, 1, flat + y.Wd + (long)nf * Hd + Pt, y.Fin, 1, w.Rt, HW, ND, HW, Pr, nullptr, 0, nullptr, 0, st));
+  {
+    ProfScope ps("head_feat", st);
+    hipLaunchKernelGGL(head_node_kernel, dim3(cdiv(BN * HW, 256)), dim3(256), 0, st, w.U, w.Tt, type, w.UT, BN, flat + y.bb, flat + y.bc,
+                       w.bsum, R);
+    GC_TRY(check_launch("head_node"));
+    hipLaunchKernelGGL(head_feat_fwd_kernel, dim3(cdiv(pairs, 4)), dim3(256), 0, st, w.UT, w.Rt, rel, w.EH, w.ET, pairs, N, dis_plus, ND);
+    GC_TRY(check_launch("head_feat_fwd"));
+  }
+  GemmArgs g;   // logits = [eh (x) et | eh | et] [W_b ; W_c]^T + (b_b + b_c)                     (glove:358)
+  g.A = w.EH, g.B = flat + y.Wb, g.C = logits, g.ldc = R;
+  g.M = (int)pairs, g.N = R, g.K = HW * HW + 2 * HW;
+  g.bias = w.bsum;
+  HeadOps o;
+  memset(&o, 0, sizeof(o));
+  o.P = w.EH, o.Q = w.ET, o.ldp = o.ldq = HW, o.KB = HW * HW, o.W2 = flat + y.Wc, o.ldw2 = 2 * HW, o.nmax = R, o.rows = (int)pairs;
+  return head_gemm(1, g, o, st);
+}
+
+int head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int dis_plus, const float* const* feats, const long long* type,
+             const long long* rel, const float* ner_emb, const float* dis_table, const int* n_valid, const float* flat, HeadBufs w,
+             const float* dlogits, float* const* dfeats, float* dner_emb, float* ddis_table, float* dflat, hipStream_t st) {
+  const HeadLayout y = head_layout(Hd, nf, Pt, Pr, R);
+  const long BN = (long)B * N, pairs = BN * N;
+  float* ws = w.scratch;
+  const long wse = w.scratch_elems;
+  {
+    ProfScope ps("head_feat", st);
+    hipLaunchKernelGGL(head_pad_kernel, dim3(cdiv(pairs * HW, 256)), dim3(256), 0, st, dlogits, n_valid, w.doutp, pairs, N, R);
+    GC_TRY(check_launch("head_pad"));
+  }
+  // bias gradients: both biases see the column sums of dlogits
+  GC_TRY(colsum(w.doutp, nullptr, w.dW, pairs, R, HW, 1, 0, 0, 0, 0, ws, st));
+  GC_REQUIRE(hipMemcpyAsync(dflat + y.bb, w.dW, sizeof(float) * R, hipMemcpyDeviceToDevice, st) == hipSuccess, "head: copy failed");
+  GC_REQUIRE(hipMemcpyAsync(dflat + y.bc, w.dW, sizeof(float) * R, hipMemcpyDeviceToDevice, st) == hipSuccess, "head: copy failed");
+  HeadOps o;
+  memset(&o, 0, sizeof(o));
+  o.ldp = o.ldq = HW, o.KB = R * HW, o.nmax = R, o.rows = (int)pairs;
+  {  // d eh = sum_(r,b) dout[p,r] et[p,b] W_b[r,a,b]  + dout W_c[:, :128]
+    GemmArgs g;
+    g.A = w.doutp, g.B = flat + y.Wb, g.C = w.dEH, g.ldc = HW, g.M = (int)pairs, g.N = HW, g.K = R * HW;
+    o.P = w.doutp, o.Q = w.ET;
+    GC_TRY(head_gemm(2, g, o, st));
+    GC_TRY(small_gemm(w.doutp, HW, 1, flat + y.Wc, 2 * HW, 0, w.dEH, HW, (int)pairs, HW, HW, nullptr, 1, nullptr, 0, st));
+  }
+  {  // d et = sum_(r,a) dout[p,r] eh[p,a] W_b[r,a,b]  + dout W_c[:, 128:]
+    GemmArgs g;
+    g.A = w.doutp, g.B = flat + y.Wb, g.C = w.dET, g.ldc = HW, g.M = (int)pairs, g.N = HW, g.K = R * HW;
+    o.P = w.doutp, o.Q = w.EH;
+    GC_TRY(head_gemm(3, g, o, st));
+    GC_TRY(small_gemm(w.doutp, HW, 1, flat + y.Wc + HW, 2 * HW, 0, w.dET, HW, (int)pairs, HW, HW, nullptr, 1, nullptr, 0, st));
+  }
+  {  // d W_b[r, (a, b)] = sum_p dout[p, r] eh[p, a] et[p, b]
+    GemmArgs g;
+    g.A = w.doutp, g.lda = HW, g.B = w.EH, g.C = dflat + y.Wb, g.ldc = HW * HW, g.M = R, g.N = HW * HW, g.K = (int)pairs;
+    g.ws = ws, g.ws_elems = wse;
+    o.P = w.EH, o.Q = w.ET, o.KB = 0;
+    GC_TRY(head_gemm(4, g, o, st));
+  }
+  // d W_c = dout^T [eh | et]    (computed 128 rows deep into a workspace, the R real rows copied out)
+  GC_TRY(small_gemm(w.doutp, HW, 0, w.EH, HW, 0, w.dW, 2 * HW, HW, HW, (int)pairs, nullptr, 0, ws, wse, st));
+  GC_TRY(small_gemm(w.doutp, HW, 0, w.ET, HW, 0, w.dW + HW, 2 * HW, HW, HW, (int)pairs, nullptr, 0, ws, wse, st));
+  GC_REQUIRE(hipMemcpyAsync(dflat + y.Wc, w.dW, sizeof(float) * R * 2 * HW, hipMemcpyDeviceToDevice, st) == hipSuccess, "head: copy failed");
+  {
+    ProfScope ps("head_feat", st);
+    hipLaunchKernelGGL(head_tanh_bwd_kernel, dim3(cdiv(pairs * HW / 4, 256)), dim3(256), 0, st, w.EH, w.ET, w.dEH, w.dET, pairs * HW / 4);
+    GC_TRY(check_launch("head_tanh_bwd"));
+    hipLaunchKernelGGL(head_node_bwd_kernel, dim3((unsigned)BN), dim3(256), 0, st, w.dEH, w.dET, w.dUT, N);
+    GC_TRY(check_launch("head_node_bwd"));
+    hipLaunchKernelGGL(head_table_bwd_kernel, dim3(B, ND), dim3(256), 0, st, rel, w.dEH, w.dET, w.partR, (long)N * N, dis_plus, ND);
+    GC_TRY(check_launch("head_table_bwd/rel"));
+    hipLaunchKernelGGL(head_table_fin_kernel, dim3(cdiv((long)ND * HW, 256)), dim3(256), 0, st, w.partR, w.dRt, B, ND * HW);
+    GC_TRY(check_launch("head_table_fin/rel"));
+    hipLaunchKernelGGL(head_table_bwd_kernel, dim3(B, 7), dim3(256), 0, st, type, w.dUT, (const float*)nullptr, w.partT, (long)N, 0, 7);
+    GC_TRY(check_launch("head_table_bwd/type"));
+    hipLaunchKernelGGL(head_table_fin_kernel, dim3(cdiv(7L * HW, 256)), dim3(256), 0, st, w.partT, w.dTt, B, 7 * HW);
+    GC_TRY(check_launch("head_table_fin/type"));
+  }
+  // dense layer: entity part, type part, relative-position part
+  for (int k = 0; k < nf; ++k) {
+    GC_TRY(small_gemm(w.dUT, HW, 1, flat + y.Wd + (long)k * Hd, y.Fin, 0, dfeats[k], Hd, (int)BN, Hd, HW, nullptr, 0, ws, wse, st));
+    GC_TRY(small_gemm(w.dUT, HW, 0, feats[k], Hd, 0, dflat + y.Wd + (long)k * Hd, y.Fin, HW, Hd, (int)BN, nullptr, 0, ws, wse, st));
+  }
+  GC_TRY(colsum(w.dUT, nullptr, dflat + y.bd, BN, HW, HW, 1, 0, 0, 0, 0, ws, st));
+  GC_TRY(small_gemm(w.dTt, HW, 0, ner_emb, Pt, 0, dflat + y.Wd + (long)nf * Hd, y.Fin, HW, Pt, 7, nullptr, 0, nullptr, 0, st));
+  GC_TRY(small_gemm(w.dTt, HW, 1, flat + y.Wd + (long)nf * Hd, y.Fin, 0, dner_emb, Pt, 7, Pt, HW, nullptr, 0, nullptr, 0, st));
+  // ner_emb = nn.Embedding(7, 20, padding_idx=0) (glove:241): the padding row never receives a gradient
+  GC_REQUIRE(hipMemsetAsync(dner_emb, 0, sizeof(float) * Pt, st) == hipSuccess, "head: memset failed");
+  GC_TRY(small_gemm(w.dRt, HW, 0, dis_table, Pr, 0, dflat + y.Wd + (long)nf * Hd + Pt, y.Fin, HW, Pr, ND, nullptr, 0, nullptr, 0, st));
+  GC_TRY(small_gemm(w.dRt, HW, 1, flat + y.Wd + (long)nf * Hd + Pt, y.Fin, 0, ddis_table, Pr, ND, Pr, HW, nullptr, 0, nullptr, 0, st));
+  return 0;
+}
+
+static HeadBufs head_bind(float* fwd, float* bwd, int B, int N, int R, int ND, long* n_fwd, long* n_bwd) {
+  const long BN = (long)B * N, pairs = BN * N;
+  HeadBufs w;
+  memset(&w, 0, sizeof(w));
+  float* base = fwd;
+  long at = 0;
+  auto tf = [&](long n) { float* p = base ? base + at : nullptr; at += (n + 3) & ~3L; return p; };
+  w.U = tf(BN * HW), w.Tt = tf(7 * HW), w.Rt = tf((long)ND * HW), w.UT = tf(BN * HW), w.bsum = tf(HW), w.EH = tf(pairs * HW);
+  w.ET = tf(pairs * HW);
+  if (n_fwd) *n_fwd = at;
+  base = bwd, at = 0;
+  w.doutp = tf(pairs * HW), w.dEH = tf(pairs * HW), w.dET = tf(pairs * HW), w.dUT = tf(BN * HW), w.partR = tf((long)B * ND * HW);
+  w.partT = tf((long)B * 7 * HW), w.dRt = tf((long)ND * HW), w.dTt = tf(7 * HW), w.dW = tf((long)HW * 2 * HW);
+  // split-K partials: up to 8 slabs of the [R, 16384] bilinear weight gradient
+  w.scratch_elems = 8L * R * HW * HW;
+  const long cs = colsum_scratch_elems(pairs, HW, 1);
+  if (w.scratch_elems < cs) w.scratch_elems = cs;
+  w.scratch = tf(w.scratch_elems);
+  if (n_bwd) *n_bwd = at;
+  return w;
+}
+
+}  // namespace gc
+
+#include "../../include/gcgcn.h"
+using namespace gc;
+
+extern "C" {
+
+int gcgcn_head_layout(int Hd, int nf, int Pt, int Pr, int R, int64_t* o) {
+  GC_REQUIRE(Hd > 0 && nf > 0 && Pt > 0 && Pr > 0 && R > 0 && R <= HW && o, "head_layout: bad arguments");
+  const HeadLayout y = head_layout(Hd, nf, Pt, Pr, R);
+  o[0] = y.Wd, o[1] = y.bd, o[2] = y.Wc, o[3] = y.bc, o[4] = y.bb, o[5] = y.Wb, o[6] = y.total;
+  return 0;
+}
+
+int gcgcn_head_sizes(int B, int N, int R, int ND, int64_t* out2) {
+  GC_REQUIRE(B > 0 && N > 0 && R > 0 && R <= HW && ND > 0 && out2, "head_sizes: bad arguments");
+  long a = 0, b = 0;
+  head_bind(nullptr, nullptr, B, N, R, ND, &a, &b);
+  out2[0] = a, out2[1] = b;
+  return 0;
+}
+
+int gcgcn_head_fwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int dis_plus, const float* const* feats,
+                   const int64_t* node_type, const int64_t* node_relative_pos, const float* ner_emb, const float* dis_table,
+                   const float* flat, float* fbuf, float* logits, void* stream) {
+  GC_REQUIRE(B > 0 && N > 0 && Hd > 0 && nf > 0 && nf <= 8 && Pt > 0 && Pr > 0 && R > 0 && ND > 0, "head_fwd: bad shape");
+  GC_REQUIRE(Hd % 4 == 0 && Pt % 4 == 0 && Pr % 4 == 0, "head_fwd: feature widths must be multiples of 4 (16-byte rows)");
+  GC_REQUIRE(feats && node_type && node_relative_pos && ner_emb && dis_table && flat && fbuf && logits, "head_fwd: null pointer");
+  const HeadBufs w = head_bind(fbuf, nullptr, B, N, R, ND, nullptr, nullptr);
+  return head_fwd(B, N, Hd, nf, Pt, Pr, R, ND, dis_plus, feats, (const long long*)node_type, (const long long*)node_relative_pos, ner_emb,
+                  dis_table, flat, w, logits, (hipStream_t)stream);
+}
+
+int gcgcn_head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int dis_plus, const float* const* feats,
+                   const int64_t* node_type, const int64_t* node_relative_pos, const float* ner_emb, const float* dis_table,
+                   const int32_t* n_valid, const float* flat, float* fbuf, float* bbuf, const float* dlogits, float* const* dfeats,
+                   float* dner_emb, float* ddis_table, float* dflat, void* stream) {
+  GC_REQUIRE(B > 0 && N > 0 && Hd > 0 && nf > 0 && nf <= 8 && Pt > 0 && Pr > 0 && R > 0 && ND > 0, "head_bwd: bad shape");
+  GC_REQUIRE(feats && node_type && node_relative_pos && ner_emb && dis_table && flat && fbuf && bbuf && dlogits && dfeats && dner_emb &&
+                 ddis_table && dflat,
+             "head_bwd: null pointer");
+  const HeadBufs w = head_bind(fbuf, bbuf, B, N, R, ND, nullptr, nullptr);
+  return head_bwd(B, N, Hd, nf, Pt, Pr, R, ND, dis_plus, feats, (const long long*)node_type, (const long long*)node_relative_pos, ner_emb,
+                  dis_table, n_valid, flat, w, dlogits, dfeats, dner_emb, ddis_table, dflat, (hipStream_t)stream);
+}
+
+}  // extern "C"

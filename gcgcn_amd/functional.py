@@ -540,6 +540,59 @@ class ProducerFn(torch.autograd.Function):
         return dtok, dnode, dtab, dflat, None, None, None, None, None, None
 
 
+class HeadFn(torch.autograd.Function):
+    """(flat, ner_emb[7,Pt], dis_table[ND,Pr], feats_0 .. feats_{nf-1} [B,N,Hd]; node_type, node_relative_pos) ->
+    logits[B,N,N,R].  The classifier head, GCGCN_glove.py:306-307, 344-358."""
+
+    @staticmethod
+    def forward(ctx, flat, ner_emb, dis_table, node_type, rel, n_valid, R, dis_plus, *feats):
+        B, N, Hd = feats[0].shape
+        nf, Pt, (ND, Pr) = len(feats), ner_emb.shape[1], dis_table.shape
+        dev = flat.device
+        sizes = (ctypes.c_int64 * 2)()
+        call("gcgcn_head_sizes", B, N, R, ND, ctypes.cast(sizes, ctypes.c_void_p))
+        fbuf = torch.empty(sizes[0], device=dev)
+        logits = torch.empty(B, N, N, R, device=dev)
+        fp = (ctypes.c_void_p * nf)(*[f.data_ptr() for f in feats])
+        call("gcgcn_head_fwd", B, N, Hd, nf, Pt, Pr, R, ND, dis_plus, ctypes.cast(fp, ctypes.c_void_p), _p(node_type), _p(rel),
+             _p(ner_emb), _p(dis_table), _p(flat), _p(fbuf), _p(logits), _stream())
+        ctx.save_for_backward(flat, ner_emb, dis_table, node_type, rel, fbuf, *feats)
+        ctx.n_valid, ctx.R, ctx.dis_plus, ctx.nbwd = n_valid, R, dis_plus, int(sizes[1])
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        flat, ner_emb, dis_table, node_type, rel, fbuf, *feats = ctx.saved_tensors
+        B, N, Hd = feats[0].shape
+        nf, Pt, (ND, Pr) = len(feats), ner_emb.shape[1], dis_table.shape
+        dev = flat.device
+        dlogits = dlogits.contiguous()
+        bbuf = torch.empty(ctx.nbwd, device=dev)
+        dfeats = [torch.empty_like(f) for f in feats]
+        dner, dtab, dflat = torch.empty_like(ner_emb), torch.empty_like(dis_table), torch.empty_like(flat)
+        fp = (ctypes.c_void_p * nf)(*[f.data_ptr() for f in feats])
+        dp = (ctypes.c_void_p * nf)(*[f.data_ptr() for f in dfeats])
+        call("gcgcn_head_bwd", B, N, Hd, nf, Pt, Pr, ctx.R, ND, ctx.dis_plus, ctypes.cast(fp, ctypes.c_void_p), _p(node_type),
+             _p(rel), _p(ner_emb), _p(dis_table), _p(ctx.n_valid), _p(flat), _p(fbuf), _p(bbuf), _p(dlogits),
+             ctypes.cast(dp, ctypes.c_void_p), _p(dner), _p(dtab), _p(dflat), _stream())
+        return (dflat, dner, dtab, None, None, None, None, None, *dfeats)
+
+
+def classifier_head(feats, node_type, node_relative_pos, ner_emb, dis_table, flat, relation_num, n_valid=None, dis_plus=10):
+    """logits[B,N,N,R] from the model's node_feats list (each [B,N,Hd]), node_type int64[B,N], node_relative_pos
+    int64[B,N,N], the two embedding tables and the head's flat parameters."""
+    feats = [_chk(f, f"node_feats[{i}]", 3) for i, f in enumerate(feats)]
+    B, N, Hd = feats[0].shape
+    if any(tuple(f.shape) != (B, N, Hd) for f in feats):
+        raise ValueError("node_feats: every entry must have the same [B,N,H] shape")
+    for nm, t, shp in (("node_type", node_type, (B, N)), ("node_relative_pos", node_relative_pos, (B, N, N))):
+        if not t.is_cuda or t.dtype != torch.int64 or tuple(t.shape) != shp:
+            raise ValueError(f"{nm}: expected a GPU int64 tensor of shape {shp}, got {t.dtype} {tuple(t.shape)} on {t.device}")
+    return HeadFn.apply(_chk(flat, "flat"), _chk(ner_emb, "ner_emb.weight", 2), _chk(dis_table, "dis_embed.weight", 2),
+                        node_type.contiguous(), node_relative_pos.contiguous(), _nv(n_valid, B, N, flat.device),
+                        int(relation_num), int(dis_plus), *feats)
+
+
 def producer_live_counts(sen: Tensor, n_valid=None):
     """(live sentence slots, entity pairs with a live slot) of a batch -- one small kernel and a device-to-host read.
     A slot is live iff token 0 belongs to it: the reference's own padding test (``~sen_matrix[..., 0:1]``, glove:305)."""

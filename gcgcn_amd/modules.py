@@ -398,6 +398,58 @@ class EdgeFeatureProducer(_FlatBlock):
 
 
 # ======================================================================================================
+class ClassifierHead(_FlatBlock):
+    """The pairwise relation classifier (GCGCN_glove.py:271-276 construction, :306-307 and :344-358
+    forward): ``dense_layer`` on ``cat(node_feats, type embedding, relative-position embedding)`` for the head and the
+    tail entity of every pair, ``tanh``, then ``bili_layer_01(eh, et) + classification_layer_01(cat(eh, et))``.
+
+    ``state_dict()`` keys equal the model's (``dense_layer.*``, ``bili_layer_01.*``, ``classification_layer_01.*``).  The
+    two embedding tables stay with the model (``ner_emb`` is also used by the encoder, ``dis_embed`` by the edge-feature
+    producer) and are passed to ``forward``.  The hidden width of the pair features is 128 as in the reference (glove:234).
+    """
+
+    def __init__(self, hidden_size: int = 128, graph_hop: int = 2, entity_type_size: int = 20, dis_size: int = 20,
+                 relation_num: int = 97, dis_plus: int = 10):
+        super().__init__()
+        self.hidden, self.nf, self.pt, self.pr, self.R, self.dis_plus = hidden_size, graph_hop + 1, entity_type_size, dis_size, \
+            relation_num, dis_plus
+        self.flat = nn.Parameter(torch.zeros(P_.head_layout(*self._dims())[-1]))
+        with torch.no_grad():
+            P_.pack_head(P_.init_head(*self._dims()), *self._dims(), self.flat)
+
+    def _dims(self):
+        return self.hidden, self.nf, self.pt, self.pr, self.R
+
+    def _ref_shapes(self):
+        s = P_.head_shapes(*self._dims())
+        return {k: s[k] for k in P_.HEAD_STATE_ORDER}
+
+    def _ref_tensors(self):
+        return P_.unpack_head(self.flat.detach(), *self._dims())
+
+    def _load_ref(self, sd):
+        P_.pack_head(sd, *self._dims(), self.flat)
+
+    def named_grads(self):
+        return P_.unpack_head(self.flat.grad, *self._dims()) if self.flat.grad is not None else {}
+
+    def forward(self, node_feats: Sequence[Tensor], node_type: Tensor, node_relative_pos: Tensor, ner_emb_weight: Tensor,
+                dis_embed_weight: Tensor, n_valid: Optional[Tensor] = None) -> Tensor:
+        """node_feats: the model's list (``graph_hop + 1`` tensors ``[N,H]`` or ``[B,N,H]``, glove:311/338); node_type
+        ``Long[N]``; node_relative_pos ``Long[N,N]`` in ``-dis_plus..dis_plus``.  Returns ``relation_before_softmax_01``:
+        ``[N,N,R]`` or ``[B,N,N,R]``."""
+        if len(node_feats) != self.nf:
+            raise ValueError(f"node_feats: expected {self.nf} tensors (graph_hop + 1), got {len(node_feats)}")
+        batched = node_feats[0].dim() == 3
+        if not batched:
+            node_feats = [f.unsqueeze(0) for f in node_feats]
+            node_type, node_relative_pos = node_type.unsqueeze(0), node_relative_pos.unsqueeze(0)
+        out = F_.classifier_head(node_feats, node_type, node_relative_pos, ner_emb_weight, dis_embed_weight, self.flat, self.R,
+                                 n_valid, self.dis_plus)
+        return out if batched else out.squeeze(0)
+
+
+# ======================================================================================================
 class GraphHops(nn.Module):
     """The model's hop loop restricted to the graph blocks (GCGCN_glove.py:254-262 construction,
     :329-341 forward): hop 0 = GATAttention + GraphConvolution (CAGGC), hop i >= 1 = MultiHeadAttention +

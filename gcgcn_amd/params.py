@@ -241,3 +241,55 @@ def init_producer(Hd: int, P: int) -> Dict[str, Tensor]:
         if k.endswith(".weight"):
             _linear_init(sd[k], sd[k[:-6] + "bias"])
     return sd
+
+
+# ---- classifier head: dense_layer + bili_layer_01 + classification_layer_01 (GCGCN_glove.py:271-276) ----
+def head_shapes(Hd: int, nf: int, Pt: int, Pr: int, R: int, HW: int = 128) -> Dict[str, tuple]:
+    return {"dense_layer.weight": (HW, Hd * nf + Pt + Pr), "dense_layer.bias": (HW,),
+            "classification_layer_01.weight": (R, 2 * HW), "classification_layer_01.bias": (R,),
+            "bili_layer_01.bias": (R,), "bili_layer_01.weight": (R, HW, HW)}
+
+
+HEAD_STATE_ORDER = ("dense_layer.weight", "dense_layer.bias", "bili_layer_01.weight", "bili_layer_01.bias",
+                    "classification_layer_01.weight", "classification_layer_01.bias")     # the model's own order
+
+
+def head_layout(Hd: int, nf: int, Pt: int, Pr: int, R: int):
+    o, at = [], 0
+    for shp in head_shapes(Hd, nf, Pt, Pr, R).values():
+        o.append(at)
+        n = 1
+        for v in shp:
+            n *= v
+        at += (n + 3) & ~3                     # every piece starts 16-byte aligned (csrc/head.hip head_layout)
+    return o + [at]
+
+
+def unpack_head(flat: Tensor, Hd: int, nf: int, Pt: int, Pr: int, R: int) -> Dict[str, Tensor]:
+    o = head_layout(Hd, nf, Pt, Pr, R)
+    shapes = head_shapes(Hd, nf, Pt, Pr, R)
+    got = {}
+    for i, (k, shp) in enumerate(shapes.items()):
+        n = 1
+        for v in shp:
+            n *= v
+        got[k] = flat[o[i]:o[i] + n].view(shp)
+    return {k: got[k] for k in HEAD_STATE_ORDER}
+
+
+def pack_head(sd: Dict[str, Tensor], Hd: int, nf: int, Pt: int, Pr: int, R: int, out: Tensor) -> Tensor:
+    o = head_layout(Hd, nf, Pt, Pr, R)
+    for i, k in enumerate(head_shapes(Hd, nf, Pt, Pr, R)):
+        v = sd[k].reshape(-1)
+        out[o[i]:o[i] + v.numel()].copy_(v)
+    return out
+
+
+def init_head(Hd: int, nf: int, Pt: int, Pr: int, R: int, HW: int = 128) -> Dict[str, Tensor]:
+    sd = {k: torch.empty(s) for k, s in head_shapes(Hd, nf, Pt, Pr, R).items()}
+    _linear_init(sd["dense_layer.weight"], sd["dense_layer.bias"])
+    _linear_init(sd["classification_layer_01.weight"], sd["classification_layer_01.bias"])
+    bound = 1.0 / math.sqrt(HW)                 # nn.Bilinear.reset_parameters: U(-1/sqrt(in1_features), ...)
+    torch.nn.init.uniform_(sd["bili_layer_01.weight"], -bound, bound)
+    torch.nn.init.uniform_(sd["bili_layer_01.bias"], -bound, bound)
+    return sd

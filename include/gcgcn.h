@@ -237,6 +237,30 @@ int gcgcn_producer_bwd(int B, int N, int S, int T, int Hd, int P, int ND, const 
                        const float* flat, int64_t cap_rows, int64_t cap_pairs, int32_t* ibuf, float* fbuf, float* bbuf,
                        const float* dE, float* dctx, float* dnode, float* ddis_table, float* dflat, void* stream);
 
+/* ---- classifier head  GCGCN_glove.py:306-307, 344-358 ------------------------------------------------ */
+/* logits[B,N,N,R] = bili_layer_01(eh, et) + classification_layer_01(cat(eh, et)) with
+ *   eh[i,j] = tanh(dense_layer(cat(feats[j], ner_emb[type[j]], dis_embed[dis_plus + rel[i,j]])))   (column entity)
+ *   et[i,j] = tanh(dense_layer(cat(feats[i], ner_emb[type[i]], dis_embed[dis_plus - rel[i,j]])))   (row entity)
+ * feats: host array of nf device pointers, the model's node_feats list (each [B,N,Hd]); node_type int64[B,N] in 0..6;
+ * node_relative_pos int64[B,N,N]; ner_emb[7,Pt] (padding_idx 0: its row 0 gets no gradient), dis_table[ND,Pr].
+ * The hidden width of eh / et is 128 (hard-coded in the reference, glove:234); R <= 128.
+ * flat = [dense_layer W [128, nf Hd + Pt + Pr] | b | classification_layer_01 W [R,256] | b | bili_layer_01 b [R] |
+ *         bili_layer_01 W [R,128,128]], pieces 16-byte aligned; out7 = 6 offsets + total.
+ * The bilinear form runs on the fp32 MFMA with the per-pair outer product eh (x) et generated in registers: no
+ * [pairs, 16384] operand and no [N,N,F] concatenations exist.  Buffers: fbuf float[sizes[0]] (forward, kept for backward),
+ * bbuf float[sizes[1]] (backward workspace) from gcgcn_head_sizes.  Deterministic (no atomics). */
+int gcgcn_head_layout(int Hd, int nf, int Pt, int Pr, int R, int64_t* out7);
+int gcgcn_head_sizes(int B, int N, int R, int ND, int64_t* out2);
+int gcgcn_head_fwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int dis_plus, const float* const* feats,
+                   const int64_t* node_type, const int64_t* node_relative_pos, const float* ner_emb, const float* dis_table,
+                   const float* flat, float* fbuf, float* logits, void* stream);
+/* dlogits[B,N,N,R] (entries of padding entities ignored when n_valid is given) -> dfeats (nf pointers, [B,N,Hd] each),
+ * dner_emb[7,Pt], ddis_table[ND,Pr], dflat. */
+int gcgcn_head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int dis_plus, const float* const* feats,
+                   const int64_t* node_type, const int64_t* node_relative_pos, const float* ner_emb, const float* dis_table,
+                   const int32_t* n_valid, const float* flat, float* fbuf, float* bbuf, const float* dlogits, float* const* dfeats,
+                   float* dner_emb, float* ddis_table, float* dflat, void* stream);
+
 /* ---- raw batched GEMM (exposed for unit tests and benchmarks of the MFMA kernel) ----------- */
 /* C[z] = alpha * opA(A[z]) opB(B[z]);  a_kc: A stored [M][K] else [K][M];  b_kc: B stored [N][K]
  * else [K][N];  z < batch with element strides sA, sB, sC;  tile: 0 auto, 1 = 64x64, 2 = 128x128;

@@ -371,3 +371,28 @@ def edge_features_folded(ctx: Tensor, sen_matrix: Tensor, pos_h: Tensor, pos_t: 
     cs_t = sentence(nterm.view(n, 1, 1, -1))                                                       # tail side: indexed by i
     ls = sub(sd, f"linear_sentence_att.{hop}")
     return torch.cat([cs_h, cs_t], 2) @ ls["weight"].t() + ls["bias"]
+
+
+# --------------------------------------------------------------------------------------
+# the classifier head                                 GCGCN_glove.py:306-307, 344-358
+# --------------------------------------------------------------------------------------
+def classifier_head(node_feats: Sequence[Tensor], node_type: Tensor, node_relative_pos: Tensor, sd: Params,
+                    dis_plus: int = 10) -> Tensor:
+    """node_feats: the model's list ``[nf_0, ..., nf_hop]`` of [N,Hd] tensors (glove:311, 338), node_type Long[N] in 0..6,
+    node_relative_pos Long[N,N] in -dis_plus..dis_plus -> logits [N,N,R].  sd keys (model names): ``ner_emb.weight``,
+    ``dis_embed.weight``, ``dense_layer.{weight,bias}``, ``bili_layer_01.{weight,bias}``,
+    ``classification_layer_01.{weight,bias}``."""
+    n = node_type.shape[0]
+    rel_h = sd["dis_embed.weight"][dis_plus + node_relative_pos]                              # :306
+    rel_t = sd["dis_embed.weight"][dis_plus - node_relative_pos]                              # :307
+    feats = torch.cat(list(node_feats), 1)                                                    # :344
+    # ner_emb = nn.Embedding(7, entity_type_size, padding_idx=0) (glove:241): row 0 receives no gradient
+    feats = torch.cat([feats, torch.nn.functional.embedding(node_type, sd["ner_emb.weight"], padding_idx=0)], 1)   # :345-347
+    with_h = torch.cat([feats.unsqueeze(0).expand(n, -1, -1), rel_h], -1)                     # :351
+    with_t = torch.cat([feats.unsqueeze(1).expand(-1, n, -1), rel_t], -1)                     # :352
+    w, b = sd["dense_layer.weight"], sd["dense_layer.bias"]
+    eh = torch.tanh(with_h @ w.t() + b)                                                       # :354
+    et = torch.tanh(with_t @ w.t() + b)                                                       # :355
+    ef = torch.cat([eh, et], -1)                                                              # :356
+    bil = torch.einsum("ija,rab,ijb->ijr", eh, sd["bili_layer_01.weight"], et) + sd["bili_layer_01.bias"]
+    return bil + ef @ sd["classification_layer_01.weight"].t() + sd["classification_layer_01.bias"]   # :358

@@ -276,6 +276,65 @@ def producer_cases(ref):
         yield f"producer_n{n}_s{s}_t{t}_h{hd}", d
 
 
+HEAD_BILI_SLICES = [0, 48, 96]
+
+
+def head_bilinear_weight(seed: int, r: int = 97, h: int = 128):
+    """The bilinear weight used by the head fixtures: U(-1/sqrt(h), 1/sqrt(h)) from torch.Generator().manual_seed(1000 + seed)
+    (tests/ regenerate it from the stored seed)."""
+    g = torch.Generator().manual_seed(1000 + int(seed))
+    return (torch.rand(r, h, h, generator=g) * 2 - 1) / (h ** 0.5)
+
+
+def head_cases(ref):
+    """SURVEY 8 row f3, pinned on the reference's own statements: a real ``GCGCN_glove`` is built (its ``dense_layer``,
+    ``bili_layer_01``, ``classification_layer_01``, ``ner_emb``, ``dis_embed`` with the reference's initialisers) and
+    lines 306-307 and 344-358 of GCGCN_glove.py are executed verbatim (read as text at generation time, nothing of them
+    is written to the repo) on synthetic ``node_feats`` / ``node_type`` / ``node_relative_pos``."""
+    import contextlib, io, textwrap
+    lines = open(REF_FILE, encoding="utf-8").read().split("\n")
+    pre = lines[305:307]
+    assert pre[0].strip().startswith("node_relative_pos_h = self.dis_embed(self.config.dis_plus + node_relative_pos)"), pre[0]
+    body = lines[343:358]
+    assert body[0].strip() == "node_feats = torch.cat(node_feats,1)", body[0]
+    assert lines[359].strip() == "return relation_before_softmax_01", lines[359]
+    code = compile(textwrap.dedent("\n".join(pre)) + "\n" + textwrap.dedent("\n".join(body)) + "\n", "GCGCN_glove.py:306-307,344-358", "exec")
+    keep = ("ner_emb.", "dis_embed.", "dense_layer.", "bili_layer_01.", "classification_layer_01.")
+    for n, seed in ((1, 0), (2, 1), (5, 2), (16, 1337)):
+        torch.manual_seed(seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = ref.GCGCN_glove(_Cfg(50)).eval()
+        # The bilinear weight (97 x 128 x 128 = 6.4 MB) is an INPUT of the statements under test: it is drawn from a
+        # documented generator (nn.Bilinear's own bound 1/sqrt(in1_features)) so that the fixture stores a seed, not the tensor.
+        with torch.no_grad():
+            model.bili_layer_01.weight.copy_(head_bilinear_weight(seed))
+        g = torch.Generator().manual_seed(seed + 7)
+        feats = [(torch.rand(n, 128, generator=g) * 2 - 1).requires_grad_() for _ in range(3)]     # [nf0, nf0', nf1]: graph_hop + 1
+        node_type = torch.randint(0, 7, (n,), generator=g)
+        rel = torch.randint(-10, 11, (n, n), generator=g)
+        ns = {"torch": torch, "self": model, "node_feats": list(feats), "node_type": node_type, "node_relative_pos": rel, "node_num": n}
+        exec(code, ns)                                                              # the model's own statements
+        out = ns["relation_before_softmax_01"]
+        cot = torch.randn(out.shape, generator=g)
+        (out * cot).sum().backward()
+        d = {"node_type": _np(node_type), "rel": _np(rel), "out": _np(out), "cot": _np(cot), "meta.bili_seed": np.int64(seed)}
+        for i, f in enumerate(feats):
+            d[f"in.f{i}"] = _np(f)
+            d[f"grad.in.f{i}"] = _np(f.grad)
+        for k, v in model.state_dict().items():
+            if k.startswith(keep) and k != "bili_layer_01.weight":
+                d["sd." + k] = _np(v)
+        for k, p in model.named_parameters():
+            if k.startswith(keep) and p.grad is not None:
+                if k == "bili_layer_01.weight":      # three relation slices + the sum over relations instead of 6.4 MB
+                    d["gradpart.bili.r"] = np.array(HEAD_BILI_SLICES)
+                    d["gradpart.bili.slices"] = _np(p.grad[HEAD_BILI_SLICES])
+                    d["gradpart.bili.sum_r"] = _np(p.grad.sum(0))
+                else:
+                    d["grad.sd." + k] = _np(p.grad)
+        yield f"head_n{n}_s{seed}", d
+
+
 def trainer_loss_lines():
     """The trainer's own loss statements, read as text from /root/reference/config/Config.py at generation time (the module
     itself is not importable: it needs torch_geometric, and the loss is a loop inside ``train``, not a function):
@@ -319,9 +378,11 @@ def main():
         cases = list(loss_cases())
     elif "--producer-only" in sys.argv:
         cases = list(producer_cases(load_reference()))
+    elif "--head-only" in sys.argv:
+        cases = list(head_cases(load_reference()))
     else:
         ref = load_reference()
-        cases = list(block_cases(ref)) + [full_model_case(ref)] + list(loss_cases()) + list(producer_cases(ref))
+        cases = list(block_cases(ref)) + [full_model_case(ref)] + list(loss_cases()) + list(producer_cases(ref)) + list(head_cases(ref))
     for name, pk in cases:
         path = os.path.join(OUT_DIR, name + ".npz")
         np.savez_compressed(path, **pk)

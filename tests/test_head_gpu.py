@@ -1,0 +1,107 @@
+"""SURVEY 8 row f3 on the GPU: the classifier head kernels (csrc/head.hip) against fixtures produced by executing the
+reference's own statements (GCGCN_glove.py:306-307, 344-358) and against the CPU oracle on batched / ragged inputs; the
+head's logits feeding the trainer's loss kernel (f2) end to end."""
+import pytest
+import torch
+
+from conftest import golden_files, ids, load_golden
+import gcgcn_amd
+from gcgcn_amd import params as P_
+from oracle import gcgcn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def head_bilinear_weight(seed, r=97, h=128):
+    g = torch.Generator().manual_seed(1000 + int(seed))
+    return (torch.rand(r, h, h, generator=g) * 2 - 1) / (h ** 0.5)
+
+
+@pytest.mark.parametrize("path", golden_files("head"), ids=ids(golden_files("head")))
+def test_head_golden(gpu_device, path):
+    g = load_golden(path)
+    r = g["raw"]
+    sd = dict(g["sd"])
+    sd["bili_layer_01.weight"] = head_bilinear_weight(g["meta"]["bili_seed"])
+    head = gcgcn_amd.ClassifierHead().to(gpu_device)
+    head.load_state_dict({k: v for k, v in sd.items() if not k.startswith(("ner_emb", "dis_embed"))}, strict=True)
+    dev = lambda t: t.to(gpu_device)
+    feats = [dev(g["in"][f"f{i}"]).requires_grad_() for i in range(3)]
+    ner, dis = dev(sd["ner_emb.weight"]).requires_grad_(), dev(sd["dis_embed.weight"]).requires_grad_()
+    out = head(feats, dev(torch.from_numpy(r["node_type"])), dev(torch.from_numpy(r["rel"])), ner, dis)
+    torch.testing.assert_close(out.cpu(), g["out"], rtol=1e-4, atol=1e-4)
+    (out * dev(g["cot"])).sum().backward()
+    for i, f in enumerate(feats):
+        torch.testing.assert_close(f.grad.cpu(), g["grad_in"][f"f{i}"], rtol=1e-3, atol=1e-4)
+    grads = head.named_grads()
+    for k, want in g["grad_sd"].items():
+        got = ner.grad if k == "ner_emb.weight" else dis.grad if k == "dis_embed.weight" else grads[k]
+        torch.testing.assert_close(got.cpu(), want, rtol=1e-3, atol=1e-4 * max(1.0, want.abs().max().item()), msg=lambda m: f"grad {k}: {m}")
+    gb = grads["bili_layer_01.weight"].cpu()
+    torch.testing.assert_close(gb[torch.from_numpy(r["gradpart.bili.r"])], torch.from_numpy(r["gradpart.bili.slices"]), rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(gb.sum(0), torch.from_numpy(r["gradpart.bili.sum_r"]), rtol=1e-3, atol=1e-3)
+    assert ner.grad[0].abs().sum().item() == 0           # padding_idx = 0 (glove:241)
+
+
+@pytest.mark.parametrize("B,N,R,hop", [(3, 9, 97, 2), (2, 64, 97, 2), (2, 13, 5, 1)])
+def test_head_batched_ragged_matches_oracle(gpu_device, B, N, R, hop):
+    g = torch.Generator().manual_seed(B * 10 + N)
+    head = gcgcn_amd.ClassifierHead(graph_hop=hop, relation_num=R).to(gpu_device)
+    sd = {k: v.cpu().clone().requires_grad_() for k, v in head.state_dict().items()}
+    sd["ner_emb.weight"] = (torch.randn(7, 20, generator=g) * 0.3).requires_grad_()
+    sd["dis_embed.weight"] = (torch.randn(21, 20, generator=g) * 0.3).requires_grad_()
+    feats = [torch.rand(B, N, 128, generator=g) * 2 - 1 for _ in range(hop + 1)]
+    ntype = torch.randint(0, 7, (B, N), generator=g)
+    rel = torch.randint(-10, 11, (B, N, N), generator=g)
+    nv = torch.tensor(([N, max(1, N // 2), 3] * B)[:B], dtype=torch.int32)
+    cot = torch.randn(B, N, N, R, generator=g)
+    dev = lambda t: t.to(gpu_device)
+    fg = [dev(f).requires_grad_() for f in feats]
+    ner, dis = dev(sd["ner_emb.weight"].detach()).requires_grad_(), dev(sd["dis_embed.weight"].detach()).requires_grad_()
+    out = head(fg, dev(ntype), dev(rel), ner, dis, n_valid=dev(nv))
+    (out * dev(cot)).sum().backward()
+    fr = [f.clone().requires_grad_() for f in feats]
+    loss = 0
+    for b in range(B):
+        n = int(nv[b])
+        ref = O.classifier_head([f[b, :n] for f in fr], ntype[b, :n], rel[b, :n, :n], sd)
+        torch.testing.assert_close(out[b, :n, :n].detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
+        loss = loss + (ref * cot[b, :n, :n]).sum()
+    loss.backward()
+    for a, b_ in zip(fg, fr):
+        torch.testing.assert_close(a.grad.cpu(), b_.grad, rtol=1e-3, atol=1e-4 * max(1.0, b_.grad.abs().max().item()))
+    grads = head.named_grads()
+    for k in grads:
+        want = sd[k].grad
+        torch.testing.assert_close(grads[k].cpu(), want, rtol=1e-3, atol=2e-4 * max(1.0, want.abs().max().item()), msg=lambda m: f"grad {k}: {m}")
+    torch.testing.assert_close(ner.grad.cpu(), sd["ner_emb.weight"].grad, rtol=1e-3, atol=1e-4 * max(1.0, sd["ner_emb.weight"].grad.abs().max().item()))
+    torch.testing.assert_close(dis.grad.cpu(), sd["dis_embed.weight"].grad, rtol=1e-3, atol=1e-4 * max(1.0, sd["dis_embed.weight"].grad.abs().max().item()))
+    # determinism (no atomics on this path)
+    head.zero_grad()
+    fg2 = [dev(f).requires_grad_() for f in feats]
+    out2 = head(fg2, dev(ntype), dev(rel), ner.detach(), dis.detach(), n_valid=dev(nv))
+    (out2 * dev(cot)).sum().backward()
+    assert torch.equal(out, out2) and torch.equal(head.flat.grad, head.flat.grad) and all(torch.equal(a.grad, b_.grad) for a, b_ in zip(fg, fg2))
+
+
+def test_head_feeds_the_trainer_loss(gpu_device):
+    """f3 -> f2: logits from the head into the trainer's per-document loss kernel, gradients back into the head, against
+    the oracle chain (classifier_head -> pair_bce_loss_loop)."""
+    g = torch.Generator().manual_seed(5)
+    N = 6
+    head = gcgcn_amd.ClassifierHead().to(gpu_device)
+    sd = {k: v.cpu().clone().requires_grad_() for k, v in head.state_dict().items()}
+    sd["ner_emb.weight"] = (torch.randn(7, 20, generator=g) * 0.3)
+    sd["dis_embed.weight"] = (torch.randn(21, 20, generator=g) * 0.3)
+    feats = [torch.rand(N, 128, generator=g) * 2 - 1 for _ in range(3)]
+    ntype, rel = torch.randint(0, 7, (N,), generator=g), torch.randint(-10, 11, (N, N), generator=g)
+    labels = (torch.rand(N, N, 97, generator=g) < 0.05).float()
+    dev = lambda t: t.to(gpu_device)
+    out = head([dev(f) for f in feats], dev(ntype), dev(rel), dev(sd["ner_emb.weight"]), dev(sd["dis_embed.weight"]))
+    loss = gcgcn_amd.pair_bce_loss(out, dev(labels))
+    loss.backward()
+    ref = O.pair_bce_loss_loop(O.classifier_head(feats, ntype, rel, sd), labels)
+    ref.backward()
+    torch.testing.assert_close(loss.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+    for k, gk in head.named_grads().items():
+        torch.testing.assert_close(gk.cpu(), sd[k].grad, rtol=1e-3, atol=1e-6 * max(1.0, sd[k].grad.abs().max().item() * 1e2))

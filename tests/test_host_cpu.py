@@ -29,6 +29,8 @@ def test_layouts_match_library(D, L, H):
     assert P.gat_layout(D, 2 * D + 3) == _lib.layout("gat", D, 2 * D + 3)          # att_input_dim != hidden_dim
     assert P.mha_layout(D) == _lib.layout("mha", D)
     assert P.gcn_layout(D, L, H) == _lib.layout("gcn", D, L, H)
+    assert P.producer_layout(D, 20) == _lib.layout("producer", D, 20)                 # f1: edge-feature producer
+    assert P.head_layout(D, L + 1, 20, 12, 97) == _lib.layout("head", D, L + 1, 20, 12, 97)   # f3: classifier head
 
 
 def test_layout_errors_are_reported_not_fatal():

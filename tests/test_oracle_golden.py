@@ -179,3 +179,32 @@ def test_edge_feature_producer(path):
         torch.testing.assert_close(table.grad, torch.from_numpy(r["grad.table"]), rtol=1e-4, atol=1e-6)
         for k, ref_g in g["grad_sd"].items():
             torch.testing.assert_close(sdl[k].grad, ref_g, rtol=1e-4, atol=1e-6, msg=lambda m: f"grad {k}: {m}")
+
+
+def head_bilinear_weight(seed, r=97, h=128):
+    """Same generator as oracle/make_golden.py::head_bilinear_weight (the fixtures store the seed, not the 6.4 MB tensor)."""
+    g = torch.Generator().manual_seed(1000 + int(seed))
+    return (torch.rand(r, h, h, generator=g) * 2 - 1) / (h ** 0.5)
+
+
+@pytest.mark.parametrize("path", golden_files("head"), ids=ids(golden_files("head")))
+def test_classifier_head(path):
+    """the restatement of the classifier head against fixtures produced by EXECUTING the reference's own
+    statements (GCGCN_glove.py:306-307, 344-358, oracle/make_golden.py::head_cases) on a real GCGCN_glove's layers: logits
+    and every gradient, incl. ner_emb's padding row (no gradient) and N = 1."""
+    g = load_golden(path)
+    r = g["raw"]
+    sd = {k: v.clone().requires_grad_() for k, v in g["sd"].items()}
+    sd["bili_layer_01.weight"] = head_bilinear_weight(g["meta"]["bili_seed"]).requires_grad_()
+    feats = [g["in"][f"f{i}"].clone().requires_grad_() for i in range(3)]
+    out = O.classifier_head(feats, torch.from_numpy(r["node_type"]), torch.from_numpy(r["rel"]), sd)
+    torch.testing.assert_close(out, g["out"], rtol=1e-5, atol=1e-5)
+    (out * g["cot"]).sum().backward()
+    for i, f in enumerate(feats):
+        torch.testing.assert_close(f.grad, g["grad_in"][f"f{i}"], rtol=1e-4, atol=1e-5)
+    for k, want in g["grad_sd"].items():
+        torch.testing.assert_close(sd[k].grad, want, rtol=1e-4, atol=1e-5 * max(1.0, want.abs().max().item()), msg=lambda m: f"grad {k}: {m}")
+    gb = sd["bili_layer_01.weight"].grad
+    torch.testing.assert_close(gb[torch.from_numpy(r["gradpart.bili.r"])], torch.from_numpy(r["gradpart.bili.slices"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(gb.sum(0), torch.from_numpy(r["gradpart.bili.sum_r"]), rtol=1e-4, atol=1e-4)
+    assert sd["ner_emb.weight"].grad[0].abs().sum() == 0
