@@ -261,6 +261,25 @@ int gcgcn_head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, 
                    const int32_t* n_valid, const float* flat, float* fbuf, float* bbuf, const float* dlogits, float* const* dfeats,
                    float* dner_emb, float* ddis_table, float* dflat, void* stream);
 
+/* ---- device-side tensorisation of packed documents  config/Config.py:162-233 -------------------------- */
+/* Expands the packed records of a batch (gcgcn_amd/data.py; all int32, device memory) into the dense inputs of the
+ * reference's forward, batched and padded to (N entities, S sentence slots, T tokens), in ONE launch.  Outputs must be
+ * zero-filled by the caller.
+ *   slots[n_slots][10]   doc, u, v, slot j, sentence start, end, head mention start, end, tail mention start, end
+ *                        -> sen[B,N,N,S,T] (uint8 0/1), pos_h / pos_t [B,N,N,S,T] (uint8 distance ids: dis_plus +- the
+ *                        bucket dis2idx of the distance to the head / tail mention, Config.py:106-116, 190-203)
+ *   edges[n_edges][3]    doc, u, v -> adj[B,N,N] = 1                                     (Config.py:183)
+ *   labels[n_labels][4]  doc, h, t, r -> label_matrix[B,N,N,R] = 1
+ *   mentions[n][2], mention_node[n][4] = (doc, entity, mentions of that entity, index inside the entity), sorted by
+ *                        (doc, entity, index) -> node_pos[B,N,T] (each mention span ASSIGNED 1 / length in order, the row
+ *                        scaled by 1 / mentions, float64 arithmetic, Config.py:170-175) and node_relative_pos[B,N,N]
+ *                        (signed bucket of the difference of the first mention starts, Config.py:206-215)
+ *   n_valid[B]           entities per document;  first_start[B,N] start of each entity's first mention */
+int gcgcn_tensorise(int B, int N, int S, int T, int R, int dis_plus, int n_slots, const int32_t* slots, int n_edges,
+                    const int32_t* edges, int n_labels, const int32_t* labels, int n_mentions, const int32_t* mentions,
+                    const int32_t* mention_node, const int32_t* n_valid, const int32_t* first_start, float* adj, uint8_t* sen, uint8_t* pos_h,
+                    uint8_t* pos_t, float* node_pos, int64_t* node_relative_pos, float* label_matrix, void* stream);
+
 /* ---- raw batched GEMM (exposed for unit tests and benchmarks of the MFMA kernel) ----------- */
 /* C[z] = alpha * opA(A[z]) opB(B[z]);  a_kc: A stored [M][K] else [K][M];  b_kc: B stored [N][K]
  * else [K][N];  z < batch with element strides sA, sB, sC;  tile: 0 auto, 1 = 64x64, 2 = 128x128;

@@ -276,6 +276,75 @@ def producer_cases(ref):
         yield f"producer_n{n}_s{s}_t{t}_h{hd}", d
 
 
+def tensorise_cases():
+    """SURVEY 8 row f4, pinned on the reference's own function: ``Config.from_list_to_tensor`` (config/Config.py:162-233) and the
+    ``dis2idx`` table (:106-116) are read as text and executed on synthetic documents (dicts with a networkx.DiGraph, the
+    reference's pickle format, gen_data_extend_graph.py:289-307).  Writes the documents in the packed format
+    (tests/golden/tensorise_docs.npz, gcgcn_amd.data.PackedDocs) and the reference's tensors for each of them
+    (tensorise_ref.npz).  Cases: overlapping mentions, a document longer than max_length, more sentence slots than max_num,
+    an edge without sentences, tokens inside / left / right of a mention, far-apart entities."""
+    import textwrap
+    import networkx as nx
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from gcgcn_amd.data import PackedDocs, pack_document
+    lines = open(os.path.join(REF_ROOT, "config", "Config.py"), encoding="utf-8").read().split("\n")
+    assert lines[161].strip().startswith("def from_list_to_tensor(self,item,train = True):"), lines[161]
+    assert lines[232].strip().startswith("return new_item"), lines[232]
+    assert lines[105].strip().startswith("self.dis2idx = np.zeros((1024)"), lines[105]
+    ns = {"torch": torch, "np": np}
+    exec(compile(textwrap.dedent("\n".join(lines[161:233])), "Config.py:162-233", "exec"), ns)
+
+    class Self:
+        pass
+    me = Self()
+    exec(compile(textwrap.dedent("\n".join(lines[105:116])), "Config.py:106-116", "exec"), {"self": me, "np": np})
+    me.dis_plus = 10
+    rs = np.random.RandomState(1337)
+    docs, refs, cfgs = [], {}, []
+    for di, (n, tlen, maxlen, maxnum) in enumerate(((4, 50, 512, 5), (6, 90, 64, 2), (1, 12, 512, 5), (7, 700, 512, 5))):
+        g = nx.DiGraph()
+        sents = sorted(set([0, tlen] + list(rs.randint(1, tlen, size=max(2, tlen // 12)))))
+        for node in range(n):
+            cnt = rs.randint(1, 4)
+            spans = []
+            for _ in range(cnt):
+                a0 = int(rs.randint(0, tlen - 3))
+                spans.append((a0, a0 + int(rs.randint(1, 4))))
+            if node == 0 and cnt > 1:
+                spans[1] = (spans[0][0], spans[0][1] + 1)                      # overlapping mentions: the later one overwrites
+            g.add_node(node, exist_pos=spans, type=[int(rs.randint(0, 7))])
+        smax = 0
+        for u in range(n):
+            for v in range(n):
+                if u == v or rs.rand() > 0.5:
+                    continue
+                k = int(rs.randint(0, 5))                                      # 0: an edge without any sentence
+                ss, ps = [], []
+                for _ in range(k):
+                    i = int(rs.randint(0, len(sents) - 1))
+                    s0, s1 = int(sents[i]), int(sents[i + 1])
+                    hp = g.nodes[u]["exist_pos"][0]
+                    tp = g.nodes[v]["exist_pos"][0]
+                    ss.append((s0, s1)), ps.append((hp[0], hp[1], tp[0], tp[1]))
+                g.add_edge(u, v, sentences=ss, position=ps)
+                smax = max(smax, k)
+        g.graph["max_sentence_num"] = max(smax, 1)
+        lab = (rs.rand(n, n, 97) < 0.02).astype(np.float32)
+        item = {"document": list(rs.randint(1, 200, size=tlen)), "document_pos": list(rs.randint(0, n + 1, size=tlen)),
+                "document_ner": list(rs.randint(0, 7, size=tlen)), "graph": g, "label_matrix": lab, "label_mask": None,
+                "title": f"doc{di}"}
+        me.max_length, me.max_num = maxlen, maxnum
+        out = ns["from_list_to_tensor"](me, item)                                                  # the reference's function
+        for k, v in out.items():
+            if isinstance(v, torch.Tensor):
+                refs[f"doc{di}.{k}"] = v.numpy()
+        docs.append(pack_document(item))
+        cfgs.append((maxlen, maxnum))
+    PackedDocs(docs).save(os.path.join(OUT_DIR, "tensorise_docs.npz"))
+    refs["cfg"] = np.asarray(cfgs, dtype=np.int64)
+    return [("tensorise_ref", refs)]
+
+
 HEAD_BILI_SLICES = [0, 48, 96]
 
 
@@ -380,9 +449,11 @@ def main():
         cases = list(producer_cases(load_reference()))
     elif "--head-only" in sys.argv:
         cases = list(head_cases(load_reference()))
+    elif "--tensorise-only" in sys.argv:
+        cases = tensorise_cases()
     else:
         ref = load_reference()
-        cases = list(block_cases(ref)) + [full_model_case(ref)] + list(loss_cases()) + list(producer_cases(ref)) + list(head_cases(ref))
+        cases = list(block_cases(ref)) + [full_model_case(ref)] + list(loss_cases()) + list(producer_cases(ref)) + list(head_cases(ref)) + tensorise_cases()
     for name, pk in cases:
         path = os.path.join(OUT_DIR, name + ".npz")
         np.savez_compressed(path, **pk)

@@ -208,3 +208,29 @@ def test_classifier_head(path):
     torch.testing.assert_close(gb[torch.from_numpy(r["gradpart.bili.r"])], torch.from_numpy(r["gradpart.bili.slices"]), rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(gb.sum(0), torch.from_numpy(r["gradpart.bili.sum_r"]), rtol=1e-4, atol=1e-4)
     assert sd["ner_emb.weight"].grad[0].abs().sum() == 0
+
+
+def test_tensorise_document_and_packed_format(tmp_path):
+    """the restatement of Config.from_list_to_tensor on packed records against the tensors the reference's own
+    function produced (oracle/make_golden.py::tensorise_cases), bit for bit incl. dtypes; the packed file format round-trips."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    from gcgcn_amd.data import PackedDocs
+    docs = PackedDocs.load(os.path.join(GOLDEN, "tensorise_docs.npz"))
+    ref = np.load(os.path.join(GOLDEN, "tensorise_ref.npz"))
+    assert len(docs) == 4
+    for i, d in enumerate(docs.docs):
+        ml, mn = (int(v) for v in ref["cfg"][i])
+        out = O.tensorise_document(d, ml, mn)
+        for k, v in out.items():
+            r = ref[f"doc{i}.{k}"]
+            assert r.shape == v.shape and r.dtype == v.dtype and np.array_equal(r, v), (i, k)
+    p = str(tmp_path / "again.npz")
+    docs.save(p)
+    again = PackedDocs.load(p)
+    for a, b in zip(docs.docs, again.docs):
+        for f in ("tokens", "node_type", "men_ptr", "mentions", "slots", "edges", "labels"):
+            assert np.array_equal(getattr(a, f), getattr(b, f))
+        assert (a.n_rel, a.max_sentence_num, a.title) == (b.n_rel, b.max_sentence_num, b.title)
+    assert [int(v) for v in O.dis2idx_table()[[0, 1, 2, 3, 4, 7, 8, 511, 512, 1023]]] == [0, 1, 2, 2, 3, 3, 4, 9, 10, 10]
