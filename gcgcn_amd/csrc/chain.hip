@@ -9,6 +9,8 @@
 // workgroup share the CU's vector L1, so no cache maintenance is needed at workgroup scope.
 // Pairs never touch each other's slices, so there is no inter-workgroup synchronisation at all
 // and every wave reaches the end of the phase list (no spin, no flag).
+#include <stdlib.h>
+
 #include "edge_body.hpp"
 #include "gcn_plan.hpp"
 #include "gemm_body.hpp"
@@ -25,6 +27,7 @@ __device__ __forceinline__ bool dev_al16(const void* p) { return (((uintptr_t)p)
 // last tile without storing it.
 constexpr int TEAM_LDS = lds_floats<1, 1, true, true>();
 constexpr int CHAIN_LDS = 2 * TEAM_LDS;
+constexpr int XCHG_LDS = 64 * 64;  // passenger tiles of parked products: the two teams' partial sums meet here
 constexpr int CW = 8;   // waves per chain workgroup
 constexpr int RB = 8;   // rows a wave keeps in flight in the row-wise phases (8 waves x 8 rows: a 64-node graph in one pass)
 
@@ -121,11 +124,11 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_fwd_kernel(const GcnCtx c) 
 // workgroups follow the chain workgroups in dispatch order, two 64x64 tiles each.
 template <bool ALIGNED>
 __global__ __launch_bounds__(64 * CW) void gcn_chain_bwd_kernel(const GcnCtx c, const GemmGroup4 cg) {
-  __shared__ __attribute__((aligned(16))) float lds[CHAIN_LDS];
+  __shared__ __attribute__((aligned(16))) float lds[CHAIN_LDS + XCHG_LDS];
   if (blockIdx.x >= c.B * c.H) {
     const int pb = blockIdx.x - c.B * c.H, ng = cg.tile_begin[cg.nprob];
-    if (pb < ng) {  // passenger workgroup: two tiles of a parked product
-      gemm_group_pair_block(cg, pb, lds, TEAM_LDS);
+    if (pb < ng) {  // passenger workgroup: one tile of a parked product, K split over the two tile teams
+      gemm_group_splitk_block(cg, pb, lds, TEAM_LDS, lds + CHAIN_LDS);
       return;
     }
     const EdgeRide& r = c.ride;  // passenger workgroup: one entity row of the riding dE broadcast
@@ -199,6 +202,23 @@ bool chain_can_carry(const EdgeRide& r) {
          (long)r.B * r.N <= 0x3fffffffL;
 }
 
+// GCGCN_CHAIN_CARRY=0: no parked products in the chain launches (A/B knob)
+static bool chain_passengers() {
+  static const int v = [] {
+    const char* e = getenv("GCGCN_CHAIN_CARRY");
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
+  return v != 0;
+}
+
+static long carry_budget_pct() {  // GCGCN_CHAIN_CARRY_PCT: tuning knob, default 50
+  static const long v = [] {
+    const char* e = getenv("GCGCN_CHAIN_CARRY_PCT");
+    return e ? atol(e) : 50L;
+  }();
+  return v;
+}
+
 static unsigned chain_grid(const GcnCtx& c, int kind) {
   return (unsigned)(c.B * c.H) + (c.ride.kind == kind ? (unsigned)(c.ride.B * c.ride.N) : 0u);
 }
@@ -221,17 +241,23 @@ int gcn_chain_bwd(const GcnCtx& c, hipStream_t st, DeferQueue* carry) {
   fl *= (double)c.B * c.H;
   GemmGroup4 cg;
   cg.nprob = 0, cg.tile_begin[0] = 0;
-  // Parked products ride only where the chain leaves the chip mostly empty (few (doc, head) pairs) AND runs long enough:
-  // a passenger workgroup (two unsplit tiles) is matrix-pipe-bound at ~0.85 us per 32-deep k-step and occupies its
-  // compute unit alone (register footprint of this kernel), so it only hides behind a chain of several such times.
-  // The chain itself costs ~8 us per dependent product and tile pass (measured, cfg 2 / cfg 3).
+  // Parked products ride only where the chain leaves the chip mostly empty (few (doc, head) pairs): a passenger workgroup
+  // runs ONE unsplit-output tile, its K split over the two tile teams -- matrix-pipe-bound at ~0.47 us per 32-deep k-step
+  // of the tile -- and occupies its compute unit alone (register footprint of this kernel).  As many tiles ride as fit
+  // beside the chain's own duration (~8 us per dependent product and tile pass, measured at cfg 2 / cfg 3); a problem is
+  // split at the budget, the rest of its tiles rides in GATAttention's edge pass.  K % 64 == 0 for equal halves.
   int ng = 0;
-  if (carry && carry->n > 0 && (long)c.B * c.H <= 64) {
+  if (carry && carry->n > 0 && (long)c.B * c.H <= 64 && ((long)c.B * c.N) % 64 == 0 && chain_passengers()) {
     const int passes = (((c.N + 63) / 64) * ((c.gh + 63) / 64) + 1) / 2;
     const double t_chain = 8.0 * (4 * c.L - 1) * passes;                  // us
-    const double t_wg = 0.85 * ((double)c.B * c.N / 32.0);                // us: weight gradients have K = B N
-    const long rounds = t_wg > 0 ? (long)((t_chain - t_wg) / t_wg) : 0;
-    if (rounds > 0) ng = gemm_take_deferred_pairs(carry, cg, &fl, rounds * (256 - (long)c.B * c.H));
+    const double t_tile = 0.47 * ((double)c.B * c.N / 32.0);              // us: weight gradients have K = B N
+    const long rounds = t_tile > 0 ? (long)(t_chain / t_tile) : 0;
+    bool halves = true;
+    for (int i = 0; i < carry->n; ++i) halves = halves && carry->p[i].K % 64 == 0;
+    // the riding dE broadcast needs its share of the idle compute units too: with it aboard only half of them take a tile
+    long budget = rounds * (256 - (long)c.B * c.H);
+    if (c.ride.kind == 2) budget = carry_budget_pct() * budget / 100;
+    if (rounds > 0 && halves && budget > 0) ng = gemm_take_deferred_pairs(carry, cg, &fl, budget);
   }
   dim3 grid(chain_grid(c, 2) + (unsigned)ng), block(64 * CW);
   if (chain_aligned(c, true)) GC_LAUNCH_TIMED("gcn_chain_bwd", fl, gcn_chain_bwd_kernel<true>, grid, block, 0, st, c, cg);

@@ -296,6 +296,7 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* 
     tiles = (tiles + 7) & ~7;
     gg.tile_begin[gg.nprob] = tiles;
     gg.tile_count[gg.nprob] = (int)(own * g.splits);
+    gg.tile_first[gg.nprob] = 0, gg.tile_take[gg.nprob] = (int)(own * g.splits);
     gg.red_begin[gg.nprob] = reds;
     tiles += (int)(own * g.splits);
     if (g.splits > 1) reds += (int)(nb * cdiv((long)g.M * g.N / 4, 256));
@@ -434,6 +435,7 @@ bool gemm_defer(DeferQueue* q, const GemmArgs& g_in) {
   if (prepare(g, 1, 1, 0) < 0) return false;
   if (!(g.vecA && g.vecB && g.M % 64 == 0 && g.N % 64 == 0 && g.K % BK == 0)) return false;
   g.ws = nullptr, g.ws_elems = 0;  // unsplit: the whole K inside one workgroup
+  q->done[q->n] = 0;
   q->p[q->n++] = g;
   return true;
 }
@@ -442,49 +444,74 @@ static void sort_parked(DeferQueue* q) {  // longest K first (they run the longe
   for (int i = 1; i < q->n; ++i)
     for (int j = i; j > 0 && q->p[j].K > q->p[j - 1].K; --j) {
       const GemmArgs t = q->p[j];
+      const int d = q->done[j];
       q->p[j] = q->p[j - 1], q->p[j - 1] = t;
+      q->done[j] = q->done[j - 1], q->done[j - 1] = d;
     }
 }
 
 static double flops_of(const GemmArgs& g) { return 2.0 * g.M * g.N * g.K * g.batch1 * g.batch2; }
+static int tiles_of(const GemmArgs& g) { return (g.M >> 6) * (g.N >> 6) * g.batch1 * g.batch2; }
 
+// Move parked work into gg: up to G::MAXP problems, at most max_tiles tiles in all; a problem is split when the budget
+// ends inside it (its remaining tiles stay parked).  Returns the number of workgroups (one per tile, ranges 8-aligned).
 template <class G>
-static int take_parked(DeferQueue* q, G& gg, double* flops, int tiles_per_wg, long max_wgs) {
+static int take_parked(DeferQueue* q, G& gg, double* flops, long max_tiles) {
   gg.nprob = 0;
   gg.tile_begin[0] = 0;
-  if (!q || q->n == 0) return 0;
+  if (!q || q->n == 0 || max_tiles <= 0) return 0;
   sort_parked(q);
-  int take = 0;
-  for (long got = 0; take < q->n && take < G::MAXP; ++take) {
-    const GemmArgs& g = q->p[take];
-    got += ((long)(g.M >> 6) * (g.N >> 6) * g.batch1 * g.batch2 + tiles_per_wg - 1) / tiles_per_wg;
-    if (got > max_wgs) break;
-  }
-  if (take == 0) return 0;
-  int wgs = 0;
-  for (int i = 0; i < take; ++i) {
+  int wgs = 0, np = 0, keep = 0;
+  for (int i = 0; i < q->n; ++i) {
     const GemmArgs& g = q->p[i];
-    const int own = (g.M >> 6) * (g.N >> 6) * g.batch1 * g.batch2;
-    wgs = (wgs + 7) & ~7;
-    gg.tile_begin[i] = wgs, gg.tile_count[i] = own, gg.red_begin[i] = 0;
-    wgs += (own + tiles_per_wg - 1) / tiles_per_wg;
-    gg.p[i] = g;
-    if (flops) *flops += flops_of(g);
+    const int total = tiles_of(g), avail = total - q->done[i];
+    const long take = (np < G::MAXP && max_tiles > 0) ? (avail < max_tiles ? avail : max_tiles) : 0;
+    if (take > 0) {
+      wgs = (wgs + 7) & ~7;
+      gg.tile_begin[np] = wgs, gg.tile_count[np] = total, gg.tile_first[np] = q->done[i], gg.tile_take[np] = (int)take;
+      gg.red_begin[np] = 0;
+      gg.p[np++] = g;
+      wgs += (int)take;
+      max_tiles -= take;
+      if (flops) *flops += flops_of(g) * (double)take / total;
+    }
+    if (q->done[i] + take < total) {  // (part of) the problem stays parked
+      q->p[keep] = g, q->done[keep] = q->done[i] + (int)take;
+      ++keep;
+    }
   }
-  gg.nprob = take;
-  gg.tile_begin[take] = wgs, gg.red_begin[take] = 0;
-  for (int i = take; i < q->n; ++i) q->p[i - take] = q->p[i];
-  q->n -= take;
+  q->n = keep;
+  for (int i = keep; i < DeferQueue::CAP; ++i) q->done[i] = 0;
+  gg.nprob = np;
+  gg.tile_begin[np] = wgs, gg.red_begin[np] = 0;
   return wgs;
 }
 
-int gemm_take_deferred(DeferQueue* q, GemmGroup& gg, double* flops) { return take_parked(q, gg, flops, 1, 1L << 40); }
+int gemm_take_deferred(DeferQueue* q, GemmGroup& gg, double* flops) { return take_parked(q, gg, flops, 1L << 40); }
 int gemm_take_deferred_pairs(DeferQueue* q, GemmGroup4& gg, double* flops, long max_wgs) {
-  return take_parked(q, gg, flops, 2, max_wgs);
+  return take_parked(q, gg, flops, max_wgs);
+}
+
+// tiles of parked problems, unsplit, as a launch of their own (what a carrying kernel would have run as passengers)
+__global__ __launch_bounds__(256, 4) void gemm_parked_kernel(const GemmGroup gg) {
+  __shared__ __attribute__((aligned(16))) float lds[lds_floats<1, 1, true, true>()];
+  gemm_group_block(gg, blockIdx.x, lds);
 }
 
 int gemm_flush_deferred(DeferQueue* q, hipStream_t stream) {
   while (q && q->n > 0) {
+    bool partial = false;
+    for (int i = 0; i < q->n; ++i) partial = partial || q->done[i] > 0;
+    if (partial) {  // the rest of a partly carried problem: same unsplit tiles, same tile list
+      GemmGroup gg;
+      double fl = 0;
+      const int wgs = gemm_take_deferred(q, gg, &fl);
+      if (wgs > 0) {
+        GC_LAUNCH_TIMED("gemm_group", fl, gemm_parked_kernel, dim3(wgs), dim3(256), 0, stream, gg);
+        if (int e = check_launch("gemm_parked")) return e;
+      }
+      continue;
+    }
     GemmArgs probs[GemmGroup::MAXP];
     const int n = q->n < GemmGroup::MAXP ? q->n : GemmGroup::MAXP;
     for (int i = 0; i < n; ++i) probs[i] = q->p[q->n - n + i];

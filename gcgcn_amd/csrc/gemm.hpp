@@ -81,7 +81,9 @@ struct GemmGroupT {
   static constexpr int MAXP = NP;
   GemmArgs p[NP];
   int tile_begin[NP + 1];  // first workgroup of each problem, a multiple of 8 (see gemm_group_kernel)
-  int tile_count[NP];      // 64x64 tiles of each problem
+  int tile_count[NP];      // 64x64 tiles of each problem (the domain of the XCD remap)
+  int tile_first[NP];      // this launch carries tiles [tile_first, tile_first + tile_take) of the problem's (remapped) list:
+  int tile_take[NP];       // a parked problem may be split over two carrying launches
   int red_begin[NP + 1];
   int nprob;
   ColRide col;  // col.X == nullptr: nothing rides
@@ -103,14 +105,16 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* 
 struct DeferQueue {
   static constexpr int CAP = 32;
   GemmArgs p[CAP];
+  int done[CAP] = {};  // tiles of p[i] already carried by an earlier launch
   int n = 0;
 };
 bool gemm_defer(DeferQueue* q, const GemmArgs& g);  // q == nullptr: never parks
 // Move up to MAXP parked problems into gg (longest K first, per-problem XCD-aligned tile ranges); returns the number
 // of workgroups (0: nothing parked).  flops (optional) accumulates 2MNK of the taken problems.
 int gemm_take_deferred(DeferQueue* q, GemmGroup& gg, double* flops);
-// Same for a chain launch: workgroups of 512 threads run TWO tiles each (tile_begin counts workgroups).
-// Takes parked problems (longest first) only while their workgroups fit into `max_wgs`; the rest waits for a later carrier.
+// Same for a chain launch: a workgroup of 512 threads runs ONE tile, its two tile teams splitting K (the partial sums meet
+// in LDS).  Takes at most `max_wgs` tiles, longest problems first; a problem may be taken partially -- the rest of its
+// tiles waits for a later carrier.
 int gemm_take_deferred_pairs(DeferQueue* q, GemmGroup4& gg, double* flops, long max_wgs);
 // Launch whatever is still parked as ordinary group launches (end of backward without a carrying launch).
 int gemm_flush_deferred(DeferQueue* q, hipStream_t stream);

@@ -227,7 +227,7 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, const Epi& e, const 
 template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED, int EG = 4, int MASK = 0, int RT = EPI_ALL, class OPS = PlainOperands>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__ lds, const int bx, const int by,
                                           const int zs, const int t = threadIdx.x, const bool do_store = true,
-                                          const OPS& ops = OPS()) {
+                                          const OPS& ops = OPS(), float* __restrict__ xchg = nullptr, const int role = 0) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int LDA = AKC ? BM + 1 : BM;
   constexpr int LDB = BKC ? BN + 1 : BN;
@@ -316,9 +316,21 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
     __syncthreads();
   }
 
+  // ---- two tile teams of one workgroup split K (role 1 gives, role 2 takes): the partial sums meet in LDS --------
+  if (xchg) {
+    if (role == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xchg[r * 256 + t] = acc[0][0][r];
+      __syncthreads();
+      return;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] += xchg[r * 256 + t];
+  }
   // ---- store ------------------------------------------------------------------------------
   if (!do_store) return;
-  if (g.splits > 1) {  // raw partial sums -> workspace [split][batch][M][N]
+  if (g.splits > 1 && !xchg) {  // raw partial sums -> workspace [split][batch][M][N]
     float* __restrict__ W = g.ws + ((long)sp * g.batch1 * g.batch2 + z) * g.M * g.N;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -370,8 +382,8 @@ __device__ __forceinline__ void gemm_group_block(const G& gg, int hb, float* __r
   int i = 0;
   while (i + 1 < gg.nprob && hb >= gg.tile_begin[i + 1]) ++i;
   int b = hb - gg.tile_begin[i];
-  if (b >= gg.tile_count[i]) return;
-  b = xcd_remap(b, gg.tile_count[i]);
+  if (b >= gg.tile_take[i]) return;
+  b = xcd_remap(b + gg.tile_first[i], gg.tile_count[i]);
   const GemmArgs& g = gg.p[i];
   const int tn = g.N >> 6, tm = g.M >> 6;
   // walk the short side fastest: the tiles that are neighbours in the list (and therefore on one XCD) then share BOTH
@@ -387,30 +399,32 @@ __device__ __forceinline__ void gemm_group_block(const G& gg, int hb, float* __r
   }
 }
 
-// The same for a 512-thread workgroup of two tile teams (chain kernels): workgroup hb runs tiles 2p and 2p + 1 of its
-// problem side by side; with an odd tile count the last workgroup's second team recomputes the last tile without
-// storing it, so both teams pass the same barriers.
+// The same for a 512-thread workgroup of two tile teams (chain kernels): workgroup hb runs ONE unsplit-output tile of its
+// problem, team 0 the first half of K and team 1 the second (K % 64 == 0: equal halves, same number of barriers); team 1
+// hands its partial sums to team 0 through xchg (64 * 64 floats of LDS).  Two waves per SIMD on one tile: the compute
+// unit's matrix pipe finishes a tile in the time one team would need for it alone, with the second wave hiding latency.
 template <class G>
-__device__ __forceinline__ void gemm_group_pair_block(const G& gg, int hb, float* __restrict__ lds, int team_lds) {
+__device__ __forceinline__ void gemm_group_splitk_block(const G& gg, int hb, float* __restrict__ lds, int team_lds,
+                                                        float* __restrict__ xchg) {
   int i = 0;
   while (i + 1 < gg.nprob && hb >= gg.tile_begin[i + 1]) ++i;
-  const int p = hb - gg.tile_begin[i];
-  const int cnt = gg.tile_count[i];
-  if (2 * p >= cnt) return;  // padding workgroup (uniform over the workgroup)
+  int q = hb - gg.tile_begin[i];
+  if (q >= gg.tile_take[i]) return;  // padding workgroup (uniform over the workgroup)
+  q = xcd_remap(q + gg.tile_first[i], gg.tile_count[i]);
   const int team = threadIdx.x >> 8, t = threadIdx.x & 255;
-  int q = 2 * p + team;
-  const bool live = q < cnt;
-  if (!live) q = cnt - 1;
-  const GemmArgs& g = gg.p[i];
+  GemmArgs g = gg.p[i];
   const int tn = g.N >> 6, tm = g.M >> 6;
-  const int bx = q % tn, by = (q / tn) % tm, zs = q / (tn * tm);
+  const int z = q / (tn * tm), r = q - z * (tn * tm);
+  const int bx = (tm < tn) ? r / tm : r % tn, by = (tm < tn) ? r % tm : r / tn;   // same tile list as gemm_group_block
+  g.splits = 2, g.ksplit = g.K >> 1;
   float* tl = lds + team * team_lds;
+  const int zs = z * 2 + team, role = team ? 1 : 2;
   if (g.a_kc) {
-    if (g.b_kc) gemm_body<1, 1, true, true, true>(g, tl, bx, by, zs, t, live);
-    else gemm_body<1, 1, true, false, true>(g, tl, bx, by, zs, t, live);
+    if (g.b_kc) gemm_body<1, 1, true, true, true>(g, tl, bx, by, zs, t, true, PlainOperands(), xchg, role);
+    else gemm_body<1, 1, true, false, true>(g, tl, bx, by, zs, t, true, PlainOperands(), xchg, role);
   } else {
-    if (g.b_kc) gemm_body<1, 1, false, true, true>(g, tl, bx, by, zs, t, live);
-    else gemm_body<1, 1, false, false, true>(g, tl, bx, by, zs, t, live);
+    if (g.b_kc) gemm_body<1, 1, false, true, true>(g, tl, bx, by, zs, t, true, PlainOperands(), xchg, role);
+    else gemm_body<1, 1, false, false, true>(g, tl, bx, by, zs, t, true, PlainOperands(), xchg, role);
   }
 }
 

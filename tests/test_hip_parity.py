@@ -479,7 +479,9 @@ def test_deferred_and_immediate_weight_gradients_agree_at_batch(gpu_device, B, N
         torch.testing.assert_close(a_, b_, rtol=2e-5, atol=2e-5 * max(1.0, b_.abs().max().item()))
     outs, gx, ge1, ge2, sdl = _oracle_stack(x, e1, e2, adj, sd, L, H)
     sum(o[2].sum() for o in outs).backward()
-    _check_stack_param_grads(hops, sdl)
+    # (sums over up to 1024 rows of D = 768 features against a CPU reference with another summation order: 1e-3 of the
+    # largest entry; the deferred-vs-immediate comparison above is the tight one)
+    _check_stack_param_grads(hops, sdl, rtol=2e-3, atol=1e-3)
 
 
 def test_edge_mean_handoff_is_used_and_safe(gpu_device):
