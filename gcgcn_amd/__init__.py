@@ -4,11 +4,11 @@ Drop-in ``nn.Module``s (same names / constructor args / forward signatures / sta
 reference's ``models/GCGCN_glove.py:18-168``) whose arithmetic runs in hand-written HIP kernels for
 gfx950 behind a C ABI (``include/gcgcn.h`` -> ``gcgcn_amd/lib/libgcgcn_hip.so``).  No CPU fallback.
 """
-from .modules import (ClassifierHead, EdgeFeatureProducer, GATAttention, GraphConv, GraphConvolution, GraphHops,  # noqa: F401
+from .modules import (ClassifierHead, EdgeFeatureProducer, GraphModelTail, GATAttention, GraphConv, GraphConvolution, GraphHops,  # noqa: F401
                       MultiGraphConvolution, MultiHeadAttention)
 from .functional import manual_seed, pair_bce_loss  # noqa: F401
 from . import functional, params  # noqa: F401
 
 __all__ = ["GraphConv", "GATAttention", "MultiHeadAttention", "GraphConvolution", "MultiGraphConvolution", "GraphHops",
-           "EdgeFeatureProducer", "ClassifierHead",
+           "EdgeFeatureProducer", "ClassifierHead", "GraphModelTail",
            "manual_seed", "pair_bce_loss", "functional", "params"]

@@ -563,3 +563,81 @@ class GraphHops(nn.Module):
             lo, _hi = torch.cuda.Stream.priority_range()
             cls._streams[key] = torch.cuda.Stream(device=dev, priority=lo)
         return cls._streams[key]
+
+
+# ======================================================================================================
+class GraphModelTail(nn.Module):
+    """Everything GCGCN_glove.forward does AFTER the token encoder (glove:293-360) on the HIP kernels: entity pooling is
+    left to the caller (``node_feat = node_pos @ context_output``, glove:297-298, a plain matmul), then per hop the
+    edge-feature producer (f1), the CAGGC / MAGGC block (the hot path) and the hop glue, and finally the classifier head
+    (f3).  ``state_dict()`` keys are the model's own (``word_attention.{i}.*``, ``linear_word_att.{i}.*``,
+    ``sentence_attention.{i}.*``, ``linear_sentence_att.{i}.*``, ``get_weighted_adj_matrix.*``, ``get_adj_matrix.{i}.*``,
+    ``graphcnn.{i}.*``, ``dense_layer.*``, ``bili_layer_01.*``, ``classification_layer_01.*``): the matching slice of a
+    GCGCN_glove checkpoint loads with ``strict=True``.  The embeddings ``dis_embed`` / ``ner_emb`` stay with the encoder side
+    of the model and are passed in.
+
+    Reference behaviour kept: the model's ``node_feats`` list records the PRE-update features (glove:338), so the last hop's
+    output never reaches the classifier -- it is still computed, as in the reference.
+    """
+
+    def __init__(self, hidden_size: int = 128, layer_num: int = 2, head_num: int = 8, graph_hop: int = 2, alpha: float = 1.0,
+                 dis_size: int = 20, entity_type_size: int = 20, relation_num: int = 97, dis_plus: int = 10, dropout: float = 0.2):
+        super().__init__()
+        self.graph_hop, self.alpha, self.p = graph_hop, float(alpha), float(dropout)
+        self.producers = nn.ModuleList([EdgeFeatureProducer(hidden_size, dis_size) for _ in range(graph_hop)])
+        self.get_weighted_adj_matrix = GATAttention(hidden_size, hidden_size)
+        self.get_adj_matrix = nn.ModuleList([MultiHeadAttention(head_num, hidden_size) for _ in range(graph_hop - 1)])
+        self.graphcnn = nn.ModuleList([GraphConvolution(layer_num, hidden_size, hidden_size) if i == 0 else
+                                       MultiGraphConvolution(layer_num, head_num, hidden_size, hidden_size) for i in range(graph_hop)])
+        self.head = ClassifierHead(hidden_size, graph_hop, entity_type_size, dis_size, relation_num, dis_plus)
+
+    # ---- the model's key names: producers.{i}.<mod>.<rest> <-> <mod>.{i}.<rest>, head.<k> <-> <k> ---------------------------
+    @staticmethod
+    def _to_model_key(k: str) -> str:
+        p = k.split(".")
+        if p[0] == "producers":
+            return ".".join([p[2], p[1]] + p[3:])
+        if p[0] == "head":
+            return ".".join(p[1:])
+        return k
+
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        return type(sd)((self._to_model_key(k), v) for k, v in sd.items())
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        mine = {}
+        prod = set(k.split(".", 1)[0] for k in P_.producer_shapes(1, 1))
+        heads = set(k.split(".", 1)[0] for k in P_.HEAD_STATE_ORDER)
+        for k, v in state_dict.items():
+            p = k.split(".")
+            if p[0] in prod and len(p) > 2 and p[1].isdigit():
+                mine[".".join(["producers", p[1], p[0]] + p[2:])] = v
+            elif p[0] in heads:
+                mine["head." + k] = v
+            else:
+                mine[k] = v
+        return super().load_state_dict(mine, strict=strict, **kw)
+
+    def forward(self, context_output: Tensor, node_feat: Tensor, adj_matrix: Optional[Tensor], sen_matrix: Tensor,
+                pos_matrix_h: Tensor, pos_matrix_t: Tensor, node_type: Tensor, node_relative_pos: Tensor,
+                dis_embed_weight: Tensor, ner_emb_weight: Tensor, n_valid: Optional[Tensor] = None) -> Tensor:
+        """Shapes as in the reference (one document: context_output ``[T,H]`` or ``[1,T,H]``, node_feat ``[N,H]``, ...) or with a
+        leading batch axis everywhere.  Returns ``relation_before_softmax_01``."""
+        x = node_feat
+        feats = [x]
+        mask = None
+        for i in range(self.graph_hop):
+            e = self.producers[i](context_output, sen_matrix, pos_matrix_h, pos_matrix_t, x, dis_embed_weight, n_valid=n_valid)
+            if i < 1:
+                if self.get_weighted_adj_matrix.apply_mask and adj_matrix is not None:
+                    mask = torch.eq(adj_matrix, 0)                                              # glove:330
+                a = self.get_weighted_adj_matrix(x, e, mask, n_valid=n_valid)                  # glove:332
+                new = self.graphcnn[i](x, e, a, n_valid=n_valid)                               # glove:333
+            else:
+                al = self.get_adj_matrix[i - 1](x, e, n_valid=n_valid)                         # glove:336
+                new = self.graphcnn[i](x, e, al, n_valid=n_valid)                              # glove:337
+            feats.append(x)                                                                    # glove:338 (pre-update)
+            x = new if self.alpha == 1.0 else self.alpha * new + (1 - self.alpha) * x          # glove:339
+            x = F_.dropout(x, self.p, self.training)                                           # glove:341
+        return self.head(feats, node_type, node_relative_pos, ner_emb_weight, dis_embed_weight, n_valid=n_valid)

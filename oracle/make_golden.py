@@ -276,6 +276,57 @@ def producer_cases(ref):
         yield f"producer_n{n}_s{s}_t{t}_h{hd}", d
 
 
+def tail_case(ref, docs=2, n=12, t=48, s=3, vocab=120):
+    """The whole post-encoder model on the REAL GCGCN_glove: forward hooks / a wrapped ``linear_re`` record the token states
+    (``context_output``, glove:292) of each document; the fixture holds them, the raw inputs, every parameter from the
+    producers to the classifier (the 6.4 MB bilinear weight as a seed, see head_bilinear_weight) and the model's logits.
+    tests/ run EdgeFeatureProducer -> GAT / CAGGC -> producer -> MHA / MAGGC -> ClassifierHead on the same inputs."""
+    import contextlib, io
+    torch.manual_seed(4242)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = ref.GCGCN_glove(_Cfg(vocab)).eval()
+    with torch.no_grad():
+        model.bili_layer_01.weight.copy_(head_bilinear_weight(4242))
+    rec = {}
+    model.linear_re.register_forward_hook(lambda m, i, o: rec.__setitem__("pre_tanh", o))
+    g = torch.Generator().manual_seed(4242)
+    pk = {"meta.docs": docs, "meta.bili_seed": np.int64(4242)}
+    tail = ("get_weighted_adj_matrix.", "get_adj_matrix.", "graphcnn.", "word_attention.", "sentence_attention.", "linear_word_att.",
+            "linear_sentence_att.", "dense_layer.", "classification_layer_01.", "bili_layer_01.bias", "dis_embed.", "ner_emb.")
+    for k, v in model.state_dict().items():
+        if k.startswith(tail):
+            pk["sd." + k] = _np(v)
+    for di in range(docs):
+        document = torch.randint(1, vocab, (t,), generator=g)
+        ner = torch.randint(0, 7, (t,), generator=g)
+        pos = torch.randint(0, n + 1, (t,), generator=g)
+        adj = (torch.rand(n, n, generator=g) < 0.3).float() * (1 - torch.eye(n))
+        sen = torch.zeros(n, n, s, t, dtype=torch.bool)
+        for i in range(n):
+            for j in range(n):
+                if adj[i, j] > 0:
+                    for k in range(int(torch.randint(1, s + 1, (1,), generator=g))):
+                        ln = int(torch.randint(4, 12, (1,), generator=g))
+                        a0 = 0 if torch.rand(1, generator=g).item() < 0.5 else int(torch.randint(0, t - ln, (1,), generator=g))
+                        sen[i, j, k, a0:a0 + ln] = True               # half of the sentences start at token 0: live slots (glove:305)
+        ph = torch.randint(0, 21, (n, n, s, t), generator=g)
+        pt = torch.randint(0, 21, (n, n, s, t), generator=g)
+        node_pos = torch.zeros(n, t)
+        for i in range(n):
+            a0 = int(torch.randint(0, t - 3, (1,), generator=g))
+            node_pos[i, a0:a0 + 3] = 1.0 / 3
+        node_type = torch.randint(0, 7, (n,), generator=g)
+        rel = torch.randint(-10, 11, (n, n), generator=g)
+        with torch.no_grad():
+            logits = model(document, ner, pos, adj, sen, ph, pt, node_pos, node_type, rel)
+        ctx = torch.tanh(rec["pre_tanh"])[0]                                           # glove:292
+        p = f"doc{di}."
+        pk[p + "ctx"], pk[p + "node_pos"], pk[p + "adj"] = _np(ctx), _np(node_pos), _np(adj)
+        pk[p + "sen"], pk[p + "pos_h"], pk[p + "pos_t"] = _np(sen), _np(ph.to(torch.uint8)), _np(pt.to(torch.uint8))
+        pk[p + "node_type"], pk[p + "rel"], pk[p + "logits"] = _np(node_type), _np(rel), _np(logits)
+    return "tail_c1", pk
+
+
 def tensorise_cases():
     """SURVEY 8 row f4, pinned on the reference's own function: ``Config.from_list_to_tensor`` (config/Config.py:162-233) and the
     ``dis2idx`` table (:106-116) are read as text and executed on synthetic documents (dicts with a networkx.DiGraph, the
@@ -451,9 +502,11 @@ def main():
         cases = list(head_cases(load_reference()))
     elif "--tensorise-only" in sys.argv:
         cases = tensorise_cases()
+    elif "--tail-only" in sys.argv:
+        cases = [tail_case(load_reference())]
     else:
         ref = load_reference()
-        cases = list(block_cases(ref)) + [full_model_case(ref)] + list(loss_cases()) + list(producer_cases(ref)) + list(head_cases(ref)) + tensorise_cases()
+        cases = list(block_cases(ref)) + [full_model_case(ref)] + list(loss_cases()) + list(producer_cases(ref)) + list(head_cases(ref)) + tensorise_cases() + [tail_case(ref)]
     for name, pk in cases:
         path = os.path.join(OUT_DIR, name + ".npz")
         np.savez_compressed(path, **pk)

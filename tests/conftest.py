@@ -54,3 +54,32 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+def tail_oracle(r, sd, di):
+    """The oracle's post-encoder chain on document di of the tail fixture: producer -> CAGGC -> producer -> MAGGC -> head,
+    with the model's pre-update node_feats list (glove:338)."""
+    p = f"doc{di}."
+    ctx = torch.from_numpy(r[p + "ctx"])
+    x = torch.from_numpy(r[p + "node_pos"]) @ ctx                                              # glove:297-298
+    sen, ph, pt = torch.from_numpy(r[p + "sen"]), torch.from_numpy(r[p + "pos_h"]).long(), torch.from_numpy(r[p + "pos_t"]).long()
+    adj = torch.from_numpy(r[p + "adj"])
+    feats = [x]
+    for i in range(2):
+        e = _O().edge_features_folded(ctx, sen, ph, pt, x, sd["dis_embed.weight"], sd, i)
+        if i == 0:
+            a = _O().gat_attention(x, e, _O().sub(sd, "get_weighted_adj_matrix"), torch.eq(adj, 0))
+            new = _O().graph_convolution(x, e, a, _O().sub(sd, "graphcnn.0"), 2)
+        else:
+            al = _O().multi_head_attention(x, _O().sub(sd, "get_adj_matrix.0"), 8)
+            new = _O().multi_graph_convolution(x, e, al, _O().sub(sd, "graphcnn.1"), 2, 8)
+        feats.append(x)
+        x = new
+    return _O().classifier_head(feats, torch.from_numpy(r[p + "node_type"]), torch.from_numpy(r[p + "rel"]), sd)
+
+
+
+
+def _O():
+    from oracle import gcgcn_oracle
+    return gcgcn_oracle

@@ -3,7 +3,7 @@ own classes (oracle/make_golden.py).  This is what pins the oracle; tolerance 1e
 import pytest
 import torch
 
-from conftest import golden_files, ids, load_golden
+from conftest import golden_files, ids, load_golden, tail_oracle
 from oracle import gcgcn_oracle as O
 
 TOL = dict(rtol=1e-5, atol=1e-5)
@@ -234,3 +234,14 @@ def test_tensorise_document_and_packed_format(tmp_path):
             assert np.array_equal(getattr(a, f), getattr(b, f))
         assert (a.n_rel, a.max_sentence_num, a.title) == (b.n_rel, b.max_sentence_num, b.title)
     assert [int(v) for v in O.dis2idx_table()[[0, 1, 2, 3, 4, 7, 8, 511, 512, 1023]]] == [0, 1, 2, 2, 3, 3, 4, 9, 10, 10]
+
+
+def test_post_encoder_model_chain():
+    """The oracle functions chained as the model chains them reproduce the REAL GCGCN_glove's logits from its own token
+    states (fixture tail_c1: oracle/make_golden.py::tail_case)."""
+    g = load_golden(golden_files("tail")[0])
+    sd = dict(g["sd"])
+    sd["bili_layer_01.weight"] = head_bilinear_weight(g["meta"]["bili_seed"])
+    for di in range(g["meta"]["docs"]):
+        out = tail_oracle(g["raw"], sd, di)
+        torch.testing.assert_close(out, torch.from_numpy(g["raw"][f"doc{di}.logits"]), rtol=1e-4, atol=1e-4)
