@@ -16,8 +16,9 @@
 // (glove:205, 212).
 //
 // Per-slot / per-pair arithmetic runs in wave-per-row kernels (lanes over the Hd feature columns, token states read
-// from L2); backward scatter-adds (token-state, score-table and node-term gradients, shared by many slots) use fp32
-// atomics, so those gradients are reproducible only up to summation order.
+// from L2).  Backward sums shared by many slots are owner-computed where the owner is cheap to find (token-state and
+// score-table gradients: one workgroup per (document, token) scans the document's live rows); the per-entity node-term
+// gradient and a few parameter-sized partials still use fp32 atomics (reproducible up to summation order).
 #include <string.h>
 
 #include "gemm.hpp"
@@ -27,7 +28,7 @@ namespace gc {
 
 constexpr int PW = 4;      // waves per workgroup of the row kernels
 constexpr int PGRID = 2048;  // persistent grid of the row kernels (8 workgroups per CU)
-constexpr int HCMAX = 8;   // Hd <= 64 * HCMAX
+constexpr int HCLIM = 8;   // Hd <= 64 * HCLIM
 
 struct ProdIdx {           // compact index of the live slots / pairs (device memory, int32)
   int* doc_counts;         // [B][2] live slots, live pairs per document
@@ -38,6 +39,9 @@ struct ProdIdx {           // compact index of the live slots / pairs (device me
   int* row_slot;           // [cap_rows] flat slot index ((b*N + i)*N + j)*S + s of a compact row
   int* prow_pair;          // [cap_pairs] flat pair index of a compact pair
   int* counts;             // [4] rows, pairs, overflow flag, unused
+  int* doc_off;            // [B + 1] first compact row of each document (its live rows are consecutive)
+  int* row_rng;            // [cap_rows] token range of the row's slot, t0 | t1 << 16 (written by the forward's word kernel)
+  int* tmax;               // [B] one past the last token any live slot of the document covers
 };
 
 __device__ __forceinline__ int pos_at(const void* pos, int pos_bytes, long idx) {
@@ -114,6 +118,10 @@ __global__ __launch_bounds__(256) void prod_index_b_kernel(const int* __restrict
   const bool over = red[0][0] > cap_rows || red[1][0] > cap_pairs;
   if (blockIdx.x == 0 && b == 0 && tid == 0)
     ix.counts[0] = over ? 0 : red[0][0], ix.counts[1] = over ? 0 : red[1][0], ix.counts[2] = over, ix.counts[3] = 0;
+  if (blockIdx.x == 0 && tid == 0) {
+    ix.doc_off[b] = over ? 0 : off[0];
+    if (b == B - 1) ix.doc_off[B] = over ? 0 : red[0][0];
+  }
   const int p = blockIdx.x * 256 + tid;
   if (p >= NN) return;
   const long pp = (long)b * NN + p;
@@ -139,6 +147,7 @@ __global__ __launch_bounds__(256) void prod_index_b_kernel(const int* __restrict
 }
 
 // ---- word score table: table[b, k, t] = w_a . tanh(sentF[b, t, :] + disF[k, :]) + b_a   (glove:178-182 folded) ------
+template <int HC>
 __global__ __launch_bounds__(64 * PW) void prod_table_fwd_kernel(const float* __restrict__ sentF, const float* __restrict__ disF,
                                                                  const float* __restrict__ wa,
                                                                  const float* __restrict__ ba, float* __restrict__ table,
@@ -148,9 +157,9 @@ __global__ __launch_bounds__(64 * PW) void prod_table_fwd_kernel(const float* __
   const int lane = threadIdx.x & 63;
   const long b = bt / T;
   const int t = (int)(bt - b * T);
-  float sf[HCMAX], w[HCMAX];
+  float sf[HC], w[HC];
 #pragma unroll
-  for (int cc = 0; cc < HCMAX; ++cc) {
+  for (int cc = 0; cc < HC; ++cc) {
     const int c = lane + 64 * cc;
     sf[cc] = c < Hd ? sentF[bt * Hd + c] : 0.f;
     w[cc] = c < Hd ? wa[c] : 0.f;
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(64 * PW) void prod_table_fwd_kernel(const float* __
   for (int k = 0; k < ND; ++k) {
     float a = 0.f;
 #pragma unroll
-    for (int cc = 0; cc < HCMAX; ++cc) {
+    for (int cc = 0; cc < HC; ++cc) {
       const int c = lane + 64 * cc;
       if (c < Hd) a = fmaf(w[cc], tanhf(sf[cc] + disF[(long)k * Hd + c]), a);
     }
@@ -168,8 +177,33 @@ __global__ __launch_bounds__(64 * PW) void prod_table_fwd_kernel(const float* __
   }
 }
 
+// Gathered scores of one (slot, side) for the wave's tokens t = c0 + 64 u + lane, u < 8: the mask byte, the position id and
+// the table entry of all eight chunks are requested before the first one is used (clamped addresses, not guarded loads: a
+// load inside a branch is waited for at the branch's end).  sc[u] = -inf for masked / out-of-range tokens.
+__device__ __forceinline__ void slot_scores8(const unsigned char* __restrict__ m, const void* __restrict__ pos, int pos_bytes,
+                                             long slot_base, const float* __restrict__ tab, int T, int ND, int c0, int lane,
+                                             float (&sc)[8]) {
+  unsigned char mm[8];
+  int kk[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int tc = min(c0 + 64 * u + lane, T - 1);
+    mm[u] = m[tc];
+    kk[u] = pos_at(pos, pos_bytes, slot_base + tc);
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int tc = min(c0 + 64 * u + lane, T - 1);
+    sc[u] = tab[(long)min(max(kk[u], 0), ND - 1) * T + tc];
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+    if (c0 + 64 * u + lane >= T || !mm[u]) sc[u] = -INFINITY;
+}
+
 // ---- word attention of the live slots (glove:184-187): CW[row, side*Hd + c] = sum_t softmax_t(score)[t] ctx[b, t, c] -
 // dynamic LDS: PW * T floats (the un-normalised weights of the wave's slot)
+template <int HC>
 __global__ __launch_bounds__(64 * PW) void prod_word_fwd_kernel(const float* __restrict__ ctx, const unsigned char* __restrict__ sen,
                                                                 const void* __restrict__ pos_h, const void* __restrict__ pos_t,
                                                                 int pos_bytes, const float* __restrict__ table, ProdIdx ix,
@@ -194,15 +228,18 @@ __global__ __launch_bounds__(64 * PW) void prod_word_fwd_kernel(const float* __r
       const void* pos = side ? pos_t : pos_h;
       const float* tab = table + b * ND * T;
       float mx = -INFINITY;
-      for (int t = lane; t < T; t += 64) {
-        float sc = -INFINITY;
-        if (m[t]) {
-          const int k = min(max(pos_at(pos, pos_bytes, slot * T + t), 0), ND - 1);
-          sc = tab[(long)k * T + t];
-          t0 = min(t0, t), t1 = max(t1, t + 1);
+      for (int c0 = 0; c0 < T; c0 += 512) {
+        float sc[8];
+        slot_scores8(m, pos, pos_bytes, slot * T, tab, T, ND, c0, lane, sc);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int t = c0 + 64 * u + lane;
+          if (t < T) {
+            ev[t] = sc[u];
+            if (sc[u] != -INFINITY) t0 = min(t0, t), t1 = max(t1, t + 1);
+            mx = fmaxf(mx, sc[u]);
+          }
         }
-        ev[t] = sc;
-        mx = fmaxf(mx, sc);
       }
       mx = wave_max(mx);
       t0 = -(int)wave_max((float)-t0), t1 = (int)wave_max((float)t1);   // exact for |t| < 2^24
@@ -214,44 +251,47 @@ __global__ __launch_bounds__(64 * PW) void prod_word_fwd_kernel(const float* __r
       }
       sum = wave_sum(sum);
       inv = 1.f / sum;
-      if (lane == 0) stats[2 * (long)r] = mx, stats[2 * (long)r + 1] = inv;
+      if (lane == 0) {
+        stats[2 * (long)r] = mx, stats[2 * (long)r + 1] = inv;
+        if (side == 0) ix.row_rng[row] = t0 | (t1 << 16);   // the slot's token range (T <= 2048): read again by the backward
+      }
     }
     __syncthreads();  // ev[] written lane-wise, read by every lane below (uniform trip count: every wave gets here)
     if (on) {
       const int row = r >> 1, side = r & 1;
       const float* cb = ctx + b * T * Hd;
-      for (int c0 = 0; c0 < Hd; c0 += 256) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        int t = t0;
-        for (; t + 3 < t1; t += 4) {  // four token rows in flight
-          float x[4][4];
+      float acc[HC];
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
+      for (int cc = 0; cc < HC; ++cc) acc[cc] = 0.f;
+      int t = t0;
+      for (; t + 3 < t1; t += 4) {  // four token rows in flight
+        float x[4][HC];
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-              const int c = c0 + lane + 64 * cc;
-              x[u][cc] = c < Hd ? cb[(long)(t + u) * Hd + c] : 0.f;
-            }
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const float e = ev[t + u];
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) acc[cc] = fmaf(e, x[u][cc], acc[cc]);
+          for (int cc = 0; cc < HC; ++cc) {
+            const int c = lane + 64 * cc;
+            x[u][cc] = c < Hd ? cb[(long)(t + u) * Hd + c] : 0.f;
           }
-        }
-        for (; t < t1; ++t) {
-          const float e = ev[t];
 #pragma unroll
-          for (int cc = 0; cc < 4; ++cc) {
-            const int c = c0 + lane + 64 * cc;
-            if (c < Hd) acc[cc] = fmaf(e, cb[(long)t * Hd + c], acc[cc]);
-          }
-        }
+        for (int u = 0; u < 4; ++u) {
+          const float e = ev[t + u];
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          const int c = c0 + lane + 64 * cc;
-          if (c < Hd) CW[(long)row * 2 * Hd + side * Hd + c] = acc[cc] * inv;
+          for (int cc = 0; cc < HC; ++cc) acc[cc] = fmaf(e, x[u][cc], acc[cc]);
         }
+      }
+      for (; t < t1; ++t) {
+        const float e = ev[t];
+#pragma unroll
+        for (int cc = 0; cc < HC; ++cc) {
+          const int c = lane + 64 * cc;
+          if (c < Hd) acc[cc] = fmaf(e, cb[(long)t * Hd + c], acc[cc]);
+        }
+      }
+#pragma unroll
+      for (int cc = 0; cc < HC; ++cc) {
+        const int c = lane + 64 * cc;
+        if (c < Hd) CW[(long)row * 2 * Hd + side * Hd + c] = acc[cc] * inv;
       }
     }
     __syncthreads();  // before the next slot overwrites ev[]
@@ -263,9 +303,22 @@ __global__ __launch_bounds__(64 * PW) void prod_word_fwd_kernel(const float* __r
   }
 }
 
+// ---- tmax[b] = one past the last token any live slot of document b covers (bounds the backward's per-token work) -------
+__global__ __launch_bounds__(256) void prod_tmax_kernel(ProdIdx ix) {
+  __shared__ int red[4];
+  const int b = blockIdx.x;
+  int m = 0;
+  for (int row = ix.doc_off[b] + threadIdx.x; row < ix.doc_off[b + 1]; row += 256) m = max(m, ix.row_rng[row] >> 16);
+  m = (int)wave_max((float)m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) ix.tmax[b] = max(max(red[0], red[1]), max(red[2], red[3]));
+}
+
 // ---- sentence attention of the live pairs (glove:201-212) ----------------------------------------------------------
 //   score_h[s] = w . tanh(sfeat[row] + nterm[b, j]) + c,  score_t[s] uses nterm[b, i];  att = relu(score)
 //   CS[prow] = [ sum_s att_h[s] cwa[row] / div | sum_s att_t[s] cwa[row] / div ]
+template <int HC>
 __global__ __launch_bounds__(64 * PW) void prod_sent_fwd_kernel(const float* __restrict__ sfeat, const float* __restrict__ cwa,
                                                                 const float* __restrict__ nterm, const float* __restrict__ wsa,
                                                                 const float* __restrict__ bsa, ProdIdx ix,
@@ -273,9 +326,9 @@ __global__ __launch_bounds__(64 * PW) void prod_sent_fwd_kernel(const float* __r
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int npairs = ix.counts[1];
   const long NN = (long)N * N;
-  float w[HCMAX];
+  float w[HC];
 #pragma unroll
-  for (int cc = 0; cc < HCMAX; ++cc) w[cc] = (lane + 64 * cc) < Hd ? wsa[lane + 64 * cc] : 0.f;
+  for (int cc = 0; cc < HC; ++cc) w[cc] = (lane + 64 * cc) < Hd ? wsa[lane + 64 * cc] : 0.f;
   const float bias = bsa[0];
   for (int prow = blockIdx.x * PW + wave; prow < npairs; prow += gridDim.x * PW) {
     const long pair = ix.prow_pair[prow];
@@ -285,17 +338,17 @@ __global__ __launch_bounds__(64 * PW) void prod_sent_fwd_kernel(const float* __r
     const float div = ix.pair_div[pair];
     const float* nj = nterm + (b * N + j) * Hd;   // head side: node_feat.unsqueeze(0) -> indexed by the column entity
     const float* ni = nterm + (b * N + i) * Hd;   // tail side: node_feat.unsqueeze(1) -> indexed by the row entity
-    float nh[HCMAX], nt[HCMAX], ch[HCMAX], ct[HCMAX];
+    float nh[HC], nt[HC], ch[HC], ct[HC];
 #pragma unroll
-    for (int cc = 0; cc < HCMAX; ++cc) {
+    for (int cc = 0; cc < HC; ++cc) {
       const int c = lane + 64 * cc;
       nh[cc] = c < Hd ? nj[c] : 0.f, nt[cc] = c < Hd ? ni[c] : 0.f, ch[cc] = 0.f, ct[cc] = 0.f;
     }
     for (int k = 0; k < n; ++k) {
       const long row = row0 + k;
-      float ph = 0.f, pt = 0.f, cw[HCMAX];
+      float ph = 0.f, pt = 0.f, cw[HC];
 #pragma unroll
-      for (int cc = 0; cc < HCMAX; ++cc) {
+      for (int cc = 0; cc < HC; ++cc) {
         const int c = lane + 64 * cc;
         cw[cc] = 0.f;
         if (c < Hd) {
@@ -309,10 +362,10 @@ __global__ __launch_bounds__(64 * PW) void prod_sent_fwd_kernel(const float* __r
       if (lane == 0) score[2 * row] = sh, score[2 * row + 1] = st;
       const float ah = fmaxf(sh, 0.f), at = fmaxf(st, 0.f);
 #pragma unroll
-      for (int cc = 0; cc < HCMAX; ++cc) ch[cc] = fmaf(ah, cw[cc], ch[cc]), ct[cc] = fmaf(at, cw[cc], ct[cc]);
+      for (int cc = 0; cc < HC; ++cc) ch[cc] = fmaf(ah, cw[cc], ch[cc]), ct[cc] = fmaf(at, cw[cc], ct[cc]);
     }
 #pragma unroll
-    for (int cc = 0; cc < HCMAX; ++cc) {
+    for (int cc = 0; cc < HC; ++cc) {
       const int c = lane + 64 * cc;
       if (c < Hd) CS[(long)prow * 2 * Hd + c] = ch[cc] / div, CS[(long)prow * 2 * Hd + Hd + c] = ct[cc] / div;
     }
@@ -362,6 +415,7 @@ __global__ __launch_bounds__(64 * PW) void prod_gather_kernel(const float* __res
 // ---- backward of the sentence attention ------------------------------------------------------------------------------
 //   in : dCS[prow] = [dcs_h | dcs_t];  out: dcwa[row] (attention-weighted part), dsfeat[row], dnterm += (atomics),
 //        dwb[0..Hd) += d w, dwb[Hd] += d c (atomics, once per workgroup).  dynamic LDS: (Hd + 1) floats.
+template <int HC>
 __global__ __launch_bounds__(64 * PW) void prod_sent_bwd_kernel(const float* __restrict__ sfeat, const float* __restrict__ cwa,
                                                                 const float* __restrict__ nterm, const float* __restrict__ wsa,
                                                                 const float* __restrict__ score, const float* __restrict__ dCS,
@@ -373,9 +427,9 @@ __global__ __launch_bounds__(64 * PW) void prod_sent_bwd_kernel(const float* __r
   __syncthreads();
   const int npairs = ix.counts[1], nrows = ix.counts[0];
   const long NN = (long)N * N;
-  float w[HCMAX], dw[HCMAX];
+  float w[HC], dw[HC];
 #pragma unroll
-  for (int cc = 0; cc < HCMAX; ++cc) w[cc] = (lane + 64 * cc) < Hd ? wsa[lane + 64 * cc] : 0.f, dw[cc] = 0.f;
+  for (int cc = 0; cc < HC; ++cc) w[cc] = (lane + 64 * cc) < Hd ? wsa[lane + 64 * cc] : 0.f, dw[cc] = 0.f;
   float dbias = 0.f;
   for (int prow = blockIdx.x * PW + wave; prow < npairs; prow += gridDim.x * PW) {
     const long pair = ix.prow_pair[prow];
@@ -384,9 +438,9 @@ __global__ __launch_bounds__(64 * PW) void prod_sent_bwd_kernel(const float* __r
     const int row0 = ix.pair_row0[pair], n = __popc(ix.pair_bits[pair]);
     const float div = ix.pair_div[pair];
     const long oj = (b * N + j) * Hd, oi = (b * N + i) * Hd;
-    float nh[HCMAX], nt[HCMAX], gh[HCMAX], gt[HCMAX], dnh[HCMAX], dnt[HCMAX];
+    float nh[HC], nt[HC], gh[HC], gt[HC], dnh[HC], dnt[HC];
 #pragma unroll
-    for (int cc = 0; cc < HCMAX; ++cc) {
+    for (int cc = 0; cc < HC; ++cc) {
       const int c = lane + 64 * cc;
       nh[cc] = c < Hd ? nterm[oj + c] : 0.f, nt[cc] = c < Hd ? nterm[oi + c] : 0.f;
       gh[cc] = c < Hd ? dCS[(long)prow * 2 * Hd + c] / div : 0.f;          // d(sum_s att_h cwa)
@@ -397,9 +451,9 @@ __global__ __launch_bounds__(64 * PW) void prod_sent_bwd_kernel(const float* __r
       const long row = row0 + k;
       const float sh = score[2 * row], st = score[2 * row + 1];
       const float ah = fmaxf(sh, 0.f), at = fmaxf(st, 0.f);
-      float cw[HCMAX], zh[HCMAX], zt[HCMAX], ph = 0.f, pt = 0.f;
+      float cw[HC], zh[HC], zt[HC], ph = 0.f, pt = 0.f;
 #pragma unroll
-      for (int cc = 0; cc < HCMAX; ++cc) {
+      for (int cc = 0; cc < HC; ++cc) {
         const int c = lane + 64 * cc;
         cw[cc] = 0.f, zh[cc] = 0.f, zt[cc] = 0.f;
         if (c < Hd) {
@@ -413,7 +467,7 @@ __global__ __launch_bounds__(64 * PW) void prod_sent_bwd_kernel(const float* __r
       const float dsh = sh > 0.f ? wave_sum(ph) : 0.f, dst = st > 0.f ? wave_sum(pt) : 0.f;
       dbias += dsh + dst;
 #pragma unroll
-      for (int cc = 0; cc < HCMAX; ++cc) {
+      for (int cc = 0; cc < HC; ++cc) {
         const int c = lane + 64 * cc;
         if (c < Hd) {
           const float dzh = dsh * w[cc] * (1.f - zh[cc] * zh[cc]), dzt = dst * w[cc] * (1.f - zt[cc] * zt[cc]);
@@ -425,7 +479,7 @@ __global__ __launch_bounds__(64 * PW) void prod_sent_bwd_kernel(const float* __r
       }
     }
 #pragma unroll
-    for (int cc = 0; cc < HCMAX; ++cc) {
+    for (int cc = 0; cc < HC; ++cc) {
       const int c = lane + 64 * cc;
       if (c < Hd) {
         atomicAdd(dnterm + oj + c, dnh[cc]);
@@ -434,7 +488,7 @@ __global__ __launch_bounds__(64 * PW) void prod_sent_bwd_kernel(const float* __r
     }
   }
 #pragma unroll
-  for (int cc = 0; cc < HCMAX; ++cc)
+  for (int cc = 0; cc < HC; ++cc)
     if ((lane + 64 * cc) < Hd) atomicAdd(&sacc[lane + 64 * cc], dw[cc]);
   if (lane == 0) atomicAdd(&sacc[Hd], dbias);   // every lane holds the same dbias
   __syncthreads();
@@ -446,63 +500,90 @@ __global__ __launch_bounds__(64 * PW) void prod_sent_bwd_kernel(const float* __r
   }
 }
 
-// ---- backward of the word attention --------------------------------------------------------------------------------
-//   dcw = dCW[row, side]: g[t] = dcw . ctx[t];  dscore[t] = att[t] (g[t] - sum_t att g);  dtable[b, pos[t], t] += dscore
-//   dctx[b, t, :] += att[t] dcw          (atomics: many slots share a token / a table entry)
-// dynamic LDS: PW * 2 * T floats (weights, then g)
-__global__ __launch_bounds__(64 * PW) void prod_word_bwd_kernel(const float* __restrict__ ctx, const unsigned char* __restrict__ sen,
-                                                                const void* __restrict__ pos_h, const void* __restrict__ pos_t,
-                                                                int pos_bytes, const float* __restrict__ table,
-                                                                const float* __restrict__ stats, const float* __restrict__ dCW,
-                                                                ProdIdx ix, float* __restrict__ dtable, float* __restrict__ dctx,
-                                                                int N, int S, int T, int Hd, int ND) {
+// ---- backward of the word attention, two passes, no atomics -------------------------------------------------------------
+//   dcw = dCW[row, side]:  g[t] = dcw . ctx[t];  dscore[t] = att[t] (g[t] - sum_t att g)
+//   dtable[b, pos[t], t] += dscore,  dctx[b, t, :] += att[t] dcw     -- sums over MANY (row, side) per (document, token)
+// Pass 1 (one wave per (row, side), like the forward): the softmax-weighted sum  dots[r] = sum_t att[t] g[t], the slot's
+// token range and the document's last covered token.  Pass 2 (one workgroup per (document, token), the OWNER of
+// dctx[b, t, :] and dtable[b, :, t]): scans the document's live rows, and for those whose slot holds the token recomputes
+// att and g (a 128-wide dot with the token state it keeps in registers) and accumulates in a fixed order -- deterministic,
+// and ~20x faster than scatter-adding with fp32 atomics.
+// dynamic LDS pass 1: PW * T floats
+template <int HC>
+__global__ __launch_bounds__(64 * PW) void prod_word_bwd_rows_kernel(const float* __restrict__ ctx, const unsigned char* __restrict__ sen,
+                                                                     const void* __restrict__ pos_h, const void* __restrict__ pos_t,
+                                                                     int pos_bytes, const float* __restrict__ table,
+                                                                     const float* __restrict__ stats, const float* __restrict__ dCW,
+                                                                     ProdIdx ix, float* __restrict__ dots, int N, int S, int T, int Hd,
+                                                                     int ND) {
   extern __shared__ float wsm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* av = wsm + (long)wave * 2 * T;  // att[t]
-  float* gv = av + T;                    // g[t]
+  float* av = wsm + (long)wave * T;  // att[t]
   const int nrows = ix.counts[0], total = 2 * nrows;
   const long slots_per_doc = (long)N * N * S;
   for (int r0 = blockIdx.x * PW; r0 < total; r0 += gridDim.x * PW) {
     const int r = r0 + wave;
     const bool on = r < total;
     int t0 = T, t1 = 0;
-    long b = 0, slot = 0;
-    const void* pos = pos_h;
+    long b = 0;
     if (on) {
       const int row = r >> 1, side = r & 1;
-      slot = ix.row_slot[row];
+      const long slot = ix.row_slot[row];
       b = slot / slots_per_doc;
-      pos = side ? pos_t : pos_h;
+      const void* pos = side ? pos_t : pos_h;
       const unsigned char* m = sen + slot * T;
       const float* tab = table + b * ND * T;
       const float mx = stats[2 * (long)r], inv = stats[2 * (long)r + 1];
-      for (int t = lane; t < T; t += 64) {
-        float a = 0.f;
-        if (m[t]) {
-          const int k = min(max(pos_at(pos, pos_bytes, slot * T + t), 0), ND - 1);
-          a = expf(tab[(long)k * T + t] - mx) * inv;
-          t0 = min(t0, t), t1 = max(t1, t + 1);
+      for (int c0 = 0; c0 < T; c0 += 512) {
+        float sc[8];
+        slot_scores8(m, pos, pos_bytes, slot * T, tab, T, ND, c0, lane, sc);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int t = c0 + 64 * u + lane;
+          if (t < T) {
+            av[t] = sc[u] == -INFINITY ? 0.f : expf(sc[u] - mx) * inv;
+            if (sc[u] != -INFINITY) t0 = min(t0, t), t1 = max(t1, t + 1);
+          }
         }
-        av[t] = a;
       }
       t0 = -(int)wave_max((float)-t0), t1 = (int)wave_max((float)t1);
     }
+    float* dl = wsm + (long)PW * T + (long)wave * Hd;   // this (row, side)'s dCW row, broadcast to every lane below
+    if (on)
+      for (int c = lane; c < Hd; c += 64) dl[c] = dCW[(long)(r >> 1) * 2 * Hd + (r & 1) * Hd + c];
     __syncthreads();
-    float dotsum = 0.f;
-    if (on) {
+    if (on && (Hd & 3) == 0) {
+      // lanes over TOKENS: g[t] = dcw . ctx[t] is a private 128-wide dot per lane (16-byte loads of the lane's own token row,
+      // dcw broadcast from LDS) -- one wave reduction per 64 tokens instead of one per token
+      const float* cb = ctx + b * T * Hd;
+      float dotsum = 0.f;
+      for (int tb = t0; tb < t1; tb += 64) {
+        const int t = tb + lane;
+        const float4* cr = reinterpret_cast<const float4*>(cb + (long)min(t, t1 - 1) * Hd);
+        float g0 = 0.f, g1 = 0.f;
+        for (int q = 0; q < Hd / 4; q += 2) {
+          const float4 x0 = cr[q], x1 = cr[q + 1 < Hd / 4 ? q + 1 : q];
+          const float4 d0 = *reinterpret_cast<const float4*>(dl + 4 * q), d1 = *reinterpret_cast<const float4*>(dl + 4 * (q + 1 < Hd / 4 ? q + 1 : q));
+          g0 = fmaf(x0.x, d0.x, fmaf(x0.y, d0.y, fmaf(x0.z, d0.z, fmaf(x0.w, d0.w, g0))));
+          if (q + 1 < Hd / 4) g1 = fmaf(x1.x, d1.x, fmaf(x1.y, d1.y, fmaf(x1.z, d1.z, fmaf(x1.w, d1.w, g1))));
+        }
+        if (t < t1) dotsum = fmaf(av[t], g0 + g1, dotsum);
+      }
+      dotsum = wave_sum(dotsum);
+      if (lane == 0) dots[r] = dotsum;
+    } else if (on) {
       const int row = r >> 1, side = r & 1;
       const float* cb = ctx + b * T * Hd;
-      float* db = dctx + b * T * Hd;
-      float dcw[HCMAX];
+      float dcw[HC], dotsum = 0.f;
 #pragma unroll
-      for (int cc = 0; cc < HCMAX; ++cc) dcw[cc] = (lane + 64 * cc) < Hd ? dCW[(long)row * 2 * Hd + side * Hd + lane + 64 * cc] : 0.f;
+      for (int cc = 0; cc < HC; ++cc) dcw[cc] = (lane + 64 * cc) < Hd ? dCW[(long)row * 2 * Hd + side * Hd + lane + 64 * cc] : 0.f;
       for (int t = t0; t < t1; t += 4) {  // four tokens at a time: independent loads, interleaved reductions
         float p[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int tt = min(t + u, t1 - 1);
 #pragma unroll
-          for (int cc = 0; cc < HCMAX; ++cc) {
+          for (int cc = 0; cc < HC; ++cc) {
             const int c = lane + 64 * cc;
             if (c < Hd) p[u] = fmaf(dcw[cc], cb[(long)tt * Hd + c], p[u]);
           }
@@ -510,87 +591,202 @@ __global__ __launch_bounds__(64 * PW) void prod_word_bwd_kernel(const float* __r
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const float g = wave_sum(p[u]);
-          if (t + u < t1) {
-            const float a = av[t + u];
-            if (lane == 0) gv[t + u] = g;
-            dotsum = fmaf(a, g, dotsum);
-            if (a != 0.f) {
-#pragma unroll
-              for (int cc = 0; cc < HCMAX; ++cc) {
-                const int c = lane + 64 * cc;
-                if (c < Hd) atomicAdd(db + (long)(t + u) * Hd + c, a * dcw[cc]);
-              }
-            }
-          }
+          if (t + u < t1) dotsum = fmaf(av[t + u], g, dotsum);
         }
       }
-    }
-    __syncthreads();
-    if (on) {
-      float* dt = dtable + b * ND * T;
-      for (int t = t0 + lane; t < t1; t += 64) {
-        const float a = av[t];
-        if (a != 0.f) {
-          const int k = min(max(pos_at(pos, pos_bytes, slot * T + t), 0), ND - 1);
-          atomicAdd(dt + (long)k * T + t, a * (gv[t] - dotsum));
-        }
-      }
+      if (lane == 0) dots[r] = dotsum;
     }
     __syncthreads();
   }
 }
 
+// pass 2: one workgroup per (document, token); LDS: PW * (Hd + ND) floats
+template <int HC>
+__global__ __launch_bounds__(64 * PW) void prod_word_bwd_tok_kernel(const float* __restrict__ ctx, const unsigned char* __restrict__ sen,
+                                                                    const void* __restrict__ pos_h, const void* __restrict__ pos_t,
+                                                                    int pos_bytes, const float* __restrict__ table,
+                                                                    const float* __restrict__ stats, const float* __restrict__ dCW,
+                                                                    const float* __restrict__ dots, ProdIdx ix,
+                                                                    float* __restrict__ dtable, float* __restrict__ dctx, int T, int Hd,
+                                                                    int ND) {
+  extern __shared__ float sm[];  // [PW][Hd] partial dctx rows | [PW][ND] partial dtable columns
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long bt = blockIdx.x;
+  const int b = (int)(bt / T), t = (int)(bt - (long)b * T);
+  float* accs = sm;
+  float* dts = sm + (long)PW * Hd;
+  for (int e = threadIdx.x; e < PW * ND; e += 64 * PW) dts[e] = 0.f;
+  float acc[HC], cx[HC];
+#pragma unroll
+  for (int cc = 0; cc < HC; ++cc) acc[cc] = 0.f, cx[cc] = (lane + 64 * cc) < Hd ? ctx[bt * Hd + lane + 64 * cc] : 0.f;
+  __syncthreads();
+  if (t < ix.tmax[b]) {
+    const int r_lo = ix.doc_off[b], r_hi = ix.doc_off[b + 1];
+    const float* tab = table + (long)b * ND * T;
+    float* dtw = dts + wave * ND;
+    for (int base = r_lo + wave * 64; base < r_hi; base += PW * 64) {
+      // lane-parallel: everything a hit needs except the dCW rows -- one latency chain per 64 candidate rows, not per hit
+      const int row = base + lane;
+      bool hit = false;
+      float ah = 0.f, at = 0.f, dh = 0.f, dt = 0.f;
+      int kh = 0, kt = 0;
+      if (row < r_hi) {
+        const int rg = ix.row_rng[row];
+        if (t >= (rg & 0xffff) && t < (rg >> 16)) {
+          const long slot = ix.row_slot[row];
+          if (sen[slot * T + t]) {
+            hit = true;
+            kh = min(max(pos_at(pos_h, pos_bytes, slot * T + t), 0), ND - 1);
+            kt = min(max(pos_at(pos_t, pos_bytes, slot * T + t), 0), ND - 1);
+            const float4 st = *reinterpret_cast<const float4*>(stats + 4L * row);   // max / 1/sum of the head, of the tail side
+            ah = expf(tab[(long)kh * T + t] - st.x) * st.y;
+            at = expf(tab[(long)kt * T + t] - st.z) * st.w;
+            dh = dots[2L * row], dt = dots[2L * row + 1];
+          }
+        }
+      }
+      unsigned long long todo = __ballot(hit);
+      float nh[HC], nt[HC];   // dCW rows of the NEXT hit, requested one hit ahead
+      int l = todo ? __ffsll((long long)todo) - 1 : 0;
+#pragma unroll
+      for (int cc = 0; cc < HC; ++cc) {
+        const int c = lane + 64 * cc;
+        nh[cc] = (todo && c < Hd) ? dCW[(long)(base + l) * 2 * Hd + c] : 0.f;
+        nt[cc] = (todo && c < Hd) ? dCW[(long)(base + l) * 2 * Hd + Hd + c] : 0.f;
+      }
+      while (todo) {
+        const int cur = l;
+        todo &= todo - 1;
+        float ch[HC], ct[HC], ph = 0.f, pt = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < HC; ++cc) ch[cc] = nh[cc], ct[cc] = nt[cc];
+        if (todo) {
+          l = __ffsll((long long)todo) - 1;
+#pragma unroll
+          for (int cc = 0; cc < HC; ++cc) {
+            const int c = lane + 64 * cc;
+            nh[cc] = c < Hd ? dCW[(long)(base + l) * 2 * Hd + c] : 0.f;
+            nt[cc] = c < Hd ? dCW[(long)(base + l) * 2 * Hd + Hd + c] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int cc = 0; cc < HC; ++cc) ph = fmaf(ch[cc], cx[cc], ph), pt = fmaf(ct[cc], cx[cc], pt);
+        const float gh = wave_sum(ph), gt = wave_sum(pt);
+        const float a_h = lane_value(ah, cur), a_t = lane_value(at, cur);
+        if (lane == 0) {   // one lane, program order: deterministic
+          dtw[__builtin_amdgcn_readlane(kh, cur)] += a_h * (gh - lane_value(dh, cur));
+          dtw[__builtin_amdgcn_readlane(kt, cur)] += a_t * (gt - lane_value(dt, cur));
+        }
+#pragma unroll
+        for (int cc = 0; cc < HC; ++cc) acc[cc] = fmaf(a_h, ch[cc], fmaf(a_t, ct[cc], acc[cc]));
+      }
+    }
+  }
+#pragma unroll
+  for (int cc = 0; cc < HC; ++cc)
+    if ((lane + 64 * cc) < Hd) accs[wave * Hd + lane + 64 * cc] = acc[cc];
+  __syncthreads();
+  for (int c = threadIdx.x; c < Hd; c += 64 * PW) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < PW; ++w) v += accs[w * Hd + c];
+    dctx[bt * Hd + c] = v;
+  }
+  for (int k = threadIdx.x; k < ND; k += 64 * PW) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < PW; ++w) v += dts[w * ND + k];
+    dtable[((long)b * ND + k) * T + t] = v;
+  }
+}
+
 // ---- backward of the score table ------------------------------------------------------------------------------------
-//   dsentF[b, t, c] = sum_k dtable[b,k,t] w_a[c] (1 - z^2),  ddisF[k, c] += (same, summed over b, t),  dwab[c] += dtable z,
-//   dwab[Hd] += dtable          z = tanh(sentF[b,t,c] + disF[k,c]).   dynamic LDS: (ND * Hd + Hd + 1) floats.
+//   dsentF[b, t, c] = sum_k dtable[b,k,t] w_a[c] (1 - z^2),  ddisF[k, c] = (the same, summed over b, t),  dwa[c] = sum dtable z,
+//   dba = sum dtable          z = tanh(sentF[b,t,c] + disF[k,c]).
+// Only tokens below tmax[b] carry a gradient.  Grid (token chunks of TCH, B): a workgroup whose chunk lies beyond tmax[b]
+// zeroes its dsentF rows and leaves; the others accumulate per wave in LDS (fixed order) and write ONE partial record
+// [ND * Hd | Hd | 1]; prod_table_fin_kernel sums the live records in (document, chunk) order -- deterministic, no atomics.
+constexpr int TCH = 16;  // tokens per workgroup (4 per wave)
+template <int HC>
 __global__ __launch_bounds__(64 * PW) void prod_table_bwd_kernel(const float* __restrict__ sentF, const float* __restrict__ disF,
                                                                  const float* __restrict__ wa, const float* __restrict__ dtable,
-                                                                 float* __restrict__ dsentF, float* __restrict__ ddisF,
-                                                                 float* __restrict__ dwab, long BT, int T, int Hd, int ND) {
-  extern __shared__ float sacc[];  // [ND][Hd] ddisF partial | [Hd] dwa | [1] dba
+                                                                 const int* __restrict__ tmax, float* __restrict__ dsentF,
+                                                                 float* __restrict__ part, int T, int Hd, int ND) {
+  extern __shared__ float sacc[];  // [PW][ND * Hd + Hd + 1]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tot = ND * Hd + Hd + 1;
-  for (int e = threadIdx.x; e < tot; e += 64 * PW) sacc[e] = 0.f;
-  __syncthreads();
-  float w[HCMAX], dw[HCMAX];
+  const int b = blockIdx.y, chunk = blockIdx.x, rec = ND * Hd + Hd + 1;
+  const int tlim = min(tmax[b], T);
+  const int tb = chunk * TCH + wave * (TCH / PW);
+  if (chunk * TCH >= tlim) {  // nothing reaches these tokens (uniform over the workgroup)
+    for (int i = 0; i < TCH / PW; ++i) {
+      const int t = tb + i;
+      if (t < T)
+        for (int c = lane; c < Hd; c += 64) dsentF[((long)b * T + t) * Hd + c] = 0.f;
+    }
+    return;
+  }
+  float* mine = sacc + (long)wave * rec;
+  for (int e = lane; e < rec; e += 64) mine[e] = 0.f;
+  float w[HC], dw[HC];
 #pragma unroll
-  for (int cc = 0; cc < HCMAX; ++cc) w[cc] = (lane + 64 * cc) < Hd ? wa[lane + 64 * cc] : 0.f, dw[cc] = 0.f;
+  for (int cc = 0; cc < HC; ++cc) w[cc] = (lane + 64 * cc) < Hd ? wa[lane + 64 * cc] : 0.f, dw[cc] = 0.f;
   float dbias = 0.f;
-  for (long bt = (long)blockIdx.x * PW + wave; bt < BT; bt += (long)gridDim.x * PW) {
-    const long b = bt / T;
-    const int t = (int)(bt - b * T);
-    float sf[HCMAX], ds[HCMAX];
+  for (int i = 0; i < TCH / PW; ++i) {
+    const int t = tb + i;
+    if (t >= T) break;
+    const long bt = (long)b * T + t;
+    float sf[HC], ds[HC];
 #pragma unroll
-    for (int cc = 0; cc < HCMAX; ++cc) sf[cc] = (lane + 64 * cc) < Hd ? sentF[bt * Hd + lane + 64 * cc] : 0.f, ds[cc] = 0.f;
-    for (int k = 0; k < ND; ++k) {
-      const float g = dtable[(b * ND + k) * T + t];   // uniform over the wave
-      if (g == 0.f) continue;
+    for (int cc = 0; cc < HC; ++cc) sf[cc] = (lane + 64 * cc) < Hd ? sentF[bt * Hd + lane + 64 * cc] : 0.f, ds[cc] = 0.f;
+    const float gl = lane < ND ? dtable[((long)b * ND + lane) * T + t] : 0.f;   // all ND ids at once
+    unsigned long long todo = __ballot(gl != 0.f);
+    while (todo) {
+      const int k = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const float g = lane_value(gl, k);
       dbias += g;
 #pragma unroll
-      for (int cc = 0; cc < HCMAX; ++cc) {
+      for (int cc = 0; cc < HC; ++cc) {
         const int c = lane + 64 * cc;
         if (c < Hd) {
           const float z = tanhf(sf[cc] + disF[(long)k * Hd + c]);
           const float d = g * w[cc] * (1.f - z * z);
           ds[cc] += d;
-          atomicAdd(&sacc[k * Hd + c], d);
+          mine[k * Hd + c] += d;          // this wave's own LDS record, program order
           dw[cc] = fmaf(g, z, dw[cc]);
         }
       }
     }
 #pragma unroll
-    for (int cc = 0; cc < HCMAX; ++cc)
+    for (int cc = 0; cc < HC; ++cc)
       if ((lane + 64 * cc) < Hd) dsentF[bt * Hd + lane + 64 * cc] = ds[cc];
   }
 #pragma unroll
-  for (int cc = 0; cc < HCMAX; ++cc)
-    if ((lane + 64 * cc) < Hd) atomicAdd(&sacc[ND * Hd + lane + 64 * cc], dw[cc]);
-  if (lane == 0) atomicAdd(&sacc[ND * Hd + Hd], dbias);
+  for (int cc = 0; cc < HC; ++cc)
+    if ((lane + 64 * cc) < Hd) mine[ND * Hd + lane + 64 * cc] = dw[cc];
+  if (lane == 0) mine[ND * Hd + Hd] = dbias;
   __syncthreads();
-  for (int e = threadIdx.x; e < ND * Hd; e += 64 * PW)
-    if (sacc[e] != 0.f) atomicAdd(ddisF + e, sacc[e]);
-  for (int e = threadIdx.x; e <= Hd; e += 64 * PW)
-    if (sacc[ND * Hd + e] != 0.f) atomicAdd(dwab + e, sacc[ND * Hd + e]);
+  float* out = part + ((long)b * gridDim.x + chunk) * rec;
+  for (int e = threadIdx.x; e < rec; e += 64 * PW) {
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < PW; ++q) v += sacc[(long)q * rec + e];
+    out[e] = v;
+  }
+}
+// ddisF | dwa | dba = sum of the live partial records, documents and chunks in order
+__global__ __launch_bounds__(256) void prod_table_fin_kernel(const float* __restrict__ part, const int* __restrict__ tmax, int B, int T,
+                                                             int nchunk, int rec, int nd_hd, float* __restrict__ ddisF,
+                                                             float* __restrict__ dwab) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= rec) return;
+  float v = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const int live = (min(tmax[b], T) + TCH - 1) / TCH;
+    for (int c = 0; c < live; ++c) v += part[((long)b * nchunk + c) * rec + e];
+  }
+  if (e < nd_hd) ddisF[e] = v;
+  else dwab[e - nd_hd] = v;
 }
 
 // ---- column sums over the compact rows (bias gradients): part[slice][C], then out[c] = sum of the slices in order ----
@@ -620,6 +816,16 @@ __global__ __launch_bounds__(256) void prod_colsum_fin_kernel(const float* __res
 // =====================================================================================================================
 // host side
 // =====================================================================================================================
+// kernels are instantiated for HC = ceil(Hd / 64) in {1, 2, 4, 8} column chunks per lane (the reference's Hd = 128: HC = 2)
+#define PROD_LAUNCH(kernel, Hd, grid, block, lds, st, ...)                                            \
+  do {                                                                                                \
+    const int _hc = ((Hd) + 63) / 64;                                                                 \
+    if (_hc <= 1) hipLaunchKernelGGL((kernel<1>), grid, block, lds, st, __VA_ARGS__);                 \
+    else if (_hc <= 2) hipLaunchKernelGGL((kernel<2>), grid, block, lds, st, __VA_ARGS__);            \
+    else if (_hc <= 4) hipLaunchKernelGGL((kernel<4>), grid, block, lds, st, __VA_ARGS__);            \
+    else hipLaunchKernelGGL((kernel<8>), grid, block, lds, st, __VA_ARGS__);                          \
+  } while (0)
+
 struct ProdLayout {  // offsets (floats) inside the block's flat parameter buffer; reference tensors keep their [out, in] layout
   long Ws, bs, Wp, bp, wa, ba;           // word_attention.{attention_sent, attention_pos, attention_all}
   long Wlw, blw;                         // linear_word_att            [Hd, 2Hd]
@@ -630,7 +836,7 @@ struct ProdLayout {  // offsets (floats) inside the block's flat parameter buffe
 ProdLayout prod_layout(int Hd, int P) {
   ProdLayout y;
   long o = 0;
-  auto take = [&](long n) { const long at = o; o += n; return at; };
+  auto take = [&](long n) { const long at = o; o += (n + 3) & ~3L; return at; };   // every piece 16-byte aligned (float4 GEMM loads)
   y.Ws = take((long)Hd * Hd), y.bs = take(Hd), y.Wp = take((long)Hd * P), y.bp = take(Hd), y.wa = take(Hd), y.ba = take(1);
   y.Wlw = take(2L * Hd * Hd), y.blw = take(Hd);
   y.Wss = take((long)Hd * Hd), y.bss = take(Hd), y.Wsp = take((long)Hd * Hd), y.bsp = take(Hd), y.wsa = take(Hd), y.bsa = take(1);
@@ -698,7 +904,7 @@ struct ProdBufs {  // caller-owned device memory (include/gcgcn.h lists the size
 int prod_fwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx, const unsigned char* sen, const void* pos_h,
              const void* pos_t, int pos_bytes, const float* node, const float* dis_table, const int* n_valid, const float* flat,
              ProdIdx ix, long cap_rows, long cap_pairs, ProdBufs w, float* E, float* ws, long wse, hipStream_t st) {
-  GC_REQUIRE(Hd >= 1 && Hd <= 64 * HCMAX, "producer: hidden width %d (1..%d supported)", Hd, 64 * HCMAX);
+  GC_REQUIRE(Hd >= 1 && Hd <= 64 * HCLIM, "producer: hidden width %d (1..%d supported)", Hd, 64 * HCLIM);
   GC_REQUIRE(pos_bytes == 8 || pos_bytes == 4 || pos_bytes == 1, "producer: position ids must be int64, int32 or uint8");
   GC_REQUIRE((size_t)PW * 2 * T * sizeof(float) <= 64 * 1024, "producer: T=%d tokens exceed the LDS budget", T);
   const ProdLayout y = prod_layout(Hd, P);
@@ -707,23 +913,25 @@ int prod_fwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx
   GC_TRY(linear_fwd(dis_table, ND, P, flat + y.Wp, flat + y.bp, Hd, w.disF, ws, wse, st));      // glove:179 on the 21 ids
   {
     ProfScope ps("prod_table", st);
-    hipLaunchKernelGGL(prod_table_fwd_kernel, dim3(cdiv(BT, PW)), dim3(64 * PW), 0, st, w.sentF, w.disF, flat + y.wa,
+    PROD_LAUNCH(prod_table_fwd_kernel, Hd, dim3(cdiv(BT, PW)), dim3(64 * PW), 0, st, w.sentF, w.disF, flat + y.wa,
                        flat + y.ba, w.table, BT, T, Hd, ND);
     GC_TRY(check_launch("prod_table_fwd"));
   }
   GC_TRY(prod_index(sen, n_valid, ix, B, N, S, T, cap_rows, cap_pairs, st));
   {
     ProfScope ps("prod_word", st);
-    hipLaunchKernelGGL(prod_word_fwd_kernel, dim3(PGRID), dim3(64 * PW), (size_t)PW * T * sizeof(float), st, ctx, sen, pos_h, pos_t,
+    PROD_LAUNCH(prod_word_fwd_kernel, Hd, dim3(PGRID), dim3(64 * PW), (size_t)PW * T * sizeof(float), st, ctx, sen, pos_h, pos_t,
                        pos_bytes, w.table, ix, w.CW, w.stats, N, S, T, Hd, ND);
     GC_TRY(check_launch("prod_word_fwd"));
+    hipLaunchKernelGGL(prod_tmax_kernel, dim3(B), dim3(256), 0, st, ix);
+    GC_TRY(check_launch("prod_tmax"));
   }
   GC_TRY(linear_fwd(w.CW, 0, 2 * Hd, flat + y.Wlw, flat + y.blw, Hd, w.cwa, ws, wse, st, ix.counts, cap_rows));       // :320-321
   GC_TRY(linear_fwd(w.cwa, 0, Hd, flat + y.Wss, flat + y.bss, Hd, w.sfeat, ws, wse, st, ix.counts, cap_rows));        // :201
   GC_TRY(linear_fwd(node, (long)B * N, Hd, flat + y.Wsp, flat + y.bsp, Hd, w.nterm, ws, wse, st));                    // :202 per entity
   {
     ProfScope ps("prod_sent", st);
-    hipLaunchKernelGGL(prod_sent_fwd_kernel, dim3(PGRID), dim3(64 * PW), 0, st, w.sfeat, w.cwa, w.nterm, flat + y.wsa, flat + y.bsa,
+    PROD_LAUNCH(prod_sent_fwd_kernel, Hd, dim3(PGRID), dim3(64 * PW), 0, st, w.sfeat, w.cwa, w.nterm, flat + y.wsa, flat + y.bsa,
                        ix, w.CS, w.score, N, Hd);
     GC_TRY(check_launch("prod_sent_fwd"));
   }
@@ -738,7 +946,7 @@ int prod_fwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx
 }
 
 struct ProdGrads {  // caller-owned workspace of the backward pass
-  float *dEc, *dCS, *dcwa, *dsfeat, *dnterm, *dCW, *dtable, *dsentF, *ddisF, *dwb, *part, *wpair;
+  float *dEc, *dCS, *dcwa, *dsfeat, *dnterm, *dCW, *dtable, *dsentF, *ddisF, *dwb, *part, *wpair, *dots, *tpart;
 };
 
 static int colsum_dyn(const float* X, const int* cnt, int C, float* part, float* out, hipStream_t st) {
@@ -757,11 +965,9 @@ int prod_bwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx
   const long BT = (long)B * T, BN = (long)B * N, BNN = BN * N;
   const int* nrows = ix.counts;
   const int* npairs = ix.counts + 1;
+  GC_REQUIRE(sizeof(float) * PW * ((size_t)ND * Hd + Hd + 1) <= 150 * 1024, "producer_bwd: hidden width %d exceeds the LDS budget of the table backward", Hd);
   // zero the atomics' targets
-  GC_REQUIRE(hipMemsetAsync(dctx, 0, sizeof(float) * BT * Hd, st) == hipSuccess, "producer: memset failed");
   GC_REQUIRE(hipMemsetAsync(g.dnterm, 0, sizeof(float) * BN * Hd, st) == hipSuccess, "producer: memset failed");
-  GC_REQUIRE(hipMemsetAsync(g.dtable, 0, sizeof(float) * B * ND * T, st) == hipSuccess, "producer: memset failed");
-  GC_REQUIRE(hipMemsetAsync(g.ddisF, 0, sizeof(float) * ND * Hd, st) == hipSuccess, "producer: memset failed");
   GC_REQUIRE(hipMemsetAsync(g.dwb, 0, sizeof(float) * 2 * (Hd + 1), st) == hipSuccess, "producer: memset failed");
   // linear_sentence_att: E = CS W_ls^T + b_ls on live pairs, b_ls on every other real pair
   {
@@ -775,12 +981,13 @@ int prod_bwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx
   GC_TRY(linear_bwd_x(g.dEc, 0, Hd, flat + y.Wls, 2 * Hd, g.dCS, 0, ws, wse, st, npairs, cap_pairs));
   {
     ProfScope ps("prod_sent", st);
-    hipLaunchKernelGGL(prod_sent_bwd_kernel, dim3(PGRID), dim3(64 * PW), sizeof(float) * (Hd + 1), st, w.sfeat, w.cwa, w.nterm,
+    PROD_LAUNCH(prod_sent_bwd_kernel, Hd, dim3(PGRID), dim3(64 * PW), sizeof(float) * (Hd + 1), st, w.sfeat, w.cwa, w.nterm,
                        flat + y.wsa, w.score, g.dCS, ix, g.dcwa, g.dsfeat, g.dnterm, g.dwb, N, Hd);
     GC_TRY(check_launch("prod_sent_bwd"));
   }
-  GC_REQUIRE(hipMemcpyAsync(dflat + y.wsa, g.dwb, sizeof(float) * (Hd + 1), hipMemcpyDeviceToDevice, st) == hipSuccess,
-             "producer: copy failed");   // wsa | bsa are adjacent in the layout
+  GC_REQUIRE(hipMemcpyAsync(dflat + y.wsa, g.dwb, sizeof(float) * Hd, hipMemcpyDeviceToDevice, st) == hipSuccess &&
+                 hipMemcpyAsync(dflat + y.bsa, g.dwb + Hd, sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess,
+             "producer: copy failed");
   // sentence_attention.attention_sent / attention_pos
   GC_TRY(linear_bwd_w(g.dsfeat, w.cwa, 0, Hd, Hd, dflat + y.Wss, ws, wse, st, nrows, cap_rows));
   GC_TRY(colsum_dyn(g.dsfeat, nrows, Hd, g.part, dflat + y.bss, st));
@@ -795,19 +1002,26 @@ int prod_bwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx
   // word attention -> score table and token states
   {
     ProfScope ps("prod_word", st);
-    hipLaunchKernelGGL(prod_word_bwd_kernel, dim3(PGRID), dim3(64 * PW), (size_t)PW * 2 * T * sizeof(float), st, ctx, sen, pos_h,
-                       pos_t, pos_bytes, w.table, w.stats, g.dCW, ix, g.dtable, dctx, N, S, T, Hd, ND);
-    GC_TRY(check_launch("prod_word_bwd"));
+    PROD_LAUNCH(prod_word_bwd_rows_kernel, Hd, dim3(PGRID), dim3(64 * PW), (size_t)PW * (T + Hd) * sizeof(float), st, ctx, sen, pos_h,
+                       pos_t, pos_bytes, w.table, w.stats, g.dCW, ix, g.dots, N, S, T, Hd, ND);
+    GC_TRY(check_launch("prod_word_bwd_rows"));
+    PROD_LAUNCH(prod_word_bwd_tok_kernel, Hd, dim3((unsigned)BT), dim3(64 * PW), sizeof(float) * PW * (size_t)(Hd + ND), st, ctx, sen,
+                       pos_h, pos_t, pos_bytes, w.table, w.stats, g.dCW, g.dots, ix, g.dtable, dctx, T, Hd, ND);
+    GC_TRY(check_launch("prod_word_bwd_tok"));
   }
   {
     ProfScope ps("prod_table", st);
-    const int grid = (int)(cdiv(BT, PW) < 1024 ? cdiv(BT, PW) : 1024);
-    hipLaunchKernelGGL(prod_table_bwd_kernel, dim3(grid), dim3(64 * PW), sizeof(float) * ((size_t)ND * Hd + Hd + 1), st, w.sentF,
-                       w.disF, flat + y.wa, g.dtable, g.dsentF, g.ddisF, g.dwb + Hd + 1, BT, T, Hd, ND);
+    const int nchunk = cdiv(T, TCH), rec = ND * Hd + Hd + 1;
+    PROD_LAUNCH(prod_table_bwd_kernel, Hd, dim3(nchunk, B), dim3(64 * PW), sizeof(float) * PW * (size_t)rec, st, w.sentF, w.disF,
+                flat + y.wa, g.dtable, ix.tmax, g.dsentF, g.tpart, T, Hd, ND);
     GC_TRY(check_launch("prod_table_bwd"));
+    hipLaunchKernelGGL(prod_table_fin_kernel, dim3(cdiv(rec, 256)), dim3(256), 0, st, g.tpart, ix.tmax, B, T, nchunk, rec, ND * Hd, g.ddisF,
+                       g.dwb + Hd + 1);
+    GC_TRY(check_launch("prod_table_fin"));
   }
-  GC_REQUIRE(hipMemcpyAsync(dflat + y.wa, g.dwb + Hd + 1, sizeof(float) * (Hd + 1), hipMemcpyDeviceToDevice, st) == hipSuccess,
-             "producer: copy failed");   // wa | ba adjacent
+  GC_REQUIRE(hipMemcpyAsync(dflat + y.wa, g.dwb + Hd + 1, sizeof(float) * Hd, hipMemcpyDeviceToDevice, st) == hipSuccess &&
+                 hipMemcpyAsync(dflat + y.ba, g.dwb + 2 * Hd + 1, sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess,
+             "producer: copy failed");
   // word_attention.attention_sent / attention_pos
   GC_TRY(linear_bwd_w(g.dsentF, ctx, BT, Hd, Hd, dflat + y.Ws, ws, wse, st));
   GC_TRY(colsum(g.dsentF, nullptr, dflat + y.bs, BT, Hd, Hd, 1, 0, 0, 0, 0, ws, st));
@@ -876,6 +1090,7 @@ static ProdBound prod_bind(int32_t* ibuf, float* fwd, float* bwd, bool want_bwd,
   auto ti = [&](long n) { int32_t* p = ibuf ? ibuf + at : nullptr; at += (n + 3) & ~3L; return p; };
   o.ix.doc_counts = ti(2L * B), o.ix.pair_bits = ti(BNN), o.ix.pair_row0 = ti(BNN), o.ix.pair_prow = ti(BNN);
   o.ix.pair_div = (float*)ti(BNN), o.ix.row_slot = ti(R), o.ix.prow_pair = ti(Q), o.ix.counts = ti(4);
+  o.ix.doc_off = ti(B + 1), o.ix.row_rng = ti(R), o.ix.tmax = ti(B);
   o.n_int = at;
   float* base = fwd;
   at = 0;
@@ -888,7 +1103,8 @@ static ProdBound prod_bind(int32_t* ibuf, float* fwd, float* bwd, bool want_bwd,
     base = bwd, at = 0;
     o.g.dEc = tf(Q * Hd), o.g.dCS = tf(Q * 2 * Hd), o.g.dcwa = tf(R * Hd), o.g.dsfeat = tf(R * Hd), o.g.dnterm = tf((long)B * N * Hd);
     o.g.dCW = tf(R * 2 * Hd), o.g.dtable = tf((long)B * ND * T), o.g.dsentF = tf((long)B * T * Hd), o.g.ddisF = tf((long)ND * Hd);
-    o.g.dwb = tf(2 * (Hd + 1)), o.g.part = tf((long)DCS * 2 * Hd), o.g.wpair = tf(BNN);
+    o.g.dwb = tf(2 * (Hd + 1)), o.g.part = tf((long)DCS * 2 * Hd), o.g.wpair = tf(BNN), o.g.dots = tf(2 * R);
+    o.g.tpart = tf((long)B * cdiv(T, TCH) * ((long)ND * Hd + Hd + 1));
     o.scratch = base ? base + at : nullptr;
     o.n_bwd = at;
   }

@@ -533,7 +533,7 @@ class ProducerFn(torch.autograd.Function):
         dE = dE.contiguous()
         bbuf = torch.empty(ctx_.nbwd, device=dev)
         dtok, dnode = torch.empty_like(tok), torch.empty_like(node)
-        dtab, dflat = torch.empty_like(dis_table), torch.empty_like(flat)
+        dtab, dflat = torch.empty_like(dis_table), torch.zeros_like(flat)       # (zeros: the layout's alignment gaps)
         call("gcgcn_producer_bwd", B, N, S, T, Hd, P, ND, _p(tok), _p(sen), _p(pos_h), _p(pos_t), pos_h.element_size(), _p(node),
              _p(dis_table), _p(ctx_.n_valid), _p(flat), ctx_.caps[0], ctx_.caps[1], _p(ibuf), _p(fbuf), _p(bbuf), _p(dE), _p(dtok),
              _p(dnode), _p(dtab), _p(dflat), _stream())
@@ -569,7 +569,7 @@ class HeadFn(torch.autograd.Function):
         dlogits = dlogits.contiguous()
         bbuf = torch.empty(ctx.nbwd, device=dev)
         dfeats = [torch.empty_like(f) for f in feats]
-        dner, dtab, dflat = torch.empty_like(ner_emb), torch.empty_like(dis_table), torch.empty_like(flat)
+        dner, dtab, dflat = torch.empty_like(ner_emb), torch.empty_like(dis_table), torch.zeros_like(flat)   # (gaps stay zero)
         fp = (ctypes.c_void_p * nf)(*[f.data_ptr() for f in feats])
         dp = (ctypes.c_void_p * nf)(*[f.data_ptr() for f in dfeats])
         call("gcgcn_head_bwd", B, N, Hd, nf, Pt, Pr, ctx.R, ND, ctx.dis_plus, ctypes.cast(fp, ctypes.c_void_p), _p(node_type),

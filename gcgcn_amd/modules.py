@@ -352,7 +352,7 @@ class EdgeFeatureProducer(_FlatBlock):
     def __init__(self, hidden_size: int = 128, dis_size: int = 20):
         super().__init__()
         self.hidden, self.dis_size = hidden_size, dis_size
-        self.flat = nn.Parameter(torch.empty(P_.producer_layout(hidden_size, dis_size)[-1]))
+        self.flat = nn.Parameter(torch.zeros(P_.producer_layout(hidden_size, dis_size)[-1]))     # (alignment gaps stay zero)
         with torch.no_grad():
             P_.pack_producer(P_.init_producer(hidden_size, dis_size), hidden_size, dis_size, self.flat)
 

@@ -219,19 +219,26 @@ def producer_layout(Hd: int, P: int):
         n = 1
         for v in shp:
             n *= v
-        at += n
+        at += (n + 3) & ~3                     # every piece starts 16-byte aligned (csrc/producer.hip prod_layout)
     return o + [at]
+
+
+def _numel(shp):
+    n = 1
+    for v in shp:
+        n *= v
+    return n
 
 
 def unpack_producer(flat: Tensor, Hd: int, P: int) -> Dict[str, Tensor]:
     o = producer_layout(Hd, P)
-    return {k: flat[o[i]:o[i + 1]].view(shp) for i, (k, shp) in enumerate(producer_shapes(Hd, P).items())}
+    return {k: flat[o[i]:o[i] + _numel(shp)].view(shp) for i, (k, shp) in enumerate(producer_shapes(Hd, P).items())}
 
 
 def pack_producer(sd: Dict[str, Tensor], Hd: int, P: int, out: Tensor) -> Tensor:
     o = producer_layout(Hd, P)
-    for i, k in enumerate(producer_shapes(Hd, P)):
-        out[o[i]:o[i + 1]].copy_(sd[k].reshape(-1))
+    for i, (k, shp) in enumerate(producer_shapes(Hd, P).items()):
+        out[o[i]:o[i] + _numel(shp)].copy_(sd[k].reshape(-1))
     return out
 
 
