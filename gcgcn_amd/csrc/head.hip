@@ -13,6 +13,7 @@
 // (gemm_body's operand policy) -- the 8.6 GB a [pairs, 16384] operand would take at B = 32 never exists.  Backward: the
 // same trick three times (d eh: rows dout[p] (x) et[p] against W viewed [(r, b), a]; d et: dout[p] (x) eh[p] against
 // [(r, a), b]; d W: dout^T against the generated [pairs, 16384] operand).
+#include <stdlib.h>
 #include <string.h>
 
 #include "gemm_body.hpp"
@@ -108,6 +109,186 @@ __global__ __launch_bounds__(256, 4) void head_gemm_kernel(const GemmArgs g, con
   HeadOperands<MODE> ops;
   ops.o = o;
   gemm_body<1, 1, AKC, BKC, false, 4, 0, EPI_ALL, HeadOperands<MODE>>(g, lds, bx, by, zs, threadIdx.x, true, ops);
+}
+
+// ---- second generation of the three passes whose A operand is an outer product (MODE 1..3) -------------------------
+// The operand never touches LDS at all: with K ordered (b-chunk of 32, then a), the MFMA A operand of lane (row i, k-half)
+// is P[i, a] * Q[i, b]: the 16 Q values a lane needs for a whole b-chunk sit in registers (reloaded 4 times per tile),
+// P[i, a] is one prefetched dword per k-step, and the operand is ONE v_mul per MFMA pair.  Only the weight panel is staged
+// through LDS (k-major image, register double buffering as in gemm_body).  Workgroup tile 64 pairs x 128 columns, four
+// waves of 32 x 64 (two accumulators: each generated A value feeds two MFMAs).
+//   MODE 1: C[p, r]  = sum_(a,b) eh[p,a] et[p,b] W_b[r,a,b] + sum_k [eh | et][p,k] W_c[r,k] + bias    (P = eh, Q = et)
+//   MODE 2: C[p, a]  = sum_(r,b) dout[p,r] et[p,b] W_b[r,a,b]                                         (P = doutp, Q = et)
+//   MODE 3: C[p, b]  = sum_(r,a) dout[p,r] eh[p,a] W_b[r,a,b]                                         (P = doutp, Q = eh)
+struct Bil2 {
+  const float* P; const float* Q; const float* W; const float* W2; const float* bias;
+  float* C;
+  int rows, nA, ncol, ldc, accumulate_unused;
+};
+
+// position in the k-step sequence: for bc in 0..3: aa in 0..per_bc-1 (aa == nA: the Linear's et half, MODE 1), then tail steps
+struct BilPos {
+  int bc, aa;
+  __device__ __forceinline__ void next(int per_bc) {
+    if (++aa == per_bc && bc < 4) aa = 0, ++bc;   // bc == 4: the tail (aa keeps counting)
+  }
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256, 3) void head_bil2_kernel(const Bil2 a) {
+  constexpr int BN = 128, LDB = (MODE == 3) ? BN : BN + 1, SB = BK * LDB;
+  __shared__ __attribute__((aligned(16))) float lds[2 * SB];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1, l31 = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * 64;
+  const long row = min(m0 + wr * 32 + l31, a.rows - 1);   // this lane's A row (clamped: rows past the end are never stored)
+  const float* __restrict__ prow = a.P + row * HW;
+  const float* __restrict__ qrow = a.Q + row * HW;
+  const int per_bc = a.nA + (MODE == 1 ? 1 : 0), nsteps = 4 * per_bc + (MODE == 1 ? 4 : 0);
+  // per-thread offsets of its four 16-byte pieces of a weight tile (32-bit: the weights are < 2^31 floats), the step adds
+  // a uniform offset
+  unsigned offW[4], offW2[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int f = t + 256 * q;
+    if (MODE == 1) {
+      const unsigned nn = (unsigned)min(f >> 3, a.ncol - 1);
+      offW[q] = nn * (HW * HW) + ((f & 7) << 2), offW2[q] = nn * (2 * HW) + ((f & 7) << 2);
+    } else if (MODE == 2) {
+      offW[q] = (unsigned)(f >> 3) * HW + ((f & 7) << 2), offW2[q] = 0;
+    } else {
+      offW[q] = (unsigned)(f >> 5) * HW + ((f & 31) << 2), offW2[q] = 0;
+    }
+  }
+  auto loadB = [&](float (&r)[4][4], const BilPos& p) {   // uniform: which array, which offset
+    const float* base = a.W;
+    unsigned so;
+    bool second = false;
+    if (MODE == 1) {
+      if (p.bc >= 4) second = true, so = (unsigned)min(p.aa, 3) * BK;                 // W_c[r][32 j ..]        (tail, clamped)
+      else if (p.aa == a.nA) second = true, so = HW + p.bc * BK;                      // W_c[r][128 + 32 bc ..]
+      else so = (unsigned)p.aa * HW + p.bc * BK;                                      // W_b[r][a][32 bc ..]
+      if (second) base = a.W2;
+    } else if (MODE == 2) {
+      so = (unsigned)min(p.aa, a.nA - 1) * (HW * HW) + min(p.bc, 3) * BK;             // W_b[r][a = n][32 bc ..]
+    } else {
+      so = ((unsigned)min(p.aa, a.nA - 1) * HW + min(p.bc, 3) * BK) * HW;             // W_b[r][a = 32 bc + k][b = n]
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = ld4(base + so + (second ? offW2[q] : offW[q]));
+      r[q][0] = v.x, r[q][1] = v.y, r[q][2] = v.z, r[q][3] = v.w;
+    }
+  };
+  auto storeB = [&](const float (&r)[4][4], float* __restrict__ dst) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f = t + 256 * q;
+      if (MODE == 3) {
+        *reinterpret_cast<float4*>(dst + (f >> 5) * LDB + ((f & 31) << 2)) = make_float4(r[q][0], r[q][1], r[q][2], r[q][3]);
+      } else {
+        float* d = dst + ((f & 7) << 2) * LDB + (f >> 3);
+        d[0] = r[q][0], d[LDB] = r[q][1], d[2 * LDB] = r[q][2], d[3 * LDB] = r[q][3];
+      }
+    }
+  };
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
+  float qv[16];
+  auto loadQ = [&](int bc) {   // the lane's 16 Q values of this b-chunk: Q[row, 32 bc + 2 kk + lh]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 v = ld4(qrow + bc * BK + 4 * j);
+      qv[2 * j] = lh ? v.y : v.x, qv[2 * j + 1] = lh ? v.w : v.z;
+    }
+  };
+  auto pval = [&](const BilPos& p) -> float {  // the step's P factor, requested one step ahead
+    if (p.bc >= 4) return 0.f;
+    return (MODE == 1 && p.aa == a.nA) ? 1.f : prow[min(p.aa, a.nA - 1)];
+  };
+  const float* bl0 = lds + lh * LDB + wc * 64 + l31;
+  auto compute = [&](const float* __restrict__ bl, const BilPos& p, float pa) {
+    if (MODE == 1 && p.bc >= 4) {   // Linear, eh half: A = P[row, 32 j + k]
+      const float* ph = prow + min(p.aa, 3) * BK;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const float av = ph[2 * kk + lh];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bl[2 * kk * LDB], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bl[2 * kk * LDB + 32], acc1, 0, 0, 0);
+      }
+      return;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const float av = pa * qv[kk];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bl[2 * kk * LDB], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bl[2 * kk * LDB + 32], acc1, 0, 0, 0);
+    }
+  };
+  float rb0[4][4], rb1[4][4];
+  BilPos pc = {0, 0}, pl = {0, 0};   // compute position, load position (two steps ahead)
+  loadB(rb0, pl);
+  storeB(rb0, lds);
+  pl.next(per_bc);
+  loadB(rb0, pl);
+  pl.next(per_bc);
+  BilPos pp = pc;
+  float pa = pval(pp);
+  pp.next(per_bc);
+  float pn = pval(pp);
+  loadQ(0);
+  __syncthreads();
+  for (int s = 0; s < nsteps; s += 2) {
+    loadB(rb1, pl);
+    pl.next(per_bc);
+    if (pc.aa == 0 && pc.bc > 0 && pc.bc < 4) loadQ(pc.bc);
+    compute(bl0, pc, pa);
+    pc.next(per_bc), pp.next(per_bc);
+    pa = pn, pn = pval(pp);
+    storeB(rb0, lds + SB);
+    __syncthreads();
+    if (s + 1 >= nsteps) break;
+    loadB(rb0, pl);
+    pl.next(per_bc);
+    if (pc.aa == 0 && pc.bc > 0 && pc.bc < 4) loadQ(pc.bc);
+    compute(bl0 + SB, pc, pa);
+    pc.next(per_bc), pp.next(per_bc);
+    pa = pn, pn = pval(pp);
+    storeB(rb1, lds);
+    __syncthreads();
+  }
+  // epilogue: lane holds column wc*64 + {0, 32} + l31 of rows m0 + wr*32 + (r & 3) + 8 (r >> 2) + 4 lh
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = wc * 64 + j * 32 + l31;
+    if (col >= a.ncol) continue;
+    const float bias = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long rw = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (rw < a.rows) a.C[rw * a.ldc + col] = (j ? acc1[r] : acc0[r]) + bias;
+    }
+  }
+}
+
+static bool head_v1() {  // GCGCN_HEAD_V1=1: the first-generation passes (operands staged through LDS) for A/B runs
+  static const int v = [] {
+    const char* e = getenv("GCGCN_HEAD_V1");
+    return (e && e[0] == '1') ? 1 : 0;
+  }();
+  return v != 0;
+}
+
+static int head_bil2(int mode, const float* P, const float* Q, const float* W, const float* W2, const float* bias, float* C, long rows,
+                     int nA, int ncol, int ldc, hipStream_t st) {
+  Bil2 a;
+  a.P = P, a.Q = Q, a.W = W, a.W2 = W2, a.bias = bias, a.C = C, a.rows = (int)rows, a.nA = nA, a.ncol = ncol, a.ldc = ldc, a.accumulate_unused = 0;
+  const dim3 grid((unsigned)cdiv(rows, 64)), block(256);
+  const double flops = 2.0 * rows * ncol * (double)(nA * HW + (mode == 1 ? 2 * HW : 0));
+  if (mode == 1) GC_LAUNCH_TIMED("head_bilinear", flops, (head_bil2_kernel<1>), grid, block, 0, st, a);
+  else if (mode == 2) GC_LAUNCH_TIMED("head_bilinear", flops, (head_bil2_kernel<2>), grid, block, 0, st, a);
+  else GC_LAUNCH_TIMED("head_bilinear", flops, (head_bil2_kernel<3>), grid, block, 0, st, a);
+  return check_launch("head_bil2");
 }
 
 static int head_gemm(int mode, GemmArgs g, const HeadOps& o, hipStream_t st) {
@@ -307,6 +488,7 @@ int head_fwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int di
   HeadOps o;
   memset(&o, 0, sizeof(o));
   o.P = w.EH, o.Q = w.ET, o.ldp = o.ldq = HW, o.KB = HW * HW, o.W2 = flat + y.Wc, o.ldw2 = 2 * HW, o.nmax = R, o.rows = (int)pairs;
+  if (!head_v1()) return head_bil2(1, w.EH, w.ET, flat + y.Wb, flat + y.Wc, w.bsum, logits, pairs, HW, R, R, st);
   return head_gemm(1, g, o, st);
 }
 
@@ -333,14 +515,16 @@ int head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int di
     GemmArgs g;
     g.A = w.doutp, g.B = flat + y.Wb, g.C = w.dEH, g.ldc = HW, g.M = (int)pairs, g.N = HW, g.K = R * HW;
     o.P = w.doutp, o.Q = w.ET;
-    GC_TRY(head_gemm(2, g, o, st));
+    if (!head_v1()) GC_TRY(head_bil2(2, w.doutp, w.ET, flat + y.Wb, nullptr, nullptr, w.dEH, pairs, R, HW, HW, st));
+    else GC_TRY(head_gemm(2, g, o, st));
     GC_TRY(small_gemm(w.doutp, HW, 1, flat + y.Wc, 2 * HW, 0, w.dEH, HW, (int)pairs, HW, HW, nullptr, 1, nullptr, 0, st));
   }
   {  // d et = sum_(r,a) dout[p,r] eh[p,a] W_b[r,a,b]  + dout W_c[:, 128:]
     GemmArgs g;
     g.A = w.doutp, g.B = flat + y.Wb, g.C = w.dET, g.ldc = HW, g.M = (int)pairs, g.N = HW, g.K = R * HW;
     o.P = w.doutp, o.Q = w.EH;
-    GC_TRY(head_gemm(3, g, o, st));
+    if (!head_v1()) GC_TRY(head_bil2(3, w.doutp, w.EH, flat + y.Wb, nullptr, nullptr, w.dET, pairs, R, HW, HW, st));
+    else GC_TRY(head_gemm(3, g, o, st));
     GC_TRY(small_gemm(w.doutp, HW, 1, flat + y.Wc + HW, 2 * HW, 0, w.dET, HW, (int)pairs, HW, HW, nullptr, 1, nullptr, 0, st));
   }
   {  // d W_b[r, (a, b)] = sum_p dout[p, r] eh[p, a] et[p, b]

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""The whole post-encoder model (gcgcn_amd.GraphModelTail: f1 producer -> CAGGC -> f1 -> MAGGC -> f3 head) + the trainer's loss
+(f2), forward + backward, on DocRED-shaped synthetic batches: documents/second and where the time goes.
+
+    python tools/tail_bench.py [--B 32] [--N 42] [--S 5] [--T 512] [--live 0.15] [--steps 10]
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=32)
+    ap.add_argument("--N", type=int, default=42)
+    ap.add_argument("--S", type=int, default=5)
+    ap.add_argument("--T", type=int, default=512)
+    ap.add_argument("--live", type=float, default=0.15)
+    ap.add_argument("--steps", type=int, default=10)
+    a = ap.parse_args()
+    import gcgcn_amd
+    from gcgcn_amd import _lib
+    from producer_bench import synth
+    dev = torch.device("cuda:0")
+    B, N, S, T, Hd, P, R = a.B, a.N, a.S, a.T, 128, 20, 97
+    ctx, node, table, sen, ph, pt = synth(B, N, S, T, Hd, P, a.live, dev)
+    ph, pt = ph.to(torch.uint8), pt.to(torch.uint8)
+    g = torch.Generator(device=dev).manual_seed(7)
+    ner = (torch.randn(7, 20, generator=g, device=dev) * 0.3).requires_grad_()
+    table.requires_grad_(), ctx.requires_grad_(), node.requires_grad_()
+    ntype = torch.randint(0, 7, (B, N), generator=g, device=dev)
+    rel = torch.randint(-10, 11, (B, N, N), generator=g, device=dev)
+    labels = (torch.rand(B, N, N, R, generator=g, device=dev) < 0.03).float()
+    tail = gcgcn_amd.GraphModelTail().to(dev).train()
+    gcgcn_amd.manual_seed(1337, dev)
+
+    def step():
+        for t in [ctx, node, table, ner] + list(tail.parameters()):
+            t.grad = None
+        logits = tail(ctx, node, None, sen, ph, pt, ntype, rel, table, ner)
+        loss = gcgcn_amd.pair_bce_loss(logits, labels).sum() / B
+        loss.backward()
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    groups = {"producer (f1)": ["prod_", "gemm_dyn"], "classifier head (f3)": ["head_"], "loss (f2)": ["pair_bce"],
+              "graph blocks (hot path)": ["gemm_group", "gemm_single", "gcn_chain", "edge_", "mha_core", "head_sum", "gat_", "node_score",
+                                          "mask_rows", "softmax", "rowsum", "relu_norm", "dropout"],
+              "shared small kernels": ["gemm_splitk_reduce", "colsum"]}
+    shares = {}
+    for name, prefs in groups.items():
+        tot = 0.0
+        for f in prefs:
+            _lib.call("gcgcn_prof_start", f.encode(), 1024)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            ms, n, w = ctypes.c_double(0), ctypes.c_int(0), ctypes.c_double(0)
+            _lib.call("gcgcn_prof_stop", ctypes.byref(ms), ctypes.byref(n), ctypes.byref(w))
+            tot += ms.value / 2
+        shares[name] = round(tot, 3)
+    print(json.dumps({"metric": "docs/sec fwd+bwd through the whole post-encoder model + loss", "value": round(B / dt, 1), "unit": "docs/s",
+                      "ms_per_step": round(dt * 1e3, 3),
+                      "config": {"workload": f"GraphModelTail (2 hops, hidden 128, L=2, H=8, R=97) + pair_bce_loss, train mode, B={B} N={N} "
+                                             f"S={S} T={T}, {a.live:.0%} of the sentence slots start at token 0, uint8 position ids, eager launches"},
+                      "gpu_ms_per_step_by_part": shares}))
+
+
+if __name__ == "__main__":
+    main()
