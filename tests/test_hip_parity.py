@@ -271,16 +271,26 @@ def _oracle_stack(x, e1, e2, adj, sd, L, H, nv=None, keeps=None):
     return outs, gx, ge1, ge2, sdl
 
 
-def _check_stack_param_grads(hops, sdl, rtol=1e-3, atol=2e-4):
-    """Every parameter gradient of the four blocks against the oracle's (sums over B*N rows: fp32 summation-order slack)."""
+def _check_stack_param_grads(hops, sdl, rtol=1e-3, atol=2e-4, relu_flips=False):
+    """Every parameter gradient of the four blocks against the oracle's (sums over B*N rows: fp32 summation-order slack).
+    relu_flips: at millions of relu inputs a handful sit within one fp32 rounding of zero, and two correct fp32 evaluations in
+    different summation orders put them on different sides -- one such element shifts a whole weight-gradient column by
+    |input row| x |upstream gradient| (seen: 0.4 % of one tensor's elements off by 1 % of its largest entry).  Then a tensor
+    passes if at most 1 % of its elements miss the tolerance and none by more than 5 % of the largest entry."""
     ref_grads = {k: v.grad for k, v in sdl.items() if v.grad is not None}
     seen = 0
     for mod, pre in ((hops.get_weighted_adj_matrix, "get_weighted_adj_matrix."), (hops.graphcnn[0], "graphcnn.0."),
                      (hops.get_adj_matrix[0], "get_adj_matrix.0."), (hops.graphcnn[1], "graphcnn.1.")):
         for k, gk in mod.named_grads().items():
             ref = ref_grads[pre + k]        # absolute slack relative to the tensor's largest entry (long fp32 sums)
-            torch.testing.assert_close(gk.cpu(), ref, rtol=rtol, atol=atol * max(1.0, ref.abs().max().item()),
-                                       msg=lambda m: f"grad {pre + k}: {m}")
+            top = max(1.0, ref.abs().max().item())
+            if relu_flips:
+                err = (gk.cpu() - ref).abs()
+                bad = err > atol * top + rtol * ref.abs()
+                assert bad.float().mean().item() <= 0.01 and err.max().item() <= 0.05 * top, \
+                    f"grad {pre + k}: {int(bad.sum())} of {bad.numel()} elements off, max {err.max().item():.3e} (largest entry {top:.3e})"
+            else:
+                torch.testing.assert_close(gk.cpu(), ref, rtol=rtol, atol=atol * top, msg=lambda m: f"grad {pre + k}: {m}")
             seen += 1
     assert seen == len(ref_grads), (seen, len(ref_grads))       # nothing the reference differentiates is missing
 
@@ -481,7 +491,7 @@ def test_deferred_and_immediate_weight_gradients_agree_at_batch(gpu_device, B, N
     sum(o[2].sum() for o in outs).backward()
     # (sums over up to 1024 rows of D = 768 features against a CPU reference with another summation order: 1e-3 of the
     # largest entry; the deferred-vs-immediate comparison above is the tight one)
-    _check_stack_param_grads(hops, sdl, rtol=2e-3, atol=1e-3)
+    _check_stack_param_grads(hops, sdl, rtol=2e-3, atol=1e-3, relu_flips=True)
 
 
 def test_edge_mean_handoff_is_used_and_safe(gpu_device):
