@@ -748,4 +748,18 @@ int gcgcn_gemm(int M, int N, int K, const float* A, int64_t lda, int a_kc, const
   return gemm(g, (hipStream_t)stream, tile, splits);
 }
 
+
+int gcgcn_gemm_dyn(int M, int N, int K, const float* A, int64_t lda, int a_kc, const float* B, int64_t ldb, int b_kc, float* C,
+                   int64_t ldc, const float* bias, int accumulate, const int32_t* count, int dyn, int64_t cap, float* ws,
+                   int64_t ws_elems, void* stream) {
+  GemmArgs g;
+  g.A = A, g.lda = lda, g.a_kc = a_kc;
+  g.B = B, g.ldb = ldb, g.b_kc = b_kc;
+  g.C = C, g.ldc = ldc;
+  g.M = M, g.N = N, g.K = K;
+  g.bias = bias, g.accumulate = accumulate;
+  g.ws = ws, g.ws_elems = ws_elems;
+  return gemm_dyn(g, count, dyn, cap, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -289,6 +289,14 @@ int gcgcn_gemm(int M, int N, int K, const float* A, int64_t lda, int a_kc, const
                float* C, int64_t ldc, int batch, int64_t sA, int64_t sB, int64_t sC, float alpha, const float* bias,
                int relu, int accumulate, int tile, int splits, float* ws, int64_t ws_elems, void* stream);
 
+/* The same product with ONE dimension read from device memory (exposed for unit tests; used by the edge-feature producer for
+ * its compacted rows): dyn = 1: M = *count, dyn = 2: K = *count (the M / K argument is ignored); cap = a host-side upper bound of
+ * *count.  Interior shapes run the unguarded tile body on the count rounded up to 64: operand buffers must be readable (C
+ * writable, dyn = 1) that far, and for dyn = 2 at least one operand's rows in [*count, roundup64) must be zero. */
+int gcgcn_gemm_dyn(int M, int N, int K, const float* A, int64_t lda, int a_kc, const float* B, int64_t ldb, int b_kc, float* C,
+                   int64_t ldc, const float* bias, int accumulate, const int32_t* count, int dyn, int64_t cap, float* ws,
+                   int64_t ws_elems, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

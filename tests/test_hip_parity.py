@@ -833,3 +833,48 @@ def test_many_sublayers(gpu_device):
             _check_stack_param_grads(hops, sdl)
     finally:
         F_.defer_weight_grads = True
+
+
+@pytest.mark.parametrize("N,K,a_kc_b", [(128, 256, 1), (64, 32, 0), (40, 24, 1)])
+@pytest.mark.parametrize("count,cap", [(0, 64), (1, 64), (63, 200), (64, 64), (65, 200), (1000, 1500), (1500, 1500)])
+def test_gemm_device_side_rows(gpu_device, N, K, a_kc_b, count, cap):
+    """gemm_dyn, dyn = 1: C[:count] = A[:count] W^T + bias with the row count in device memory (persistent tile loop); rows
+    beyond roundup64(count) are not touched; interior and ragged widths."""
+    g = torch.Generator().manual_seed(count * 7 + N)
+    R = (cap + 63) // 64 * 64
+    A = torch.randn(R, K, generator=g)
+    A[count:] = 0
+    W = torch.randn(N, K, generator=g) if a_kc_b else torch.randn(K, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    C = torch.full((R, N), 7.0, device=gpu_device)
+    cnt = torch.tensor([count], dtype=torch.int32, device=gpu_device)
+    Ad, Wd, bd = A.to(gpu_device), W.to(gpu_device), bias.to(gpu_device)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.call("gcgcn_gemm_dyn", 0, N, K, p(Ad), K, 1, p(Wd), K if a_kc_b else N, a_kc_b, p(C), N, p(bd), 0, p(cnt), 1, cap, None, 0, None)
+    ref = (A[:count].double() @ (W.t() if a_kc_b else W).double() + bias.double()).float()
+    torch.testing.assert_close(C[:count].cpu(), ref, rtol=1e-4, atol=1e-4)
+    hi = (count + 63) // 64 * 64
+    assert (C[hi:] == 7.0).all()
+
+
+@pytest.mark.parametrize("M,N", [(128, 256), (64, 64), (24, 40)])
+@pytest.mark.parametrize("count,cap", [(0, 64), (1, 64), (63, 200), (65, 4096), (3000, 4096), (20000, 20000)])
+def test_gemm_device_side_reduction(gpu_device, M, N, count, cap):
+    """gemm_dyn, dyn = 2: dW = dY[:count]^T X[:count] with the reduction length in device memory (split-K chosen from the
+    capacity, empty slices write zero partials, count == 0 gives zeros), deterministic."""
+    g = torch.Generator().manual_seed(count + M)
+    R = (cap + 63) // 64 * 64
+    dY, X = torch.randn(R, M, generator=g), torch.randn(R, N, generator=g)
+    dY[count:] = 0                                     # the zero tail the producer's kernels guarantee
+    ws = torch.empty(64 * M * N + 16, device=gpu_device)
+    cnt = torch.tensor([count], dtype=torch.int32, device=gpu_device)
+    dYd, Xd = dY.to(gpu_device), X.to(gpu_device)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    outs = []
+    for _ in range(2):
+        C = torch.full((M, N), float("nan"), device=gpu_device)
+        _lib.call("gcgcn_gemm_dyn", M, N, 0, p(dYd), M, 0, p(Xd), N, 0, p(C), N, None, 0, p(cnt), 2, cap, p(ws), ws.numel(), None)
+        outs.append(C.cpu())
+    ref = (dY[:count].double().t() @ X[:count].double()).float()
+    torch.testing.assert_close(outs[0], ref, rtol=1e-4, atol=2e-4 * max(1.0, (count / 256) ** 0.5))
+    assert torch.equal(outs[0], outs[1])
