@@ -43,7 +43,7 @@ SIGNATURES = {
     "gcgcn_dropout_keep": (I, [P, L, P, c_uint64, F, P]),
     "gcgcn_dropout": (I, [P, P, L, P, c_uint64, F, P]),
     "gcgcn_gat_layout": (I, [I, I, P]),
-    "gcgcn_gat_fwd": (I, [I, I, I, I, P, P, P, P, P, F, P, P, P, P, P, P, P, I, P, P]),
+    "gcgcn_gat_fwd": (I, [I, I, I, I, P, P, P, P, P, F, P, P, P, P, P, P, P, I, P, I, P]),
     "gcgcn_gat_bwd_scratch": (L, [I, I, I]),
     "gcgcn_gat_bwd": (I, [I, I, I, I, P, P, P, P, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_edge_mean_fwd": (I, [I, I, I, P, P, P, P]),

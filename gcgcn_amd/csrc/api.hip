@@ -245,7 +245,7 @@ int gcgcn_gat_layout(int D, int Dh, int64_t* o) {
 
 int gcgcn_gat_fwd(int B, int N, int D, int Dh, const float* X, const float* E, const int32_t* n_valid, const float* flat,
                   const void* rng_snap, float p, float* uvc, float* s, float* P, float* A, float* Ebar, void* rng_state,
-                  void* rng_snaps, int rng_count, const uint8_t* mask, void* stream) {
+                  void* rng_snaps, int rng_count, const uint8_t* mask, int uvc_valid, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("gat_fwd", B, N, D, 1, 1));
   GC_REQUIRE(Dh > 0, "gat_fwd: hidden_dim=%d", Dh);
@@ -254,8 +254,12 @@ int gcgcn_gat_fwd(int B, int N, int D, int Dh, const float* X, const float* E, c
   GC_REQUIRE(!drop.snap || A, "gat_fwd: dropout on but A is NULL");
   const long M = (long)B * N;
   GC_REQUIRE(!rng_state || (rng_snaps && rng_count > 0), "gat_fwd: rng_state given without snapshots to fill");
-  GC_TRY(gat_fold_fwd(flat, uvc, D, Dh, st, rng_state, rng_snaps, rng_count));  // + gcgcn_rng_next, if asked to
-  GC_TRY(node_score_fwd(X, uvc, s, M, D, st));
+  if (!uvc_valid) {
+    GC_TRY(gat_fold_fwd(flat, uvc, D, Dh, st, rng_state, rng_snaps, rng_count));  // + gcgcn_rng_next, if asked to
+    GC_TRY(node_score_fwd(X, uvc, s, M, D, st));
+  } else {  // the caller kept uvc from an earlier call with the same parameters: the draw rides in the next kernel instead
+    GC_TRY(node_score_fwd(X, uvc, s, M, D, st, rng_state, rng_snaps, rng_count));
+  }
   GC_TRY(edge_fwd(E, uvc + D, n_valid, Ebar, s, P, A, drop, B, N, D, st, mask));  // + row softmax + dropout
   return 0;
 }

@@ -481,8 +481,15 @@ __global__ __launch_bounds__(256) void gat_dlogit_kernel(const float* __restrict
 }
 
 // s[m] = u . X[m, :] + c      (one wave per node row)
+// rng_state != NULL: workgroup 0 also advances the dropout generator (see gat_fold_fwd_kernel: used when the fold is skipped)
 __global__ __launch_bounds__(64 * RW) void node_score_fwd_kernel(const float* __restrict__ X, const float* __restrict__ uvc,
-                                                                 float* __restrict__ s, long M, int D) {
+                                                                 float* __restrict__ s, long M, int D, uint64_t* rng_state,
+                                                                 uint64_t* rng_snaps, int rng_count) {
+  if (rng_state && blockIdx.x == 0 && threadIdx.x < 64) {
+    const uint64_t seed = rng_state[0], ctr = rng_state[1];
+    for (int i = threadIdx.x; i < rng_count; i += 64) rng_snaps[2 * i] = seed, rng_snaps[2 * i + 1] = ctr + (uint64_t)i;
+    if (threadIdx.x == 0) rng_state[1] = ctr + (uint64_t)rng_count;
+  }
   const long m = (long)blockIdx.x * RW + (threadIdx.x >> 6);
   if (m >= M) return;
   const int lane = threadIdx.x & 63;
@@ -666,9 +673,11 @@ int gat_dlogit(const float* P, const float* dA, const float* uvc, const float* d
   hipLaunchKernelGGL(gat_dlogit_kernel, dim3(B, slices), dim3(256), 0, st, P, dA, uvc, dXin, dlogit, ds, dX, N, D, drop);
   return check_launch("gat_dlogit");
 }
-int node_score_fwd(const float* X, const float* uvc, float* s, long M, int D, hipStream_t st) {
+int node_score_fwd(const float* X, const float* uvc, float* s, long M, int D, hipStream_t st, void* rng_state, void* rng_snaps,
+                   int rng_count) {
   ProfScope ps("node_score_fwd", st);
-  hipLaunchKernelGGL(node_score_fwd_kernel, dim3(cdiv(M, RW)), dim3(64 * RW), 0, st, X, uvc, s, M, D);
+  hipLaunchKernelGGL(node_score_fwd_kernel, dim3(cdiv(M, RW)), dim3(64 * RW), 0, st, X, uvc, s, M, D, (uint64_t*)rng_state,
+                     (uint64_t*)rng_snaps, rng_count);
   return check_launch("node_score_fwd");
 }
 int node_score_bwd(const float* ds, const float* uvc, const float* dXin, float* dX, long M, int D, hipStream_t st) {

@@ -30,7 +30,8 @@ int gat_fold_bwd(const float* flat, const float* duvc, float* dflat, int D, int 
 bool gat_dlogit_ok(int N);
 int gat_dlogit(const float* P, const float* dA, const float* uvc, const float* dXin, float* dlogit, float* ds, float* dX,
                int B, int N, int D, Drop drop, hipStream_t st);
-int node_score_fwd(const float* X, const float* uvc, float* s, long M, int D, hipStream_t st);
+int node_score_fwd(const float* X, const float* uvc, float* s, long M, int D, hipStream_t st, void* rng_state = nullptr,
+                   void* rng_snaps = nullptr, int rng_count = 0);
 int node_score_bwd(const float* ds, const float* uvc, const float* dXin, float* dX, long M, int D, hipStream_t st);
 int mask_rows(const float* x, float* y, long M, int D, int N, const int* n_valid, Drop drop, hipStream_t st);
 

@@ -146,17 +146,18 @@ class GatFn(torch.autograd.Function):
     here, where the attention's own dX kernel adds it -- instead of autograd summing the two with one more launch."""
 
     @staticmethod
-    def forward(ctx, x, e, flat, n_valid, p, snap, pending, Dh, mask):
+    def forward(ctx, x, e, flat, n_valid, p, snap, pending, Dh, mask, uvc, uvc_valid):
         B, N, D = x.shape
         dev = x.device
         st, sn, cnt = pending if pending is not None else (None, None, 0)
-        uvc = torch.empty(2 * D + 1, device=dev)
+        if uvc is None:
+            uvc, uvc_valid = torch.empty(2 * D + 1, device=dev), False
         s = torch.empty(B, N, device=dev)
         P = torch.empty(B, N, N, device=dev)
         A = torch.empty(B, N, N, device=dev) if snap is not None else None
         ebar = torch.empty(B, N, D, device=dev)
         call("gcgcn_gat_fwd", B, N, D, Dh, _p(x), _p(e), _p(n_valid), _p(flat), _p(snap), float(p), _p(uvc), _p(s),
-             _p(P), _p(A), _p(ebar), _p(st), _p(sn), cnt, _p(mask), _stream())
+             _p(P), _p(A), _p(ebar), _p(st), _p(sn), cnt, _p(mask), 1 if uvc_valid else 0, _stream())
         ctx.save_for_backward(x, e, flat, uvc, P)
         ctx.n_valid, ctx.p, ctx.snap, ctx.Dh = n_valid, float(p), snap, Dh
         return (P if A is None else A), ebar, x.view_as(x)
@@ -182,7 +183,7 @@ class GatFn(torch.autograd.Function):
         call("gcgcn_gat_bwd", B, N, D, ctx.Dh, _p(x), _p(e), _p(ctx.n_valid), _p(flat), _p(ctx.snap), ctx.p, _p(uvc), _p(P),
              _p(dA), _p(dEbar), _p(dXin), _p(dX), _p(dE), _p(dflat), _p(dlogit), _p(ds), _p(dvpart), _p(duvc),
              _p(scratch), None if bp is None else bp.queue, _stream())
-        return dX, dE, dflat, None, None, None, None, None, None
+        return dX, dE, dflat, None, None, None, None, None, None, None, None
 
 
 class EdgeMeanFn(torch.autograd.Function):
@@ -642,8 +643,10 @@ def _snap_for(training: bool, p: float, dev) -> Optional[Tensor]:
     return rng_snapshot(dev) if (training and p > 0.0) else None
 
 
-def gat_attention(x, e, flat, n_valid=None, p=0.1, training=False, hidden_dim=None, mask=None):
-    """``mask`` (bool/uint8 ``[B,N,N]``, True = fill with -100000): the paper-faithful opt-in; None = the reference."""
+def gat_attention(x, e, flat, n_valid=None, p=0.1, training=False, hidden_dim=None, mask=None, uvc=None, uvc_valid=False):
+    """``mask`` (bool/uint8 ``[B,N,N]``, True = fill with -100000): the paper-faithful opt-in; None = the reference.
+    ``uvc``: caller-owned buffer ``[2D+1]`` for the folded projection; ``uvc_valid``: it already holds the fold of THESE
+    parameter values (kept from an earlier call) and the fold kernel is skipped."""
     x, e = _chk(x, "node_feat", 3), _chk(e, "edge_feat", 4)
     B, N, D = x.shape
     if e.shape != (B, N, N, D):
@@ -655,7 +658,7 @@ def gat_attention(x, e, flat, n_valid=None, p=0.1, training=False, hidden_dim=No
             raise ValueError(f"mask: expected a GPU tensor of shape {(B, N, N)}, got {tuple(mask.shape)} on {mask.device}")
         mask = (mask != 0).to(torch.uint8).contiguous()
     return GatFn.apply(x, e, _chk(flat, "flat"), nv, p, snap, _take_pending_rng(x.device),
-                       D if hidden_dim is None else int(hidden_dim), mask)                    # (A, Ebar, alias of x)
+                       D if hidden_dim is None else int(hidden_dim), mask, uvc, bool(uvc_valid))   # (A, Ebar, alias of x)
 
 
 def edge_mean(e, n_valid=None):

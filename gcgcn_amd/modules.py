@@ -108,6 +108,8 @@ class GATAttention(_FlatBlock):
         self.dim = att_input_dim                 # width of node_feat / edge_feat
         self.hidden_dim = hidden_dim             # rows of the three nn.Linear(att_input_dim, hidden_dim), glove:148-150
         self.apply_mask = bool(apply_mask)
+        self.cache_fold = True                   # keep (u, v, c) while the parameters are unchanged (see forward)
+        self._uvc = None
         self.p = float(dropout) if dropout is not None else 0.0
         self.flat = nn.Parameter(torch.empty(P_.gat_layout(self.dim, hidden_dim)[-1]))
         with torch.no_grad():
@@ -132,8 +134,21 @@ class GATAttention(_FlatBlock):
         mk = None
         if self.apply_mask and mask is not None:
             mk, _ = _batched(mask, 2)
+        # The folded projection (u, v, c) is a function of the parameters only: kept while they are unchanged (several
+        # documents per optimiser step -- the reference's gradient accumulation -- and inference); any in-place update of
+        # .flat (optimiser step, load_state_dict) bumps its version counter and the fold runs again.
+        # Never inside a hipGraph capture (a replay does not re-run this check), and a refold goes into a NEW buffer (an older
+        # autograd graph may still hold the previous one for its backward).
+        uvc, valid = None, False
+        if self.cache_fold and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+            key = (self.flat._version, self.flat.data_ptr(), x.device)
+            if self._uvc is not None and self._uvc[0] == key:
+                uvc, valid = self._uvc[1], True
+            else:
+                uvc = torch.empty(2 * self.dim + 1, device=x.device)
+                self._uvc = (key, uvc)
         a, ebar, xa = F_.gat_attention(x, e, self.flat, n_valid, self.p, self.training, hidden_dim=self.hidden_dim,
-                                       mask=mk)
+                                       mask=mk, uvc=uvc, uvc_valid=valid)
         F_.park_edge_mean(edge_feat, n_valid, ebar)
         a = a if batched else a.squeeze(0)
         # extension: (A, alias of node_feat).  Feeding the alias to the convolution of the same hop routes the

@@ -87,10 +87,12 @@ int gcgcn_gat_layout(int D, int Dh, int64_t* out9);
  * mask: NULL (default: the reference DISCARDS its masked_fill result, glove:163-164, so its mask is a no-op), or a
  * uint8/bool [B,N,N] whose non-zero entries get energy -100000 before the softmax: the paper-faithful partially
  * connected adjacency, an explicit opt-in (GATAttention(apply_mask=True)).  The backward needs no mask: masked entries
- * have P == 0 exactly, hence a zero logit gradient. */
+ * have P == 0 exactly, hence a zero logit gradient.
+ * uvc_valid != 0: uvc already holds the folded projection of THESE parameters (a function of flat only: the caller may
+ * keep it while flat is unchanged -- inference, several documents per optimiser step); the fold kernel is skipped. */
 int gcgcn_gat_fwd(int B, int N, int D, int Dh, const float* X, const float* E, const int32_t* n_valid, const float* flat,
                   const void* rng_snap, float p, float* uvc, float* s, float* P, float* A, float* Ebar, void* rng_state,
-                  void* rng_snaps, int rng_count, const uint8_t* mask, void* stream);
+                  void* rng_snaps, int rng_count, const uint8_t* mask, int uvc_valid, void* stream);
 
 /* backward.  dA[B,N,N], dEbar[B,N,D] (NULL = zero), dX_in[B,N,D] (NULL = zero: gradient node_feat has
  * already collected from its other consumers -- the convolution of the same hop -- added here instead of

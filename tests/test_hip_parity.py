@@ -878,3 +878,33 @@ def test_gemm_device_side_reduction(gpu_device, M, N, count, cap):
     ref = (dY[:count].double().t() @ X[:count].double()).float()
     torch.testing.assert_close(outs[0], ref, rtol=1e-4, atol=2e-4 * max(1.0, (count / 256) ** 0.5))
     assert torch.equal(outs[0], outs[1])
+
+
+def test_gat_fold_is_kept_while_parameters_are_unchanged(gpu_device):
+    """(u, v, c) depends on the parameters only: the second call with unchanged parameters skips the fold kernel (same
+    output), an in-place parameter update (optimiser step) or load_state_dict triggers a new fold -- into a NEW buffer, so
+    that a graph built earlier keeps the one it saved."""
+    D, N = 64, 12
+    torch.manual_seed(0)
+    m = gcgcn_amd.GATAttention(D, D).to(gpu_device).eval()
+    x, e = torch.randn(2, N, D, device=gpu_device), torch.randn(2, N, N, D, device=gpu_device)
+    a1 = m(x, e)
+    buf1 = m._uvc[1]
+    a2 = m(x, e)
+    assert m._uvc[1] is buf1 and torch.equal(a1, a2)                       # cached
+    with torch.no_grad():
+        m.flat.mul_(1.5)                                                   # what an optimiser step does: version bump
+    a3 = m(x, e)
+    assert m._uvc[1] is not buf1 and not torch.allclose(a3, a1)            # refolded into a new buffer
+    m.cache_fold = False
+    ref = m(x, e)
+    m.cache_fold = True
+    assert torch.equal(a3, ref)
+    xs = x.clone().requires_grad_()
+    m(xs, e).sum().backward()                                              # gradients flow through a cached fold too
+    assert torch.isfinite(xs.grad).all() and m.flat.grad is not None
+    sd = {k: v * 2 for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    a4 = m(x, e)
+    m.cache_fold = False
+    assert torch.equal(a4, m(x, e))
