@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--prof-kernel", default="auto",
                     help="kernel family timed with HIP events inside the timed region (auto = the one with the largest time share)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eval-mode", action="store_true", help="A/B only: dropout off (the metric is defined in train mode)")
     ap.add_argument("--input-sets", type=int, default=3,
                     help="resident synthetic batches rotated through the steps (default 3: 3 x (E1 + E2) = 805 MB at cfg 2, "
                          "more than the 256 MiB Infinity Cache, so no step finds its inputs cached by the step before -- as in "
@@ -158,6 +159,8 @@ def main():
     B, N, D, L, H = (cfg[k] for k in "BNDLH")
     torch.manual_seed(1337)                       # identical parameters on every rank
     hops = gcgcn_amd.GraphHops(D, L, H).to(dev).train()
+    if args.eval_mode:
+        hops.eval()
     hops.overlap_edge_mean = args.overlap
     hops.early_edge_mean = args.early_mean
     gcgcn_amd.manual_seed(1337 + rank, dev)
@@ -369,7 +372,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: GraphHops fwd+bwd, B={B}/GPU N={N} D={D} L={L} H={H}, train mode, "
+            "config": {"workload": f"{args.config}: GraphHops fwd+bwd, B={B}/GPU N={N} D={D} L={L} H={H}, {'EVAL mode (A/B run, not the metric)' if args.eval_mode else 'train mode'}, "
                                    f"E1/E2/X/params require grad" + (", ragged n_valid (mean %.1f)" % n_valid.float().mean().item()
                                                                       if n_valid is not None else "")
                                    + (f", rotating inputs: {nsets} resident batches ({nsets * 8 * N * N * D * B / 1e6:.0f} MB of E "
