@@ -213,8 +213,8 @@ class MultiHeadAttention(_FlatBlock):
 # ======================================================================================================
 class _GcnBase(_FlatBlock):
     def _setup(self, layer_num: int, head_num: int, input_dim: int, output_dim: int, bias: bool):
-        if bias:
-            raise NotImplementedError("GraphConv bias=True is never used by the reference (glove:60,94)")
+        # `bias` is accepted and ignored exactly like the reference: its constructors take the argument (glove:53, 83) and
+        # build every inner GraphConv without it (glove:60, 94), so no bias parameter ever exists in these blocks
         if input_dim != output_dim:
             raise ValueError("residual connection needs input_dim == output_dim (glove:76)")
         if output_dim % layer_num != 0:

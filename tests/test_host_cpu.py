@@ -101,6 +101,9 @@ def test_constructor_contract():
     with pytest.raises(ValueError):
         gcgcn_amd.GraphConvolution(3, 8, 8)                  # D % L
     m = gcgcn_amd.MultiGraphConvolution(2, 4, 16, 16)
+    # bias=True is accepted and ignored like the reference's blocks (glove:53/60, 83/94): same keys, no bias parameter
+    assert list(gcgcn_amd.GraphConvolution(2, 16, 16, bias=True).state_dict()) == list(gcgcn_amd.GraphConvolution(2, 16, 16).state_dict())
+    assert list(gcgcn_amd.MultiGraphConvolution(2, 4, 16, 16, bias=True).state_dict()) == list(m.state_dict())
     assert m.flat.numel() == sum(math_prod(s) for s in P.gcn_shapes(16, 2, 4).values())
 
 
