@@ -271,12 +271,17 @@ __global__ __launch_bounds__(256, 3) void head_bil2_kernel(const Bil2 a) {
   }
 }
 
-static bool head_v1() {  // GCGCN_HEAD_V1=1: the first-generation passes (operands staged through LDS) for A/B runs
+// Which generation runs the three outer-product passes.  The second one (64 x 128 tiles, 3 workgroups per compute unit) wins
+// once the pairs fill the chip twice over (B = 32, N = 64: 18.4 vs 19.2 ms per step); below that its coarser tiles quantise
+// badly (B = 32, N = 42: 882 tiles on 768 slots, 9.96 vs 9.08 ms) and the first one (64 x 64 tiles, 4 per compute unit) stays.
+// GCGCN_HEAD_V1=1 / =0 forces one of them (A/B runs).
+static bool head_v1(long pairs) {
   static const int v = [] {
     const char* e = getenv("GCGCN_HEAD_V1");
-    return (e && e[0] == '1') ? 1 : 0;
+    return !e ? -1 : (e[0] == '1' ? 1 : 0);
   }();
-  return v != 0;
+  if (v >= 0) return v != 0;
+  return cdiv(pairs, 64) < 1536;
 }
 
 static int head_bil2(int mode, const float* P, const float* Q, const float* W, const float* W2, const float* bias, float* C, long rows,
@@ -488,7 +493,7 @@ int head_fwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int di
   HeadOps o;
   memset(&o, 0, sizeof(o));
   o.P = w.EH, o.Q = w.ET, o.ldp = o.ldq = HW, o.KB = HW * HW, o.W2 = flat + y.Wc, o.ldw2 = 2 * HW, o.nmax = R, o.rows = (int)pairs;
-  if (!head_v1()) return head_bil2(1, w.EH, w.ET, flat + y.Wb, flat + y.Wc, w.bsum, logits, pairs, HW, R, R, st);
+  if (!head_v1(pairs)) return head_bil2(1, w.EH, w.ET, flat + y.Wb, flat + y.Wc, w.bsum, logits, pairs, HW, R, R, st);
   return head_gemm(1, g, o, st);
 }
 
@@ -515,7 +520,7 @@ int head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int di
     GemmArgs g;
     g.A = w.doutp, g.B = flat + y.Wb, g.C = w.dEH, g.ldc = HW, g.M = (int)pairs, g.N = HW, g.K = R * HW;
     o.P = w.doutp, o.Q = w.ET;
-    if (!head_v1()) GC_TRY(head_bil2(2, w.doutp, w.ET, flat + y.Wb, nullptr, nullptr, w.dEH, pairs, R, HW, HW, st));
+    if (!head_v1(pairs)) GC_TRY(head_bil2(2, w.doutp, w.ET, flat + y.Wb, nullptr, nullptr, w.dEH, pairs, R, HW, HW, st));
     else GC_TRY(head_gemm(2, g, o, st));
     GC_TRY(small_gemm(w.doutp, HW, 1, flat + y.Wc, 2 * HW, 0, w.dEH, HW, (int)pairs, HW, HW, nullptr, 1, nullptr, 0, st));
   }
@@ -523,7 +528,7 @@ int head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int di
     GemmArgs g;
     g.A = w.doutp, g.B = flat + y.Wb, g.C = w.dET, g.ldc = HW, g.M = (int)pairs, g.N = HW, g.K = R * HW;
     o.P = w.doutp, o.Q = w.EH;
-    if (!head_v1()) GC_TRY(head_bil2(3, w.doutp, w.EH, flat + y.Wb, nullptr, nullptr, w.dET, pairs, R, HW, HW, st));
+    if (!head_v1(pairs)) GC_TRY(head_bil2(3, w.doutp, w.EH, flat + y.Wb, nullptr, nullptr, w.dET, pairs, R, HW, HW, st));
     else GC_TRY(head_gemm(3, g, o, st));
     GC_TRY(small_gemm(w.doutp, HW, 1, flat + y.Wc + HW, 2 * HW, 0, w.dET, HW, (int)pairs, HW, HW, nullptr, 1, nullptr, 0, st));
   }
