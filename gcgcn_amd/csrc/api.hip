@@ -10,6 +10,7 @@
 
 #include <stdlib.h>
 
+#include "gat_body.hpp"
 #include "gcn_plan.hpp"
 #include "gemm.hpp"
 #include "rowops.hpp"
@@ -282,7 +283,12 @@ int gcgcn_gat_bwd(int B, int N, int D, int Dh, const float* X, const float* E, c
   const long M = (long)B * N;
   GC_REQUIRE(scratch, "gat_bwd: scratch is required");
   const bool small = gat_dlogit_ok(N);
-  if (small) {  // dlogit, ds and dX = ds u + dX_in in one launch, one workgroup per document
+  static const bool ride = [] { const char* e = getenv("GCGCN_GAT_RIDE"); return !(e && e[0] == '0'); }();
+  GatTail tail{P, dA, uvc, dX_in, ds, dX, drop, B, gat_dlogit_slices(D)};
+  if (small && ride) {
+    // dlogit, ds and dX = ds u + dX_in ride in the edge pass below: its entity rows take their dlogit row from P and dA
+    // themselves, B * slices passenger workgroups produce ds and dX (dlogit is never stored)
+  } else if (small) {  // the same in a launch of its own, one workgroup per (document, slice)
     GC_TRY(gat_dlogit(P, dA, uvc, dX_in, dlogit, ds, dX, B, N, D, drop, st));
   } else {
     GC_TRY(softmax_bwd(P, dA, dlogit, M, N, drop, st));
@@ -290,7 +296,8 @@ int gcgcn_gat_bwd(int B, int N, int D, int Dh, const float* X, const float* E, c
     GC_TRY(colsum(dlogit, nullptr, ds, N, N, N, B, (long)N * N, 0, N, 0, nullptr, st));
     GC_TRY(node_score_bwd(ds, uvc, dX_in, dX, M, D, st));
   }
-  GC_TRY(edge_bwd(E, uvc + D, n_valid, dlogit, dEbar, dE, dvpart, B, N, D, st, (DeferQueue*)defer_queue));  // + parked weight gradients
+  GC_TRY(edge_bwd(E, uvc + D, n_valid, dlogit, dEbar, dE, dvpart, B, N, D, st, (DeferQueue*)defer_queue,  // + parked weight gradients
+                  small && ride ? &tail : nullptr));
   // du = sum_m ds[m] X[m,:],  dv = sum partials,  dc = sum_m ds[m]: row-slice partials in one launch; the fold's
   // backward sums the slices itself (duvc stays unused)
   long part_off[3];

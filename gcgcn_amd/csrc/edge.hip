@@ -17,8 +17,10 @@
 // Ragged batches: n_valid[b] <= N entities are real; padding rows/columns are neither read nor
 // averaged, and their outputs are zero.
 #include <stdlib.h>
+#include <string.h>
 
 #include "edge_body.hpp"
+#include "gat_body.hpp"
 #include "gemm_body.hpp"
 
 namespace gc {
@@ -42,7 +44,7 @@ __device__ __forceinline__ void edge_bwd_row(const float* __restrict__ E, const 
                                              const int* __restrict__ n_valid, const float* __restrict__ dlogit,
                                              const float* __restrict__ dEbar, float* __restrict__ dE,
                                              float* __restrict__ dvpart, int N, int D, int nt, const int bi,
-                                             float* __restrict__ sm) {
+                                             float* __restrict__ sm, const GatTail& gt) {
   float* dl = sm;                    // [N]
   float* cs = sm + ((N + 3) & ~3);   // [EW][D]
   const int b = bi / N, i = bi - b * N;
@@ -58,7 +60,18 @@ __device__ __forceinline__ void edge_bwd_row(const float* __restrict__ E, const 
     }
     return;
   }
-  for (int j = t; j < N; j += 64 * EW) dl[j] = dlogit[(long)bi * N + j];
+  if (gt.P) {  // N <= 64: the row's softmax gradient straight from P and dA (dropout replayed), no dlogit tensor in between
+    if (wave == 0) {
+      const long o = (long)bi * N + min(lane, N - 1);
+      float p = gt.P[o], g = gt.dA[o];
+      if (lane >= N) p = 0.f, g = 0.f;
+      if (gt.drop.snap) g = (rng_u32(drop_key(gt.drop), (uint64_t)((long)bi * N + lane)) >= gt.drop.thresh) ? g * gt.drop.scale : 0.f;
+      const float dot = wave_sum(g * p);
+      if (lane < N) dl[lane] = p * (g - dot);
+    }
+  } else {
+    for (int j = t; j < N; j += 64 * EW) dl[j] = dlogit[(long)bi * N + j];
+  }
   __syncthreads();
   const float* __restrict__ Er = E + (long)bi * N * D;
   const float inv = 1.f / (float)nv;
@@ -142,9 +155,17 @@ __global__ __launch_bounds__(64 * EW) void edge_bwd_kernel(const float* __restri
                                                            const int* __restrict__ n_valid,
                                                            const float* __restrict__ dlogit,
                                                            const float* __restrict__ dEbar, float* __restrict__ dE,
-                                                           float* __restrict__ dvpart, int N, int D, int nt) {
+                                                           float* __restrict__ dvpart, int N, int D, int nt,
+                                                           const GatTail gt) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  edge_bwd_row<VEC, NTL>(E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D, nt, blockIdx.x, sm);
+  // the GATAttention backward of the node scores (gat_body.hpp) rides in front: B * slices short workgroups
+  const int ngat = gt.P ? gt.B * gt.slices : 0;
+  if ((int)blockIdx.x < ngat) {
+    const int b = blockIdx.x / gt.slices;
+    gat_dlogit_doc(gt.P, gt.dA, gt.uvc, gt.dXin, nullptr, gt.ds, gt.dX, N, D, gt.drop, b, blockIdx.x - b * gt.slices, gt.slices, sm);
+    return;
+  }
+  edge_bwd_row<VEC, NTL>(E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D, nt, blockIdx.x - ngat, sm, gt);
 }
 
 // The same pass carrying deferred GEMM problems (gemm.hpp): the first gg.tile_begin[gg.nprob] workgroups each run one
@@ -156,7 +177,7 @@ __global__ __launch_bounds__(64 * EW) void edge_bwd_carry_kernel(const float* __
                                                                  const float* __restrict__ dlogit,
                                                                  const float* __restrict__ dEbar, float* __restrict__ dE,
                                                                  float* __restrict__ dvpart, int N, int D, int nt,
-                                                                 const GemmGroup gg) {
+                                                                 const GatTail gt, const GemmGroup gg) {
   // one LDS image for both kinds of workgroup (the rows need N + EW * D floats of it): a fourth workgroup fits per CU
   __shared__ __attribute__((aligned(16))) float tile_lds[lds_floats<1, 1, true, true>()];
   const int ntile = gg.tile_begin[gg.nprob];
@@ -164,7 +185,14 @@ __global__ __launch_bounds__(64 * EW) void edge_bwd_carry_kernel(const float* __
     gemm_group_block(gg, blockIdx.x, tile_lds);
     return;
   }
-  edge_bwd_row<VEC, NTL>(E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D, nt, blockIdx.x - ntile, tile_lds);
+  const int ngat = gt.P ? gt.B * gt.slices : 0;
+  const int r = blockIdx.x - ntile;
+  if (r < ngat) {
+    const int b = r / gt.slices;
+    gat_dlogit_doc(gt.P, gt.dA, gt.uvc, gt.dXin, nullptr, gt.ds, gt.dX, N, D, gt.drop, b, r - b * gt.slices, gt.slices, tile_lds);
+    return;
+  }
+  edge_bwd_row<VEC, NTL>(E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D, nt, r - ngat, tile_lds, gt);
 }
 
 template <int VEC>
@@ -226,33 +254,41 @@ int edge_fwd(const float* E, const float* v, const int* n_valid, float* Ebar, co
 }
 
 int edge_bwd(const float* E, const float* v, const int* n_valid, const float* dlogit, const float* dEbar, float* dE,
-             float* dvpart, int B, int N, int D, hipStream_t st, DeferQueue* carry) {
-  GC_REQUIRE(E && v && dlogit && dvpart, "edge_bwd: null pointer");
+             float* dvpart, int B, int N, int D, hipStream_t st, DeferQueue* carry, const GatTail* tail) {
+  GatTail gt;
+  memset(&gt, 0, sizeof gt);
+  if (tail) gt = *tail;
+  GC_REQUIRE(E && v && (dlogit || gt.P) && dvpart, "edge_bwd: null pointer");
+  GC_REQUIRE(!gt.P || (N <= GT && gt.B == B && gt.slices > 0 && gt.dA && gt.uvc && gt.ds && gt.dX), "edge_bwd: bad GAT passenger");
+  static_assert(sizeof(GatTail) + sizeof(GemmGroup) + 96 <= 4096, "edge_bwd_carry_kernel: kernel arguments exceed 4 KB");
+  static_assert(sizeof(float) * GAT_DOC_LDS <= sizeof(float) * lds_floats<1, 1, true, true>(), "GAT passenger needs more LDS than a tile");
+  const int ngat = gt.P ? B * gt.slices : 0;
   const bool vec = (D % 4 == 0) && al16(E) && al16(v) && (!dE || al16(dE)) && (!dEbar || al16(dEbar));
-  const size_t lds = ((size_t)((N + 3) & ~3) + (size_t)EW * D) * sizeof(float);
-  GC_REQUIRE(lds <= 160 * 1024, "edge_bwd: N=%d D=%d needs %zu B of LDS", N, D, lds);
+  const size_t lds_row = ((size_t)((N + 3) & ~3) + (size_t)EW * D) * sizeof(float);
+  GC_REQUIRE(lds_row <= 160 * 1024, "edge_bwd: N=%d D=%d needs %zu B of LDS", N, D, lds_row);
+  const size_t lds = (ngat && lds_row < sizeof(float) * GAT_DOC_LDS) ? sizeof(float) * GAT_DOC_LDS : lds_row;
   dim3 block(64 * EW);
   GemmGroup gg;
   double gflops = 0;
-  const int ntile = (carry && carry->n > 0 && vec && lds <= sizeof(float) * lds_floats<1, 1, true, true>())
+  const int ntile = (carry && carry->n > 0 && vec && lds_row <= sizeof(float) * lds_floats<1, 1, true, true>())
                         ? gemm_take_deferred(carry, gg, &gflops)
                         : 0;
   if (ntile > 0) {  // parked weight-gradient products ride along
-    dim3 grid((unsigned)((long)B * N + ntile));
+    dim3 grid((unsigned)((long)B * N + ngat + ntile));
     const double bytes = (dE ? 8.0 : 4.0) * B * N * N * D;
     if (nt_e1())
       GC_LAUNCH_TIMED("edge_bwd", bytes, (edge_bwd_carry_kernel<4, true>), grid, block, 0, st, E, v, n_valid, dlogit, dEbar, dE,
-                      dvpart, N, D, nt_store(), gg);
+                      dvpart, N, D, nt_store(), gt, gg);
     else
       GC_LAUNCH_TIMED("edge_bwd", bytes, (edge_bwd_carry_kernel<4, false>), grid, block, 0, st, E, v, n_valid, dlogit, dEbar, dE,
-                      dvpart, N, D, nt_store(), gg);
+                      dvpart, N, D, nt_store(), gt, gg);
     return check_launch("edge_bwd_carry");
   }
-  dim3 grid((unsigned)((long)B * N));
+  dim3 grid((unsigned)((long)B * N + ngat));
   const double bytes = (dE ? 8.0 : 4.0) * B * N * N * D;
 #define GC_EDGE_BWD(V, NT)                                                                                                 \
   GC_LAUNCH_TIMED("edge_bwd", bytes, (edge_bwd_kernel<V, NT>), grid, block, lds, st, E, v, n_valid, dlogit, dEbar, dE, dvpart, N, D, \
-                  nt_store())
+                  nt_store(), gt)
   if (vec) { if (nt_e1()) GC_EDGE_BWD(4, true); else GC_EDGE_BWD(4, false); }
   else { if (nt_e1()) GC_EDGE_BWD(1, true); else GC_EDGE_BWD(1, false); }
 #undef GC_EDGE_BWD

@@ -2,6 +2,7 @@
 // adjacency row normaliser, relu/normaliser backward, dropout, column reductions, the folded
 // GAT projection, and the device-side dropout RNG state.  All are launch-latency sized; the
 // big terms live in edge.hip (HBM) and gemm.hip (MFMA).
+#include "gat_body.hpp"
 #include "gemm.hpp"
 #include "rowops.hpp"
 
@@ -411,73 +412,14 @@ __global__ __launch_bounds__(64 * RW) void gat_fold_bwd_kernel(const float* __re
   }
 }
 
-// GATAttention backward up to the edge pass, one workgroup per document (N <= 64):
-//   dlogit = softmax_bwd(P, dropout_bwd(dA))      [N x N, also kept in LDS]
-//   ds[j]  = sum_i dlogit[i, j]                   (gradient of the node score u.x_j + c)
-//   dX[j]  = ds[j] u (+ dXin[j])
-// replaces three launches (row softmax gradient, batched column sum, node-score gradient).
-constexpr int GT = 64;
+// GATAttention backward up to the edge pass as its own launch (gat_body.hpp): used when the edge pass cannot take the
+// documents along as passengers.
 __global__ __launch_bounds__(256) void gat_dlogit_kernel(const float* __restrict__ P, const float* __restrict__ dA,
                                                          const float* __restrict__ uvc, const float* __restrict__ dXin,
                                                          float* __restrict__ dlogit, float* __restrict__ ds,
                                                          float* __restrict__ dX, int N, int D, Drop drop) {
-  __shared__ float T[GT][GT + 1];
-  __shared__ float dss[GT];
-  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const bool dd = drop.snap != nullptr;
-  const uint64_t key = dd ? drop_key(drop) : 0;
-  {  // all 16 rows of a wave are requested before the first one is reduced: one memory round trip, not sixteen
-    float p[GT / 4], g[GT / 4];
-#pragma unroll
-    for (int u = 0; u < GT / 4; ++u) {
-      const int i = wave + 4 * u;
-      const long oc = ((long)b * N + min(i, N - 1)) * N + min(lane, N - 1);  // clamped: unconditional loads (a load
-      const bool ok = i < N && lane < N;                                      // inside a branch is waited for at its end)
-      p[u] = P[oc], g[u] = dA[oc];
-      if (!ok) p[u] = 0.f, g[u] = 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < GT / 4; ++u) {
-      const int i = wave + 4 * u;
-      const long o = ((long)b * N + i) * N + lane;
-      float gg = g[u];
-      if (dd) gg = (rng_u32(key, (uint64_t)o) >= drop.thresh) ? gg * drop.scale : 0.f;
-      const float dot = wave_sum(gg * p[u]);
-      const float v = p[u] * (gg - dot);
-      if (i < N && lane < N && blockIdx.y == 0) dlogit[o] = v;
-      T[i][lane] = v;
-    }
-  }
-  __syncthreads();
-  if (t < GT) {
-    float a = 0.f;
-#pragma unroll 8
-    for (int i = 0; i < GT; ++i) a += T[i][t];
-    dss[t] = a;
-    if (t < N && blockIdx.y == 0) ds[(long)b * N + t] = a;
-  }
-  __syncthreads();
-  // dX: this workgroup's slice of the feature columns (gridDim.y slices share the document; each recomputes the
-  // cheap phases above, only slice 0 stores dlogit / ds), four independent elements in flight per thread
-  const int cw = (D + gridDim.y - 1) / gridDim.y, c0 = blockIdx.y * cw;
-  const int cn = min(cw, D - c0);
-  const long base = (long)b * N * D;
-  for (int e0 = t; e0 < N * cn; e0 += 4 * 256) {
-    float v[4], xin[4];
-    long o[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = e0 + u * 256;
-      const bool ok = e < N * cn;
-      const int j = ok ? e / cn : 0, c = c0 + (ok ? e - j * cn : 0);
-      o[u] = ok ? base + (long)j * D + c : -1;
-      v[u] = dss[j] * uvc[c];
-      xin[u] = dXin ? dXin[ok ? o[u] : base] : 0.f;   // dXin != NULL is uniform; the address is clamped, not guarded
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (o[u] >= 0) dX[o[u]] = v[u] + xin[u];
-  }
+  __shared__ float sm[GAT_DOC_LDS];
+  gat_dlogit_doc(P, dA, uvc, dXin, dlogit, ds, dX, N, D, drop, blockIdx.x, blockIdx.y, gridDim.y, sm);
 }
 
 // s[m] = u . X[m, :] + c      (one wave per node row)
@@ -666,10 +608,11 @@ int gat_fold_bwd(const float* flat, const float* duvc, float* dflat, int D, int 
   return check_launch("gat_fold_bwd");
 }
 bool gat_dlogit_ok(int N) { return N <= GT; }
+int gat_dlogit_slices(int D) { return D >= 256 ? 8 : (D >= 64 ? 4 : 1); }
 int gat_dlogit(const float* P, const float* dA, const float* uvc, const float* dXin, float* dlogit, float* ds, float* dX,
                int B, int N, int D, Drop drop, hipStream_t st) {
   ProfScope ps("gat_dlogit", st);
-  const int slices = D >= 256 ? 8 : (D >= 64 ? 4 : 1);
+  const int slices = gat_dlogit_slices(D);
   hipLaunchKernelGGL(gat_dlogit_kernel, dim3(B, slices), dim3(256), 0, st, P, dA, uvc, dXin, dlogit, ds, dX, N, D, drop);
   return check_launch("gat_dlogit");
 }

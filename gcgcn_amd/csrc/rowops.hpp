@@ -28,6 +28,8 @@ int gat_fold_fwd(const float* flat, float* uvc, int D, int Dh, hipStream_t st, v
 int gat_fold_bwd(const float* flat, const float* duvc, float* dflat, int D, int Dh, hipStream_t st,
                  const float* part = nullptr, const long* part_off = nullptr, int ns = 0);
 bool gat_dlogit_ok(int N);
+int gat_dlogit_slices(int D);
+struct GatTail;   // gat_body.hpp: the GATAttention node-score backward as passenger of edge_bwd
 int gat_dlogit(const float* P, const float* dA, const float* uvc, const float* dXin, float* dlogit, float* ds, float* dX,
                int B, int N, int D, Drop drop, hipStream_t st);
 int node_score_fwd(const float* X, const float* uvc, float* s, long M, int D, hipStream_t st, void* rng_state = nullptr,
@@ -38,7 +40,7 @@ int mask_rows(const float* x, float* y, long M, int D, int N, const int* n_valid
 int edge_fwd(const float* E, const float* v, const int* n_valid, float* Ebar, const float* coladd, float* P, float* A,
              Drop drop, int B, int N, int D, hipStream_t st, const unsigned char* mask = nullptr);
 int edge_bwd(const float* E, const float* v, const int* n_valid, const float* dlogit, const float* dEbar, float* dE,
-             float* dvpart, int B, int N, int D, hipStream_t st, DeferQueue* carry = nullptr);
+             float* dvpart, int B, int N, int D, hipStream_t st, DeferQueue* carry = nullptr, const GatTail* tail = nullptr);
 int edge_bcast(const float* dEbar, const int* n_valid, float* dE, int B, int N, int D, hipStream_t st);
 
 // mha_core.hip: fused attention core of MultiHeadAttention for N <= 64
