@@ -11,6 +11,8 @@
 // and every wave reaches the end of the phase list (no spin, no flag).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "edge_body.hpp"
 #include "gcn_plan.hpp"
 #include "gemm_body.hpp"
@@ -28,6 +30,7 @@ __device__ __forceinline__ bool dev_al16(const void* p) { return (((uintptr_t)p)
 constexpr int TEAM_LDS = lds_floats<1, 1, true, true>();
 constexpr int CHAIN_LDS = 2 * TEAM_LDS;
 constexpr int XCHG_LDS = 64 * 64;  // passenger tiles of parked products: the two teams' partial sums meet here
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int CW = 8;   // waves per chain workgroup
 constexpr int RB = 8;   // rows a wave keeps in flight in the row-wise phases (8 waves x 8 rows: a 64-node graph in one pass)
 
@@ -187,6 +190,383 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_bwd_kernel(const GcnCtx c, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same two sequences for the shape the model runs at by default -- 64 entities, two sub-layers of 128 features
+// per head (hidden 256, glove:254-262) -- with every tile that one product hands to the next kept in LDS.
+//
+// The generic kernels above hand a product's output to the next product through global memory: stores, a barrier,
+// then loads that have to come back from L2 -- ~5 us per dependent product for ~1 us of matrix work.  Here a
+// (document, head) pair's whole working set lives in one compute unit's 160 KB of LDS: the adjacency image (17 KB),
+// the Pn / Y (forward) or dM / Pn / dPn (backward) operand images (34 KB each).  Eight waves each own one 32x32 block
+// of a 64x128 result (or one block and one K half of the 64x64 dA); operands are read from LDS in MFMA order -- the
+// operand stored with its reduction index contiguous as one 16-byte read per four MFMAs (the four k of a read go to
+// the four MFMAs, lanes 32-63 take the next four: a permutation of the reduction order), the other one as four
+// 4-byte reads.  Weights (Wd, shared by all documents, L2-hot) go from global memory straight into the B-operand
+// registers, requested a whole product ahead.  Results are stored to global memory as the saved tensors of
+// backward / outputs, but nobody waits for those stores.  Barriers: 3 forward, 6 backward.
+// ---------------------------------------------------------------------------------------------
+constexpr int S_LA = 68;    // row pitch of the 64x64 adjacency image (floats; 16-byte rows, conflict-free 16-byte reads)
+constexpr int S_LP = 132;   // row pitch of a 64x128 operand image
+constexpr int S_GH = 128;
+constexpr int S_FWD_LDS = 64 * S_LA + 2 * 64 * S_LP + 64;
+constexpr int S_BWD_LDS = 64 * S_LA + 3 * 64 * S_LP + 128;
+static_assert(S_FWD_LDS >= CHAIN_LDS && S_BWD_LDS >= CHAIN_LDS + XCHG_LDS, "passengers use the chain kernels' LDS");
+static_assert(S_BWD_LDS * sizeof(float) <= 160 * 1024, "LDS of one compute unit");
+
+// Workgroup barrier for hand-overs through LDS: waits for this wave's LDS operations only.  __syncthreads() also waits
+// for every global store to be acknowledged and every outstanding prefetch to land -- microseconds the chain need not spend,
+// since nothing one wave stores to global memory is read by another wave of the kernel.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// acc += A[32 x K] B[K x 32].  AV: pa points at this lane's A row, 4 * (lane / 32) floats in, k contiguous;
+// otherwise at row 4 * (lane / 32) of a [k][row] image, this lane's row.  The same for B with its column.
+template <int K, bool AV, bool BV>
+__device__ __forceinline__ void mma_lds(f32x16& acc, const float* __restrict__ pa, const int la,
+                                        const float* __restrict__ pb, const int lb) {
+#pragma unroll
+  for (int k0 = 0; k0 < K; k0 += 8) {
+    float a[4], b[4];
+    if (AV) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(pa + k0);
+      a[0] = v.x, a[1] = v.y, a[2] = v.z, a[3] = v.w;
+    } else {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) a[m] = pa[(k0 + m) * la];
+    }
+    if (BV) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(pb + k0);
+      b[0] = v.x, b[1] = v.y, b[2] = v.z, b[3] = v.w;
+    } else {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) b[m] = pb[(k0 + m) * lb];
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[m], acc, 0, 0, 0);
+  }
+}
+// the same with the B operand already in registers (bw[k0 / 8] = the four k of this lane)
+template <int K>
+__device__ __forceinline__ void mma_lds_reg(f32x16& acc, const float* __restrict__ pa, const f32x4 (&bw)[K / 8]) {
+#pragma unroll
+  for (int k0 = 0; k0 < K; k0 += 8) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(pa + k0);
+    const f32x4 w = bw[k0 / 8];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, w.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, w.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, w.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, w.w, acc, 0, 0, 0);
+  }
+}
+// row of accumulator element q of the lane (its column is lane % 32): rows r0 + {0..3} + 8 * {0..3}, r0 = block row + 4 * (lane / 32)
+__device__ __forceinline__ int acc_row(int r0, int q) { return r0 + (q & 3) + 8 * (q >> 2); }
+
+__global__ __launch_bounds__(64 * CW) void gcn_chain_s_fwd_kernel(const GcnCtx c) {
+  __shared__ __attribute__((aligned(16))) float lds[S_FWD_LDS];
+  if (blockIdx.x >= c.B * c.H) {  // passenger workgroup: one entity row of the riding edge mean
+    const EdgeRide& r = c.ride;
+    edge_fwd_row<4, false, true, CW>(r.in, nullptr, r.n_valid, r.out, nullptr, nullptr, nullptr, Drop(), r.N, r.D,
+                                     blockIdx.x - c.B * c.H, lds);
+    return;
+  }
+  float* const As = lds;
+  float* const Ps = As + 64 * S_LA;
+  float* const Ys = Ps + 64 * S_LP;
+  float* const Rs = Ys + 64 * S_LP;
+  const int z = blockIdx.x, b = z / c.H, h = z - b * c.H;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, hf = lane >> 5;
+  const int rb = wave & 1, cb = wave >> 1;             // this wave's 32x32 block of a 64x128 result
+  const unsigned HD = (unsigned)c.HD, D = (unsigned)c.D;
+  const long zoff = (long)b * 64 * c.HD + (long)h * 2 * S_GH;  // (b, row 0, h, l = 0, k = 0) in [B*N, H, L, gh]
+  const float* __restrict__ Ag = c.A + (long)z * 64 * 64;
+  const float* __restrict__ Pg = c.Pn + zoff;
+  const float* __restrict__ Gg = c.G + zoff;
+  const float* __restrict__ Xg = c.X + (long)b * 64 * c.D;
+  float* __restrict__ Yg = c.Y + zoff;
+  float* __restrict__ Hg = c.HO + zoff;
+  const int r0 = rb * 32 + hf * 4, col = cb * 32 + r;
+  const bool dd = c.drop.snap != nullptr;
+  const uint64_t key = dd ? drop_key(c.drop) : 0;
+
+  // ---- requests, in the order their data is needed ---------------------------------------------------------------
+  f32x4 a[2], p[4];   // A_h and Pn_0 = X Wn_0 (written by the launch before): the first product's operands
+  float s[8];          // A's rows once more for the normaliser (glove:47-49)
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int idx = t + 512 * u;
+    a[u] = *reinterpret_cast<const f32x4*>(Ag + (idx >> 4) * 64 + (idx & 15) * 4);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int idx = t + 512 * u;
+    p[u] = *reinterpret_cast<const f32x4*>(Pg + (unsigned)(idx >> 5) * HD + (idx & 31) * 4);
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s[u] = Ag[(wave * 8 + u) * 64 + lane];
+  float gv[2][16], xv[2][16], pv[16];   // epilogue operands of both sub-layers, Pn_1 = X Wn_1 as the dense product's start
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const unsigned row = (unsigned)acc_row(r0, q);
+    gv[0][q] = Gg[row * HD + (unsigned)col];
+    xv[0][q] = Xg[row * D + (unsigned)col];
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int idx = t + 512 * u;
+    *reinterpret_cast<f32x4*>(As + (idx >> 4) * S_LA + (idx & 15) * 4) = a[u];
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int idx = t + 512 * u;
+    *reinterpret_cast<f32x4*>(Ps + (idx >> 5) * S_LP + (idx & 31) * 4) = p[u];
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const float tt = wave_sum(s[u]);
+    if (lane == 0) {
+      const float ri = 1.f / (tt + (tt == 0.f ? 1.f : 0.f));
+      Rs[wave * 8 + u] = ri;
+      c.rinv[(long)z * 64 + wave * 8 + u] = ri;
+    }
+  }
+  // Wd_1 (the dense connection's weight, [128 x 128] of this head, L2-hot): this lane's B operands of the second product
+  f32x4 bw[S_GH / 8];
+  {
+    const float* __restrict__ W = c.flat + c.wd_off(1) + (long)h * c.wd_head + col;
+#pragma unroll
+    for (int g = 0; g < S_GH / 8; ++g) {
+      const int k = 8 * g + 4 * hf;
+      bw[g] = f32x4{W[(k + 0) * S_GH], W[(k + 1) * S_GH], W[(k + 2) * S_GH], W[(k + 3) * S_GH]};
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) pv[q] = Pg[(unsigned)acc_row(r0, q) * HD + S_GH + (unsigned)col];
+  lds_barrier();
+
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    const unsigned lo = (unsigned)l * S_GH + (unsigned)col;
+    f32x16 acc;
+    if (l == 1) {  // Pn_1 = X Wn_1 (in memory) + Y_0 Wd_1          (dense connection, glove:73 / 110)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {  // the second sub-layer's epilogue operands land while this product runs
+        const unsigned row = (unsigned)acc_row(r0, q);
+        gv[1][q] = Gg[row * HD + S_GH + (unsigned)col];
+        xv[1][q] = Xg[row * D + S_GH + (unsigned)col];
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = pv[q];
+      mma_lds_reg<S_GH>(acc, Ys + (rb * 32 + r) * S_LP + 4 * hf, bw);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = acc_row(r0, q);
+        c.Pn[zoff + (unsigned)row * HD + lo] = acc[q];
+        Ps[row * S_LP + col] = acc[q];
+      }
+      lds_barrier();
+    }
+    // Y_l = relu((G_l + A_h Pn_l) rinv);  HO_l = dropout(Y_l) + X_l          (glove:42-50, 71-76)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    mma_lds<64, true, false>(acc, As + (rb * 32 + r) * S_LA + 4 * hf, 0, Ps + (4 * hf) * S_LP + col, S_LP);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = acc_row(r0, q);
+      const unsigned o = (unsigned)row * HD + lo;
+      const float v = fmaxf((acc[q] + gv[l][q]) * Rs[row], 0.f);
+      Yg[o] = v;
+      if (l == 0) Ys[row * S_LP + col] = v;
+      float w = v;
+      if (dd) w = (rng_u32(key, (uint64_t)(zoff + (long)o)) >= c.drop.thresh) ? v * c.drop.scale : 0.f;
+      Hg[o] = w + xv[l][q];
+    }
+    if (l == 0) lds_barrier();
+  }
+}
+
+// Backward of the same sequence (last sub-layer first); dA stays in registers over both sub-layers, its reduction
+// split over two waves per block.  dYa is read, never written back: nothing after the chain needs it.
+// Requests go out in the order their data is needed (row phase of sub-layer 1 first); the barriers wait for LDS only.
+__global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c, const GemmGroup4 cg) {
+  __shared__ __attribute__((aligned(16))) float lds[S_BWD_LDS];
+  if (blockIdx.x >= c.B * c.H) {
+    const int pb = blockIdx.x - c.B * c.H, ng = cg.tile_begin[cg.nprob];
+    if (pb < ng) {  // passenger workgroup: one tile of a parked product, K split over the two tile teams
+      gemm_group_splitk_block(cg, pb, lds, TEAM_LDS, lds + CHAIN_LDS);
+      return;
+    }
+    const EdgeRide& r = c.ride;  // passenger workgroup: one entity row of the riding dE broadcast
+    edge_bcast_row<4, CW>(r.in, r.n_valid, r.out, r.N, r.D, 0, pb - ng);
+    return;
+  }
+  float* const As = lds;
+  float* const Ds = As + 64 * S_LA;     // dM_l; between the sub-layers the updated dY_0
+  float* const Ps = Ds + 64 * S_LP;     // Pn_l
+  float* const Ws = Ds;                 // Wd_1 [128 x 128] over both images while dY_0 += dPn_1 Wd_1^T runs
+  float* const Qs = Ps + 64 * S_LP;     // dPn_1; at the end the K halves of dA meet here
+  float* const Rs = Qs + 64 * S_LP;     // rinv
+  float* const Ts = Rs + 64;            // gradient of the normaliser's row sums
+  const int z = blockIdx.x, b = z / c.H, h = z - b * c.H;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, hf = lane >> 5;
+  const int rb = wave & 1, cb = wave >> 1;             // block of a 64x128 result
+  const int ab = wave & 3, kh = wave >> 2;             // block of dA (rows ab & 1, columns ab >> 1) and K half
+  const unsigned HD = (unsigned)c.HD;
+  const long zoff = (long)b * 64 * c.HD + (long)h * 2 * S_GH;
+  const float* __restrict__ Ag = c.A + (long)z * 64 * 64;
+  const float* __restrict__ Pg = c.Pn + zoff;
+  const float* __restrict__ Yg = c.Y + zoff;
+  const float* __restrict__ Gy = c.dYa + zoff;
+  const float* __restrict__ Rg = c.rinv + (long)z * 64;
+  float* __restrict__ Mg = c.dM + zoff;
+  float* __restrict__ Qg = c.dP + zoff;
+  const int r0 = rb * 32 + hf * 4, col = cb * 32 + r;
+
+  // ---- requests ------------------------------------------------------------------------------------------------
+  float y[8][2], gy[8][2], rv[8];   // row phase: rows wave + 8 u, columns lane + 64 kk
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int i = wave + 8 * u;
+    rv[u] = Rg[i];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const unsigned o = (unsigned)i * HD + S_GH + (unsigned)(lane + 64 * kk);
+      y[u][kk] = Yg[o];
+      gy[u][kk] = Gy[o];
+    }
+  }
+  f32x4 a[2], p1[4], p0[4], wd[8];   // the images of sub-layer 1; Pn_0, Wd_1, Y_0 and dY_0 are requested later
+  float y0[8][2], gv[16];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int idx = t + 512 * u;
+    a[u] = *reinterpret_cast<const f32x4*>(Ag + (idx >> 4) * 64 + (idx & 15) * 4);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int idx = t + 512 * u;
+    p1[u] = *reinterpret_cast<const f32x4*>(Pg + (unsigned)(idx >> 5) * HD + S_GH + (idx & 31) * 4);
+  }
+  const float rs = (t < 64) ? Rg[t] : 0.f;
+  f32x16 dacc;     // this wave's K half of its dA block
+#pragma unroll
+  for (int q = 0; q < 16; ++q) dacc[q] = 0.f;
+
+  auto sublayer = [&](auto lt) __attribute__((always_inline)) {   // l is a compile-time constant: the two passes differ in what they read and hand on
+    constexpr int l = decltype(lt)::value;
+    const unsigned lo = (unsigned)l * S_GH;
+    // through Y = relu(S), S = M rinv:  dS = dY [Y > 0];  dM = dS rinv;  drow -= rinv sum_c dS Y
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = wave + 8 * u;
+      float acc = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const float yy = (l == 1) ? y[u][kk] : y0[u][kk];
+        const float gg = (l == 1) ? gy[u][kk] : Ds[i * S_LP + lane + 64 * kk];
+        const float g = yy > 0.f ? gg : 0.f;
+        const float dm = g * rv[u];
+        Mg[(unsigned)i * HD + lo + (unsigned)(lane + 64 * kk)] = dm;
+        Ds[i * S_LP + lane + 64 * kk] = dm;
+        acc = fmaf(g, yy, acc);
+      }
+      const float tt = wave_sum(acc);
+      if (lane == 0) Ts[i] = (l == 1) ? -rv[u] * tt : Ts[i] - rv[u] * tt;
+    }
+    if constexpr (l == 1) {  // the images the products of this sub-layer read
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int idx = t + 512 * u;
+        *reinterpret_cast<f32x4*>(As + (idx >> 4) * S_LA + (idx & 15) * 4) = a[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = t + 512 * u;
+        *reinterpret_cast<f32x4*>(Ps + (idx >> 5) * S_LP + (idx & 31) * 4) = p1[u];
+      }
+      if (t < 64) Rs[t] = rs;
+    }
+    lds_barrier();
+    // dPn_l = A_h^T dM_l   and   dA += dM_l Pn_l^T (this wave's K half): both wait only for dM_l
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    mma_lds<64, false, false>(acc, As + (4 * hf) * S_LA + rb * 32 + r, S_LA, Ds + (4 * hf) * S_LP + col, S_LP);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = acc_row(r0, q);
+      Qg[(unsigned)row * HD + lo + (unsigned)col] = acc[q];
+      if constexpr (l == 1) Qs[row * S_LP + col] = acc[q];
+    }
+    if constexpr (l == 1) {  // Wd_1 row by row (L2-hot, coalesced), transposed through LDS once the images below are free
+      const float* __restrict__ W = c.flat + c.wd_off(1) + (long)h * c.wd_head;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) wd[u] = *reinterpret_cast<const f32x4*>(W + (t + 512 * u) * 4);
+    }
+    mma_lds<64, true, true>(dacc, Ds + ((ab & 1) * 32 + r) * S_LP + kh * 64 + 4 * hf, 0,
+                            Ps + ((ab >> 1) * 32 + r) * S_LP + kh * 64 + 4 * hf, 0);
+    if constexpr (l == 1) {
+      lds_barrier();  // dPn_1 complete in LDS; dM_1 and Pn_1 images free
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = t + 512 * u;
+        *reinterpret_cast<f32x4*>(Ws + (idx >> 5) * S_LP + (idx & 31) * 4) = wd[u];
+      }
+      // requests for the second sub-layer: they land while the product below runs
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = t + 512 * u;
+        p0[u] = *reinterpret_cast<const f32x4*>(Pg + (unsigned)(idx >> 5) * HD + (idx & 31) * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) y0[u][kk] = Yg[(unsigned)(wave + 8 * u) * HD + (unsigned)(lane + 64 * kk)];
+#pragma unroll
+      for (int q = 0; q < 16; ++q)  // dY_0 as it arrives (dropout_bwd(dHO_0) + residual)
+        gv[q] = Gy[(unsigned)acc_row(r0, q) * HD + (unsigned)col];
+      lds_barrier();
+      // dY_0 += dPn_1 Wd_1^T:  B[k][n] = Wd_1[n][k], this lane's column n is a row of the image
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+      mma_lds<S_GH, true, true>(acc, Qs + (rb * 32 + r) * S_LP + 4 * hf, 0, Ws + col * S_LP + 4 * hf, 0);
+      lds_barrier();  // everybody is done with Wd_1's image
+#pragma unroll
+      for (int q = 0; q < 16; ++q) Ds[acc_row(r0, q) * S_LP + col] = acc[q] + gv[q];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = t + 512 * u;
+        *reinterpret_cast<f32x4*>(Ps + (idx >> 5) * S_LP + (idx & 31) * 4) = p0[u];
+      }
+      lds_barrier();
+    }
+  };
+  sublayer(std::integral_constant<int, 1>());
+  sublayer(std::integral_constant<int, 0>());
+  // dA = K half 0 + K half 1 + drow (every column of a row)
+  if (kh == 1) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Qs[(ab * 16 + q) * 64 + lane] = dacc[q];
+  }
+  lds_barrier();
+  if (kh == 0) {
+    float* __restrict__ dAg = c.dA + (long)z * 64 * 64;
+    const int ar0 = (ab & 1) * 32 + hf * 4, acol = (ab >> 1) * 32 + r;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = acc_row(ar0, q);
+      dAg[row * 64 + acol] = dacc[q] + Qs[(ab * 16 + q) * 64 + lane] + Ts[row];
+    }
+  } else if (t >= 256 && t < 320) {
+    c.drow[(long)z * 64 + (t - 256)] = Ts[t - 256];
+  }
+}
+
+// the shape the LDS-resident kernels are written for
+static bool chain_small_ok(const GcnCtx& c, bool bwd) {
+  static const bool on = [] { const char* e = getenv("GCGCN_CHAIN_S"); return !(e && e[0] == '0'); }();
+  return on && c.N == 64 && c.L == 2 && c.gh == S_GH && c.D == 2 * S_GH && (c.flat + c.oWd) && c.wd_head % 4 == 0 &&
+         (c.wd_off(1) % 4) == 0;
+}
+
 static bool chain_aligned(const GcnCtx& c, bool bwd) {
   auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
   bool ok = c.N % 64 == 0 && c.gh % 64 == 0 && al(c.A) && al(c.flat + c.oWd) && al(c.Pn) && al(c.Y);
@@ -229,7 +609,9 @@ int gcn_chain_fwd(const GcnCtx& c, hipStream_t st) {
   dim3 grid(chain_grid(c, 1)), block(64 * CW);
   double fl = 0;
   for (int l = 0; l < c.L; ++l) fl += 2.0 * c.N * c.gh * (c.N + (double)l * c.gh);
-  if (chain_aligned(c, false)) GC_LAUNCH_TIMED("gcn_chain_fwd", fl * c.B * c.H, gcn_chain_fwd_kernel<true>, grid, block, 0, st, c);
+  if (chain_aligned(c, false) && chain_small_ok(c, false))
+    GC_LAUNCH_TIMED("gcn_chain_fwd", fl * c.B * c.H, gcn_chain_s_fwd_kernel, grid, block, 0, st, c);
+  else if (chain_aligned(c, false)) GC_LAUNCH_TIMED("gcn_chain_fwd", fl * c.B * c.H, gcn_chain_fwd_kernel<true>, grid, block, 0, st, c);
   else GC_LAUNCH_TIMED("gcn_chain_fwd", fl * c.B * c.H, gcn_chain_fwd_kernel<false>, grid, block, 0, st, c);
   return check_launch("gcn_chain_fwd");
 }
@@ -260,7 +642,9 @@ int gcn_chain_bwd(const GcnCtx& c, hipStream_t st, DeferQueue* carry) {
     if (rounds > 0 && halves && budget > 0) ng = gemm_take_deferred_pairs(carry, cg, &fl, budget);
   }
   dim3 grid(chain_grid(c, 2) + (unsigned)ng), block(64 * CW);
-  if (chain_aligned(c, true)) GC_LAUNCH_TIMED("gcn_chain_bwd", fl, gcn_chain_bwd_kernel<true>, grid, block, 0, st, c, cg);
+  if (chain_aligned(c, true) && chain_small_ok(c, true))
+    GC_LAUNCH_TIMED("gcn_chain_bwd", fl, gcn_chain_s_bwd_kernel, grid, block, 0, st, c, cg);
+  else if (chain_aligned(c, true)) GC_LAUNCH_TIMED("gcn_chain_bwd", fl, gcn_chain_bwd_kernel<true>, grid, block, 0, st, c, cg);
   else GC_LAUNCH_TIMED("gcn_chain_bwd", fl, gcn_chain_bwd_kernel<false>, grid, block, 0, st, c, cg);
   return check_launch("gcn_chain_bwd");
 }
