@@ -185,8 +185,8 @@ __global__ __launch_bounds__(64 * EW) void edge_bwd_carry_kernel(const float* __
     gemm_group_block(gg, blockIdx.x, tile_lds);
     return;
   }
-  const int ngat = gt.P ? gt.B * gt.slices : 0;
   const int r = blockIdx.x - ntile;
+  const int ngat = gt.P ? gt.B * gt.slices : 0;
   if (r < ngat) {
     const int b = r / gt.slices;
     gat_dlogit_doc(gt.P, gt.dA, gt.uvc, gt.dXin, nullptr, gt.ds, gt.dX, N, D, gt.drop, b, r - b * gt.slices, gt.slices, tile_lds);
@@ -206,14 +206,16 @@ __global__ __launch_bounds__(64 * EW) void edge_bcast_kernel(const float* __rest
 // host launchers
 // ---------------------------------------------------------------------------------------------
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
-// GCGCN_NT_STORE=1 switches the dE stores to non-temporal (A/B knob).  Measured in the step (cfg 2): E1 then
-// survives in the Infinity Cache (edge_fwd_att 31 -> 27 us) but the stores themselves get slower (edge_bwd 56 -> 69 us,
-// edge_bcast 24 -> 26 us): 0.873 vs 0.867 ms per step.  Off.  (The non-temporal E2 LOADS of the mean-only pass stay:
-// edge_fwd_mean 43 -> 25 us.)
+// E is read once per pass and never again before something else has flushed the caches (a training step feeds new
+// documents): all E loads are non-temporal.  GCGCN_NT_E1=0 restores ordinary loads for the attention pass over E1 --
+// that was the round-1 setting, tuned on a bench that replayed ONE batch (part of E1 still sat in the Infinity Cache
+// from the previous backward); with rotating batches ordinary loads cost 8 us in edge_fwd_att (33.6 -> 25.7 us) and
+// 3 us in the backward edge pass.  GCGCN_NT_STORE=1 switches the dE stores to non-temporal too (A/B knob; no gain
+// with rotating batches, slower stores with a replayed one: edge_bwd 56 -> 69 us).
 static int nt_e1() {
   static const int v = [] {
     const char* e = getenv("GCGCN_NT_E1");
-    return (e && e[0] == '1') ? 1 : 0;
+    return (e && e[0] == '0') ? 0 : 1;
   }();
   return v;
 }
@@ -237,8 +239,7 @@ int edge_fwd(const float* E, const float* v, const int* n_valid, float* Ebar, co
   dim3 grid((unsigned)((long)B * N)), block(64 * EW);
   const char* tag = att ? "edge_fwd_att" : "edge_fwd_mean";
   const double bytes = 4.0 * B * N * N * D;
-  // the mean-only pass reads E once per step: always non-temporal.  The attention pass over E1 keeps ordinary
-  // loads by default (part of E1 is still in the Infinity Cache from the previous backward); GCGCN_NT_E1=1 streams it too.
+  // the mean-only pass reads E once per step: always non-temporal; the attention pass over E1 too unless GCGCN_NT_E1=0
   const bool ntl = !att || nt_e1();
 #define GC_EDGE_FWD(V, AT, NT) \
   GC_LAUNCH_TIMED(tag, bytes, (edge_fwd_kernel<V, AT, NT>), grid, block, lds, st, E, v, n_valid, Ebar, coladd, P, A, drop, N, D, mask)
