@@ -550,39 +550,52 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
   float* dM = W2;   // gradient of M_l = G_l + A_h Pn_l  (== dG)
   float* dP = W3;   // gradient of Pn_l
 
+  // The chain kernel of the default shape computes dHO = dout Wlin and dXres = sum_h dHO_h itself (chain.hip): no launch for
+  // that product, no head-sum / dropout kernel, dHO never in HBM.  Decided on the same context the chain will get.
+  GcnCtx c = make_ctx(B, N, D, L, H, y, X, A, flat, n_valid, drop);
+  c.Pn = const_cast<float*>(Pn), c.Y = const_cast<float*>(Y), c.rinv = const_cast<float*>(rinv);
+  c.dYa = dYa, c.dM = dM, c.dP = dP, c.dA = dA, c.drow = drow;
+  const bool fuse = use_chain() && chain_bwd_fusable(c) && (((uintptr_t)dXres) & 15) == 0 &&
+                    (((uintptr_t)(n_valid || odrop.snap ? dout_m : dout)) & 15) == 0 && (long)M * HD >= (long)D * D;
+  float* wsum = (fuse && H > 1) ? dYa : nullptr;   // dYa's buffer is free when the chain computes dHO itself
   if (n_valid || odrop.snap) {  // gradients arriving on padding rows are ignored; back through the output dropout
-    GC_TRY(mask_rows(dout, dout_m, M, D, N, n_valid, odrop, st));
+    GC_TRY(mask_rows(dout, dout_m, M, D, N, n_valid, odrop, st, flat + y.oWlin, wsum, H));  // + sum_h Wlin_h in trailing workgroups
     dout = dout_m;
+  } else if (wsum) {
+    GC_TRY(mask_rows(nullptr, nullptr, M, D, N, nullptr, odrop, st, flat + y.oWlin, wsum, H));
   }
   ColRide cr;
-  bool col_later = false;
-  {  // one launch: dHO = dout Wlin  and  dWlin = dout^T HO
-    GemmArgs gs[2];
-    gs[0].ws = gs[1].ws = scratch, gs[0].ws_elems = gs[1].ws_elems = wse;
-    gs[0].A = dout, gs[0].lda = D, gs[0].a_kc = 1;
-    gs[0].B = flat + y.oWlin, gs[0].ldb = HD, gs[0].b_kc = 0;
-    gs[0].C = dYa, gs[0].ldc = HD;
-    gs[0].M = (int)M, gs[0].N = (int)HD, gs[0].K = D;
-    gs[1].A = dout, gs[1].lda = D, gs[1].a_kc = 0;
-    gs[1].B = HO, gs[1].ldb = HD, gs[1].b_kc = 0;
-    gs[1].C = dflat + y.oWlin, gs[1].ldc = HD;
-    gs[1].M = D, gs[1].N = (int)HD, gs[1].K = (int)M;
-    // a weight gradient nobody needs before the end of backward: parked for a later launch with idle matrix pipes
-    const int ng1 = gemm_defer(dq, gs[1]) ? 1 : 2;
-    if (scratch) {  // dblin = column sums of dout ride in this launch (stage 1) and in its reduce or the next kernel (stage 2)
-      cr.X = dout, cr.out = dflat + y.oblin, cr.part = scratch + wse, cr.R = M, cr.ld = D, cr.C = D;
-      GC_TRY(gemm_group(gs, ng1, st, &cr, &col_later));
-    } else {
-      GC_TRY(gemm_group(gs, ng1, st));
-      GC_TRY(colsum(dout, nullptr, dflat + y.oblin, M, D, D, 1, 0, 0, 0, 0, scratch, st));
+  bool col_later = false, col_pending = false;
+  if (fuse) {  // dWlin = dout^T HO is parked or joins the launch after the chain; dblin's column sums ride there too
+    c.dout = dout, c.dXres = dXres, c.Wsum = wsum, c.oWlin = y.oWlin;
+    if (scratch) cr.X = dout, cr.out = dflat + y.oblin, cr.part = scratch + wse, cr.R = M, cr.ld = D, cr.C = D, col_pending = true;
+    else GC_TRY(colsum(dout, nullptr, dflat + y.oblin, M, D, D, 1, 0, 0, 0, 0, scratch, st));
+  } else {
+    {  // one launch: dHO = dout Wlin  and  dWlin = dout^T HO
+      GemmArgs gs[2];
+      gs[0].ws = gs[1].ws = scratch, gs[0].ws_elems = gs[1].ws_elems = wse;
+      gs[0].A = dout, gs[0].lda = D, gs[0].a_kc = 1;
+      gs[0].B = flat + y.oWlin, gs[0].ldb = HD, gs[0].b_kc = 0;
+      gs[0].C = dYa, gs[0].ldc = HD;
+      gs[0].M = (int)M, gs[0].N = (int)HD, gs[0].K = D;
+      gs[1].A = dout, gs[1].lda = D, gs[1].a_kc = 0;
+      gs[1].B = HO, gs[1].ldb = HD, gs[1].b_kc = 0;
+      gs[1].C = dflat + y.oWlin, gs[1].ldc = HD;
+      gs[1].M = D, gs[1].N = (int)HD, gs[1].K = (int)M;
+      // a weight gradient nobody needs before the end of backward: parked for a later launch with idle matrix pipes
+      const int ng1 = gemm_defer(dq, gs[1]) ? 1 : 2;
+      if (scratch) {  // dblin = column sums of dout ride in this launch (stage 1) and in its reduce or the next kernel (stage 2)
+        cr.X = dout, cr.out = dflat + y.oblin, cr.part = scratch + wse, cr.R = M, cr.ld = D, cr.C = D;
+        GC_TRY(gemm_group(gs, ng1, st, &cr, &col_later));
+      } else {
+        GC_TRY(gemm_group(gs, ng1, st));
+        GC_TRY(colsum(dout, nullptr, dflat + y.oblin, M, D, D, 1, 0, 0, 0, 0, scratch, st));
+      }
     }
+    GC_TRY(head_sum_drop_bwd(dYa, dYa, dXres, M, H, D, drop, st, col_later ? &cr : nullptr));  // residual + dropout backward
   }
-  GC_TRY(head_sum_drop_bwd(dYa, dYa, dXres, M, H, D, drop, st, col_later ? &cr : nullptr));  // residual + dropout backward
 
   {  // the dependent per-(doc, head) sequence, last sub-layer first
-    GcnCtx c = make_ctx(B, N, D, L, H, y, X, A, flat, n_valid, drop);
-    c.Pn = const_cast<float*>(Pn), c.Y = const_cast<float*>(Y), c.rinv = const_cast<float*>(rinv);
-    c.dYa = dYa, c.dM = dM, c.dP = dP, c.dA = dA, c.drow = drow;
     if (er.kind && !(use_chain() && chain_can_carry(er))) {
       GC_TRY(edge_bcast(er.in, er.n_valid, er.out, er.B, er.N, er.D, st));
       er.kind = 0;
@@ -614,6 +627,14 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
     auto park = [&]() {  // the problem just described is a weight gradient: park it if asked to (and possible)
       if (gemm_defer(dq, gs[n - 1])) --n;
     };
+    if (fuse) {  // dWlin = dout^T HO
+      GemmArgs& g = next();
+      g.A = dout, g.lda = D, g.a_kc = 0;
+      g.B = HO, g.ldb = HD, g.b_kc = 0;
+      g.C = dflat + y.oWlin, g.ldc = HD;
+      g.M = D, g.N = (int)HD, g.K = (int)M;
+      park();
+    }
     {
       GemmArgs& g = next();
       g.A = X, g.lda = D, g.a_kc = 0;
@@ -658,7 +679,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
       g.batch2 = H;
       park();
     }
-    GC_TRY(gemm_group(gs, n, st));
+    GC_TRY(gemm_group(gs, n, st, col_pending ? &cr : nullptr));
   }
   return 0;
 }

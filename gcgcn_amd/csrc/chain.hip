@@ -257,6 +257,39 @@ __device__ __forceinline__ void mma_lds_reg(f32x16& acc, const float* __restrict
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, w.w, acc, 0, 0, 0);
   }
 }
+// NB accumulators sharing the A operand (LDS, k contiguous); the B operands come straight from global memory (weights, L2-hot:
+// B[k][n] at base[k * ldb + off + j * bstep], n contiguous across lanes), requested PF groups of 8 k ahead of their use.
+template <int K, int NB>
+__device__ __forceinline__ void mma_lds_glb(f32x16 (&acc)[NB], const float* __restrict__ pa, const float* __restrict__ base,
+                                            const unsigned off, const unsigned ldb, const unsigned bstep) {
+  constexpr int G = K / 8, PF = 4;
+  float bq[PF][NB][4];
+#pragma unroll
+  for (int g = 0; g < PF; ++g)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) bq[g][j][m] = base[(unsigned)(8 * g + m) * ldb + off + j * bstep];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(pa + 8 * g);
+    float bc[NB][4];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) bc[j][m] = bq[g % PF][j][m];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bc[j][m], acc[j], 0, 0, 0);
+    if (g + PF < G) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) bq[g % PF][j][m] = base[(unsigned)(8 * (g + PF) + m) * ldb + off + j * bstep];
+    }
+  }
+}
 // row of accumulator element q of the lane (its column is lane % 32): rows r0 + {0..3} + 8 * {0..3}, r0 = block row + 4 * (lane / 32)
 __device__ __forceinline__ int acc_row(int r0, int q) { return r0 + (q & 3) + 8 * (q >> 2); }
 
@@ -386,6 +419,11 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_fwd_kernel(const GcnCtx c
 // Backward of the same sequence (last sub-layer first); dA stays in registers over both sub-layers, its reduction
 // split over two waves per block.  dYa is read, never written back: nothing after the chain needs it.
 // Requests go out in the order their data is needed (row phase of sub-layer 1 first); the barriers wait for LDS only.
+// FUSE: the gradient of the block's output projection input is computed here instead of arriving in dYa --
+//   dHO_{b,h} = dout_b Wlin[:, h]  (64 x 256 x 256, Wlin streamed from L2 into the B registers),  dY = dropout_bwd(dHO),
+//   dXres_b = sum_h dHO_{b,h} = dout_b (sum_h Wlin[:, h]): this workgroup's D / H columns of it (H = 1: dHO itself)
+// which removes a GEMM launch, the head-sum / dropout kernel and 2 x B N H D floats of HBM traffic (glove:74-78 / 111-118).
+template <bool FUSE>
 __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c, const GemmGroup4 cg) {
   __shared__ __attribute__((aligned(16))) float lds[S_BWD_LDS];
   if (blockIdx.x >= c.B * c.H) {
@@ -419,8 +457,19 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
   float* __restrict__ Mg = c.dM + zoff;
   float* __restrict__ Qg = c.dP + zoff;
   const int r0 = rb * 32 + hf * 4, col = cb * 32 + r;
+  constexpr int S_LX = 260;             // row pitch of the 64 x 256 dout image (over the Pn and dPn images)
+  float* const Xs = Ps;
+  static_assert(64 * S_LX <= 2 * 64 * S_LP, "dout image");
+  const bool dd = FUSE && c.drop.snap != nullptr;
+  const uint64_t key = dd ? drop_key(c.drop) : 0;
 
   // ---- requests ------------------------------------------------------------------------------------------------
+  f32x4 dv[8];   // FUSE: dout_b
+  if constexpr (FUSE) {
+    const float* __restrict__ Dg = c.dout + (long)b * 64 * 256;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) dv[u] = *reinterpret_cast<const f32x4*>(Dg + (t + 512 * u) * 4);
+  }
   float y[8][2], gy[8][2], rv[8];   // row phase: rows wave + 8 u, columns lane + 64 kk
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
@@ -430,7 +479,7 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
     for (int kk = 0; kk < 2; ++kk) {
       const unsigned o = (unsigned)i * HD + S_GH + (unsigned)(lane + 64 * kk);
       y[u][kk] = Yg[o];
-      gy[u][kk] = Gy[o];
+      if constexpr (!FUSE) gy[u][kk] = Gy[o];
     }
   }
   f32x4 a[2], p1[4], p0[4], wd[8];   // the images of sub-layer 1; Pn_0, Wd_1, Y_0 and dY_0 are requested later
@@ -450,6 +499,72 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
 #pragma unroll
   for (int q = 0; q < 16; ++q) dacc[q] = 0.f;
 
+  if constexpr (FUSE) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = t + 512 * u;
+      *reinterpret_cast<f32x4*>(Xs + (idx >> 6) * S_LX + (idx & 63) * 4) = dv[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = t + 512 * u;
+      *reinterpret_cast<f32x4*>(As + (idx >> 4) * S_LA + (idx & 15) * 4) = a[u];
+    }
+    if (t < 64) Rs[t] = rs;
+    lds_barrier();
+    f32x16 ho[2];   // this wave's blocks of dHO_0 and dHO_1
+#pragma unroll
+    for (int q = 0; q < 16; ++q) ho[0][q] = 0.f, ho[1][q] = 0.f;
+    mma_lds_glb<256, 2>(ho, Xs + (rb * 32 + r) * S_LX + 4 * hf, c.flat + c.oWlin + (long)h * 256,
+                        (unsigned)(4 * hf) * HD + (unsigned)col, HD, S_GH);
+    float* __restrict__ Xr = c.dXres + (long)b * 64 * 256;
+    f32x16 xs[1];   // H == 8: rows (wave & 1), K quarter (wave >> 1) of this head's 32 columns of dXres
+    const int rb2 = wave & 1, kq = wave >> 1;
+    if (c.H == 1) {
+#pragma unroll
+      for (int l = 0; l < 2; ++l)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Xr[acc_row(r0, q) * 256 + l * S_GH + col] = ho[l][q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) xs[0][q] = 0.f;
+      mma_lds_glb<64, 1>(xs, Xs + (rb2 * 32 + r) * S_LX + kq * 64 + 4 * hf, c.Wsum, (unsigned)(kq * 64 + 4 * hf) * 256u + (unsigned)(h * 32 + r),
+                         256u, 0u);
+    }
+    lds_barrier();  // everybody is done with the dout image
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = t + 512 * u;
+      *reinterpret_cast<f32x4*>(Ps + (idx >> 5) * S_LP + (idx & 31) * 4) = p1[u];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {  // dY = dropout_bwd(dHO): sub-layer 1 to the row phase through LDS, sub-layer 0 stays here
+      const int row = acc_row(r0, q);
+      const long o = zoff + (long)((unsigned)row * HD + (unsigned)col);
+      float g1 = ho[1][q], g0 = ho[0][q];
+      if (dd) {
+        g1 = (rng_u32(key, (uint64_t)(o + S_GH)) >= c.drop.thresh) ? g1 * c.drop.scale : 0.f;
+        g0 = (rng_u32(key, (uint64_t)o) >= c.drop.thresh) ? g0 * c.drop.scale : 0.f;
+      }
+      Ds[row * S_LP + col] = g1;
+      gv[q] = g0;
+    }
+    if (c.H != 1 && kq > 0) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) Qs[(((kq - 1) * 2 + rb2) * 16 + q) * 64 + lane] = xs[0][q];
+    }
+    lds_barrier();
+    if (c.H != 1 && kq == 0) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        float v = xs[0][q];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v += Qs[((k * 2 + rb2) * 16 + q) * 64 + lane];
+        Xr[acc_row(rb2 * 32 + hf * 4, q) * 256 + h * 32 + r] = v;
+      }
+    }
+  }
+
   auto sublayer = [&](auto lt) __attribute__((always_inline)) {   // l is a compile-time constant: the two passes differ in what they read and hand on
     constexpr int l = decltype(lt)::value;
     const unsigned lo = (unsigned)l * S_GH;
@@ -461,7 +576,7 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const float yy = (l == 1) ? y[u][kk] : y0[u][kk];
-        const float gg = (l == 1) ? gy[u][kk] : Ds[i * S_LP + lane + 64 * kk];
+        const float gg = (l == 1 && !FUSE) ? gy[u][kk] : Ds[i * S_LP + lane + 64 * kk];
         const float g = yy > 0.f ? gg : 0.f;
         const float dm = g * rv[u];
         Mg[(unsigned)i * HD + lo + (unsigned)(lane + 64 * kk)] = dm;
@@ -471,7 +586,7 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
       const float tt = wave_sum(acc);
       if (lane == 0) Ts[i] = (l == 1) ? -rv[u] * tt : Ts[i] - rv[u] * tt;
     }
-    if constexpr (l == 1) {  // the images the products of this sub-layer read
+    if constexpr (l == 1 && !FUSE) {  // the images the products of this sub-layer read
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int idx = t + 512 * u;
@@ -520,9 +635,11 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
       for (int u = 0; u < 8; ++u)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) y0[u][kk] = Yg[(unsigned)(wave + 8 * u) * HD + (unsigned)(lane + 64 * kk)];
+      if constexpr (!FUSE) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q)  // dY_0 as it arrives (dropout_bwd(dHO_0) + residual)
-        gv[q] = Gy[(unsigned)acc_row(r0, q) * HD + (unsigned)col];
+        for (int q = 0; q < 16; ++q)  // dY_0 as it arrives (dropout_bwd(dHO_0))
+          gv[q] = Gy[(unsigned)acc_row(r0, q) * HD + (unsigned)col];
+      }
       lds_barrier();
       // dY_0 += dPn_1 Wd_1^T:  B[k][n] = Wd_1[n][k], this lane's column n is a row of the image
 #pragma unroll
@@ -567,10 +684,18 @@ static bool chain_small_ok(const GcnCtx& c, bool bwd) {
          (c.wd_off(1) % 4) == 0;
 }
 
+static bool chain_aligned(const GcnCtx& c, bool bwd);
+bool chain_bwd_fusable(const GcnCtx& c) {
+  static const bool on = [] { const char* e = getenv("GCGCN_CHAIN_FUSE"); return !(e && e[0] == '0'); }();
+  auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+  return on && chain_small_ok(c, true) && c.N == 64 && (c.H == 1 || c.H == 8) && al(c.A) && al(c.Pn) && al(c.Y) && al(c.dM) &&
+         al(c.dP) && al(c.dA) && al(c.flat + c.oWd);
+}
+
 static bool chain_aligned(const GcnCtx& c, bool bwd) {
   auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
   bool ok = c.N % 64 == 0 && c.gh % 64 == 0 && al(c.A) && al(c.flat + c.oWd) && al(c.Pn) && al(c.Y);
-  if (bwd) ok = ok && al(c.dYa) && al(c.dM) && al(c.dP) && al(c.dA);
+  if (bwd) ok = ok && (c.dout ? al(c.dout) && al(c.dXres) : al(c.dYa)) && al(c.dM) && al(c.dP) && al(c.dA);
   else ok = ok && al(c.G) && al(c.HO) && al(c.X);
   return ok;
 }
@@ -642,8 +767,12 @@ int gcn_chain_bwd(const GcnCtx& c, hipStream_t st, DeferQueue* carry) {
     if (rounds > 0 && halves && budget > 0) ng = gemm_take_deferred_pairs(carry, cg, &fl, budget);
   }
   dim3 grid(chain_grid(c, 2) + (unsigned)ng), block(64 * CW);
-  if (chain_aligned(c, true) && chain_small_ok(c, true))
-    GC_LAUNCH_TIMED("gcn_chain_bwd", fl, gcn_chain_s_bwd_kernel, grid, block, 0, st, c, cg);
+  if (c.dout) {  // the caller asked for the fused output-projection gradient (after chain_bwd_fusable said yes)
+    GC_REQUIRE(chain_aligned(c, true) && chain_bwd_fusable(c) && c.dXres && (c.H == 1 || c.Wsum), "gcn_chain_bwd: fused backward not available");
+    fl += 2.0 * c.B * c.N * c.D * c.D * (c.H + (c.H > 1 ? 1 : 0));
+    GC_LAUNCH_TIMED("gcn_chain_bwd", fl, gcn_chain_s_bwd_kernel<true>, grid, block, 0, st, c, cg);
+  } else if (chain_aligned(c, true) && chain_small_ok(c, true))
+    GC_LAUNCH_TIMED("gcn_chain_bwd", fl, gcn_chain_s_bwd_kernel<false>, grid, block, 0, st, c, cg);
   else if (chain_aligned(c, true)) GC_LAUNCH_TIMED("gcn_chain_bwd", fl, gcn_chain_bwd_kernel<true>, grid, block, 0, st, c, cg);
   else GC_LAUNCH_TIMED("gcn_chain_bwd", fl, gcn_chain_bwd_kernel<false>, grid, block, 0, st, c, cg);
   return check_launch("gcn_chain_bwd");

@@ -42,6 +42,12 @@ struct GcnCtx {
   float* dP;    // gradient of Pn_l
   float* dA;
   float* drow;  // gradient of the normaliser's row sum
+  // backward with the output projection's input gradient computed by the chain itself (chain.hip, fused kernels):
+  // dHO = dout Wlin per (document, head) instead of a launch of its own, dXres = sum_h dHO_h = dout (sum_h Wlin_h)
+  const float* dout;   // [B*N, D]   gradient of the block's output (padding rows zeroed, output dropout undone)
+  const float* Wsum;   // [D, D]     sum over heads of Wlin's column blocks (H > 1)
+  float* dXres;        // [B*N, D]
+  long oWlin;
   __host__ __device__ long wd_off(int l) const { return oWd + (long)gh * gh * l * (l - 1) / 2; }
 };
 
@@ -128,5 +134,6 @@ __host__ __device__ inline GemmArgs plan_bwd_dY(const GcnCtx& c, int l) {
 bool chain_can_carry(const EdgeRide& r);
 int gcn_chain_fwd(const GcnCtx& c, hipStream_t st);
 int gcn_chain_bwd(const GcnCtx& c, hipStream_t st, DeferQueue* carry = nullptr);
+bool chain_bwd_fusable(const GcnCtx& c);   // c.dout / c.dXres / c.Wsum may be used instead of c.dYa
 
 }  // namespace gc

@@ -454,8 +454,20 @@ __global__ __launch_bounds__(256) void node_score_bwd_kernel(const float* __rest
 
 // y[m, :] = dropout_bwd(x[m, :]) for real entities, 0 for padding rows (m = b * N + i, i >= n_valid[b]);
 // n_valid == NULL: no padding, drop.snap == NULL: no dropout
+// Trailing workgroups (blockIdx >= main_blocks): wsum[k, c] = sum_h wlin[k, h, c] for the fused chain backward (chain.hip).
 __global__ __launch_bounds__(256) void mask_rows_kernel(const float* __restrict__ x, float* __restrict__ y, long M, int D,
-                                                        int N, const int* __restrict__ n_valid, Drop drop) {
+                                                        int N, const int* __restrict__ n_valid, Drop drop, int main_blocks,
+                                                        const float* __restrict__ wlin, float* __restrict__ wsum, int H) {
+  if ((int)blockIdx.x >= main_blocks) {
+    const int e = (blockIdx.x - main_blocks) * 256 + threadIdx.x;
+    if (e < D * D) {
+      const int k = e / D, c = e - k * D;
+      float s = 0.f;
+      for (int h = 0; h < H; ++h) s += wlin[((long)k * H + h) * D + c];
+      wsum[e] = s;
+    }
+    return;
+  }
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= M * D) return;
   const long m = e / D;
@@ -628,9 +640,13 @@ int node_score_bwd(const float* ds, const float* uvc, const float* dXin, float* 
   hipLaunchKernelGGL(node_score_bwd_kernel, dim3(cdiv(M * D, 256)), dim3(256), 0, st, ds, uvc, dXin, dX, M, D);
   return check_launch("node_score_bwd");
 }
-int mask_rows(const float* x, float* y, long M, int D, int N, const int* n_valid, Drop drop, hipStream_t st) {
+int mask_rows(const float* x, float* y, long M, int D, int N, const int* n_valid, Drop drop, hipStream_t st, const float* wlin,
+              float* wsum, int H) {
   ProfScope ps("mask_rows", st);
-  hipLaunchKernelGGL(mask_rows_kernel, dim3(cdiv(M * D, 256)), dim3(256), 0, st, x, y, M, D, N, n_valid, drop);
+  const int main_blocks = x ? cdiv(M * D, 256) : 0, extra = wsum ? cdiv((long)D * D, 256) : 0;
+  if (main_blocks + extra == 0) return 0;
+  hipLaunchKernelGGL(mask_rows_kernel, dim3(main_blocks + extra), dim3(256), 0, st, x, y, M, D, N, n_valid, drop, main_blocks,
+                     wlin, wsum, H);
   return check_launch("mask_rows");
 }
 

@@ -35,7 +35,8 @@ int gat_dlogit(const float* P, const float* dA, const float* uvc, const float* d
 int node_score_fwd(const float* X, const float* uvc, float* s, long M, int D, hipStream_t st, void* rng_state = nullptr,
                    void* rng_snaps = nullptr, int rng_count = 0);
 int node_score_bwd(const float* ds, const float* uvc, const float* dXin, float* dX, long M, int D, hipStream_t st);
-int mask_rows(const float* x, float* y, long M, int D, int N, const int* n_valid, Drop drop, hipStream_t st);
+int mask_rows(const float* x, float* y, long M, int D, int N, const int* n_valid, Drop drop, hipStream_t st,
+              const float* wlin = nullptr, float* wsum = nullptr, int H = 0);   // x == NULL: only wsum = sum_h wlin[:, h, :]
 
 int edge_fwd(const float* E, const float* v, const int* n_valid, float* Ebar, const float* coladd, float* P, float* A,
              Drop drop, int B, int N, int D, hipStream_t st, const unsigned char* mask = nullptr);
