@@ -554,7 +554,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
   // that product, no head-sum / dropout kernel, dHO never in HBM.  Decided on the same context the chain will get.
   GcnCtx c = make_ctx(B, N, D, L, H, y, X, A, flat, n_valid, drop);
   c.Pn = const_cast<float*>(Pn), c.Y = const_cast<float*>(Y), c.rinv = const_cast<float*>(rinv);
-  c.dYa = dYa, c.dM = dM, c.dP = dP, c.dA = dA, c.drow = drow;
+  c.dYa = dYa, c.dM = dM, c.dP = dP, c.dA = dA, c.drow = drow, c.oWlin = y.oWlin;
   const bool fuse = use_chain() && chain_bwd_fusable(c) && (((uintptr_t)dXres) & 15) == 0 &&
                     (((uintptr_t)(n_valid || odrop.snap ? dout_m : dout)) & 15) == 0 && (long)M * HD >= (long)D * D;
   float* wsum = (fuse && H > 1) ? dYa : nullptr;   // dYa's buffer is free when the chain computes dHO itself

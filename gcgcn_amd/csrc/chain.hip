@@ -258,36 +258,70 @@ __device__ __forceinline__ void mma_lds_reg(f32x16& acc, const float* __restrict
   }
 }
 // NB accumulators sharing the A operand (LDS, k contiguous); the B operands come straight from global memory (weights, L2-hot:
-// B[k][n] at base[k * ldb + off + j * bstep], n contiguous across lanes), requested PF groups of 8 k ahead of their use.
+// B[k][n] at base[k * ldb + off + j * bstep], n contiguous across lanes) in batches of GB groups of 8 k: while one batch is
+// multiplied the next one is in flight.  The scheduling barriers keep the compiler from sinking the requests next to their
+// uses (it did: one group of lookahead, the matrix pipe idle 40 % of the time).
 template <int K, int NB>
 __device__ __forceinline__ void mma_lds_glb(f32x16 (&acc)[NB], const float* __restrict__ pa, const float* __restrict__ base,
                                             const unsigned off, const unsigned ldb, const unsigned bstep) {
-  constexpr int G = K / 8, PF = 4;
-  float bq[PF][NB][4];
+  constexpr int G = K / 8, GB = 4, NBT = G / GB;
+  static_assert(G % GB == 0, "K must be a multiple of 32");
+  float bq[2][GB][NB][4];
+  auto request = [&](const int bt, float (&dst)[GB][NB][4]) __attribute__((always_inline)) {
 #pragma unroll
-  for (int g = 0; g < PF; ++g)
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-#pragma unroll
-      for (int m = 0; m < 4; ++m) bq[g][j][m] = base[(unsigned)(8 * g + m) * ldb + off + j * bstep];
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(pa + 8 * g);
-    float bc[NB][4];
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-#pragma unroll
-      for (int m = 0; m < 4; ++m) bc[j][m] = bq[g % PF][j][m];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bc[j][m], acc[j], 0, 0, 0);
-    if (g + PF < G) {
+    for (int g = 0; g < GB; ++g)
 #pragma unroll
       for (int j = 0; j < NB; ++j)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) bq[g % PF][j][m] = base[(unsigned)(8 * (g + PF) + m) * ldb + off + j * bstep];
+        for (int m = 0; m < 4; ++m) dst[g][j][m] = base[(unsigned)(8 * (bt * GB + g) + m) * ldb + off + j * bstep];
+  };
+  request(0, bq[0]);
+#pragma unroll
+  for (int bt = 0; bt < NBT; ++bt) {
+    if (bt + 1 < NBT) request(bt + 1, bq[(bt + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < GB; ++g) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(pa + 8 * (bt * GB + g));
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bq[bt & 1][g][j][m], acc[j], 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// Four accumulators whose columns interleave: lane r owns columns 4 r .. 4 r + 3 of a 128-column range, accumulator j the
+// columns = j (mod 4).  One 16-byte global load per B row then feeds four MFMAs (and the results leave as 16-byte stores):
+// the vector memory pipe of a compute unit takes one wave instruction every ~16 cycles, 4-byte loads at one per MFMA
+// saturate it long before the matrix pipe (measured: 150 cycles per MFMA per wave).  base[k * ldb + off4 .. + 3], k < K.
+template <int K>
+__device__ __forceinline__ void mma_lds_glb4(f32x16 (&acc)[4], const float* __restrict__ pa, const float* __restrict__ base,
+                                             const unsigned off4, const unsigned ldb, const int hf) {
+  constexpr int G = K / 8, GB = 4, NBT = G / GB;
+  static_assert(G % GB == 0, "K must be a multiple of 32");
+  f32x4 bq[2][GB][4];
+  auto request = [&](const int bt, f32x4 (&dst)[GB][4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < GB; ++g)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        dst[g][m] = *reinterpret_cast<const f32x4*>(base + (unsigned)(8 * (bt * GB + g) + 4 * hf + m) * ldb + off4);
+  };
+  request(0, bq[0]);
+#pragma unroll
+  for (int bt = 0; bt < NBT; ++bt) {
+    if (bt + 1 < NBT) request(bt + 1, bq[(bt + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < GB; ++g) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(pa + 8 * (bt * GB + g));
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bq[bt & 1][g][m][j], acc[j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 // row of accumulator element q of the lane (its column is lane % 32): rows r0 + {0..3} + 8 * {0..3}, r0 = block row + 4 * (lane / 32)
@@ -443,7 +477,16 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
   float* const Qs = Ps + 64 * S_LP;     // dPn_1; at the end the K halves of dA meet here
   float* const Rs = Qs + 64 * S_LP;     // rinv
   float* const Ts = Rs + 64;            // gradient of the normaliser's row sums
-  const int z = blockIdx.x, b = z / c.H, h = z - b * c.H;
+  // Workgroups go to the eight XCDs round robin (blockIdx % 8).  With z = b H + h and H = 8 an XCD would run ONE head; give
+  // each XCD all heads of a few documents instead: the heads of a document share dout_b (and X_b, A's neighbours) in its L2.
+  int b, h;
+  if (c.H == 8 && (c.B & 7) == 0) {
+    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+    h = q & 7, b = x + 8 * (q >> 3);
+  } else {
+    b = blockIdx.x / c.H, h = blockIdx.x - b * c.H;
+  }
+  const int z = b * c.H + h;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, hf = lane >> 5;
   const int rb = wave & 1, cb = wave >> 1;             // block of a 64x128 result
   const int ab = wave & 3, kh = wave >> 2;             // block of dA (rows ab & 1, columns ab >> 1) and K half
@@ -471,17 +514,20 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
     for (int u = 0; u < 8; ++u) dv[u] = *reinterpret_cast<const f32x4*>(Dg + (t + 512 * u) * 4);
   }
   float y[8][2], gy[8][2], rv[8];   // row phase: rows wave + 8 u, columns lane + 64 kk
+  auto request_rows = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int i = wave + 8 * u;
-    rv[u] = Rg[i];
+    for (int u = 0; u < 8; ++u) {
+      const int i = wave + 8 * u;
+      rv[u] = Rg[i];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const unsigned o = (unsigned)i * HD + S_GH + (unsigned)(lane + 64 * kk);
-      y[u][kk] = Yg[o];
-      if constexpr (!FUSE) gy[u][kk] = Gy[o];
+      for (int kk = 0; kk < 2; ++kk) {
+        const unsigned o = (unsigned)i * HD + S_GH + (unsigned)(lane + 64 * kk);
+        y[u][kk] = Yg[o];
+        if constexpr (!FUSE) gy[u][kk] = Gy[o];
+      }
     }
-  }
+  };
+  if constexpr (!FUSE) request_rows();
   f32x4 a[2], p1[4], p0[4], wd[8];   // the images of sub-layer 1; Pn_0, Wd_1, Y_0 and dY_0 are requested later
   float y0[8][2], gv[16];
 #pragma unroll
@@ -489,11 +535,14 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
     const int idx = t + 512 * u;
     a[u] = *reinterpret_cast<const f32x4*>(Ag + (idx >> 4) * 64 + (idx & 15) * 4);
   }
+  auto request_pn1 = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int idx = t + 512 * u;
-    p1[u] = *reinterpret_cast<const f32x4*>(Pg + (unsigned)(idx >> 5) * HD + S_GH + (idx & 31) * 4);
-  }
+    for (int u = 0; u < 4; ++u) {
+      const int idx = t + 512 * u;
+      p1[u] = *reinterpret_cast<const f32x4*>(Pg + (unsigned)(idx >> 5) * HD + S_GH + (idx & 31) * 4);
+    }
+  };
+  if constexpr (!FUSE) request_pn1();
   const float rs = (t < 64) ? Rg[t] : 0.f;
   f32x16 dacc;     // this wave's K half of its dA block
 #pragma unroll
@@ -512,57 +561,77 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
     }
     if (t < 64) Rs[t] = rs;
     lds_barrier();
-    f32x16 ho[2];   // this wave's blocks of dHO_0 and dHO_1
+    // dHO_b = dout_b Wlin[:, h]: wave = (rows rb, sub-layer l2 = its 128 columns, K half k2), 4 interleaved accumulators
+    const int l2 = (wave >> 1) & 1, k2 = wave >> 2;
+    f32x16 ho[4];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) ho[0][q] = 0.f, ho[1][q] = 0.f;
-    mma_lds_glb<256, 2>(ho, Xs + (rb * 32 + r) * S_LX + 4 * hf, c.flat + c.oWlin + (long)h * 256,
-                        (unsigned)(4 * hf) * HD + (unsigned)col, HD, S_GH);
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) ho[j][q] = 0.f;
+    mma_lds_glb4<128>(ho, Xs + (rb * 32 + r) * S_LX + k2 * 128 + 4 * hf,
+                      c.flat + c.oWlin + (long)h * 256 + (long)k2 * 128 * c.HD, (unsigned)(l2 * S_GH + 4 * r), HD, hf);
+    request_rows();   // for the row phase and the images of sub-layer 1: they land while the products below finish
+    request_pn1();
     float* __restrict__ Xr = c.dXres + (long)b * 64 * 256;
     f32x16 xs[1];   // H == 8: rows (wave & 1), K quarter (wave >> 1) of this head's 32 columns of dXres
     const int rb2 = wave & 1, kq = wave >> 1;
-    if (c.H == 1) {
-#pragma unroll
-      for (int l = 0; l < 2; ++l)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) Xr[acc_row(r0, q) * 256 + l * S_GH + col] = ho[l][q];
-    } else {
+    if (c.H != 1) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) xs[0][q] = 0.f;
       mma_lds_glb<64, 1>(xs, Xs + (rb2 * 32 + r) * S_LX + kq * 64 + 4 * hf, c.Wsum, (unsigned)(kq * 64 + 4 * hf) * 256u + (unsigned)(h * 32 + r),
                          256u, 0u);
     }
-    lds_barrier();  // everybody is done with the dout image
+    lds_barrier();  // everybody is done with the dout image: the K halves meet in its place, dXres's K quarters in Ds
+    if (k2 == 1) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = t + 512 * u;
-      *reinterpret_cast<f32x4*>(Ps + (idx >> 5) * S_LP + (idx & 31) * 4) = p1[u];
-    }
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {  // dY = dropout_bwd(dHO): sub-layer 1 to the row phase through LDS, sub-layer 0 stays here
-      const int row = acc_row(r0, q);
-      const long o = zoff + (long)((unsigned)row * HD + (unsigned)col);
-      float g1 = ho[1][q], g0 = ho[0][q];
-      if (dd) {
-        g1 = (rng_u32(key, (uint64_t)(o + S_GH)) >= c.drop.thresh) ? g1 * c.drop.scale : 0.f;
-        g0 = (rng_u32(key, (uint64_t)o) >= c.drop.thresh) ? g0 * c.drop.scale : 0.f;
-      }
-      Ds[row * S_LP + col] = g1;
-      gv[q] = g0;
+        for (int q = 0; q < 16; ++q) Xs[(((wave & 3) * 4 + j) * 16 + q) * 64 + lane] = ho[j][q];
     }
     if (c.H != 1 && kq > 0) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) Qs[(((kq - 1) * 2 + rb2) * 16 + q) * 64 + lane] = xs[0][q];
+      for (int q = 0; q < 16; ++q) Ds[(((kq - 1) * 2 + rb2) * 16 + q) * 64 + lane] = xs[0][q];
     }
     lds_barrier();
+    if (k2 == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) ho[j][q] += Xs[(((wave & 3) * 4 + j) * 16 + q) * 64 + lane];
+    }
     if (c.H != 1 && kq == 0) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         float v = xs[0][q];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) v += Qs[((k * 2 + rb2) * 16 + q) * 64 + lane];
+        for (int k = 0; k < 3; ++k) v += Ds[((k * 2 + rb2) * 16 + q) * 64 + lane];
         Xr[acc_row(rb2 * 32 + hf * 4, q) * 256 + h * 32 + r] = v;
       }
     }
+    lds_barrier();  // the exchange areas are free
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = t + 512 * u;
+      *reinterpret_cast<f32x4*>(Ps + (idx >> 5) * S_LP + (idx & 31) * 4) = p1[u];
+    }
+    if (k2 == 0) {  // dY = dropout_bwd(dHO): images for the row phase (sub-layer 1) and for dY_0's accumulator start
+      float* const img = l2 ? Ds : Qs;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = acc_row(r0, q);
+        f32x4 g = {ho[0][q], ho[1][q], ho[2][q], ho[3][q]};
+        if (c.H == 1) *reinterpret_cast<f32x4*>(Xr + row * 256 + l2 * S_GH + 4 * r) = g;
+        if (dd) {
+          const long o = zoff + (long)((unsigned)row * HD + (unsigned)(l2 * S_GH + 4 * r));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) g[j] = (rng_u32(key, (uint64_t)(o + j)) >= c.drop.thresh) ? g[j] * c.drop.scale : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(img + row * S_LP + 4 * r) = g;
+      }
+    }
+    lds_barrier();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) gv[q] = Qs[acc_row(r0, q) * S_LP + col];
   }
 
   auto sublayer = [&](auto lt) __attribute__((always_inline)) {   // l is a compile-time constant: the two passes differ in what they read and hand on
@@ -689,7 +758,7 @@ bool chain_bwd_fusable(const GcnCtx& c) {
   static const bool on = [] { const char* e = getenv("GCGCN_CHAIN_FUSE"); return !(e && e[0] == '0'); }();
   auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
   return on && chain_small_ok(c, true) && c.N == 64 && (c.H == 1 || c.H == 8) && al(c.A) && al(c.Pn) && al(c.Y) && al(c.dM) &&
-         al(c.dP) && al(c.dA) && al(c.flat + c.oWd);
+         al(c.dP) && al(c.dA) && al(c.flat + c.oWd) && al(c.flat + c.oWlin) && c.HD % 4 == 0;
 }
 
 static bool chain_aligned(const GcnCtx& c, bool bwd) {
