@@ -568,8 +568,12 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
   bool col_later = false, col_pending = false;
   if (fuse) {  // dWlin = dout^T HO is parked or joins the launch after the chain; dblin's column sums ride there too
     c.dout = dout, c.dXres = dXres, c.Wsum = wsum, c.oWlin = y.oWlin;
-    if (scratch) cr.X = dout, cr.out = dflat + y.oblin, cr.part = scratch + wse, cr.R = M, cr.ld = D, cr.C = D, col_pending = true;
-    else GC_TRY(colsum(dout, nullptr, dflat + y.oblin, M, D, D, 1, 0, 0, 0, 0, scratch, st));
+    if (scratch) {
+      cr.X = dout, cr.out = dflat + y.oblin, cr.part = scratch + wse, cr.R = M, cr.ld = D, cr.C = D, col_pending = true;
+      if (2 * B <= COL_RIDE_SLICES) c.colpart = cr.part, cr.ready_slices = 2 * B;  // stage 1 inside the chain (it holds dout_b in LDS)
+    } else {
+      GC_TRY(colsum(dout, nullptr, dflat + y.oblin, M, D, D, 1, 0, 0, 0, 0, scratch, st));
+    }
   } else {
     {  // one launch: dHO = dout Wlin  and  dWlin = dout^T HO
       GemmArgs gs[2];

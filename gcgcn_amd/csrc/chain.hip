@@ -561,6 +561,13 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
     }
     if (t < 64) Rs[t] = rs;
     lds_barrier();
+    if (c.colpart && h == 0) {  // the output bias gradient's column sums of this document: rows 0-31 and 32-63
+      const int cc = t & 255, half = t >> 8;
+      float sacc = 0.f;
+#pragma unroll 8
+      for (int i = 0; i < 32; ++i) sacc += Xs[(half * 32 + i) * S_LX + cc];
+      c.colpart[(long)(2 * b + half) * 256 + cc] = sacc;
+    }
     // dHO_b = dout_b Wlin[:, h]: wave = (rows rb, sub-layer l2 = its 128 columns, K half k2), 4 interleaved accumulators
     const int l2 = (wave >> 1) & 1, k2 = wave >> 2;
     f32x16 ho[4];

@@ -47,6 +47,7 @@ struct GcnCtx {
   const float* dout;   // [B*N, D]   gradient of the block's output (padding rows zeroed, output dropout undone)
   const float* Wsum;   // [D, D]     sum over heads of Wlin's column blocks (H > 1)
   float* dXres;        // [B*N, D]
+  float* colpart;      // [2 B, D] or NULL: column sums of dout over each half of a document's rows (bias gradient, stage 1)
   long oWlin;
   __host__ __device__ long wd_off(int l) const { return oWd + (long)gh * gh * l * (l - 1) / 2; }
 };

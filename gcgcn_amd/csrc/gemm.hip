@@ -71,7 +71,17 @@ __global__ __launch_bounds__(256, 4) void gemm_group_kernel(const GemmGroup gg) 
   __shared__ __attribute__((aligned(16))) float lds[lds_floats<1, 1, true, true>()];
   const int tiles = gg.tile_begin[gg.nprob];
   if ((int)blockIdx.x >= tiles) {  // past the GEMM tiles (dispatched last, round-robin over the XCDs): the riding column sum
-    col_ride_stage1(gg.col, blockIdx.x - tiles, lds);
+    const ColRide& cr = gg.col;
+    if (cr.ready_slices > 0) {  // partial sums from an earlier launch: out[c] = their sum, slices in order
+      const int c = (blockIdx.x - tiles) * 256 + threadIdx.x;
+      if (c < cr.C) {
+        float s = 0.f;
+        for (int q = 0; q < cr.ready_slices; ++q) s += cr.part[(long)q * cr.C + c];
+        cr.out[c] = s;
+      }
+      return;
+    }
+    col_ride_stage1(cr, blockIdx.x - tiles, lds);
     return;
   }
   gemm_group_block(gg, blockIdx.x, lds);
@@ -303,16 +313,22 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* 
     flops += 2.0 * g.M * g.N * g.K * nb;
     gg.p[gg.nprob++] = g;
   }
-  const bool ride = col && col->X && col->C > 0 && col->R > 0;
-  if (ride) GC_REQUIRE(col->out && col->part, "gemm_group: column ride without out / part");
-  if (gg.nprob == 0)  // nothing to ride on
+  const bool ride2 = col && col->ready_slices > 0 && col->C > 0;
+  const bool ride = !ride2 && col && col->X && col->C > 0 && col->R > 0;
+  if (ride || ride2) GC_REQUIRE(col->out && col->part, "gemm_group: column ride without out / part");
+  if (gg.nprob == 0) {  // nothing to ride on
+    if (ride2) return colsum(col->part, nullptr, col->out, col->ready_slices, col->C, col->C, 1, 0, 0, 0, 0, nullptr, stream);
     return ride ? colsum(col->X, nullptr, col->out, col->R, col->C, col->ld, 1, 0, 0, 0, 0, col->part, stream) : 0;
+  }
   gg.tile_begin[gg.nprob] = tiles;
   gg.red_begin[gg.nprob] = reds;
   int col1 = 0, col2 = 0;
   if (ride) {
     gg.col = *col;
     col1 = cdiv(col->C, 64) * COL_RIDE_SLICES, col2 = cdiv(col->C, 256);
+  } else if (ride2) {
+    gg.col = *col;
+    col1 = cdiv(col->C, 256);
   }
   GC_LAUNCH_TIMED("gemm_group", flops, gemm_group_kernel, dim3(tiles + col1), dim3(256), 0, stream, gg);
   if (int e = check_launch("gemm_group")) return e;

@@ -73,6 +73,8 @@ struct ColRide {
   float* part = nullptr;
   long R = 0, ld = 0;
   int C = 0;
+  int ready_slices = 0;  // > 0: part[ready_slices][C] was filled by an earlier launch (X unused); only stage 2 rides, in the
+                         // trailing workgroups of the group launch itself
 };
 
 // Up to NP independent problems carried by one launch.
