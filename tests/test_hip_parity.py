@@ -319,9 +319,12 @@ def test_batched_matches_per_doc_oracle(gpu_device, B, N, D, L, H):
     _check_stack_param_grads(hops, sdl)
 
 
-def test_ragged_batch_matches_truncated_docs(gpu_device):
-    B, N, D, L, H = 4, 32, 64, 2, 4
-    nv = torch.tensor([32, 7, 19, 2])
+@pytest.mark.parametrize("B,N,D,L,H,nv", [(4, 32, 64, 2, 4, [32, 7, 19, 2]),
+                                          # cfg 2 document shape: the LDS-resident chain kernels and the fused output-
+                                          # projection backward on a ragged batch (B % 8 == 0: XCD-aware document order)
+                                          (8, 64, 256, 2, 8, [64, 7, 19, 2, 64, 33, 1, 50])])
+def test_ragged_batch_matches_truncated_docs(gpu_device, B, N, D, L, H, nv):
+    nv = torch.tensor(nv)
     sd = O.init_stack_params(D, L, H, seed=11)
     x, e1, e2, adj = O.synth_docs(B, N, D, seed=9)
     for b in range(B):                                     # padding rows of X must be zero (gcgcn.h)
@@ -345,9 +348,7 @@ def test_ragged_batch_matches_truncated_docs(gpu_device):
         if n < N:
             assert e1g.grad[b, n:].abs().max().item() == 0 and e1g.grad[b, :, n:].abs().max().item() == 0
             assert e2g.grad[b, n:].abs().max().item() == 0 and e2g.grad[b, :, n:].abs().max().item() == 0
-    ref_grads = {k: v.grad for k, v in sdl.items() if v.grad is not None}
-    for k, gk in hops.graphcnn[1].named_grads().items():
-        torch.testing.assert_close(gk.cpu(), ref_grads["graphcnn.1." + k], rtol=1e-3, atol=2e-4)
+    _check_stack_param_grads(hops, sdl)
 
 
 @pytest.mark.parametrize("B,N,D,L,H", [(2, 16, 32, 2, 4),        # guarded (ragged-shape) kernel instantiations
