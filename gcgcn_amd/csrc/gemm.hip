@@ -74,9 +74,15 @@ __global__ __launch_bounds__(256, 4) void gemm_group_kernel(const GemmGroup gg) 
     const ColRide& cr = gg.col;
     if (cr.ready_slices > 0) {  // partial sums from an earlier launch: out[c] = their sum, slices in order
       const int c = (blockIdx.x - tiles) * 256 + threadIdx.x;
-      if (c < cr.C) {
+      if (c < cr.C) {  // 16 independent loads in flight, summed in slice order
         float s = 0.f;
-        for (int q = 0; q < cr.ready_slices; ++q) s += cr.part[(long)q * cr.C + c];
+        for (int q0 = 0; q0 < cr.ready_slices; q0 += 16) {
+          float v[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) v[u] = cr.part[(long)min(q0 + u, cr.ready_slices - 1) * cr.C + c];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) s += (q0 + u < cr.ready_slices) ? v[u] : 0.f;
+        }
         cr.out[c] = s;
       }
       return;
