@@ -1,3 +1,5 @@
+# One gpurun call for the end-of-round evidence: GPU test suite, bench lines of every config, rocprofv3 kernel stats and the
+# per-dispatch timeline of the default bench command (outputs under gpurun_out/; copy what is judged into profiles/).
 set -e
 R=$GRAFT_REPO_ROOT
 cd $R
