@@ -293,11 +293,18 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
 #pragma unroll
         for (int j = 0; j < TN; ++j) b[n][j] = bs[(kk + 2) * LDB + j * 32];
       }
+      // Pin the read-ahead in front of the MFMAs it overlaps with.  Left to itself the compiler folds the register double
+      // buffer away and sinks each pair of operand reads next to its use (read, wait, two MFMAs, read, ...): other waves
+      // fill those waits at four waves per SIMD, but tiles that ride in other kernels (edge_bwd_carry, the chain launches)
+      // and launches of few workgroups run at two or fewer.  Measured: edge_bwd_carry 104 -> 98 us, cfg 3 -1..3 %, cfg 5
+      // -1 %, classifier head -0.8 %, no launch slower.
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   for (int kt = 0; kt < nk; kt += 2) {
