@@ -463,7 +463,13 @@ __global__ __launch_bounds__(256) void mask_rows_kernel(const float* __restrict_
     if (e < D * D) {
       const int k = e / D, c = e - k * D;
       float s = 0.f;
-      for (int h = 0; h < H; ++h) s += wlin[((long)k * H + h) * D + c];
+      for (int h0 = 0; h0 < H; h0 += 8) {  // eight heads in flight, summed in head order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = wlin[((long)k * H + min(h0 + u, H - 1)) * D + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (h0 + u < H) ? v[u] : 0.f;
+      }
       wsum[e] = s;
     }
     return;
