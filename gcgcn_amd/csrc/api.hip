@@ -555,25 +555,24 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
   GcnCtx c = make_ctx(B, N, D, L, H, y, X, A, flat, n_valid, drop);
   c.Pn = const_cast<float*>(Pn), c.Y = const_cast<float*>(Y), c.rinv = const_cast<float*>(rinv);
   c.dYa = dYa, c.dM = dM, c.dP = dP, c.dA = dA, c.drow = drow, c.oWlin = y.oWlin;
-  const bool fuse = use_chain() && chain_bwd_fusable(c) && (((uintptr_t)dXres) & 15) == 0 &&
-                    (((uintptr_t)(n_valid || odrop.snap ? dout_m : dout)) & 15) == 0 && (long)M * HD >= (long)D * D;
+  const bool fuse = use_chain() && scratch && chain_bwd_fusable(c) && (((uintptr_t)dXres) & 15) == 0 &&
+                    (((uintptr_t)dout) & 15) == 0 && (((uintptr_t)dout_m) & 15) == 0 && (long)M * HD >= (long)D * D;
   float* wsum = (fuse && H > 1) ? dYa : nullptr;   // dYa's buffer is free when the chain computes dHO itself
-  if (n_valid || odrop.snap) {  // gradients arriving on padding rows are ignored; back through the output dropout
-    GC_TRY(mask_rows(dout, dout_m, M, D, N, n_valid, odrop, st, flat + y.oWlin, wsum, H));  // + sum_h Wlin_h in trailing workgroups
+  const float* dout_raw = dout;
+  if (fuse) {  // the chain masks / un-drops dout while staging it (and writes dout_m back for dWlin); only sum_h Wlin_h is left
+    if (wsum) GC_TRY(mask_rows(nullptr, nullptr, M, D, N, nullptr, odrop, st, flat + y.oWlin, wsum, H));
+    if (n_valid || odrop.snap) dout = dout_m;
+  } else if (n_valid || odrop.snap) {  // gradients arriving on padding rows are ignored; back through the output dropout
+    GC_TRY(mask_rows(dout, dout_m, M, D, N, n_valid, odrop, st));
     dout = dout_m;
-  } else if (wsum) {
-    GC_TRY(mask_rows(nullptr, nullptr, M, D, N, nullptr, odrop, st, flat + y.oWlin, wsum, H));
   }
   ColRide cr;
   bool col_later = false, col_pending = false;
   if (fuse) {  // dWlin = dout^T HO is parked or joins the launch after the chain; dblin's column sums ride there too
-    c.dout = dout, c.dXres = dXres, c.Wsum = wsum, c.oWlin = y.oWlin;
-    if (scratch) {
-      cr.X = dout, cr.out = dflat + y.oblin, cr.part = scratch + wse, cr.R = M, cr.ld = D, cr.C = D, col_pending = true;
-      if (2 * B <= COL_RIDE_SLICES) c.colpart = cr.part, cr.ready_slices = 2 * B;  // stage 1 inside the chain (it holds dout_b in LDS)
-    } else {
-      GC_TRY(colsum(dout, nullptr, dflat + y.oblin, M, D, D, 1, 0, 0, 0, 0, scratch, st));
-    }
+    c.dout = dout_raw, c.dXres = dXres, c.Wsum = wsum, c.oWlin = y.oWlin;
+    if (dout != dout_raw) c.dout_m = dout_m, c.odrop = odrop;   // c.n_valid is set
+    cr.X = dout, cr.out = dflat + y.oblin, cr.part = scratch + wse, cr.R = M, cr.ld = D, cr.C = D, col_pending = true;
+    if (2 * B <= COL_RIDE_SLICES) c.colpart = cr.part, cr.ready_slices = 2 * B;  // stage 1 inside the chain (it holds dout_b in LDS)
   } else {
     {  // one launch: dHO = dout Wlin  and  dWlin = dout^T HO
       GemmArgs gs[2];

@@ -512,6 +512,24 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
     const float* __restrict__ Dg = c.dout + (long)b * 64 * 256;
 #pragma unroll
     for (int u = 0; u < 8; ++u) dv[u] = *reinterpret_cast<const f32x4*>(Dg + (t + 512 * u) * 4);
+    if (c.dout_m) {  // padding rows get no gradient; back through the hop's output dropout (glove:341) -- was a launch of its own
+      const int nvb = c.n_valid ? c.n_valid[b] : 64;
+      const bool od = c.odrop.snap != nullptr;
+      const uint64_t okey = od ? drop_key(c.odrop) : 0;
+      float* __restrict__ Dm = c.dout_m + (long)b * 64 * 256;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = (t + 512 * u) * 4;   // element of the document's [64, 256] slice: row e / 256
+        const bool keep = (e >> 8) < nvb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = keep ? dv[u][j] : 0.f;
+          if (od) v = (rng_u32(okey, (uint64_t)((long)b * 64 * 256 + e + j)) >= c.odrop.thresh) ? v * c.odrop.scale : 0.f;
+          dv[u][j] = v;
+        }
+        if (h == 0) *reinterpret_cast<f32x4*>(Dm + e) = dv[u];
+      }
+    }
   }
   float y[8][2], gy[8][2], rv[8];   // row phase: rows wave + 8 u, columns lane + 64 kk
   auto request_rows = [&]() __attribute__((always_inline)) {

@@ -44,7 +44,10 @@ struct GcnCtx {
   float* drow;  // gradient of the normaliser's row sum
   // backward with the output projection's input gradient computed by the chain itself (chain.hip, fused kernels):
   // dHO = dout Wlin per (document, head) instead of a launch of its own, dXres = sum_h dHO_h = dout (sum_h Wlin_h)
-  const float* dout;   // [B*N, D]   gradient of the block's output (padding rows zeroed, output dropout undone)
+  const float* dout;   // [B*N, D]   gradient of the block's output; with dout_m set: as it arrives, the chain zeroes the
+                       //            padding rows (n_valid) and undoes the output dropout (odrop) while it stages the rows
+  float* dout_m;       // [B*N, D] or NULL: the masked gradient, written back for the products that need it later (dWlin)
+  Drop odrop;
   const float* Wsum;   // [D, D]     sum over heads of Wlin's column blocks (H > 1)
   float* dXres;        // [B*N, D]
   float* colpart;      // [2 B, D] or NULL: column sums of dout over each half of a document's rows (bias gradient, stage 1)
