@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GCGCN_LIB=<path> loads another build of the same ABI (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("GCGCN_LIB") or os.path.join(_HERE, "lib", "libgcgcn_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 SALT_GAT = 0x47415431
 SALT_MHA = 0x4D484131
@@ -54,8 +54,8 @@ SIGNATURES = {
     "gcgcn_mha_bwd": (I, [I, I, I, I, P, P, P, F, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_gcn_layout": (I, [I, I, I, P]),
     "gcgcn_gcn_scratch": (L, [I, I, I, I]),
-    "gcgcn_gcn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, F, P, P, P, P, P, P, P, P, P]),
-    "gcgcn_gcn_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_gcn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, F, P, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_gcn_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_defer_create": (P, []),
     "gcgcn_defer_destroy": (None, [P]),
     "gcgcn_defer_count": (I, [P]),

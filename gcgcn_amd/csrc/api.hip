@@ -149,7 +149,7 @@ using namespace gc;
 
 extern "C" {
 
-int gcgcn_version(void) { return 2; }
+int gcgcn_version(void) { return 3; }
 const char* gcgcn_last_error(void) { return g_err; }
 
 int gcgcn_set_option(const char* name, int value) {
@@ -457,7 +457,7 @@ int gcgcn_gcn_layout(int D, int L, int H, int64_t* o) {
 
 int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float* Ebar, const float* A,
                   const int32_t* n_valid, const float* flat, const void* rng_snap, float p, const void* out_rng_snap,
-                  float out_p, float* out, float* Pn, float* Y, float* HO, float* rinv, float* G, float* scratch,
+                  float out_p, float* out, float* Pn, float* Y, float* HO, float* rinv, float* G, float* wsum, float* scratch,
                   const gcgcn_edge_ride* ride, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("gcn_fwd", B, N, D, L, H));
@@ -482,7 +482,9 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
       g.C = q ? G : Pn, g.ldc = HD;
       g.M = (int)M, g.N = (int)HD, g.K = D;
     }
-    GC_TRY(gemm_group(gs, 2, st));
+    ColRide hs;  // wsum = sum_h Wlin[:, h, :] (a by-product for gcgcn_gcn_bwd) in trailing workgroups of this launch
+    if (wsum && H > 1) hs.X = flat + y.oWlin, hs.out = wsum, hs.R = H, hs.ld = D, hs.C = D * D, hs.ready_slices = -1;
+    GC_TRY(gemm_group(gs, 2, st, hs.X ? &hs : nullptr));
   }
   {  // the dependent per-(doc, head) sequence: normaliser, then per sub-layer dense connection + aggregation
     GcnCtx c = make_ctx(B, N, D, L, H, y, X, A, flat, n_valid, drop);
@@ -526,8 +528,8 @@ int64_t gcgcn_gcn_scratch(int B, int N, int D, int H) { return scratch_elems(B, 
 
 int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float* Ebar, const float* A,
                   const int32_t* n_valid, const float* flat, const void* rng_snap, float p, const void* out_rng_snap,
-                  float out_p, const float* Pn, const float* Y, const float* HO, const float* rinv, const float* dout,
-                  float* dX, float* dEbar,
+                  float out_p, const float* Pn, const float* Y, const float* HO, const float* rinv, const float* wsum_fwd,
+                  const float* dout, float* dX, float* dEbar,
                   float* dA, float* dflat, float* W1, float* W2, float* W3, float* drow, float* dXres, float* dout_m,
                   float* scratch, const gcgcn_edge_ride* ride, void* defer_queue, void* stream) {
   DeferQueue* dq = (DeferQueue*)defer_queue;
@@ -557,10 +559,11 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
   c.dYa = dYa, c.dM = dM, c.dP = dP, c.dA = dA, c.drow = drow, c.oWlin = y.oWlin;
   const bool fuse = use_chain() && scratch && chain_bwd_fusable(c) && (((uintptr_t)dXres) & 15) == 0 &&
                     (((uintptr_t)dout) & 15) == 0 && (((uintptr_t)dout_m) & 15) == 0 && (long)M * HD >= (long)D * D;
-  float* wsum = (fuse && H > 1) ? dYa : nullptr;   // dYa's buffer is free when the chain computes dHO itself
+  // sum_h Wlin_h: from the forward call if it left one, else summed here into dYa's buffer (free when the chain computes dHO)
+  const float* wsum = (fuse && H > 1) ? (wsum_fwd ? wsum_fwd : dYa) : nullptr;
   const float* dout_raw = dout;
   if (fuse) {  // the chain masks / un-drops dout while staging it (and writes dout_m back for dWlin); only sum_h Wlin_h is left
-    if (wsum) GC_TRY(mask_rows(nullptr, nullptr, M, D, N, nullptr, odrop, st, flat + y.oWlin, wsum, H));
+    if (wsum && !wsum_fwd) GC_TRY(mask_rows(nullptr, nullptr, M, D, N, nullptr, odrop, st, flat + y.oWlin, dYa, H));
     if (n_valid || odrop.snap) dout = dout_m;
   } else if (n_valid || odrop.snap) {  // gradients arriving on padding rows are ignored; back through the output dropout
     GC_TRY(mask_rows(dout, dout_m, M, D, N, n_valid, odrop, st));

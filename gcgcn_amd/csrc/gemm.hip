@@ -72,6 +72,22 @@ __global__ __launch_bounds__(256, 4) void gemm_group_kernel(const GemmGroup gg) 
   const int tiles = gg.tile_begin[gg.nprob];
   if ((int)blockIdx.x >= tiles) {  // past the GEMM tiles (dispatched last, round-robin over the XCDs): the riding column sum
     const ColRide& cr = gg.col;
+    if (cr.ready_slices < 0) {  // sum over heads (sum_h Wlin[:, h, :] for the fused chain backward), eight loads in flight
+      const int e = (blockIdx.x - tiles) * 256 + threadIdx.x;
+      if (e < cr.C) {
+        const int ld = (int)cr.ld, H = (int)cr.R, k = e / ld, c = e - k * ld;
+        float s = 0.f;
+        for (int h0 = 0; h0 < H; h0 += 8) {
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = cr.X[((long)k * H + min(h0 + u, H - 1)) * ld + c];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) s += (h0 + u < H) ? v[u] : 0.f;
+        }
+        cr.out[e] = s;
+      }
+      return;
+    }
     if (cr.ready_slices > 0) {  // partial sums from an earlier launch: out[c] = their sum, slices in order
       const int c = (blockIdx.x - tiles) * 256 + threadIdx.x;
       if (c < cr.C) {  // 16 independent loads in flight, summed in slice order
@@ -319,10 +335,13 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* 
     flops += 2.0 * g.M * g.N * g.K * nb;
     gg.p[gg.nprob++] = g;
   }
+  const bool ride3 = col && col->ready_slices < 0 && col->C > 0;   // head sum: no partials, no second stage
   const bool ride2 = col && col->ready_slices > 0 && col->C > 0;
-  const bool ride = !ride2 && col && col->X && col->C > 0 && col->R > 0;
+  const bool ride = !ride2 && !ride3 && col && col->X && col->C > 0 && col->R > 0;
   if (ride || ride2) GC_REQUIRE(col->out && col->part, "gemm_group: column ride without out / part");
+  if (ride3) GC_REQUIRE(col->X && col->out && col->R > 0 && col->ld > 0 && col->C == col->ld * col->ld, "gemm_group: bad head sum");
   if (gg.nprob == 0) {  // nothing to ride on
+    if (ride3) return mask_rows(nullptr, nullptr, 0, (int)col->ld, 1, nullptr, make_drop(nullptr, 0, 0.f), stream, col->X, col->out, (int)col->R);
     if (ride2) return colsum(col->part, nullptr, col->out, col->ready_slices, col->C, col->C, 1, 0, 0, 0, 0, nullptr, stream);
     return ride ? colsum(col->X, nullptr, col->out, col->R, col->C, col->ld, 1, 0, 0, 0, 0, col->part, stream) : 0;
   }
@@ -332,7 +351,7 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* 
   if (ride) {
     gg.col = *col;
     col1 = cdiv(col->C, 64) * COL_RIDE_SLICES, col2 = cdiv(col->C, 256);
-  } else if (ride2) {
+  } else if (ride2 || ride3) {
     gg.col = *col;
     col1 = cdiv(col->C, 256);
   }

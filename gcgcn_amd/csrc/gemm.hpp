@@ -75,6 +75,8 @@ struct ColRide {
   int C = 0;
   int ready_slices = 0;  // > 0: part[ready_slices][C] was filled by an earlier launch (X unused); only stage 2 rides, in the
                          // trailing workgroups of the group launch itself
+                         // < 0: not a column sum but a sum over R interleaved blocks (heads) of ld columns, in trailing
+                         // workgroups of the launch: out[k * ld + c] = sum_{h < R} X[(k * R + h) * ld + c], k * ld + c < C
 };
 
 // Up to NP independent problems carried by one launch.

@@ -356,6 +356,11 @@ def _ride(inp, n_valid, out, B, N, D):
     return r, ctypes.cast(ctypes.pointer(r), ctypes.c_void_p)
 
 
+# The sum over heads of the output projection (gcgcn_gcn_fwd's wsum) rides in the forward call and is kept for backward;
+# False: backward sums it itself in a small launch (what a caller of the C ABI that passes NULL gets).  A/B and test switch.
+head_sum_in_forward = True
+
+
 class GcnFn(torch.autograd.Function):
     """(X[B,N,D], Ebar[B,N,D], A[B,H,N,N], flat[, E_next[B,N,N,D]]) -> out[B,N,D][, mean_j E_next].
     GraphConvolution.forward (H = 1) / MultiGraphConvolution.forward, GCGCN_glove.py:63-80 / 97-120.  The optional
@@ -373,15 +378,19 @@ class GcnFn(torch.autograd.Function):
         HO = torch.empty(B, N, HD, device=dev)
         rinv = torch.empty(B, H, N, device=dev)
         G = torch.empty(B, N, HD, device=dev)
+        # sum over heads of the output projection's column blocks: a by-product of the first launch, used by backward
+        wsum = torch.empty(D, D, device=dev) if (H > 1 and head_sum_in_forward and any(ctx.needs_input_grad[:4])) else None
         scratch = torch.empty(max(_lib.lib().gcgcn_gcn_scratch(B, N, D, H), 1), device=dev)
         ebar_next, ride, ride_p = None, None, None
         if e_next is not None:
             ebar_next = torch.empty(e_next.shape[0], e_next.shape[1], e_next.shape[3], device=dev)
             ride, ride_p = _ride(e_next, n_valid, ebar_next, *ebar_next.shape)
         call("gcgcn_gcn_fwd", B, N, D, L, H, _p(x), _p(ebar), _p(adj), _p(n_valid), _p(flat), _p(snap), float(p),
-             _p(out_snap), float(out_p), _p(out), _p(Pn), _p(Y), _p(HO), _p(rinv), _p(G), _p(scratch), ride_p, _stream())
+             _p(out_snap), float(out_p), _p(out), _p(Pn), _p(Y), _p(HO), _p(rinv), _p(G), _p(wsum), _p(scratch), ride_p,
+             _stream())
         del ride
         ctx.save_for_backward(x, ebar, adj, flat, Pn, Y, HO, rinv)
+        ctx.wsum = wsum
         ctx.n_valid, ctx.L, ctx.H, ctx.p, ctx.snap = n_valid, L, H, float(p), snap
         ctx.out_p, ctx.out_snap = float(out_p), out_snap
         ctx.flat_leaf = flat if flat.is_leaf else None      # to see in backward whether .grad will be installed or added to
@@ -413,7 +422,7 @@ class GcnFn(torch.autograd.Function):
             ride, ride_p = _ride(debar_next, ctx.n_valid, dE_next, *debar_next.shape)
         bp = _pass_for_parking(ctx, 3)
         call("gcgcn_gcn_bwd", B, N, D, L, H, _p(x), _p(ebar), _p(adj), _p(ctx.n_valid), _p(flat), _p(ctx.snap),
-             ctx.p, _p(ctx.out_snap), ctx.out_p, _p(Pn), _p(Y), _p(HO), _p(rinv), _p(dout), _p(dX), _p(dEbar), _p(dA),
+             ctx.p, _p(ctx.out_snap), ctx.out_p, _p(Pn), _p(Y), _p(HO), _p(rinv), _p(ctx.wsum), _p(dout), _p(dX), _p(dEbar), _p(dA),
              _p(dflat), _p(W1), _p(W2), _p(W3), _p(drow), _p(dXres), _p(dout_m), _p(scratch), ride_p,
              None if bp is None else bp.queue, _stream())
         del ride

@@ -154,18 +154,20 @@ typedef struct gcgcn_edge_ride {
 } gcgcn_edge_ride;
 /* out_rng_snap / out_p: the hop's output dropout x <- dropout(block(x)) (glove:341, site GCGCN_SALT_GLUE) applied
  * in the epilogue of the block's last product; NULL / 0 = the plain block output.  gcgcn_gcn_bwd given the same
- * pair takes dout = gradient of the DROPPED output. */
+ * pair takes dout = gradient of the DROPPED output.
+ * wsum[D,D] (may be NULL; H > 1 only): sum over heads of linear_layer.weight's column blocks, a function of the parameters
+ * alone that rides in this call's first launch; gcgcn_gcn_bwd given the same buffer skips the launch that would sum it. */
 int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float* Ebar, const float* A,
                   const int32_t* n_valid, const float* flat, const void* rng_snap, float p, const void* out_rng_snap,
-                  float out_p, float* out, float* Pn, float* Y, float* HO, float* rinv, float* G, float* scratch,
+                  float out_p, float* out, float* Pn, float* Y, float* HO, float* rinv, float* G, float* wsum, float* scratch,
                   const gcgcn_edge_ride* ride, void* stream);
 /* backward.  dout[B,N,D] -> dX, dEbar [B,N,D], dA[B,H,N,N], dflat.
  * Workspace: W1, W2, W3 (each [B,N,H*D]), drow[B,H,N], dXres[B,N,D], dout_m[B,N,D] (only used
  * when n_valid != NULL or out_rng_snap != NULL), scratch[gcgcn_gcn_scratch]. */
 int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float* Ebar, const float* A,
                   const int32_t* n_valid, const float* flat, const void* rng_snap, float p, const void* out_rng_snap,
-                  float out_p, const float* Pn, const float* Y, const float* HO, const float* rinv, const float* dout,
-                  float* dX, float* dEbar,
+                  float out_p, const float* Pn, const float* Y, const float* HO, const float* rinv, const float* wsum,
+                  const float* dout, float* dX, float* dEbar,
                   float* dA, float* dflat, float* W1, float* W2, float* W3, float* drow, float* dXres, float* dout_m,
                   float* scratch, const gcgcn_edge_ride* ride, void* defer_queue, void* stream);
 /* defer_queue != NULL: the block's weight-gradient products (dWlin, dWnX, dWe, dWd: nobody needs them before the end

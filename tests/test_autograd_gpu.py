@@ -199,3 +199,25 @@ def test_backward_from_another_thread(gpu_device, setup):
     t.join()
     assert not err, err
     _same(_grads(hops), want)
+
+
+def test_head_sum_from_forward_or_backward(gpu_device):
+    """gcgcn_gcn_fwd's by-product wsum (sum over heads of the output projection, used by the fused chain backward) against
+    the same sum computed inside gcgcn_gcn_bwd when the caller kept none: identical gradients."""
+    B, N, D, L, H = 8, 64, 256, 2, 8
+    sd = O.init_stack_params(D, L, H, seed=81)
+    x, e1, e2, _ = O.synth_docs(B, N, D, seed=82)
+    hops = gcgcn_amd.GraphHops(D, L, H).to(gpu_device).train()
+    hops.load_state_dict(sd, strict=True)
+    res = {}
+    try:
+        for keep in (True, False):
+            F_.head_sum_in_forward = keep
+            gcgcn_amd.manual_seed(7)
+            hops.zero_grad()
+            xs = [_leaf(t, gpu_device) for t in (x, e1, e2)]
+            hops(xs[0], [xs[1], xs[2]])[-1].sum().backward()
+            res[keep] = [t.grad.clone() for t in xs] + _grads(hops)
+    finally:
+        F_.head_sum_in_forward = True
+    _same(res[True], res[False], rtol=0, atol=0)
