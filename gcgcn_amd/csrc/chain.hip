@@ -295,7 +295,7 @@ __device__ __forceinline__ void mma_lds_glb(f32x16 (&acc)[NB], const float* __re
 // columns = j (mod 4).  One 16-byte global load per B row then feeds four MFMAs (and the results leave as 16-byte stores):
 // the vector memory pipe of a compute unit takes one wave instruction every ~16 cycles, 4-byte loads at one per MFMA
 // saturate it long before the matrix pipe (measured: 150 cycles per MFMA per wave).  base[k * ldb + off4 .. + 3], k < K.
-template <int K>
+template <int K, int KS = 8>   // KS: distance between this wave's groups of 8 k (16: two waves interleave their groups)
 __device__ __forceinline__ void mma_lds_glb4(f32x16 (&acc)[4], const float* __restrict__ pa, const float* __restrict__ base,
                                              const unsigned off4, const unsigned ldb, const int hf) {
   constexpr int G = K / 8, GB = 4, NBT = G / GB;
@@ -306,7 +306,7 @@ __device__ __forceinline__ void mma_lds_glb4(f32x16 (&acc)[4], const float* __re
     for (int g = 0; g < GB; ++g)
 #pragma unroll
       for (int m = 0; m < 4; ++m)
-        dst[g][m] = *reinterpret_cast<const f32x4*>(base + (unsigned)(8 * (bt * GB + g) + 4 * hf + m) * ldb + off4);
+        dst[g][m] = *reinterpret_cast<const f32x4*>(base + (unsigned)(KS * (bt * GB + g) + 4 * hf + m) * ldb + off4);
   };
   request(0, bq[0]);
 #pragma unroll
@@ -315,7 +315,7 @@ __device__ __forceinline__ void mma_lds_glb4(f32x16 (&acc)[4], const float* __re
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < GB; ++g) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(pa + 8 * (bt * GB + g));
+      const f32x4 a = *reinterpret_cast<const f32x4*>(pa + KS * (bt * GB + g));
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -593,8 +593,8 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int q = 0; q < 16; ++q) ho[j][q] = 0.f;
-    mma_lds_glb4<128>(ho, Xs + (rb * 32 + r) * S_LX + k2 * 128 + 4 * hf,
-                      c.flat + c.oWlin + (long)h * 256 + (long)k2 * 128 * c.HD, (unsigned)(l2 * S_GH + 4 * r), HD, hf);
+    mma_lds_glb4<128, 16>(ho, Xs + (rb * 32 + r) * S_LX + k2 * 8 + 4 * hf,
+                          c.flat + c.oWlin + (long)h * 256 + (long)k2 * 8 * c.HD, (unsigned)(l2 * S_GH + 4 * r), HD, hf);
     request_rows();   // for the row phase and the images of sub-layer 1: they land while the products below finish
     request_pn1();
     float* __restrict__ Xr = c.dXres + (long)b * 64 * 256;
