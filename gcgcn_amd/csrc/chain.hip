@@ -593,19 +593,60 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int q = 0; q < 16; ++q) ho[j][q] = 0.f;
-    mma_lds_glb4<128, 16>(ho, Xs + (rb * 32 + r) * S_LX + k2 * 8 + 4 * hf,
-                          c.flat + c.oWlin + (long)h * 256 + (long)k2 * 8 * c.HD, (unsigned)(l2 * S_GH + 4 * r), HD, hf);
-    request_rows();   // for the row phase and the images of sub-layer 1: they land while the products below finish
-    request_pn1();
     float* __restrict__ Xr = c.dXres + (long)b * 64 * 256;
     f32x16 xs[1];   // H == 8: rows (wave & 1), K quarter (wave >> 1) of this head's 32 columns of dXres
     const int rb2 = wave & 1, kq = wave >> 1;
-    if (c.H != 1) {
+    if (c.H != 1) {  // first: its 32 MFMAs per wave wait on their own loads, and the L2 path is idle now
 #pragma unroll
       for (int q = 0; q < 16; ++q) xs[0][q] = 0.f;
       mma_lds_glb<64, 1>(xs, Xs + (rb2 * 32 + r) * S_LX + kq * 64 + 4 * hf, c.Wsum, (unsigned)(kq * 64 + 4 * hf) * 256u + (unsigned)(h * 32 + r),
                          256u, 0u);
     }
+    {  // Wlin's slice goes through LDS in chunks of 16 k (two stages in the dM image's place), loaded once per workgroup by all
+       // 512 threads, coalesced: a compute unit takes in ~20 GB/s from L2, and wave pairs that fetch the same B rows
+       // themselves (through an L1 that has long dropped them) make that 512 KB per workgroup instead of 256.
+      constexpr int S_LB = 260, BST = 16 * S_LB;
+      static_assert(2 * BST <= 64 * S_LP, "B stages live in the dM image");
+      float* const Bs = Ds;
+      const float* __restrict__ W = c.flat + c.oWlin + (long)h * 256 + (long)(t >> 6) * c.HD + (t & 63) * 4;
+      f32x4 br[2][2];
+      auto gload = [&](const int ch, f32x4 (&d)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) d[u] = *reinterpret_cast<const f32x4*>(W + (long)(ch * 16 + 8 * u) * c.HD);
+      };
+      auto sstore = [&](const int st, const f32x4 (&d)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) *reinterpret_cast<f32x4*>(Bs + st * BST + ((t >> 6) + 8 * u) * S_LB + (t & 63) * 4) = d[u];
+      };
+      const float* pa = Xs + (rb * 32 + r) * S_LX + k2 * 8 + 4 * hf;
+      const float* pb = Bs + (k2 * 8 + 4 * hf) * S_LB + l2 * S_GH + 4 * r;
+      auto compute = [&](const int ch, const int st) __attribute__((always_inline)) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(pa + 16 * ch);
+        f32x4 b[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) b[m] = *reinterpret_cast<const f32x4*>(pb + st * BST + m * S_LB);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ho[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[m][j], ho[j], 0, 0, 0);
+      };
+      gload(0, br[0]);
+      gload(1, br[1]);
+      sstore(0, br[0]);
+      lds_barrier();
+      for (int ch = 0; ch < 16; ch += 2) {   // two chunks per trip: register sets and stages are compile-time constants
+        if (ch + 2 < 16) gload(ch + 2, br[0]);
+        compute(ch, 0);
+        sstore(1, br[1]);
+        lds_barrier();
+        if (ch + 3 < 16) gload(ch + 3, br[1]);
+        compute(ch + 1, 1);
+        if (ch + 2 < 16) sstore(0, br[0]);
+        lds_barrier();
+      }
+    }
+    request_rows();   // for the row phase and the images of sub-layer 1: they land while the products below finish
+    request_pn1();
     lds_barrier();  // everybody is done with the dout image: the K halves meet in its place, dXres's K quarters in Ds
     if (k2 == 1) {
 #pragma unroll
