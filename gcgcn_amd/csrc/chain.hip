@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_bwd_kernel(const GcnCtx c, 
 // the four MFMAs, lanes 32-63 take the next four: a permutation of the reduction order), the other one as four
 // 4-byte reads.  Weights (Wd, shared by all documents, L2-hot) go from global memory straight into the B-operand
 // registers, requested a whole product ahead.  Results are stored to global memory as the saved tensors of
-// backward / outputs, but nobody waits for those stores.  Barriers: 3 forward, 6 backward.
+// backward / outputs, but nobody waits for those stores.  Barriers: 3 forward, 8 backward (+ 22 in the fused product).
 // ---------------------------------------------------------------------------------------------
 constexpr int S_LA = 68;    // row pitch of the 64x64 adjacency image (floats; 16-byte rows, conflict-free 16-byte reads)
 constexpr int S_LP = 132;   // row pitch of a 64x128 operand image
@@ -287,39 +287,6 @@ __device__ __forceinline__ void mma_lds_glb(f32x16 (&acc)[NB], const float* __re
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bq[bt & 1][g][j][m], acc[j], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-// Four accumulators whose columns interleave: lane r owns columns 4 r .. 4 r + 3 of a 128-column range, accumulator j the
-// columns = j (mod 4).  One 16-byte global load per B row then feeds four MFMAs (and the results leave as 16-byte stores):
-// the vector memory pipe of a compute unit takes one wave instruction every ~16 cycles, 4-byte loads at one per MFMA
-// saturate it long before the matrix pipe (measured: 150 cycles per MFMA per wave).  base[k * ldb + off4 .. + 3], k < K.
-template <int K, int KS = 8>   // KS: distance between this wave's groups of 8 k (16: two waves interleave their groups)
-__device__ __forceinline__ void mma_lds_glb4(f32x16 (&acc)[4], const float* __restrict__ pa, const float* __restrict__ base,
-                                             const unsigned off4, const unsigned ldb, const int hf) {
-  constexpr int G = K / 8, GB = 4, NBT = G / GB;
-  static_assert(G % GB == 0, "K must be a multiple of 32");
-  f32x4 bq[2][GB][4];
-  auto request = [&](const int bt, f32x4 (&dst)[GB][4]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int g = 0; g < GB; ++g)
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-        dst[g][m] = *reinterpret_cast<const f32x4*>(base + (unsigned)(KS * (bt * GB + g) + 4 * hf + m) * ldb + off4);
-  };
-  request(0, bq[0]);
-#pragma unroll
-  for (int bt = 0; bt < NBT; ++bt) {
-    if (bt + 1 < NBT) request(bt + 1, bq[(bt + 1) & 1]);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int g = 0; g < GB; ++g) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(pa + KS * (bt * GB + g));
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bq[bt & 1][g][m][j], acc[j], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -586,7 +553,9 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
       for (int i = 0; i < 32; ++i) sacc += Xs[(half * 32 + i) * S_LX + cc];
       c.colpart[(long)(2 * b + half) * 256 + cc] = sacc;
     }
-    // dHO_b = dout_b Wlin[:, h]: wave = (rows rb, sub-layer l2 = its 128 columns, K half k2), 4 interleaved accumulators
+    // dHO_b = dout_b Wlin[:, h]: wave = (rows rb, sub-layer l2 = its 128 columns, every other group of 8 k: k2).  Four
+    // accumulators whose columns interleave: lane r owns columns 4 r .. 4 r + 3, accumulator j the columns = j (mod 4), so one
+    // 16-byte B read feeds four MFMAs and the results leave as 16-byte stores.
     const int l2 = (wave >> 1) & 1, k2 = wave >> 2;
     f32x16 ho[4];
 #pragma unroll
