@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_bwd_kernel(const GcnCtx c, 
 constexpr int S_LA = 68;    // row pitch of the 64x64 adjacency image (floats; 16-byte rows, conflict-free 16-byte reads)
 constexpr int S_LP = 132;   // row pitch of a 64x128 operand image
 constexpr int S_GH = 128;
-constexpr int S_FWD_LDS = 64 * S_LA + 2 * 64 * S_LP + 64;
+constexpr int S_FWD_LDS = 64 * S_LA + 2 * 64 * S_LP + 64 + S_GH * S_LP;   // + the Wd_1 image [128][132]
 constexpr int S_BWD_LDS = 64 * S_LA + 3 * 64 * S_LP + 128;
 static_assert(S_FWD_LDS >= CHAIN_LDS && S_BWD_LDS >= CHAIN_LDS + XCHG_LDS, "passengers use the chain kernels' LDS");
 static_assert(S_BWD_LDS * sizeof(float) <= 160 * 1024, "LDS of one compute unit");
@@ -242,19 +242,6 @@ __device__ __forceinline__ void mma_lds(f32x16& acc, const float* __restrict__ p
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[m], acc, 0, 0, 0);
-  }
-}
-// the same with the B operand already in registers (bw[k0 / 8] = the four k of this lane)
-template <int K>
-__device__ __forceinline__ void mma_lds_reg(f32x16& acc, const float* __restrict__ pa, const f32x4 (&bw)[K / 8]) {
-#pragma unroll
-  for (int k0 = 0; k0 < K; k0 += 8) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(pa + k0);
-    const f32x4 w = bw[k0 / 8];
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, w.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, w.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, w.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, w.w, acc, 0, 0, 0);
   }
 }
 // NB accumulators sharing the A operand (LDS, k contiguous); the B operands come straight from global memory (weights, L2-hot:
@@ -306,6 +293,7 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_fwd_kernel(const GcnCtx c
   float* const Ps = As + 64 * S_LA;
   float* const Ys = Ps + 64 * S_LP;
   float* const Rs = Ys + 64 * S_LP;
+  float* const Ws = Rs + 64;                           // Wd_1 [k][n], fetched once per workgroup
   const int z = blockIdx.x, b = z / c.H, h = z - b * c.H;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, hf = lane >> 5;
   const int rb = wave & 1, cb = wave >> 1;             // this wave's 32x32 block of a 64x128 result
@@ -362,14 +350,17 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_fwd_kernel(const GcnCtx c
       c.rinv[(long)z * 64 + wave * 8 + u] = ri;
     }
   }
-  // Wd_1 (the dense connection's weight, [128 x 128] of this head, L2-hot): this lane's B operands of the second product
-  f32x4 bw[S_GH / 8];
+  // Wd_1 (the dense connection's weight, [128 x 128] of this head, L2-hot): row by row into its LDS image, once per workgroup
+  // (as B-operand registers of every wave it was fetched twice: the two row blocks of a column range)
   {
-    const float* __restrict__ W = c.flat + c.wd_off(1) + (long)h * c.wd_head + col;
+    const float* __restrict__ W = c.flat + c.wd_off(1) + (long)h * c.wd_head;
+    f32x4 wv[8];
 #pragma unroll
-    for (int g = 0; g < S_GH / 8; ++g) {
-      const int k = 8 * g + 4 * hf;
-      bw[g] = f32x4{W[(k + 0) * S_GH], W[(k + 1) * S_GH], W[(k + 2) * S_GH], W[(k + 3) * S_GH]};
+    for (int u = 0; u < 8; ++u) wv[u] = *reinterpret_cast<const f32x4*>(W + (t + 512 * u) * 4);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = t + 512 * u;
+      *reinterpret_cast<f32x4*>(Ws + (idx >> 5) * S_LP + (idx & 31) * 4) = wv[u];
     }
   }
 #pragma unroll
@@ -389,7 +380,7 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_fwd_kernel(const GcnCtx c
       }
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[q] = pv[q];
-      mma_lds_reg<S_GH>(acc, Ys + (rb * 32 + r) * S_LP + 4 * hf, bw);
+      mma_lds<S_GH, true, false>(acc, Ys + (rb * 32 + r) * S_LP + 4 * hf, 0, Ws + (4 * hf) * S_LP + col, S_LP);
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = acc_row(r0, q);
