@@ -244,40 +244,6 @@ __device__ __forceinline__ void mma_lds(f32x16& acc, const float* __restrict__ p
     for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[m], acc, 0, 0, 0);
   }
 }
-// NB accumulators sharing the A operand (LDS, k contiguous); the B operands come straight from global memory (weights, L2-hot:
-// B[k][n] at base[k * ldb + off + j * bstep], n contiguous across lanes) in batches of GB groups of 8 k: while one batch is
-// multiplied the next one is in flight.  The scheduling barriers keep the compiler from sinking the requests next to their
-// uses (it did: one group of lookahead, the matrix pipe idle 40 % of the time).
-template <int K, int NB>
-__device__ __forceinline__ void mma_lds_glb(f32x16 (&acc)[NB], const float* __restrict__ pa, const float* __restrict__ base,
-                                            const unsigned off, const unsigned ldb, const unsigned bstep) {
-  constexpr int G = K / 8, GB = 4, NBT = G / GB;
-  static_assert(G % GB == 0, "K must be a multiple of 32");
-  float bq[2][GB][NB][4];
-  auto request = [&](const int bt, float (&dst)[GB][NB][4]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int g = 0; g < GB; ++g)
-#pragma unroll
-      for (int j = 0; j < NB; ++j)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) dst[g][j][m] = base[(unsigned)(8 * (bt * GB + g) + m) * ldb + off + j * bstep];
-  };
-  request(0, bq[0]);
-#pragma unroll
-  for (int bt = 0; bt < NBT; ++bt) {
-    if (bt + 1 < NBT) request(bt + 1, bq[(bt + 1) & 1]);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int g = 0; g < GB; ++g) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(pa + 8 * (bt * GB + g));
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bq[bt & 1][g][j][m], acc[j], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
 // row of accumulator element q of the lane (its column is lane % 32): rows r0 + {0..3} + 8 * {0..3}, r0 = block row + 4 * (lane / 32)
 __device__ __forceinline__ int acc_row(int r0, int q) { return r0 + (q & 3) + 8 * (q >> 2); }
 
@@ -536,6 +502,17 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
       *reinterpret_cast<f32x4*>(As + (idx >> 4) * S_LA + (idx & 15) * 4) = a[u];
     }
     if (t < 64) Rs[t] = rs;
+    // B operands of this wave's share of dXres (Wsum rows of its K quarter, column h * 32 + r): requested now, they land
+    // while the workgroup waits for dout at the barrier
+    const int rb2 = wave & 1, kq = wave >> 1;
+    float wsv[8][4];
+    if (c.H != 1) {
+      const float* __restrict__ Ws8 = c.Wsum + (unsigned)(kq * 64 + 4 * hf) * 256u + (unsigned)(h * 32 + r);
+#pragma unroll
+      for (int g = 0; g < 8; ++g)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) wsv[g][m] = Ws8[(8 * g + m) * 256];
+    }
     lds_barrier();
     if (c.colpart && h == 0) {  // the output bias gradient's column sums of this document: rows 0-31 and 32-63
       const int cc = t & 255, half = t >> 8;
@@ -555,12 +532,16 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
       for (int q = 0; q < 16; ++q) ho[j][q] = 0.f;
     float* __restrict__ Xr = c.dXres + (long)b * 64 * 256;
     f32x16 xs[1];   // H == 8: rows (wave & 1), K quarter (wave >> 1) of this head's 32 columns of dXres
-    const int rb2 = wave & 1, kq = wave >> 1;
-    if (c.H != 1) {  // first: its 32 MFMAs per wave wait on their own loads, and the L2 path is idle now
+    if (c.H != 1) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) xs[0][q] = 0.f;
-      mma_lds_glb<64, 1>(xs, Xs + (rb2 * 32 + r) * S_LX + kq * 64 + 4 * hf, c.Wsum, (unsigned)(kq * 64 + 4 * hf) * 256u + (unsigned)(h * 32 + r),
-                         256u, 0u);
+      const float* pax = Xs + (rb2 * 32 + r) * S_LX + kq * 64 + 4 * hf;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(pax + 8 * g);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xs[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], wsv[g][m], xs[0], 0, 0, 0);
+      }
     }
     {  // Wlin's slice goes through LDS in chunks of 16 k (two stages in the dM image's place), loaded once per workgroup by all
        // 512 threads, coalesced: a compute unit takes in ~20 GB/s from L2, and wave pairs that fetch the same B rows
