@@ -271,6 +271,157 @@ __global__ __launch_bounds__(256, 3) void head_bil2_kernel(const Bil2 a) {
   }
 }
 
+// MODE 1 with the relation count just past a multiple of 32 (R = 97 = 3 x 32 + 1): workgroup tile 128 pairs x 97 columns, a wave
+// owns 32 pairs and ALL columns -- three accumulators for columns 0-95 (each generated A value feeds three MFMAs) and column 96
+// on the vector ALU: the A values are in registers anyway, the column's weights are one broadcast LDS read per k, so the
+// 97th relation costs one v_fma per generated value instead of a fourth 32-column MFMA block (a quarter of the pass).
+__global__ __launch_bounds__(256, 2) void head_bil3_kernel(const Bil2 a) {
+  constexpr int MODE = 1;
+  constexpr int BN = 128, LDB = (MODE == 3) ? BN : BN + 1, SB = BK * LDB;
+  __shared__ __attribute__((aligned(16))) float lds[2 * SB];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * 128;
+  const long row = min(m0 + wave * 32 + l31, a.rows - 1);   // this lane's A row (clamped: rows past the end are never stored)
+  const float* __restrict__ prow = a.P + row * HW;
+  const float* __restrict__ qrow = a.Q + row * HW;
+  const int per_bc = a.nA + (MODE == 1 ? 1 : 0), nsteps = 4 * per_bc + (MODE == 1 ? 4 : 0);
+  // per-thread offsets of its four 16-byte pieces of a weight tile (32-bit: the weights are < 2^31 floats), the step adds
+  // a uniform offset
+  unsigned offW[4], offW2[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int f = t + 256 * q;
+    if (MODE == 1) {
+      const unsigned nn = (unsigned)min(f >> 3, a.ncol - 1);
+      offW[q] = nn * (HW * HW) + ((f & 7) << 2), offW2[q] = nn * (2 * HW) + ((f & 7) << 2);
+    } else if (MODE == 2) {
+      offW[q] = (unsigned)(f >> 3) * HW + ((f & 7) << 2), offW2[q] = 0;
+    } else {
+      offW[q] = (unsigned)(f >> 5) * HW + ((f & 31) << 2), offW2[q] = 0;
+    }
+  }
+  auto loadB = [&](float (&r)[4][4], const BilPos& p) {   // uniform: which array, which offset
+    const float* base = a.W;
+    unsigned so;
+    bool second = false;
+    if (MODE == 1) {
+      if (p.bc >= 4) second = true, so = (unsigned)min(p.aa, 3) * BK;                 // W_c[r][32 j ..]        (tail, clamped)
+      else if (p.aa == a.nA) second = true, so = HW + p.bc * BK;                      // W_c[r][128 + 32 bc ..]
+      else so = (unsigned)p.aa * HW + p.bc * BK;                                      // W_b[r][a][32 bc ..]
+      if (second) base = a.W2;
+    } else if (MODE == 2) {
+      so = (unsigned)min(p.aa, a.nA - 1) * (HW * HW) + min(p.bc, 3) * BK;             // W_b[r][a = n][32 bc ..]
+    } else {
+      so = ((unsigned)min(p.aa, a.nA - 1) * HW + min(p.bc, 3) * BK) * HW;             // W_b[r][a = 32 bc + k][b = n]
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = ld4(base + so + (second ? offW2[q] : offW[q]));
+      r[q][0] = v.x, r[q][1] = v.y, r[q][2] = v.z, r[q][3] = v.w;
+    }
+  };
+  auto storeB = [&](const float (&r)[4][4], float* __restrict__ dst) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f = t + 256 * q;
+      if (MODE == 3) {
+        *reinterpret_cast<float4*>(dst + (f >> 5) * LDB + ((f & 31) << 2)) = make_float4(r[q][0], r[q][1], r[q][2], r[q][3]);
+      } else {
+        float* d = dst + ((f & 7) << 2) * LDB + (f >> 3);
+        d[0] = r[q][0], d[LDB] = r[q][1], d[2 * LDB] = r[q][2], d[3 * LDB] = r[q][3];
+      }
+    }
+  };
+  f32x16 acc0, acc1, acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f, acc2[r] = 0.f;
+  float a96 = 0.f;   // column 96: this lane's k half of its row's dot product
+  float qv[16];
+  auto loadQ = [&](int bc) {   // the lane's 16 Q values of this b-chunk: Q[row, 32 bc + 2 kk + lh]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 v = ld4(qrow + bc * BK + 4 * j);
+      qv[2 * j] = lh ? v.y : v.x, qv[2 * j + 1] = lh ? v.w : v.z;
+    }
+  };
+  auto pval = [&](const BilPos& p) -> float {  // the step's P factor, requested one step ahead
+    if (p.bc >= 4) return 0.f;
+    return (MODE == 1 && p.aa == a.nA) ? 1.f : prow[min(p.aa, a.nA - 1)];
+  };
+  const float* bl0 = lds + lh * LDB + l31;
+  auto compute = [&](const float* __restrict__ bl, const BilPos& p, float pa) {
+    if (MODE == 1 && p.bc >= 4) {   // Linear, eh half: A = P[row, 32 j + k]
+      const float* ph = prow + min(p.aa, 3) * BK;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const float av = ph[2 * kk + lh];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bl[2 * kk * LDB], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bl[2 * kk * LDB + 32], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bl[2 * kk * LDB + 64], acc2, 0, 0, 0);
+        a96 = fmaf(av, bl[2 * kk * LDB + 96 - l31], a96);
+      }
+      return;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const float av = pa * qv[kk];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bl[2 * kk * LDB], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bl[2 * kk * LDB + 32], acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bl[2 * kk * LDB + 64], acc2, 0, 0, 0);
+      a96 = fmaf(av, bl[2 * kk * LDB + 96 - l31], a96);
+    }
+  };
+  float rb0[4][4], rb1[4][4];
+  BilPos pc = {0, 0}, pl = {0, 0};   // compute position, load position (two steps ahead)
+  loadB(rb0, pl);
+  storeB(rb0, lds);
+  pl.next(per_bc);
+  loadB(rb0, pl);
+  pl.next(per_bc);
+  BilPos pp = pc;
+  float pa = pval(pp);
+  pp.next(per_bc);
+  float pn = pval(pp);
+  loadQ(0);
+  __syncthreads();
+  for (int s = 0; s < nsteps; s += 2) {
+    loadB(rb1, pl);
+    pl.next(per_bc);
+    if (pc.aa == 0 && pc.bc > 0 && pc.bc < 4) loadQ(pc.bc);
+    compute(bl0, pc, pa);
+    pc.next(per_bc), pp.next(per_bc);
+    pa = pn, pn = pval(pp);
+    storeB(rb0, lds + SB);
+    __syncthreads();
+    if (s + 1 >= nsteps) break;
+    loadB(rb0, pl);
+    pl.next(per_bc);
+    if (pc.aa == 0 && pc.bc > 0 && pc.bc < 4) loadQ(pc.bc);
+    compute(bl0 + SB, pc, pa);
+    pc.next(per_bc), pp.next(per_bc);
+    pa = pn, pn = pval(pp);
+    storeB(rb1, lds);
+    __syncthreads();
+  }
+  // epilogue: lane holds columns {0, 32, 64} + l31 of rows m0 + wave*32 + (r & 3) + 8 (r >> 2) + 4 lh, and its k half of column 96
+  a96 += __shfl_xor(a96, 32);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int col = j * 32 + l31;
+    if (col >= a.ncol) continue;
+    const float bias = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long rw = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (rw < a.rows) a.C[rw * a.ldc + col] = (j == 0 ? acc0[r] : j == 1 ? acc1[r] : acc2[r]) + bias;
+    }
+  }
+  if (a.ncol > 96 && lh == 0) {
+    const long rw = m0 + wave * 32 + l31;
+    if (rw < a.rows) a.C[rw * a.ldc + 96] = a96 + (a.bias ? a.bias[96] : 0.f);
+  }
+}
+
 // Which generation runs the three outer-product passes.  The second one (64 x 128 tiles, 3 workgroups per compute unit) wins
 // once the pairs fill the chip twice over (B = 32, N = 64: 18.4 vs 19.2 ms per step); below that its coarser tiles quantise
 // badly (B = 32, N = 42: 882 tiles on 768 slots, 9.96 vs 9.08 ms) and the first one (64 x 64 tiles, 4 per compute unit) stays.
@@ -284,12 +435,22 @@ static bool head_v1(long pairs) {
   return cdiv(pairs, 64) < 1536;
 }
 
+// the forward pass's 128-pair tile with column 96 on the vector ALU (GCGCN_HEAD_BIL3=0: A/B knob)
+static bool head_bil3_ok(int ncol) {
+  static const bool on = [] { const char* e = getenv("GCGCN_HEAD_BIL3"); return !(e && e[0] == '0'); }();
+  return on && ncol > 64 && ncol <= 97;
+}
+
 static int head_bil2(int mode, const float* P, const float* Q, const float* W, const float* W2, const float* bias, float* C, long rows,
                      int nA, int ncol, int ldc, hipStream_t st) {
   Bil2 a;
   a.P = P, a.Q = Q, a.W = W, a.W2 = W2, a.bias = bias, a.C = C, a.rows = (int)rows, a.nA = nA, a.ncol = ncol, a.ldc = ldc, a.accumulate_unused = 0;
   const dim3 grid((unsigned)cdiv(rows, 64)), block(256);
   const double flops = 2.0 * rows * ncol * (double)(nA * HW + (mode == 1 ? 2 * HW : 0));
+  if (mode == 1 && head_bil3_ok(ncol)) {  // 3 MFMA column blocks + column 96 on the vector ALU, 128 pairs per workgroup
+    GC_LAUNCH_TIMED("head_bilinear", flops, head_bil3_kernel, dim3((unsigned)cdiv(rows, 128)), block, 0, st, a);
+    return check_launch("head_bil3");
+  }
   if (mode == 1) GC_LAUNCH_TIMED("head_bilinear", flops, (head_bil2_kernel<1>), grid, block, 0, st, a);
   else if (mode == 2) GC_LAUNCH_TIMED("head_bilinear", flops, (head_bil2_kernel<2>), grid, block, 0, st, a);
   else GC_LAUNCH_TIMED("head_bilinear", flops, (head_bil2_kernel<3>), grid, block, 0, st, a);
@@ -493,7 +654,7 @@ int head_fwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int di
   HeadOps o;
   memset(&o, 0, sizeof(o));
   o.P = w.EH, o.Q = w.ET, o.ldp = o.ldq = HW, o.KB = HW * HW, o.W2 = flat + y.Wc, o.ldw2 = 2 * HW, o.nmax = R, o.rows = (int)pairs;
-  if (!head_v1(pairs)) return head_bil2(1, w.EH, w.ET, flat + y.Wb, flat + y.Wc, w.bsum, logits, pairs, HW, R, R, st);
+  if (head_bil3_ok(R) || !head_v1(pairs)) return head_bil2(1, w.EH, w.ET, flat + y.Wb, flat + y.Wc, w.bsum, logits, pairs, HW, R, R, st);
   return head_gemm(1, g, o, st);
 }
 
