@@ -275,8 +275,11 @@ __global__ __launch_bounds__(256, 3) void head_bil2_kernel(const Bil2 a) {
 // owns 32 pairs and ALL columns -- three accumulators for columns 0-95 (each generated A value feeds three MFMAs) and column 96
 // on the vector ALU: the A values are in registers anyway, the column's weights are one broadcast LDS read per k, so the
 // 97th relation costs one v_fma per generated value instead of a fourth 32-column MFMA block (a quarter of the pass).
+// MODE 2 / 3 (128 exact columns): the same 128-pair tile with four accumulators per wave -- each generated value feeds four
+// MFMAs instead of two.
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void head_bil3_kernel(const Bil2 a) {
-  constexpr int MODE = 1;
+  constexpr int NACC = (MODE == 1) ? 3 : 4;
   constexpr int BN = 128, LDB = (MODE == 3) ? BN : BN + 1, SB = BK * LDB;
   __shared__ __attribute__((aligned(16))) float lds[2 * SB];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, lh = lane >> 5;
@@ -332,9 +335,9 @@ __global__ __launch_bounds__(256, 2) void head_bil3_kernel(const Bil2 a) {
       }
     }
   };
-  f32x16 acc0, acc1, acc2;
+  f32x16 acc0, acc1, acc2, acc3;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f, acc2[r] = 0.f;
+  for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f, acc2[r] = 0.f, acc3[r] = 0.f;
   float a96 = 0.f;   // column 96: this lane's k half of its row's dot product
   float qv[16];
   auto loadQ = [&](int bc) {   // the lane's 16 Q values of this b-chunk: Q[row, 32 bc + 2 kk + lh]
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void head_bil3_kernel(const Bil2 a) {
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bl[2 * kk * LDB], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bl[2 * kk * LDB + 32], acc1, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bl[2 * kk * LDB + 64], acc2, 0, 0, 0);
-        a96 = fmaf(av, bl[2 * kk * LDB + 96 - l31], a96);
+        a96 = fmaf(av, bl[2 * kk * LDB + 96 - l31], a96);   // (MODE 1 only reaches this branch)
       }
       return;
     }
@@ -368,7 +371,8 @@ __global__ __launch_bounds__(256, 2) void head_bil3_kernel(const Bil2 a) {
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bl[2 * kk * LDB], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bl[2 * kk * LDB + 32], acc1, 0, 0, 0);
       acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bl[2 * kk * LDB + 64], acc2, 0, 0, 0);
-      a96 = fmaf(av, bl[2 * kk * LDB + 96 - l31], a96);
+      if (NACC == 4) acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bl[2 * kk * LDB + 96], acc3, 0, 0, 0);
+      else a96 = fmaf(av, bl[2 * kk * LDB + 96 - l31], a96);
     }
   };
   float rb0[4][4], rb1[4][4];
@@ -406,33 +410,33 @@ __global__ __launch_bounds__(256, 2) void head_bil3_kernel(const Bil2 a) {
   // epilogue: lane holds columns {0, 32, 64} + l31 of rows m0 + wave*32 + (r & 3) + 8 (r >> 2) + 4 lh, and its k half of column 96
   a96 += __shfl_xor(a96, 32);
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
+  for (int j = 0; j < NACC; ++j) {
     const int col = j * 32 + l31;
     if (col >= a.ncol) continue;
     const float bias = a.bias ? a.bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const long rw = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (rw < a.rows) a.C[rw * a.ldc + col] = (j == 0 ? acc0[r] : j == 1 ? acc1[r] : acc2[r]) + bias;
+      if (rw < a.rows) a.C[rw * a.ldc + col] = (j == 0 ? acc0[r] : j == 1 ? acc1[r] : j == 2 ? acc2[r] : acc3[r]) + bias;
     }
   }
-  if (a.ncol > 96 && lh == 0) {
+  if (MODE == 1 && a.ncol > 96 && lh == 0) {
     const long rw = m0 + wave * 32 + l31;
     if (rw < a.rows) a.C[rw * a.ldc + 96] = a96 + (a.bias ? a.bias[96] : 0.f);
   }
 }
 
-// Which generation runs the three outer-product passes.  The second one (64 x 128 tiles, 3 workgroups per compute unit) wins
-// once the pairs fill the chip twice over (B = 32, N = 64: 18.4 vs 19.2 ms per step); below that its coarser tiles quantise
-// badly (B = 32, N = 42: 882 tiles on 768 slots, 9.96 vs 9.08 ms) and the first one (64 x 64 tiles, 4 per compute unit) stays.
-// GCGCN_HEAD_V1=1 / =0 forces one of them (A/B runs).
+// Which generation runs the outer-product passes.  The register-generated one (head_bil2 / head_bil3: 128-pair tiles, two
+// workgroups per compute unit) wins once there is a tile per compute unit (B = 32: N = 64 15.8 vs 19.2 ms per step, N = 42 8.1 vs
+// 8.3); below that the first one's finer tiles (64 x 64, four per compute unit) fill the chip better.  GCGCN_HEAD_V1=1 / =0 forces
+// one of them (A/B runs).
 static bool head_v1(long pairs) {
   static const int v = [] {
     const char* e = getenv("GCGCN_HEAD_V1");
     return !e ? -1 : (e[0] == '1' ? 1 : 0);
   }();
   if (v >= 0) return v != 0;
-  return cdiv(pairs, 64) < 1536;
+  return cdiv(pairs, 128) < 256;
 }
 
 // the forward pass's 128-pair tile with column 96 on the vector ALU (GCGCN_HEAD_BIL3=0: A/B knob)
@@ -448,7 +452,13 @@ static int head_bil2(int mode, const float* P, const float* Q, const float* W, c
   const dim3 grid((unsigned)cdiv(rows, 64)), block(256);
   const double flops = 2.0 * rows * ncol * (double)(nA * HW + (mode == 1 ? 2 * HW : 0));
   if (mode == 1 && head_bil3_ok(ncol)) {  // 3 MFMA column blocks + column 96 on the vector ALU, 128 pairs per workgroup
-    GC_LAUNCH_TIMED("head_bilinear", flops, head_bil3_kernel, dim3((unsigned)cdiv(rows, 128)), block, 0, st, a);
+    GC_LAUNCH_TIMED("head_bilinear", flops, head_bil3_kernel<1>, dim3((unsigned)cdiv(rows, 128)), block, 0, st, a);
+    return check_launch("head_bil3");
+  }
+  static const bool wide = [] { const char* e = getenv("GCGCN_HEAD_BIL3_BWD"); return !(e && e[0] == '0'); }();
+  if (mode != 1 && wide && ncol == 128) {  // 128-pair tiles, four accumulators per wave
+    if (mode == 2) GC_LAUNCH_TIMED("head_bilinear", flops, head_bil3_kernel<2>, dim3((unsigned)cdiv(rows, 128)), block, 0, st, a);
+    else GC_LAUNCH_TIMED("head_bilinear", flops, head_bil3_kernel<3>, dim3((unsigned)cdiv(rows, 128)), block, 0, st, a);
     return check_launch("head_bil3");
   }
   if (mode == 1) GC_LAUNCH_TIMED("head_bilinear", flops, (head_bil2_kernel<1>), grid, block, 0, st, a);
