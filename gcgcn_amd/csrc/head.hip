@@ -426,6 +426,100 @@ __global__ __launch_bounds__(256, 2) void head_bil3_kernel(const Bil2 a) {
   }
 }
 
+// ---- d W_b[r, (a, b)] = sum_p dout[p, r] eh[p, a] et[p, b]  for R just past a multiple of 32 (R = 97) ---------------------
+// The GEMM form (M = R rows, N = 16384, K = pairs) in 64 x 64 tiles pads R to 128 rows; here a workgroup owns ALL R rows of 128
+// columns (one a, every b), a wave 32 of those columns: three accumulators for rows 0-95, row 96 on the vector ALU (the generated
+// B value eh[p, a] et[p, b] is in a register, dout[p, 96] one broadcast LDS read).  The dout rows of a k-step (32 pairs x 128
+// floats, coalesced) go through LDS as the A image; et rows are read straight into the B registers (two 128-byte rows per wave
+// instruction), eh[p, a] through 32 words of LDS.  K is split over gridDim.y workgroups; the partials are summed in split
+// order by the GEMM's reduce kernel.
+struct HeadDw {
+  const float* doutp; const float* EH; const float* ET;
+  float* out;      // [splits][R][16384] partials, or dW_b itself when splits == 1
+  long pairs; int R, ksteps_per_split;
+};
+__global__ __launch_bounds__(256, 3) void head_dw_kernel(const HeadDw a) {
+  constexpr int LA = 132;                        // A image [32 k][132]: dout[p, 0..127]
+  __shared__ __attribute__((aligned(16))) float lds[2 * (32 * LA + 32)];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int ca = blockIdx.x, sp = blockIdx.y;    // column tile = the index a; K split
+  const int bcol = wave * 32 + l31;              // this lane's b
+  const long k_begin = (long)sp * a.ksteps_per_split * 32;
+  const long k_end = min(a.pairs, k_begin + (long)a.ksteps_per_split * 32);
+  const int nk = (int)((k_end - k_begin + 31) / 32);
+  f32x16 acc0, acc1, acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f, acc2[r] = 0.f;
+  float a96 = 0.f;
+  // staging: thread t loads 4 x 16 bytes of the 32 x 128 dout block (row t >> 3 + ..., coalesced) and, wave 0, eh[p, a]
+  float4 ra[4];
+  float re = 0.f, rq[16];
+  auto gload = [&](const int ks) {
+    const long p0 = k_begin + (long)ks * 32;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = t + 256 * u, row = idx >> 5, c4 = idx & 31;
+      const long p = min(p0 + row, a.pairs - 1);
+      float4 v = ld4(a.doutp + p * HW + c4 * 4);
+      if (p0 + row >= k_end) v = make_float4(0.f, 0.f, 0.f, 0.f);   // past the split's end: contributes nothing
+      ra[u] = v;
+    }
+    if (t < 32) re = a.EH[min(p0 + t, a.pairs - 1) * HW + ca];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) rq[kk] = a.ET[min(p0 + 2 * kk + lh, a.pairs - 1) * HW + bcol];
+  };
+  auto sstore = [&](float* __restrict__ st) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = t + 256 * u;
+      *reinterpret_cast<float4*>(st + (idx >> 5) * LA + (idx & 31) * 4) = ra[u];
+    }
+    if (t < 32) st[32 * LA + t] = re;
+  };
+  float qv[16];
+  auto compute = [&](const float* __restrict__ st) {
+    const float* as = st + lh * LA + l31;
+    const float* es = st + 32 * LA + lh;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const float bv = es[2 * kk] * qv[kk];                    // eh[p, a] et[p, b], p = k0 + 2 kk + lh
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(as[2 * kk * LA], bv, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(as[2 * kk * LA + 32], bv, acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(as[2 * kk * LA + 64], bv, acc2, 0, 0, 0);
+      a96 = fmaf(as[2 * kk * LA + 96 - l31], bv, a96);
+    }
+  };
+  if (nk > 0) {
+    gload(0);
+    sstore(lds);
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) qv[kk] = rq[kk];
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+      float* cur = lds + (ks & 1) * (32 * LA + 32);
+      float* nxt = lds + ((ks + 1) & 1) * (32 * LA + 32);
+      if (ks + 1 < nk) gload(ks + 1);
+      compute(cur);
+      if (ks + 1 < nk) {
+        sstore(nxt);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) qv[kk] = rq[kk];
+      }
+      __syncthreads();
+    }
+  }
+  a96 += __shfl_xor(a96, 32);
+  float* __restrict__ o = a.out + (long)sp * a.R * (HW * HW) + (long)ca * HW + bcol;
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row < a.R) o[(long)row * (HW * HW)] = (j == 0 ? acc0[r] : j == 1 ? acc1[r] : acc2[r]);
+    }
+  if (a.R > 96 && lh == 0) o[96L * (HW * HW)] = a96;
+}
+
 // Which generation runs the outer-product passes.  The register-generated one (head_bil2 / head_bil3: 128-pair tiles, two
 // workgroups per compute unit) wins once there is a tile per compute unit (B = 32: N = 64 15.8 vs 19.2 ms per step, N = 42 8.1 vs
 // 8.3); below that the first one's finer tiles (64 x 64, four per compute unit) fill the chip better.  GCGCN_HEAD_V1=1 / =0 forces
@@ -708,7 +802,23 @@ int head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int di
     g.A = w.doutp, g.lda = HW, g.B = w.EH, g.C = dflat + y.Wb, g.ldc = HW * HW, g.M = R, g.N = HW * HW, g.K = (int)pairs;
     g.ws = ws, g.ws_elems = wse;
     o.P = w.EH, o.Q = w.ET, o.KB = 0;
-    GC_TRY(head_gemm(4, g, o, st));
+    static const bool dw3 = [] { const char* e = getenv("GCGCN_HEAD_DW3"); return !(e && e[0] == '0'); }();
+    if (dw3 && R > 64 && R <= 97 && !head_v1(pairs)) {  // all R rows per workgroup, row 96 on the vector ALU (head_dw_kernel)
+      const long ksteps = cdiv(pairs, 32);
+      int splits = 1;
+      while (splits < 16 && (long)HW * splits < 2048 && ksteps / (splits * 2) >= 64 && (long)(splits * 2) * R * HW * HW <= wse) splits *= 2;
+      HeadDw d;
+      d.doutp = w.doutp, d.EH = w.EH, d.ET = w.ET, d.pairs = pairs, d.R = R, d.ksteps_per_split = (int)cdiv(ksteps, splits);
+      d.out = splits > 1 ? ws : dflat + y.Wb;
+      GC_LAUNCH_TIMED("head_bilinear", 2.0 * R * HW * HW * (double)pairs, head_dw_kernel, dim3(HW, splits), dim3(256), 0, st, d);
+      GC_TRY(check_launch("head_dw"));
+      if (splits > 1) {
+        g.splits = splits, g.batch1 = g.batch2 = 1;
+        GC_TRY(splitk_reduce(g, st));
+      }
+    } else {
+      GC_TRY(head_gemm(4, g, o, st));
+    }
   }
   // d W_c = dout^T [eh | et]    (computed 128 rows deep into a workspace, the R real rows copied out)
   GC_TRY(small_gemm(w.doutp, HW, 0, w.EH, HW, 0, w.dW, 2 * HW, HW, HW, (int)pairs, nullptr, 0, ws, wse, st));
