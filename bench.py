@@ -1,14 +1,18 @@
 #!/usr/bin/env python3
 """bench.py -- docs/sec forward+backward through the CAGGC+MAGGC stack on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5|c1] [--mode graph|eager]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5|c1] [--mode graph|eager] [--global-batch G]
 
 One step = one forward + backward of GATAttention -> GraphConvolution -> MultiHeadAttention ->
 MultiGraphConvolution (the hop loop of GCGCN_glove.py:329-341) over one batch of B synthetic
 DocRED-shaped documents per GPU, train mode (all four dropout sites on), X / E1 / E2 and every
-parameter requiring grad, loss = sum of the MAGGC output.  For N > 1 the driver
-launches one rank per GPU (torch.distributed.run); documents are sharded along the batch axis (weak
-scaling: B per GPU fixed) and the step ends with ONE RCCL all-reduce of the flat gradient bucket.
+parameter requiring grad, loss = sum of the MAGGC output.  For N > 1 there is one rank per
+GPU: either the driver launches them (torch.distributed.run sets RANK / WORLD_SIZE), or -- when
+``--gpus N`` is given without that environment -- this script starts the N ranks itself as child
+processes (before anything here touches a GPU) and relays rank 0's JSON line.  Documents are sharded
+along the batch axis -- weak scaling by default (B per GPU fixed), strong scaling with ``--global-batch G``
+(G / N documents per GPU; SURVEY 8d: G = 256) -- and the step ends with ONE RCCL all-reduce of the flat
+gradient bucket.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with two extra objects:
   roofline     -- the dominant kernel's algorithmic HBM bytes / its HIP-event-timed duration
@@ -63,7 +67,8 @@ def cpu_baseline(cfg, budget_s=20.0):
     N, D, L, H = cfg["N"], cfg["D"], cfg["L"], cfg["H"]
     # the GPU box exposes every host core but a 1-GPU job owns a 16-core share; more threads than that
     # only add oversubscription on these small per-document tensors
-    cores = min(os.cpu_count() or 1, 16)
+    ncpu = os.cpu_count() or 1
+    cores = min(ncpu, 16)
     torch.set_num_threads(cores)
     sd = {k: v.requires_grad_() for k, v in O.init_stack_params(D, L, H, seed=1337).items()}
     nd = 8
@@ -95,7 +100,26 @@ def cpu_baseline(cfg, budget_s=20.0):
         n, dt = 1, first
     return {"value": round(n / dt, 4), "unit": "docs/s", "cores": cores, "kind": "port",
             "sample": f"{n} documents (N={N}, D={D}, L={L}, H={H}) forward+backward, one per call, train mode, "
-                      f"after {1 + warm} warm-up; PyTorch CPU kernels with {cores} threads"}
+                      f"after {1 + warm} warm-up; PyTorch CPU kernels with {cores} threads (the host reports {ncpu} CPUs; a "
+                      "1-GPU lease of this pool owns a 16-core share, and more threads than that only oversubscribe these small "
+                      "per-document tensors -- BASELINE.md 3 says os.cpu_count(), this is the deviation)"}
+
+
+def self_launch(ngpus):
+    """``python bench.py --gpus N`` without a torch.distributed environment: start the N ranks as children of this process
+    (which has not touched a GPU: no HIP call, no torch.cuda.is_available()), wait, and exit with their status.  Rank 0 of the
+    children inherits this process's stdout and prints the JSON line there."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: starting", ngpus, "ranks:", " ".join(cmd), file=sys.stderr)
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -120,10 +144,15 @@ def main():
                     help="secondary run (SURVEY 8d): DocRED-like entity counts n_valid ~ clip(round(N(19.5, 6^2)), 2, 42) padded to N")
     ap.add_argument("--early-mean", action="store_true", help="issue the E2 mean before GATAttention (A/B; default off)")
     ap.add_argument("--overlap", action="store_true", help="stream the E2 mean on a side stream (A/B; default off)")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="strong scaling: this many documents per step over ALL GPUs (per GPU: global / N; SURVEY 8d uses 256). "
+                         "Default: weak scaling, the config's B per GPU")
     ap.add_argument("--overlap-grads", action="store_true",
                     help="all-reduce each block's gradient asynchronously from a backward hook (A/B; default: one "
                          "coalesced collective after backward)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     # stdout carries exactly ONE line (the JSON).  This image's RCCL writes a version banner (and, at
     # NCCL_DEBUG=WARN, warnings) to fd 1 when the communicator is created, so fd 1 is pointed at stderr for
@@ -138,7 +167,7 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE=1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
     torch.cuda.set_device(local_rank)
@@ -155,7 +184,11 @@ def main():
     from gcgcn_amd import _lib
     from gcgcn_amd.dist import FlatGradBucket
 
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config])
+    if args.global_batch is not None:                 # strong scaling: a fixed global batch split over the ranks
+        if args.global_batch % world != 0 or args.global_batch <= 0:
+            raise SystemExit(f"--global-batch {args.global_batch} is not divisible by {world} GPUs")
+        cfg["B"] = args.global_batch // world
     B, N, D, L, H = (cfg[k] for k in "BNDLH")
     torch.manual_seed(1337)                       # identical parameters on every rank
     hops = gcgcn_amd.GraphHops(D, L, H).to(dev).train()
@@ -237,6 +270,10 @@ def main():
     SMALL = ("gemm_splitk_reduce", "softmax", "mha_core", "head_sum", "dropout", "gat_fold", "gat_dlogit", "node_score",
              "colsum", "mask_rows", "rowsum", "relu_norm")
 
+    KERNEL_RE = {"gemm_group": r"gc::gemm_group_kernel", "gemm_single": r"gc::gemm_kernel<", "gcn_chain_fwd": r"gc::gcn_chain\w*_fwd_kernel",
+                 "gcn_chain_bwd": r"gc::gcn_chain\w*_bwd_kernel", "edge_bwd": r"gc::edge_bwd(_carry)?_kernel",
+                 "edge_fwd_att": r"gc::edge_fwd_kernel<\d+, true", "edge_fwd_mean": r"gc::edge_fwd_kernel<\d+, false",
+                 "edge_bcast": r"gc::edge_bcast"}
     KERNEL_NAMES = {"gemm_group": "gc::gemm_group_kernel", "gemm_single": "gc::gemm_kernel<...>",
                     "gcn_chain_fwd": "gc::gcn_chain_fwd_kernel", "gcn_chain_bwd": "gc::gcn_chain_bwd_kernel",
                     "edge_bwd": "gc::edge_bwd_carry_kernel / gc::edge_bwd_kernel", "edge_fwd_att": "gc::edge_fwd_kernel<4,true,*>"}
@@ -266,21 +303,11 @@ def main():
             dominant = max(FAMILIES, key=lambda f: shares[f]["ms_per_step"])
         sync()
 
-    # ---- the timed region: exactly K steps, the dominant family's launches bracketed by HIP events ----------
-    # Two HIP events per launch stall the queue enough to matter (19 GEMM launches a step cost +20 %), so the dominant
-    # family is sampled on a few timed steps only.  In graph mode those are issued eagerly (events cannot be recorded inside
-    # a replay; same kernels, same rotating data) and they are the LAST steps of the region: the host has by then queued
-    # the replays far ahead of the GPU, so the ~1 ms of Python per eager step hides behind the backlog instead of starving
-    # the GPU.  Eager mode samples every 10th step (every step for a one-launch family).
-    if graphs:
-        nsamp = max(1, min(5, args.steps // 4))
-        sampled_steps = set(range(args.steps - nsamp, args.steps))
-    else:
-        every = 1 if shares.get(dominant, {}).get("launches_per_step", 99) <= 2 else 10
-        sampled_steps = set(i for i in range(args.steps) if i % every == every // 2)
-    if use_prof:
-        _lib.call("gcgcn_prof_start", dominant.encode(), args.steps * 64 + 64)
-        _lib.call("gcgcn_prof_enable", 0)
+    # ---- the timed region: exactly K steps, nothing else ---------------------------------------------------------------
+    # graph mode: K replays of the captured hipGraphs (rotating inputs); eager mode: K steps issued from Python.  No HIP
+    # events, no profiling hooks inside the region: the dominant kernel's launches are timed on extra steps AFTER it (same
+    # kernels, same rotating data) -- two events per launch stall the queue, and in graph mode such steps have to be issued
+    # eagerly, which would mix two kinds of step into `value`.
     import gc
     gc.collect()
     gc.disable()                                               # no collector pauses inside the timed region
@@ -295,10 +322,7 @@ def main():
     t0 = time.perf_counter()
     _evs = []
     for i in range(args.steps):
-        sampled = i in sampled_steps
-        if use_prof:
-            _lib.call("gcgcn_prof_enable", 1 if sampled else 0)
-        step(eager=sampled)
+        step()
         if os.environ.get("GCGCN_BENCH_TRACE"):                # diagnosis only: per-step GPU and host-issue times on stderr
             e = torch.cuda.Event(enable_timing=True)
             e.record()
@@ -309,9 +333,10 @@ def main():
         print("per-step GPU ms:", [round(_evs[i][0].elapsed_time(_evs[i + 1][0]), 3) for i in range(len(_evs) - 1)], file=sys.stderr)
         print("host issue ms:", [round(t * 1e3, 2) for _, t in _evs], "total", round(dt * 1e3, 2), file=sys.stderr)
     gc.enable()
-    kms, kn, kw = ctypes.c_double(0), ctypes.c_int(0), ctypes.c_double(0)
-    if use_prof:
-        _lib.call("gcgcn_prof_stop", ctypes.byref(kms), ctypes.byref(kn), ctypes.byref(kw))
+    # the dominant kernel family, HIP events on its launches (hipExtLaunchKernelGGL start/stop events on the launch stream),
+    # on `nsamp` eagerly issued steps right after the region
+    nsamp = max(1, min(5, args.steps))
+    kms, kn, kw = profile(dominant, nsamp) if use_prof else (0.0, 0, 0.0)
 
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1 or force_dist:
@@ -329,25 +354,30 @@ def main():
              "launches": n, "work_per_launch": work / n, "sampled_steps": samp,
              "work": "executed fp32 flops (2MNK)" if bound == "mfma" else "algorithmic HBM bytes"}
         import glob
-        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c2_pmc_hbm.json")))   # latest round's PMC passes
-        if bound == "hbm" and args.config == "c2" and pmcs:    # (offline: rocprofv3 --pmc, tools/pmc_hbm.sh)
-            import re
-            r["traffic_source"] = os.path.relpath(pmcs[-1], ROOT)
-            for k, v in json.load(open(pmcs[-1]))["kernels"].items():
-                m = re.search(r"gc::(edge_\w+)_kernel<\d+(?:, (true|false))?", k)
-                if not m:
-                    continue
-                name = m.group(1).replace("_carry", "") + ({"true": "_att", "false": "_mean"}[m.group(2)] if m.group(1) == "edge_fwd" else "")
-                if name == fam:
-                    r["traffic"] = v["hbm_bytes_per_launch_corrected"]
+        import re
+        # PMC summaries of this config (offline: separate rocprofv3 --pmc passes, tools/profile_config.sh), latest round
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{args.config}_pmc.json")) or
+                      (glob.glob(os.path.join(ROOT, "profiles", "r*_c2_pmc_hbm.json")) if args.config == "c2" else []))
+        if pmcs and not args.ragged:
+            data = json.load(open(pmcs[-1]))["kernels"]
+            want = KERNEL_RE.get(fam)
+            hit = [v for k, v in data.items() if want and re.search(want, k)]
+            if hit:
+                r["pmc_source"] = os.path.relpath(pmcs[-1], ROOT)
+                tot = sum(v.get("launches", 1) for v in hit)
+                avg = lambda key: (sum(v[key] * v.get("launches", 1) for v in hit if key in v) / tot) if any(key in v for v in hit) else None
+                if bound == "hbm":
+                    r["traffic"] = avg("hbm_bytes_per_launch_corrected")
+                else:
+                    r["traffic_hbm_bytes_per_launch"] = avg("hbm_bytes_per_launch_corrected")
+                if avg("mfma_busy") is not None:
+                    r["mfma_busy"] = round(avg("mfma_busy"), 4)
         return r
 
-    roofline = roof(dominant, kms.value, kn.value, kw.value,
-                    len(sampled_steps))
+    roofline = roof(dominant, kms, kn, kw, nsamp)
     if roofline is not None:
-        roofline["sampled_on"] = (f"the last {len(sampled_steps)} of the {args.steps} timed steps (issued eagerly so that HIP events "
-                                  "bracket the launches; the others replay the hipGraphs)" if graphs else
-                                  f"{len(sampled_steps)} of the {args.steps} timed steps")
+        roofline["sampled_on"] = (f"{nsamp} eagerly issued steps directly after the {args.steps} timed steps (same kernels, same "
+                                  "rotating inputs; the timed region itself is " + ("hipGraph replays only)" if graphs else "eager steps without events)"))
     # the cache-warm figure (one batch replayed back to back, E1 partly served from the Infinity Cache) for comparison
     warm = None
     if nsets > 1 and rank == 0 and world == 1 and not force_dist:
@@ -385,7 +415,8 @@ def main():
         line = {
             "metric": "docs/sec fwd+bwd through CAGGC+MAGGC", "value": round(value, 2), "unit": "docs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong" if args.global_batch is not None else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: GraphHops fwd+bwd, B={B}/GPU N={N} D={D} L={L} H={H}, {'EVAL mode (A/B run, not the metric)' if args.eval_mode else 'train mode'}, "
                                    f"E1/E2/X/params require grad" + (", ragged n_valid (mean %.1f)" % n_valid.float().mean().item()

@@ -99,6 +99,42 @@ static long gemm_scratch_elems(int B, int N, int D, int H) {
 }
 static long scratch_elems(int B, int N, int D, int H) { return gemm_scratch_elems(B, N, D, H) + col_ride_elems(D); }
 
+// Run-time A/B switches.  option("head_v1", -1) reads gcgcn_set_option's value if one was set, else the environment
+// variable GCGCN_HEAD_V1 (read once), else the default.  Every knob a test has to flip lives here, so that one process
+// can run both sides of an A/B (function-local statics around getenv could not be switched by the test suite).
+struct Opt {
+  const char* name;
+  int value;
+  bool resolved;
+};
+static Opt g_opts[] = {{"head_v1", 0, false},   {"head_bil3", 0, false},  {"head_bil3_bwd", 0, false}, {"head_dw3", 0, false},
+                       {"chain_s", 0, false},   {"chain_fuse", 0, false}, {"chain_carry", 0, false},   {"gat_ride", 0, false},
+                       {"chain_t", 0, false},   {"fwd_fuse", 0, false},   {"splitk_fuse", 0, false},   {"mha_ride", 0, false}};
+int option(const char* name, int dflt) {
+  for (Opt& o : g_opts) {
+    if (strcmp(o.name, name) != 0) continue;
+    if (!o.resolved) {
+      char env[64] = "GCGCN_";
+      size_t n = strlen(env);
+      for (const char* c = name; *c && n + 1 < sizeof(env); ++c) env[n++] = (char)((*c >= 'a' && *c <= 'z') ? *c - 32 : *c);
+      env[n] = 0;
+      const char* e = getenv(env);
+      o.value = e ? atoi(e) : dflt;
+      o.resolved = true;
+    }
+    return o.value;
+  }
+  return dflt;
+}
+static bool set_opt(const char* name, int value) {
+  for (Opt& o : g_opts)
+    if (strcmp(o.name, name) == 0) {
+      o.value = value, o.resolved = true;
+      return true;
+    }
+  return false;
+}
+
 // GCGCN_NO_CHAIN=1 (or gcgcn_set_option("chain", 0)) runs every per-(doc, head) product as its own batched
 // launch instead of inside the chain kernels (A/B testing of chain.hip).
 static int g_chain = -1;
@@ -149,7 +185,7 @@ using namespace gc;
 
 extern "C" {
 
-int gcgcn_version(void) { return 3; }
+int gcgcn_version(void) { return 4; }
 const char* gcgcn_last_error(void) { return g_err; }
 
 int gcgcn_set_option(const char* name, int value) {
@@ -162,6 +198,7 @@ int gcgcn_set_option(const char* name, int value) {
     g_mha_core = value ? 1 : 0;
     return 0;
   }
+  if (set_opt(name, value)) return 0;
   set_error("set_option: unknown option '%s'", name);
   return 1;
 }
@@ -283,7 +320,7 @@ int gcgcn_gat_bwd(int B, int N, int D, int Dh, const float* X, const float* E, c
   const long M = (long)B * N;
   GC_REQUIRE(scratch, "gat_bwd: scratch is required");
   const bool small = gat_dlogit_ok(N);
-  static const bool ride = [] { const char* e = getenv("GCGCN_GAT_RIDE"); return !(e && e[0] == '0'); }();
+  const bool ride = option("gat_ride", 1) != 0;
   GatTail tail{P, dA, uvc, dX_in, ds, dX, drop, B, gat_dlogit_slices(D)};
   if (small && ride) {
     // dlogit, ds and dX = ds u + dX_in ride in the edge pass below: its entity rows take their dlogit row from P and dA

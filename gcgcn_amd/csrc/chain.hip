@@ -755,14 +755,14 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
 
 // the shape the LDS-resident kernels are written for
 static bool chain_small_ok(const GcnCtx& c, bool bwd) {
-  static const bool on = [] { const char* e = getenv("GCGCN_CHAIN_S"); return !(e && e[0] == '0'); }();
+  const bool on = option("chain_s", 1) != 0;
   return on && c.N == 64 && c.L == 2 && c.gh == S_GH && c.D == 2 * S_GH && (c.flat + c.oWd) && c.wd_head % 4 == 0 &&
          (c.wd_off(1) % 4) == 0;
 }
 
 static bool chain_aligned(const GcnCtx& c, bool bwd);
 bool chain_bwd_fusable(const GcnCtx& c) {
-  static const bool on = [] { const char* e = getenv("GCGCN_CHAIN_FUSE"); return !(e && e[0] == '0'); }();
+  const bool on = option("chain_fuse", 1) != 0;
   auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
   return on && chain_small_ok(c, true) && c.N == 64 && (c.H == 1 || c.H == 8) && al(c.A) && al(c.Pn) && al(c.Y) && al(c.dM) &&
          al(c.dP) && al(c.dA) && al(c.flat + c.oWd) && al(c.flat + c.oWlin) && c.HD % 4 == 0;
@@ -784,13 +784,7 @@ bool chain_can_carry(const EdgeRide& r) {
 }
 
 // GCGCN_CHAIN_CARRY=0: no parked products in the chain launches (A/B knob)
-static bool chain_passengers() {
-  static const int v = [] {
-    const char* e = getenv("GCGCN_CHAIN_CARRY");
-    return (e && e[0] == '0') ? 0 : 1;
-  }();
-  return v != 0;
-}
+static bool chain_passengers() { return option("chain_carry", 1) != 0; }
 
 static long carry_budget_pct() {  // GCGCN_CHAIN_CARRY_PCT: tuning knob, default 50
   static const long v = [] {

@@ -107,6 +107,9 @@ inline Drop make_drop(const void* snap, uint64_t salt, float p) {
   return d;
 }
 
+// run-time A/B switch `name` (gcgcn_set_option > environment variable GCGCN_<NAME> > dflt); api.hip
+int option(const char* name, int dflt);
+
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- optional per-kernel timing (gcgcn_prof_start / gcgcn_prof_stop) ------------------------------

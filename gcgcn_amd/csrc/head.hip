@@ -522,22 +522,16 @@ __global__ __launch_bounds__(256, 3) void head_dw_kernel(const HeadDw a) {
 
 // Which generation runs the outer-product passes.  The register-generated one (head_bil2 / head_bil3: 128-pair tiles, two
 // workgroups per compute unit) wins once there is a tile per compute unit (B = 32: N = 64 15.8 vs 19.2 ms per step, N = 42 8.1 vs
-// 8.3); below that the first one's finer tiles (64 x 64, four per compute unit) fill the chip better.  GCGCN_HEAD_V1=1 / =0 forces
-// one of them (A/B runs).
+// 8.3); below that the first one's finer tiles (64 x 64, four per compute unit) fill the chip better.  GCGCN_HEAD_V1=1 / =0 (or
+// gcgcn_set_option("head_v1", 1 / 0; -1 = by size) forces one of them (A/B runs and the test suite, which runs both).
 static bool head_v1(long pairs) {
-  static const int v = [] {
-    const char* e = getenv("GCGCN_HEAD_V1");
-    return !e ? -1 : (e[0] == '1' ? 1 : 0);
-  }();
+  const int v = option("head_v1", -1);
   if (v >= 0) return v != 0;
   return cdiv(pairs, 128) < 256;
 }
 
-// the forward pass's 128-pair tile with column 96 on the vector ALU (GCGCN_HEAD_BIL3=0: A/B knob)
-static bool head_bil3_ok(int ncol) {
-  static const bool on = [] { const char* e = getenv("GCGCN_HEAD_BIL3"); return !(e && e[0] == '0'); }();
-  return on && ncol > 64 && ncol <= 97;
-}
+// the forward pass's 128-pair tile with column 96 on the vector ALU (GCGCN_HEAD_BIL3=0 / set_option("head_bil3", 0): A/B knob)
+static bool head_bil3_ok(int ncol) { return option("head_bil3", 1) != 0 && ncol > 64 && ncol <= 97; }
 
 static int head_bil2(int mode, const float* P, const float* Q, const float* W, const float* W2, const float* bias, float* C, long rows,
                      int nA, int ncol, int ldc, hipStream_t st) {
@@ -549,7 +543,7 @@ static int head_bil2(int mode, const float* P, const float* Q, const float* W, c
     GC_LAUNCH_TIMED("head_bilinear", flops, head_bil3_kernel<1>, dim3((unsigned)cdiv(rows, 128)), block, 0, st, a);
     return check_launch("head_bil3");
   }
-  static const bool wide = [] { const char* e = getenv("GCGCN_HEAD_BIL3_BWD"); return !(e && e[0] == '0'); }();
+  const bool wide = option("head_bil3_bwd", 1) != 0;
   if (mode != 1 && wide && ncol == 128) {  // 128-pair tiles, four accumulators per wave
     if (mode == 2) GC_LAUNCH_TIMED("head_bilinear", flops, head_bil3_kernel<2>, dim3((unsigned)cdiv(rows, 128)), block, 0, st, a);
     else GC_LAUNCH_TIMED("head_bilinear", flops, head_bil3_kernel<3>, dim3((unsigned)cdiv(rows, 128)), block, 0, st, a);
@@ -802,7 +796,7 @@ int head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int di
     g.A = w.doutp, g.lda = HW, g.B = w.EH, g.C = dflat + y.Wb, g.ldc = HW * HW, g.M = R, g.N = HW * HW, g.K = (int)pairs;
     g.ws = ws, g.ws_elems = wse;
     o.P = w.EH, o.Q = w.ET, o.KB = 0;
-    static const bool dw3 = [] { const char* e = getenv("GCGCN_HEAD_DW3"); return !(e && e[0] == '0'); }();
+    const bool dw3 = option("head_dw3", 1) != 0;
     if (dw3 && R > 64 && R <= 97 && !head_v1(pairs)) {  // all R rows per workgroup, row 96 on the vector ALU (head_dw_kernel)
       const long ksteps = cdiv(pairs, 32);
       int splits = 1;

@@ -380,7 +380,10 @@ __global__ __launch_bounds__(64 * PW) void prod_sent_fwd_kernel(const float* __r
 // sentence sums are exactly zero), 0 for padding entities.  One workgroup per entity row (b, i).
 __global__ __launch_bounds__(256) void prod_expand_kernel(const float* __restrict__ Ec, const float* __restrict__ bls,
                                                           const int* __restrict__ n_valid, const int* __restrict__ pair_prow,
-                                                          float* __restrict__ E, int N, int Hd) {
+                                                          const int* __restrict__ counts, float* __restrict__ E, int N, int Hd) {
+  // counts[2]: the caller's capacities were too small for this batch (prod_index_b marked every pair dead).  Under a captured
+  // hipGraph nobody can raise, so the result is poisoned: NaN in every real pair instead of a plausible all-bias tensor.
+  const bool over = counts[2] != 0;
   const long bi = blockIdx.x;
   const long b = bi / N;
   const int i = (int)(bi - b * N);
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(256) void prod_expand_kernel(const float* __restric
     float v = 0.f;
     if (i < nv && j < nv) {
       const int prow = pair_prow[bi * N + j];
-      v = prow >= 0 ? Ec[(long)prow * Hd + c] : bls[c];
+      v = over ? __builtin_nanf("") : (prow >= 0 ? Ec[(long)prow * Hd + c] : bls[c]);
     }
     E[bi * tot + e] = v;
   }
@@ -939,7 +942,7 @@ int prod_fwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx
   {
     ProfScope ps("prod_expand", st, 4.0 * B * N * N * Hd);
     hipLaunchKernelGGL(prod_expand_kernel, dim3((unsigned)((long)B * N)), dim3(256), 0, st, w.Ec, flat + y.bls, n_valid, ix.pair_prow,
-                       E, N, Hd);
+                       ix.counts, E, N, Hd);
     GC_TRY(check_launch("prod_expand"));
   }
   return 0;
@@ -1079,7 +1082,7 @@ __global__ __launch_bounds__(256) void prod_count_kernel(const unsigned char* __
   }
 }
 
-struct ProdBound { ProdIdx ix; ProdBufs w; ProdGrads g; float* scratch; long n_int, n_fwd, n_bwd; };
+struct ProdBound { ProdIdx ix; ProdBufs w; ProdGrads g; float* scratch; long n_int, n_fwd, n_bwd, counts_off; };
 // Carve the caller's three buffers (every piece starts 16-byte aligned); with null bases this only measures them.
 static ProdBound prod_bind(int32_t* ibuf, float* fwd, float* bwd, bool want_bwd, int B, int N, int S, int T, int Hd, int P, int ND,
                            long cap_rows, long cap_pairs) {
@@ -1089,7 +1092,9 @@ static ProdBound prod_bind(int32_t* ibuf, float* fwd, float* bwd, bool want_bwd,
   long at = 0;
   auto ti = [&](long n) { int32_t* p = ibuf ? ibuf + at : nullptr; at += (n + 3) & ~3L; return p; };
   o.ix.doc_counts = ti(2L * B), o.ix.pair_bits = ti(BNN), o.ix.pair_row0 = ti(BNN), o.ix.pair_prow = ti(BNN);
-  o.ix.pair_div = (float*)ti(BNN), o.ix.row_slot = ti(R), o.ix.prow_pair = ti(Q), o.ix.counts = ti(4);
+  o.ix.pair_div = (float*)ti(BNN), o.ix.row_slot = ti(R), o.ix.prow_pair = ti(Q);
+  o.counts_off = at;
+  o.ix.counts = ti(4);
   o.ix.doc_off = ti(B + 1), o.ix.row_rng = ti(R), o.ix.tmax = ti(B);
   o.n_int = at;
   float* base = fwd;
@@ -1143,11 +1148,13 @@ int gcgcn_producer_count(int B, int N, int S, int T, const uint8_t* sen, const i
   return check_launch("prod_count");
 }
 
-int gcgcn_producer_sizes(int B, int N, int S, int T, int Hd, int P, int ND, int64_t cap_rows, int64_t cap_pairs, int64_t* out3) {
+int gcgcn_producer_sizes(int B, int N, int S, int T, int Hd, int P, int ND, int64_t cap_rows, int64_t cap_pairs, int64_t* out4) {
+  int64_t* out3 = out4;
   GC_REQUIRE(B > 0 && N > 0 && S > 0 && T > 0 && Hd > 0 && P > 0 && ND > 0 && cap_rows >= 0 && cap_pairs >= 0 && out3,
              "producer_sizes: bad arguments");
   const ProdBound z = prod_bind(nullptr, nullptr, nullptr, true, B, N, S, T, Hd, P, ND, cap_rows, cap_pairs);
   out3[0] = z.n_int, out3[1] = z.n_fwd, out3[2] = z.n_bwd + prod_scratch_elems(B, N, T, Hd);
+  out4[3] = z.counts_off;   // offset (in int32) of {live rows, live pairs, over-capacity flag, 0} inside ibuf
   return 0;
 }
 

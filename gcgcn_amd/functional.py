@@ -57,13 +57,19 @@ def _nv(n_valid: Optional[Tensor], B: int, N: int, dev) -> Optional[Tensor]:
 
 
 # ---- dropout RNG state -----------------------------------------------------------------------------
+# One generator per DEVICE, like torch's own default CUDA generator behind nn.Dropout (which the reference uses): a
+# device-resident {seed, counter} pair advanced by the kernels themselves.  This is the one piece of process-wide state of the
+# product path; creation / re-seeding is guarded by a lock, the counter advances on the device in stream order.
 _rng_state = {}
+_rng_lock = threading.Lock()
 
 
 def manual_seed(seed: int, device=None):
     """Seed the dropout generator of this library (per device): state = {seed, counter = 0}."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    _rng_state[dev.index or 0] = torch.tensor([seed, 0], dtype=torch.int64, device=dev)
+    st = torch.tensor([seed, 0], dtype=torch.int64, device=dev)
+    with _rng_lock:
+        _rng_state[dev.index or 0] = st
 
 
 _tls = threading.local()   # .scope: [snaps tensor [count, 2], next index, pending] while a rng_scope is active on this
@@ -76,9 +82,12 @@ def _get_scope():
 
 def _state(dev: torch.device) -> Tensor:
     idx = dev.index or 0
-    if idx not in _rng_state:
-        manual_seed(torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, dev)
-    return _rng_state[idx]
+    st = _rng_state.get(idx)
+    if st is None:
+        st = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=dev)
+        with _rng_lock:
+            st = _rng_state.setdefault(idx, st)     # two threads racing here agree on one state
+    return st
 
 
 def _new_snaps(dev: torch.device, count: int) -> Tensor:
@@ -222,7 +231,7 @@ class MhaFn(torch.autograd.Function):
              _p(scratch), _stream())
         ctx.save_for_backward(x, flat, Q, P)
         ctx.H, ctx.p, ctx.snap = H, float(p), snap
-        ctx.flat_leaf = flat if flat.is_leaf else None
+        ctx.flat_leaf = flat if (flat.is_leaf and not _under_ddp()) else None
         return (P if A is None else A), x.view_as(x)
 
     @staticmethod
@@ -261,14 +270,31 @@ class MhaFn(torch.autograd.Function):
 # accumulation, other consumers of the parameter).  Parking is refused -- the products then run inside the block's own
 # backward and the gradient takes autograd's normal route -- unless this is a ``.backward()`` pass that will reach the
 # parameter's AccumulateGrad node (not ``autograd.grad``, not ``inputs=[...]`` without it) and the parameter has no hooks.
-# Node-level hooks on AccumulateGrad (torch DistributedDataParallel) cannot be seen from here: under DDP set
-# GCGCN_DEFER=0 (gcgcn_amd.dist.FlatGradBucket needs nothing: it reduces after backward, or uses tensor hooks).
+# Node-level hooks on AccumulateGrad (torch DistributedDataParallel) cannot be seen from Python; a forward that runs inside
+# DDP's own forward is recognised instead (_under_ddp) and its blocks do not park.  (gcgcn_amd.dist.FlatGradBucket needs
+# nothing: it reduces after backward, or uses tensor hooks, which are seen.)
 #
 # State.  One _BackwardPass per autograd graph task, registered under the task's id and owned by the engine through the
 # queued callback: a pass that raises half-way is destroyed with its graph task -- parked operands, queue and all --
 # and leaves nothing behind; passes of other models, devices or threads never share a queue.
 defer_weight_grads = os.environ.get("GCGCN_DEFER", "1") != "0"      # GCGCN_DEFER=0: A/B knob
 defer_mha_weight_grads = False
+_warned_ddp = [False]
+
+
+def _under_ddp() -> bool:
+    """True while torch's DistributedDataParallel is running the forward this block is part of.  DDP reduces gradients from
+    C++ hooks on the parameters' AccumulateGrad nodes, which fire when autograd delivers a gradient -- a parked gradient is
+    installed after backward and would never be reduced.  Blocks whose forward ran under DDP therefore do not park."""
+    ddp = getattr(torch.nn.parallel, "DistributedDataParallel", None)
+    on = ddp is not None and getattr(ddp, "_active_ddp_module", None) is not None
+    if on and defer_weight_grads and not _warned_ddp[0]:
+        _warned_ddp[0] = True
+        import warnings
+        warnings.warn("gcgcn_amd: running under torch DistributedDataParallel -- deferred weight gradients are switched off "
+                      "for these blocks (their AccumulateGrad hooks need the gradient during backward); "
+                      "gcgcn_amd.dist.FlatGradBucket reduces the flat gradients without that cost")
+    return on
 _passes = {}            # graph task id -> weakref to its _BackwardPass
 _passes_lock = threading.Lock()
 
@@ -393,7 +419,8 @@ class GcnFn(torch.autograd.Function):
         ctx.wsum = wsum
         ctx.n_valid, ctx.L, ctx.H, ctx.p, ctx.snap = n_valid, L, H, float(p), snap
         ctx.out_p, ctx.out_snap = float(out_p), out_snap
-        ctx.flat_leaf = flat if flat.is_leaf else None      # to see in backward whether .grad will be installed or added to
+        # to see in backward whether .grad will be installed or added to (never parked under DDP: see _under_ddp)
+        ctx.flat_leaf = flat if (flat.is_leaf and not _under_ddp()) else None
         ctx.next_shape = None if e_next is None else tuple(e_next.shape)
         return out, ebar_next
 
@@ -521,7 +548,7 @@ class ProducerFn(torch.autograd.Function):
         N, S = sen.shape[1], sen.shape[3]
         ND, P = dis_table.shape
         dev = tok.device
-        sizes = (ctypes.c_int64 * 3)()
+        sizes = (ctypes.c_int64 * 4)()
         call("gcgcn_producer_sizes", B, N, S, T, Hd, P, ND, cap_rows, cap_pairs, ctypes.cast(sizes, ctypes.c_void_p))
         ibuf = torch.empty(sizes[0], dtype=torch.int32, device=dev)
         fbuf = torch.empty(sizes[1], device=dev)
@@ -531,10 +558,12 @@ class ProducerFn(torch.autograd.Function):
              _p(n_valid), _p(flat), cap_rows, cap_pairs, _p(ibuf), _p(fbuf), None, 0, _p(E), _stream())
         ctx_.save_for_backward(tok, node, dis_table, flat, sen, pos_h, pos_t, ibuf, fbuf)
         ctx_.n_valid, ctx_.caps, ctx_.nbwd = n_valid, (cap_rows, cap_pairs), int(sizes[2])
-        return E
+        counts = ibuf[int(sizes[3]):int(sizes[3]) + 4]      # {live rows, live pairs, over capacity, 0}, on the device
+        ctx_.mark_non_differentiable(counts)
+        return E, counts
 
     @staticmethod
-    def backward(ctx_, dE):
+    def backward(ctx_, dE, _dcounts=None):
         tok, node, dis_table, flat, sen, pos_h, pos_t, ibuf, fbuf = ctx_.saved_tensors
         B, T, Hd = tok.shape
         N, S = sen.shape[1], sen.shape[3]
@@ -588,6 +617,26 @@ class HeadFn(torch.autograd.Function):
         return (dflat, dner, dtab, None, None, None, None, None, *dfeats)
 
 
+# Range-check the integer ids handed to the head / the producer before the kernels index with them.  The reference's
+# embedding lookups raise IndexError on an id outside the table; the kernels clamp instead (an out-of-range id must never
+# become an out-of-bounds read), which would turn corrupt inputs into plausible logits.  The check is one fused reduction and
+# ONE host read per call; it is skipped inside a hipGraph capture, and a training loop that has validated its data once can
+# switch it off (``gcgcn_amd.functional.check_ids = False``).
+check_ids = True
+NER_ROWS = 7        # nn.Embedding(7, entity_type_size, padding_idx=0), GCGCN_glove.py:241 -- the head's kernels index 7 rows
+
+
+def _check_id_range(checks):
+    """checks: [(name, tensor, lo, hi)] -- raise IndexError naming the first tensor with an id outside [lo, hi]."""
+    if not check_ids or torch.cuda.is_current_stream_capturing():
+        return
+    bad = torch.stack([((t < lo) | (t > hi)).any() for _, t, lo, hi in checks])
+    if bool(bad.any().item()):
+        flags = bad.tolist()
+        name, t, lo, hi = next(c for c, f in zip(checks, flags) if f)
+        raise IndexError(f"{name}: ids must lie in [{lo}, {hi}], got min {int(t.min())} / max {int(t.max())}")
+
+
 def classifier_head(feats, node_type, node_relative_pos, ner_emb, dis_table, flat, relation_num, n_valid=None, dis_plus=10):
     """logits[B,N,N,R] from the model's node_feats list (each [B,N,Hd]), node_type int64[B,N], node_relative_pos
     int64[B,N,N], the two embedding tables and the head's flat parameters."""
@@ -598,6 +647,12 @@ def classifier_head(feats, node_type, node_relative_pos, ner_emb, dis_table, fla
     for nm, t, shp in (("node_type", node_type, (B, N)), ("node_relative_pos", node_relative_pos, (B, N, N))):
         if not t.is_cuda or t.dtype != torch.int64 or tuple(t.shape) != shp:
             raise ValueError(f"{nm}: expected a GPU int64 tensor of shape {shp}, got {t.dtype} {tuple(t.shape)} on {t.device}")
+    if ner_emb.dim() != 2 or ner_emb.shape[0] != NER_ROWS:
+        raise ValueError(f"ner_emb.weight: the head indexes {NER_ROWS} rows (nn.Embedding(7, .), glove:241), got {tuple(ner_emb.shape)}")
+    if dis_table.dim() != 2 or dis_table.shape[0] < 2 * int(dis_plus) + 1:
+        raise ValueError(f"dis_embed.weight: needs at least 2 * dis_plus + 1 = {2 * int(dis_plus) + 1} rows, got {tuple(dis_table.shape)}")
+    _check_id_range([("node_type", node_type, 0, NER_ROWS - 1),
+                     ("node_relative_pos", node_relative_pos, -int(dis_plus), int(dis_plus))])
     return HeadFn.apply(_chk(flat, "flat"), _chk(ner_emb, "ner_emb.weight", 2), _chk(dis_table, "dis_embed.weight", 2),
                         node_type.contiguous(), node_relative_pos.contiguous(), _nv(n_valid, B, N, flat.device),
                         int(relation_num), int(dis_plus), *feats)
@@ -613,12 +668,25 @@ def producer_live_counts(sen: Tensor, n_valid=None):
     return r, q
 
 
-def edge_features(tok, sen, pos_h, pos_t, node, dis_table, flat, n_valid=None, max_live_slots=None, max_live_pairs=None):
+# The position matrices are [B,N,N,S,T] (77 MB per DocRED document as int64): a range check reads them once more, which the
+# producer's own kernels do not (they touch live slots only).  Off by default; the head's ids (a few KB) are always checked.
+check_position_ids = False
+
+
+class ProducerCapacityError(RuntimeError):
+    """max_live_slots / max_live_pairs were smaller than what the batch holds."""
+
+
+def edge_features(tok, sen, pos_h, pos_t, node, dis_table, flat, n_valid=None, max_live_slots=None, max_live_pairs=None,
+                  check_capacity=False, return_counts=False):
     """E[B,N,N,Hd] of one hop from token states tok[B,T,Hd], sentence masks sen[B,N,N,S,T] (bool / uint8), distance ids
     pos_h / pos_t [B,N,N,S,T] (int64 as the reference passes them, or int32 / uint8), entity features node[B,N,Hd] and
     the distance-embedding table dis_table[ND,P].  Without ``max_live_*`` the live slots are counted first (one host
     synchronisation per call, as cheap as the reference's own ``.cuda()`` copies); with them nothing synchronises and the
-    call can be captured in a hipGraph."""
+    call can be captured in a hipGraph.  Capacities that turn out too small are never silent: the kernels compute nothing
+    and write NaN into every real pair of E (so a captured graph fails loudly downstream); ``check_capacity=True`` reads the
+    device-side flag back (one synchronisation) and raises :class:`ProducerCapacityError`; ``return_counts=True`` also returns
+    the device tensor ``int32[4] = {live slots, live pairs, over capacity, 0}`` for a check of the caller's own timing."""
     tok, node, dis_table = _chk(tok, "context_output", 3), _chk(node, "node_feat", 3), _chk(dis_table, "dis_embed.weight", 2)
     B, T, Hd = tok.shape
     if sen.dim() != 5 or sen.shape[0] != B or sen.shape[4] != T or sen.shape[1] != sen.shape[2]:
@@ -638,13 +706,22 @@ def edge_features(tok, sen, pos_h, pos_t, node, dis_table, flat, n_valid=None, m
             raise ValueError(f"{nm}: expected a GPU int64 / int32 / uint8 tensor of shape {tuple(sen.shape)}")
     if pos_t.dtype != pos_h.dtype:
         raise ValueError("pos_matrix_h and pos_matrix_t must have the same dtype")
+    if check_position_ids:
+        _check_id_range([("pos_matrix_h", pos_h, 0, dis_table.shape[0] - 1), ("pos_matrix_t", pos_t, 0, dis_table.shape[0] - 1)])
     nv = _nv(n_valid, B, N, tok.device)
-    if max_live_slots is None or max_live_pairs is None:
+    given = max_live_slots is not None and max_live_pairs is not None
+    if not given:
         r, q = producer_live_counts(sen, nv)
         max_live_slots = r if max_live_slots is None else max_live_slots
         max_live_pairs = q if max_live_pairs is None else max_live_pairs
-    return ProducerFn.apply(tok, node, dis_table, _chk(flat, "flat"), sen, pos_h.contiguous(), pos_t.contiguous(), nv,
-                            int(max_live_slots), int(max_live_pairs))
+    E, counts = ProducerFn.apply(tok, node, dis_table, _chk(flat, "flat"), sen, pos_h.contiguous(), pos_t.contiguous(), nv,
+                                 int(max_live_slots), int(max_live_pairs))
+    if check_capacity and not torch.cuda.is_current_stream_capturing():
+        if int(counts[2].item()) != 0:
+            raise ProducerCapacityError(f"edge_features: max_live_slots={max_live_slots} / max_live_pairs={max_live_pairs} are "
+                                        "smaller than the batch's live sentence slots / entity pairs (producer_live_counts "
+                                        "reports both); nothing was computed")
+    return (E, counts) if return_counts else E
 
 
 # ---- functional entry points -------------------------------------------------------------------------

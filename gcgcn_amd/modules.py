@@ -108,7 +108,9 @@ class GATAttention(_FlatBlock):
         self.dim = att_input_dim                 # width of node_feat / edge_feat
         self.hidden_dim = hidden_dim             # rows of the three nn.Linear(att_input_dim, hidden_dim), glove:148-150
         self.apply_mask = bool(apply_mask)
-        self.cache_fold = True                   # keep (u, v, c) while the parameters are unchanged (see forward)
+        # keep (u, v, c) while the parameters are unchanged (see forward): True = always, False = never, "infer" (default) =
+        # only where nothing trains the parameters between calls (eval mode or under no_grad)
+        self.cache_fold = "infer"
         self._uvc = None
         self.p = float(dropout) if dropout is not None else 0.0
         self.flat = nn.Parameter(torch.empty(P_.gat_layout(self.dim, hidden_dim)[-1]))
@@ -127,6 +129,20 @@ class GATAttention(_FlatBlock):
     def named_grads(self):
         return P_.unpack_gat(self.flat.grad, self.dim, self.hidden_dim) if self.flat.grad is not None else {}
 
+    def invalidate_fold(self):
+        """Drop the kept (u, v, c).  The cache is keyed on ``flat``'s version counter, which in-place writes through ``.data``
+        (``p.data.copy_(ema)``, ``dist.broadcast(p.data)``, ``p.data.normal_()``) do NOT bump: call this after such a write
+        (``load_state_dict``, ``.to()`` / ``.cuda()`` and every optimiser step are seen without it)."""
+        self._uvc = None
+
+    def _apply(self, fn, *args, **kwargs):
+        self._uvc = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._uvc = None
+        return super()._load_from_state_dict(*args, **kwargs)
+
     def forward(self, node_feat: Tensor, edge_feat: Tensor, mask: Optional[Tensor] = None,
                 n_valid: Optional[Tensor] = None, return_input_alias: bool = False) -> Tensor:
         x, batched = _batched(node_feat, 2)
@@ -138,9 +154,12 @@ class GATAttention(_FlatBlock):
         # documents per optimiser step -- the reference's gradient accumulation -- and inference); any in-place update of
         # .flat (optimiser step, load_state_dict) bumps its version counter and the fold runs again.
         # Never inside a hipGraph capture (a replay does not re-run this check), and a refold goes into a NEW buffer (an older
-        # autograd graph may still hold the previous one for its backward).
+        # autograd graph may still hold the previous one for its backward).  By default ("infer") only in eval mode or under
+        # no_grad: a training loop may also write parameters through ``.data`` (EMA swaps, broadcasts), which the version
+        # counter does not see -- there the fold simply runs every call (one 4-workgroup kernel); see invalidate_fold().
         uvc, valid = None, False
-        if self.cache_fold and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+        use_cache = (not (self.training and torch.is_grad_enabled())) if self.cache_fold == "infer" else bool(self.cache_fold)
+        if use_cache and x.is_cuda and not torch.cuda.is_current_stream_capturing():
             key = (self.flat._version, self.flat.data_ptr(), x.device)
             if self._uvc is not None and self._uvc[0] == key:
                 uvc, valid = self._uvc[1], True
@@ -396,10 +415,15 @@ class EdgeFeatureProducer(_FlatBlock):
 
     def forward(self, context_output: Tensor, sen_matrix: Tensor, pos_matrix_h: Tensor, pos_matrix_t: Tensor,
                 node_feat: Tensor, dis_embed_weight: Tensor, n_valid: Optional[Tensor] = None,
-                max_live_slots: Optional[int] = None, max_live_pairs: Optional[int] = None) -> Tensor:
+                max_live_slots: Optional[int] = None, max_live_pairs: Optional[int] = None,
+                check_capacity: Optional[bool] = None) -> Tensor:
         """context_output ``[T,H]`` / ``[1,T,H]`` (the reference's shapes, glove:292) or ``[B,T,H]``; sen_matrix / pos_matrix_*
         ``[N,N,S,T]`` or ``[B,N,N,S,T]``; node_feat ``[N,H]`` / ``[B,N,H]``; dis_embed_weight = ``model.dis_embed.weight``.
-        Returns ``context_sent_att``: ``[N,N,H]`` or ``[B,N,N,H]``."""
+        Returns ``context_sent_att``: ``[N,N,H]`` or ``[B,N,N,H]``.
+
+        ``max_live_slots`` / ``max_live_pairs`` (capacities given up front: no host synchronisation, capturable): if they are
+        too small nothing is computed, every real pair of the result is NaN and ``self.last_counts[2]`` (a device tensor) is 1;
+        ``check_capacity`` (default: ``self.check_capacity``, off) reads that flag back and raises ``ProducerCapacityError``."""
         batched = sen_matrix.dim() == 5
         tok = context_output
         if tok.dim() == 2:
@@ -407,9 +431,13 @@ class EdgeFeatureProducer(_FlatBlock):
         if not batched:
             sen_matrix, pos_matrix_h, pos_matrix_t = (t.unsqueeze(0) for t in (sen_matrix, pos_matrix_h, pos_matrix_t))
             node_feat = node_feat.unsqueeze(0)
-        e = F_.edge_features(tok, sen_matrix, pos_matrix_h, pos_matrix_t, node_feat, dis_embed_weight, self.flat, n_valid,
-                             max_live_slots, max_live_pairs)
+        chk = self.check_capacity if check_capacity is None else check_capacity
+        e, self.last_counts = F_.edge_features(tok, sen_matrix, pos_matrix_h, pos_matrix_t, node_feat, dis_embed_weight, self.flat,
+                                               n_valid, max_live_slots, max_live_pairs, check_capacity=chk, return_counts=True)
         return e if batched else e.squeeze(0)
+
+    check_capacity = False      # read the over-capacity flag back after every call with caller-given capacities (one sync)
+    last_counts = None          # device int32[4] of the last call: {live slots, live pairs, over capacity, 0}
 
 
 # ======================================================================================================
@@ -605,8 +633,15 @@ class GraphModelTail(nn.Module):
         self.graphcnn = nn.ModuleList([GraphConvolution(layer_num, hidden_size, hidden_size) if i == 0 else
                                        MultiGraphConvolution(layer_num, head_num, hidden_size, hidden_size) for i in range(graph_hop)])
         self.head = ClassifierHead(hidden_size, graph_hop, entity_type_size, dis_size, relation_num, dis_plus)
+        self._install_key_hooks()
 
     # ---- the model's key names: producers.{i}.<mod>.<rest> <-> <mod>.{i}.<rest>, head.<k> <-> <k> ---------------------------
+    # Done with nn.Module's prefix-aware hooks, so the mapping also holds when the tail is a SUBMODULE of a larger model (the
+    # documented integration: dis_embed / ner_emb / the encoder live in the parent): parent.state_dict() then carries
+    # ``<prefix>word_attention.0.*`` and parent.load_state_dict() accepts them.
+    _PROD_MODS = tuple(sorted(set(k.split(".", 1)[0] for k in P_.producer_shapes(1, 1))))
+    _HEAD_MODS = tuple(sorted(set(k.split(".", 1)[0] for k in P_.HEAD_STATE_ORDER)))
+
     @staticmethod
     def _to_model_key(k: str) -> str:
         p = k.split(".")
@@ -616,23 +651,32 @@ class GraphModelTail(nn.Module):
             return ".".join(p[1:])
         return k
 
-    def state_dict(self, *args, **kwargs):
-        sd = super().state_dict(*args, **kwargs)
-        return type(sd)((self._to_model_key(k), v) for k, v in sd.items())
+    @classmethod
+    def _to_module_key(cls, k: str) -> str:
+        p = k.split(".")
+        if p[0] in cls._PROD_MODS and len(p) > 2 and p[1].isdigit():
+            return ".".join(["producers", p[1], p[0]] + p[2:])
+        if p[0] in cls._HEAD_MODS:
+            return "head." + k
+        return k
 
-    def load_state_dict(self, state_dict, strict: bool = True, **kw):
-        mine = {}
-        prod = set(k.split(".", 1)[0] for k in P_.producer_shapes(1, 1))
-        heads = set(k.split(".", 1)[0] for k in P_.HEAD_STATE_ORDER)
-        for k, v in state_dict.items():
-            p = k.split(".")
-            if p[0] in prod and len(p) > 2 and p[1].isdigit():
-                mine[".".join(["producers", p[1], p[0]] + p[2:])] = v
-            elif p[0] in heads:
-                mine["head." + k] = v
-            else:
-                mine[k] = v
-        return super().load_state_dict(mine, strict=strict, **kw)
+    @staticmethod
+    def _rename_keys(sd, prefix: str, fn):
+        items = list(sd.items())            # rebuilt in place: order kept, the dict's _metadata attribute survives clear()
+        sd.clear()
+        for k, v in items:
+            sd[prefix + fn(k[len(prefix):]) if k.startswith(prefix) else k] = v
+
+    @staticmethod
+    def _state_dict_hook(module, state_dict, prefix, local_metadata):
+        module._rename_keys(state_dict, prefix, module._to_model_key)
+
+    def _load_pre_hook(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        self._rename_keys(state_dict, prefix, self._to_module_key)
+
+    def _install_key_hooks(self):
+        self._register_state_dict_hook(self._state_dict_hook)
+        self._register_load_state_dict_pre_hook(self._load_pre_hook)
 
     def forward(self, context_output: Tensor, node_feat: Tensor, adj_matrix: Optional[Tensor], sen_matrix: Tensor,
                 pos_matrix_h: Tensor, pos_matrix_t: Tensor, node_type: Tensor, node_relative_pos: Tensor,

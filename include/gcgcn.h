@@ -32,13 +32,15 @@
 extern "C" {
 #endif
 
-int gcgcn_version(void);            /* ABI version, currently 2 */
+int gcgcn_version(void);            /* ABI version, currently 4 */
 const char* gcgcn_last_error(void); /* message of the last failing call on this thread */
 
 /* Run-time switches for A/B tests.  "chain": 1 (default) = the per-(doc, head) products of a conv run inside the
  * chain kernels, 0 = one batched launch per product.  "mha_core": 1 (default) = graphs of N <= 64 entities take the
  * one-workgroup-per-(doc, head) attention kernels, 0 = batched GEMM + row softmax for every N.  Results are identical
- * up to fp32 summation order. */
+ * up to fp32 summation order.  The other names -- "head_v1" (-1 = by problem size), "head_bil3", "head_bil3_bwd",
+ * "head_dw3", "chain_s", "chain_fuse", "chain_carry", "gat_ride", ... -- select kernel generations; each also reads the
+ * environment variable GCGCN_<NAME> once when nobody set it (DESIGN.md section 6 lists them). */
 int gcgcn_set_option(const char* name, int value);
 
 /* ---- per-kernel timing for roofline reports (bench.py) ------------------------------------------- */
@@ -224,13 +226,15 @@ int gcgcn_pair_bce_bwd(int B, int N, int R, const float* logits, const float* la
  *         sentence_attention.attention_sent W,b | .attention_pos W,b | .attention_all w,b | linear_sentence_att W,b],
  * every matrix in the reference's [out, in] layout; out17 = the 16 offsets + total.
  * Capacities: cap_rows >= live slots, cap_pairs >= pairs with a live slot (gcgcn_producer_count reports both; anything
- * beyond a capacity is dropped and flagged in ibuf's counts[2]).  Buffers (caller-owned): ibuf int32[sizes[0]], fbuf
+ * beyond a capacity is NOT computed: ibuf[sizes[3] + 2] becomes 1 and every real pair of E is written as NaN, so an
+ * undersized capacity is loud even inside a captured hipGraph).  Buffers (caller-owned): ibuf int32[sizes[0]], fbuf
  * float[sizes[1]] (written by forward, read by backward), bbuf float[sizes[2]] (backward workspace) from
  * gcgcn_producer_sizes.  Gradients w.r.t. ctx, the score table and the per-entity node terms are scatter-added with
  * fp32 atomics (reproducible up to summation order). */
 int gcgcn_producer_layout(int Hd, int P, int64_t* out17);
 int gcgcn_producer_count(int B, int N, int S, int T, const uint8_t* sen, const int32_t* n_valid, int32_t* counts2, void* stream);
-int gcgcn_producer_sizes(int B, int N, int S, int T, int Hd, int P, int ND, int64_t cap_rows, int64_t cap_pairs, int64_t* out3);
+int gcgcn_producer_sizes(int B, int N, int S, int T, int Hd, int P, int ND, int64_t cap_rows, int64_t cap_pairs, int64_t* out4);
+/* out4 = {ibuf elements, fbuf elements, bbuf elements, offset of int32 {live rows, live pairs, over capacity, 0} in ibuf} */
 int gcgcn_producer_fwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx, const uint8_t* sen, const void* pos_h,
                        const void* pos_t, int pos_bytes, const float* node, const float* dis_table, const int32_t* n_valid,
                        const float* flat, int64_t cap_rows, int64_t cap_pairs, int32_t* ibuf, float* fbuf, float* scratch,

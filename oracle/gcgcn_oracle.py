@@ -33,6 +33,19 @@ Tensor = torch.Tensor
 Params = Dict[str, Tensor]
 
 
+def _relu(pre: Tensor, forced: Optional[Tensor], trace: Optional[list]) -> Tensor:
+    """torch.relu, with two test aids.  ``trace``: the pre-activation is appended (to see how close to zero a disputed
+    element sits).  ``forced``: a boolean mask that REPLACES ``pre > 0`` -- the HIP path's own relu decisions (its saved
+    ``Y > 0``).  Two correct fp32 evaluations in different summation orders can put a pre-activation of a few ulp on
+    different sides of zero; one such element shifts a whole weight-gradient column, so full-batch parameter gradients are
+    compared with the decisions replayed (like the dropout keep-masks) and the disagreements counted separately."""
+    if trace is not None:
+        trace.append(pre.detach())
+    if forced is None:
+        return torch.relu(pre)
+    return pre * forced.to(pre.dtype)
+
+
 def _drop(t: Tensor, keep: Optional[Tensor], p: float) -> Tensor:
     """nn.Dropout(p) in train mode with an explicit boolean keep-mask.
 
@@ -63,14 +76,17 @@ def graph_conv(x: Tensor, e: Tensor, adj: Tensor, w_edge: Tensor, w_node: Tensor
 # GraphConvolution.forward  (CAGGC conv)                     GCGCN_glove.py:63-80
 # --------------------------------------------------------------------------------------
 def graph_convolution(x: Tensor, e: Tensor, adj: Tensor, sd: Params, layer_num: int,
-                      keep: Optional[Sequence[Tensor]] = None, p: float = 0.2) -> Tensor:
-    """sd keys: graphconv.{l}.weights_edge / weights_node, linear_layer.weight / bias."""
+                      keep: Optional[Sequence[Tensor]] = None, p: float = 0.2,
+                      relu_masks: Optional[Sequence[Tensor]] = None, trace: Optional[list] = None) -> Tensor:
+    """sd keys: graphconv.{l}.weights_edge / weights_node, linear_layer.weight / bias.
+    relu_masks[l] / trace: see _relu (test aids; default = the reference's relu)."""
     cache = [x]
     outs = []
     cur = x
     for l in range(layer_num):
-        y = torch.relu(graph_conv(cur, e, adj, sd[f"graphconv.{l}.weights_edge"],
-                                  sd[f"graphconv.{l}.weights_node"]))          # :71
+        y = _relu(graph_conv(cur, e, adj, sd[f"graphconv.{l}.weights_edge"],
+                             sd[f"graphconv.{l}.weights_node"]),
+                  None if relu_masks is None else relu_masks[l], trace)         # :71
         cache.append(y)
         cur = torch.cat(cache, dim=-1)                                         # :73
         outs.append(_drop(y, None if keep is None else keep[l], p))            # :74
@@ -84,7 +100,9 @@ def graph_convolution(x: Tensor, e: Tensor, adj: Tensor, sd: Params, layer_num: 
 def multi_graph_convolution(x: Tensor, e: Tensor, adj_list: Sequence[Tensor], sd: Params,
                             layer_num: int, head_num: int,
                             keep: Optional[Sequence[Sequence[Tensor]]] = None,
-                            p: float = 0.2) -> Tensor:
+                            p: float = 0.2, relu_masks: Optional[Sequence[Sequence[Tensor]]] = None,
+                            trace: Optional[list] = None) -> Tensor:
+    """relu_masks[h][l] / trace (appended in (h, l) order): see _relu."""
     heads = []
     for h in range(head_num):
         cache = [x]
@@ -92,8 +110,9 @@ def multi_graph_convolution(x: Tensor, e: Tensor, adj_list: Sequence[Tensor], sd
         cur = x
         for l in range(layer_num):
             k = h * layer_num + l                                              # :107
-            y = torch.relu(graph_conv(cur, e, adj_list[h], sd[f"graphconv.{k}.weights_edge"],
-                                      sd[f"graphconv.{k}.weights_node"]))      # :108
+            y = _relu(graph_conv(cur, e, adj_list[h], sd[f"graphconv.{k}.weights_edge"],
+                                 sd[f"graphconv.{k}.weights_node"]),
+                      None if relu_masks is None else relu_masks[h][l], trace)  # :108
             cache.append(y)
             cur = torch.cat(cache, dim=-1)
             outs.append(_drop(y, None if keep is None else keep[h][l], p))     # :111
@@ -152,7 +171,8 @@ def sub(sd: Params, prefix: str) -> Params:
 
 def hop_stack(x: Tensor, e_list: Sequence[Tensor], adj: Optional[Tensor], sd: Params,
               layer_num: int, head_num: int, alpha: float = 1.0,
-              keeps: Optional[dict] = None, p_glue: float = 0.2) -> List[Tensor]:
+              keeps: Optional[dict] = None, p_glue: float = 0.2,
+              relus: Optional[dict] = None, trace: Optional[dict] = None) -> List[Tensor]:
     """The model's hop loop restricted to the graph blocks: hop 0 = GAT + CAGGC conv,
     hop i>=1 = MHA + MAGGC conv.  Returns [x0, x1, ..., x_hops] where x_{i+1} is the node
     feature after hop i (post alpha-mix and glue dropout); the model itself records the
@@ -160,9 +180,12 @@ def hop_stack(x: Tensor, e_list: Sequence[Tensor], adj: Optional[Tensor], sd: Pa
 
     sd uses the model's key names: get_weighted_adj_matrix.*, get_adj_matrix.{i-1}.*,
     graphcnn.{i}.*.  keeps (train mode): dict with optional entries 'gat', 'cag' (list L),
-    'mha.{i}' (list H), 'mag.{i}' (list H of list L), 'glue.{i}'.
+'mha.{i}' (list H), 'mag.{i}' (list H of list L), 'glue.{i}'.
+    relus (test aid, see _relu): forced relu decisions, 'cag' (list L of bool [N,gh]) and 'mag.{i}' (list H of list L);
+    trace: a dict that receives the pre-activations under the same keys (flat lists in (h, l) order).
     """
     keeps = keeps or {}
+    relus = relus or {}
     feats = [x]
     for i, e in enumerate(e_list):
         if i < 1:
@@ -170,12 +193,14 @@ def hop_stack(x: Tensor, e_list: Sequence[Tensor], adj: Optional[Tensor], sd: Pa
             a = gat_attention(x, e, sub(sd, "get_weighted_adj_matrix"), mask,
                               keep=keeps.get("gat"))                           # :332
             new = graph_convolution(x, e, a, sub(sd, f"graphcnn.{i}"), layer_num,
-                                    keep=keeps.get("cag"))                     # :333
+                                    keep=keeps.get("cag"), relu_masks=relus.get("cag"),
+                                    trace=None if trace is None else trace.setdefault("cag", []))  # :333
         else:
             al = multi_head_attention(x, sub(sd, f"get_adj_matrix.{i - 1}"), head_num,
                                       keep=keeps.get(f"mha.{i}"))              # :336
             new = multi_graph_convolution(x, e, al, sub(sd, f"graphcnn.{i}"), layer_num,
-                                          head_num, keep=keeps.get(f"mag.{i}"))  # :337
+                                          head_num, keep=keeps.get(f"mag.{i}"), relu_masks=relus.get(f"mag.{i}"),
+                                          trace=None if trace is None else trace.setdefault(f"mag.{i}", []))  # :337
         x = alpha * new + (1 - alpha) * x                                      # :339
         x = _drop(x, keeps.get(f"glue.{i}"), p_glue)                           # :341
         feats.append(x)

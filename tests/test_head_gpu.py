@@ -6,10 +6,20 @@ import torch
 
 from conftest import golden_files, ids, load_golden
 import gcgcn_amd
-from gcgcn_amd import params as P_
+from gcgcn_amd import _lib, params as P_
 from oracle import gcgcn_oracle as O
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["by_size", "gen1", "gen2"])
+def head_generation(request):
+    """The outer-product passes exist in two generations chosen by problem size (head.hip head_v1: the second one only from
+    32 641 pairs up).  Every parity test runs under the size rule AND with each generation forced, so the kernels the
+    benchmarks time (head_bil3_kernel<1..3>, head_dw_kernel, head_bil2_kernel) are the kernels the fixtures check."""
+    _lib.call("gcgcn_set_option", b"head_v1", {"by_size": -1, "gen1": 1, "gen2": 0}[request.param])
+    yield request.param
+    _lib.call("gcgcn_set_option", b"head_v1", -1)
 
 
 def head_bilinear_weight(seed, r=97, h=128):
@@ -18,7 +28,7 @@ def head_bilinear_weight(seed, r=97, h=128):
 
 
 @pytest.mark.parametrize("path", golden_files("head"), ids=ids(golden_files("head")))
-def test_head_golden(gpu_device, path):
+def test_head_golden(gpu_device, path, head_generation):
     g = load_golden(path)
     r = g["raw"]
     sd = dict(g["sd"])
@@ -44,7 +54,7 @@ def test_head_golden(gpu_device, path):
 
 
 @pytest.mark.parametrize("B,N,R,hop", [(3, 9, 97, 2), (2, 64, 97, 2), (2, 13, 5, 1)])
-def test_head_batched_ragged_matches_oracle(gpu_device, B, N, R, hop):
+def test_head_batched_ragged_matches_oracle(gpu_device, B, N, R, hop, head_generation):
     g = torch.Generator().manual_seed(B * 10 + N)
     head = gcgcn_amd.ClassifierHead(graph_hop=hop, relation_num=R).to(gpu_device)
     sd = {k: v.cpu().clone().requires_grad_() for k, v in head.state_dict().items()}
@@ -77,11 +87,86 @@ def test_head_batched_ragged_matches_oracle(gpu_device, B, N, R, hop):
     torch.testing.assert_close(ner.grad.cpu(), sd["ner_emb.weight"].grad, rtol=1e-3, atol=1e-4 * max(1.0, sd["ner_emb.weight"].grad.abs().max().item()))
     torch.testing.assert_close(dis.grad.cpu(), sd["dis_embed.weight"].grad, rtol=1e-3, atol=1e-4 * max(1.0, sd["dis_embed.weight"].grad.abs().max().item()))
     # determinism (no atomics on this path)
+    flat_grad_1 = head.flat.grad.clone()
     head.zero_grad()
     fg2 = [dev(f).requires_grad_() for f in feats]
     out2 = head(fg2, dev(ntype), dev(rel), ner.detach(), dis.detach(), n_valid=dev(nv))
     (out2 * dev(cot)).sum().backward()
-    assert torch.equal(out, out2) and torch.equal(head.flat.grad, head.flat.grad) and all(torch.equal(a.grad, b_.grad) for a, b_ in zip(fg, fg2))
+    assert torch.equal(out, out2) and torch.equal(head.flat.grad, flat_grad_1) and all(torch.equal(a.grad, b_.grad) for a, b_ in zip(fg, fg2))
+
+
+def test_head_generations_agree_at_bench_size(gpu_device):
+    """More than 32 640 pairs, not a multiple of 128 (B = 17 ragged documents of up to 45 entities: 34 425 pairs) -- the
+    problem size at which the library itself picks the register-generated kernels (head_bil3_kernel<1..3>, head_dw_kernel).
+    Every switchable variant of the second generation against the first generation on the GPU (logits and all gradients),
+    one document of the batch against the CPU oracle, and the size rule picks what it says it picks."""
+    B, N, R = 17, 45, 97
+    g = torch.Generator().manual_seed(1745)
+    head = gcgcn_amd.ClassifierHead().to(gpu_device)
+    feats = [torch.rand(B, N, 128, generator=g) * 2 - 1 for _ in range(3)]
+    ntype, rel = torch.randint(0, 7, (B, N), generator=g), torch.randint(-10, 11, (B, N, N), generator=g)
+    nv = torch.randint(2, N + 1, (B,), generator=g).to(torch.int32)
+    nv[0] = N
+    cot = torch.randn(B, N, N, R, generator=g)
+    ner0, dis0 = torch.randn(7, 20, generator=g) * 0.3, torch.randn(21, 20, generator=g) * 0.3
+    dev = lambda t: t.to(gpu_device)
+
+    def run():
+        head.zero_grad()
+        fg = [dev(f).requires_grad_() for f in feats]
+        ner, dis = dev(ner0).requires_grad_(), dev(dis0).requires_grad_()
+        out = head(fg, dev(ntype), dev(rel), ner, dis, n_valid=dev(nv))
+        (out * dev(cot)).sum().backward()
+        return [out.detach()] + [f.grad for f in fg] + [ner.grad, dis.grad, head.flat.grad.clone()]
+
+    variants = {"gen1": dict(head_v1=1), "gen2": dict(head_v1=0), "gen2 bil2 forward": dict(head_v1=0, head_bil3=0),
+                "gen2 bil2 backward": dict(head_v1=0, head_bil3_bwd=0), "gen2 gemm dW": dict(head_v1=0, head_dw3=0),
+                "by size": dict()}
+    res = {}
+    try:
+        for name, opts in variants.items():
+            for k in ("head_v1", "head_bil3", "head_bil3_bwd", "head_dw3"):
+                _lib.call("gcgcn_set_option", k.encode(), opts.get(k, -1 if k == "head_v1" else 1))
+            res[name] = run()
+    finally:
+        for k in ("head_v1", "head_bil3", "head_bil3_bwd", "head_dw3"):
+            _lib.call("gcgcn_set_option", k.encode(), -1 if k == "head_v1" else 1)
+    names = ["logits", "d f0", "d f1", "d f2", "d ner_emb", "d dis_embed", "d flat"]
+    for name, r in res.items():
+        for what, a, b_ in zip(names, r, res["gen1"]):
+            torch.testing.assert_close(a, b_, rtol=1e-4, atol=1e-4 * max(1.0, b_.abs().max().item()), msg=lambda m: f"{name}, {what}: {m}")
+    assert all(torch.equal(a, b_) for a, b_ in zip(res["by size"], res["gen2"]))      # 34 425 pairs: the size rule = generation 2
+    # one ragged document of the batch against the CPU oracle (logits + feature gradients; the sums over all documents are
+    # tied to generation 1 above, which test_head_batched_ragged_matches_oracle ties to the oracle)
+    b = 1
+    n = int(nv[b])
+    sd = {k: v.cpu() for k, v in head.state_dict().items()}
+    sd["ner_emb.weight"], sd["dis_embed.weight"] = ner0, dis0
+    fr = [f[b, :n].clone().requires_grad_() for f in feats]
+    ref = O.classifier_head(fr, ntype[b, :n], rel[b, :n, :n], sd)
+    (ref * cot[b, :n, :n]).sum().backward()
+    torch.testing.assert_close(res["gen2"][0][b, :n, :n].cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
+    for i in range(3):
+        torch.testing.assert_close(res["gen2"][1 + i][b, :n].cpu(), fr[i].grad, rtol=1e-3, atol=1e-4 * max(1.0, fr[i].grad.abs().max().item()))
+
+
+def test_head_rejects_what_it_cannot_index(gpu_device):
+    """ner_emb must have the 7 rows the kernels index (glove:241: nn.Embedding(7, ...)); ids out of range raise like the
+    reference's embedding lookups (IndexError) when checking is on (the default outside graph capture)."""
+    head = gcgcn_amd.ClassifierHead().to(gpu_device)
+    dev = lambda t: t.to(gpu_device)
+    feats = [dev(torch.rand(1, 4, 128)) for _ in range(3)]
+    ntype, rel = torch.zeros(1, 4, dtype=torch.int64), torch.zeros(1, 4, 4, dtype=torch.int64)
+    with pytest.raises(ValueError, match="7 rows"):
+        head(feats, dev(ntype), dev(rel), dev(torch.randn(5, 20)), dev(torch.randn(21, 20)))
+    bad = ntype.clone()
+    bad[0, 2] = 9
+    with pytest.raises(IndexError, match="node_type"):
+        head(feats, dev(bad), dev(rel), dev(torch.randn(7, 20)), dev(torch.randn(21, 20)))
+    bad = rel.clone()
+    bad[0, 1, 3] = 11
+    with pytest.raises(IndexError, match="node_relative_pos"):
+        head(feats, dev(ntype), dev(bad), dev(torch.randn(7, 20)), dev(torch.randn(21, 20)))
 
 
 def test_head_feeds_the_trainer_loss(gpu_device):

@@ -254,43 +254,90 @@ def test_model_c1_hooks(gpu_device):
 # ------------------------------------------------------------------------------------------------------
 # batched / ragged / train-mode against the CPU oracle
 # ------------------------------------------------------------------------------------------------------
-def _oracle_stack(x, e1, e2, adj, sd, L, H, nv=None, keeps=None):
-    """Per-document loop of the CPU oracle; returns outputs and grads (loss = sum(out * cot))."""
+def _oracle_stack(x, e1, e2, adj, sd, L, H, nv=None, keeps=None, relus=None, docs=None, traces=None):
+    """Per-document loop of the CPU oracle; returns outputs and grads (loss = sum(out * cot)).  ``relus[b]`` / ``traces``:
+    the HIP path's relu decisions replayed in the oracle and the oracle's pre-activations (oracle._relu); ``docs``: only
+    these documents of the batch (lists stay indexed by position in ``docs``)."""
     B = x.shape[0]
     outs, gx, ge1, ge2 = [], [], [], []
     sdl = {k: v.clone().requires_grad_() for k, v in sd.items()}
-    for b in range(B):
+    for b in (range(B) if docs is None else docs):
         n = x.shape[1] if nv is None else int(nv[b])
-        xb = x[b, :n].clone().requires_grad_()
-        e1b = e1[b, :n, :n].clone().requires_grad_()
-        e2b = e2[b, :n, :n].clone().requires_grad_()
+        xb = x[b, :n].detach().cpu().clone().requires_grad_()          # (device tensors: only the documents asked for travel)
+        e1b = e1[b, :n, :n].detach().cpu().clone().requires_grad_()
+        e2b = e2[b, :n, :n].detach().cpu().clone().requires_grad_()
         kb = None if keeps is None else keeps[b]
-        f = O.hop_stack(xb, [e1b, e2b], adj[b, :n, :n], sdl, L, H, keeps=kb)
+        tr = None
+        if traces is not None:
+            tr = {}
+            traces.append(tr)
+        f = O.hop_stack(xb, [e1b, e2b], None if adj is None else adj[b, :n, :n], sdl, L, H, keeps=kb,
+                        relus=None if relus is None else relus[b], trace=tr)
         outs.append(f)
         gx.append(xb), ge1.append(e1b), ge2.append(e2b)
     return outs, gx, ge1, ge2, sdl
 
 
-def _check_stack_param_grads(hops, sdl, rtol=1e-3, atol=2e-4, relu_flips=False):
-    """Every parameter gradient of the four blocks against the oracle's (sums over B*N rows: fp32 summation-order slack).
-    relu_flips: at millions of relu inputs a handful sit within one fp32 rounding of zero, and two correct fp32 evaluations in
-    different summation orders put them on different sides -- one such element shifts a whole weight-gradient column by
-    |input row| x |upstream gradient| (seen: 0.4 % of one tensor's elements off by 1 % of its largest entry).  Then a tensor
-    passes if at most 1 % of its elements miss the tolerance and none by more than 5 % of the largest entry."""
+class _relu_spy:
+    """Collects the relu outputs Y the two convolutions save for backward ([B, N, H, L, gh]; the HIP path's relu decisions
+    are Y > 0) by wrapping GcnFn.forward for the duration of a ``with`` block."""
+
+    def __enter__(self):
+        self.Y = []
+        self._orig = F_.GcnFn.forward
+        spy = self
+
+        def fwd(ctx, x, ebar, adj, flat, n_valid, L, H, *rest):
+            out = spy._orig(ctx, x, ebar, adj, flat, n_valid, L, H, *rest)
+            B, N, D = x.shape
+            spy.Y.append(ctx.to_save[5].view(B, N, H, L, D // L))          # save_for_backward(x, ebar, adj, flat, Pn, Y, ...)
+            return out
+        F_.GcnFn.forward = staticmethod(fwd)
+        return self
+
+    def __exit__(self, *exc):
+        F_.GcnFn.forward = staticmethod(self._orig)
+        return False
+
+    def relus(self, docs):
+        """{doc: oracle ``relus`` dict} from the first (CAGGC) and second (MAGGC) convolution call seen."""
+        ycag, ymag = (y.detach().cpu() > 0 for y in self.Y[:2])
+        L, H = ymag.shape[3], ymag.shape[2]
+        return {b: {"cag": [ycag[b, :, 0, l] for l in range(L)],
+                    "mag.1": [[ymag[b, :, h, l] for l in range(L)] for h in range(H)]} for b in docs}
+
+
+def _check_relu_decisions(relus, traces, docs):
+    """The HIP path's relu decisions against the oracle's own pre-activations (computed WITH the HIP decisions replayed, so
+    both sides saw the same inputs at every layer): they may differ only where the pre-activation is a rounding error away
+    from zero, and only in a handful of the millions of elements."""
+    total = flips = 0
+    worst = 0.0
+    for b, tr in zip(docs, traces):
+        for key in ("cag", "mag.1"):
+            masks = relus[b][key] if key == "cag" else [m for per_head in relus[b][key] for m in per_head]
+            for mask, pre in zip(masks, tr[key]):
+                dis = (pre > 0) != mask
+                total += mask.numel()
+                flips += int(dis.sum())
+                if dis.any():
+                    worst = max(worst, pre[dis].abs().max().item())
+    assert worst < 1e-5, f"a relu decision differs from the oracle's at |pre-activation| = {worst:.3e}"
+    assert flips <= max(16, int(2e-5 * total)), f"{flips} of {total} relu decisions differ from the oracle's"
+    return flips, total
+
+
+def _check_stack_param_grads(hops, sdl, rtol=1e-3, atol=2e-4):
+    """Every parameter gradient of the four blocks against the oracle's (sums over B*N rows: fp32 summation-order slack,
+    absolute part relative to the tensor's largest entry)."""
     ref_grads = {k: v.grad for k, v in sdl.items() if v.grad is not None}
     seen = 0
     for mod, pre in ((hops.get_weighted_adj_matrix, "get_weighted_adj_matrix."), (hops.graphcnn[0], "graphcnn.0."),
                      (hops.get_adj_matrix[0], "get_adj_matrix.0."), (hops.graphcnn[1], "graphcnn.1.")):
         for k, gk in mod.named_grads().items():
-            ref = ref_grads[pre + k]        # absolute slack relative to the tensor's largest entry (long fp32 sums)
+            ref = ref_grads[pre + k]
             top = max(1.0, ref.abs().max().item())
-            if relu_flips:
-                err = (gk.cpu() - ref).abs()
-                bad = err > atol * top + rtol * ref.abs()
-                assert bad.float().mean().item() <= 0.01 and err.max().item() <= 0.05 * top, \
-                    f"grad {pre + k}: {int(bad.sum())} of {bad.numel()} elements off, max {err.max().item():.3e} (largest entry {top:.3e})"
-            else:
-                torch.testing.assert_close(gk.cpu(), ref, rtol=rtol, atol=atol * top, msg=lambda m: f"grad {pre + k}: {m}")
+            torch.testing.assert_close(gk.cpu(), ref, rtol=rtol, atol=atol * top, msg=lambda m: f"grad {pre + k}: {m}")
             seen += 1
     assert seen == len(ref_grads), (seen, len(ref_grads))       # nothing the reference differentiates is missing
 
@@ -407,6 +454,140 @@ def test_train_mode_matches_oracle_with_replayed_masks(gpu_device, B, N, D, L, H
 
 
 # ------------------------------------------------------------------------------------------------------
+# the step bench.py times: a captured hipGraph, replayed
+# ------------------------------------------------------------------------------------------------------
+def _capture_step(hops, sets, cot, n_valid=None):
+    """One hipGraph per resident input set, captured exactly as bench.py does (a warm-up pass on a side stream, then the
+    capture; gradients of the flat parameters are the tensors the capture installed)."""
+    from gcgcn_amd.dist import FlatGradBucket
+    bucket = FlatGradBucket(hops)
+    outs = {}
+
+    def fwd_bwd(k):
+        x, e1, e2, adj = sets[k]
+        x.grad = e1.grad = e2.grad = None
+        bucket.zero_grad()
+        f = hops(x, [e1, e2], adj, n_valid=n_valid)
+        torch.autograd.backward(f[-1], cot)
+        outs[k] = (f[1], f[2])
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for k in range(len(sets)):
+            fwd_bwd(k)
+    torch.cuda.current_stream().wait_stream(s)
+    graphs, results = [], []
+    for k in range(len(sets)):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fwd_bwd(k)
+        graphs.append(g)
+        x, e1, e2, _ = sets[k]
+        results.append(dict(x1=outs[k][0], x2=outs[k][1], dx=x.grad, de1=e1.grad, de2=e2.grad,
+                            pgrads=[(p, p.grad) for p in bucket.params]))
+    return bucket, fwd_bwd, graphs, results
+
+
+def test_graph_replay_matches_eager(gpu_device):
+    """bench.py's timed region is hipGraph replays.  Under capture the step takes code the eager tests never run (the lazy rng
+    draw inside gcgcn_gat_fwd, the GAT fold forced on, the end-of-backward hand-over of deferred weight gradients as a captured
+    graph task, .grad re-binding).  Eval mode, cfg-2 document shape, two rotating input sets: every replayed output and
+    gradient is BITWISE what an eager step on the same inputs gives -- also on the second and third replay."""
+    B, N, D, L, H = 4, 64, 256, 2, 8
+    sd = O.init_stack_params(D, L, H, seed=1337)
+    hops = gcgcn_amd.GraphHops(D, L, H).to(gpu_device).eval()
+    hops.load_state_dict(sd, strict=True)
+    sets = []
+    for k in range(2):
+        x, e1, e2, adj = (t.to(gpu_device) for t in O.synth_docs(B, N, D, seed=70 + k))
+        sets.append((x.requires_grad_(), e1.requires_grad_(), e2.requires_grad_(), adj))
+    cot = torch.randn(B, N, D, generator=torch.Generator().manual_seed(9)).to(gpu_device)
+    bucket, fwd_bwd, graphs, results = _capture_step(hops, sets, cot)
+
+    def eager(k):
+        x, e1, e2, adj = (t.detach().clone() for t in sets[k])
+        for t in (x, e1, e2):
+            t.requires_grad_()
+        hops.zero_grad()
+        f = hops(x, [e1, e2], adj)
+        torch.autograd.backward(f[-1], cot)
+        return dict(x1=f[1].detach().clone(), x2=f[2].detach().clone(), dx=x.grad, de1=e1.grad, de2=e2.grad,
+                    pgrads=[p.grad.clone() for p in bucket.params])
+
+    want = [eager(k) for k in range(2)]
+    assert all(g is not None for r in want for g in r["pgrads"])
+    for rep in range(3):
+        for k in (0, 1):
+            for key in ("x1", "x2", "dx", "de1", "de2"):                     # poison: a replay has to rewrite everything
+                results[k][key].fill_(float("nan"))
+            for _, g in results[k]["pgrads"]:
+                g.fill_(float("nan"))
+            graphs[k].replay()
+            torch.cuda.synchronize()
+            for key in ("x1", "x2", "dx", "de1", "de2"):
+                assert torch.equal(results[k][key], want[k][key]), f"replay {rep}, set {k}: {key} differs from the eager step"
+            for (p, g), w_ in zip(results[k]["pgrads"], want[k]["pgrads"]):
+                assert torch.equal(g, w_), f"replay {rep}, set {k}: a flat parameter gradient differs from the eager step"
+
+
+def test_graph_replay_train_mode_draws_fresh_masks_and_matches_oracle(gpu_device):
+    """Train mode under replay: the {seed, counter} snapshots are drawn on the DEVICE inside the captured GATAttention launch,
+    so every replay sees new dropout masks.  After each of two replays the snapshot buffer is read back, the six sites' keep
+    masks are regenerated from it, and outputs + gradients equal the oracle run with exactly those masks."""
+    B, N, D, L, H = 2, 64, 256, 2, 8
+    sd = O.init_stack_params(D, L, H, seed=31)
+    x, e1, e2, adj = O.synth_docs(B, N, D, seed=32)
+    hops = gcgcn_amd.GraphHops(D, L, H).to(gpu_device).train()
+    hops.load_state_dict(sd, strict=True)
+    gcgcn_amd.manual_seed(4321)
+    sets = [(dev_leaf(x, gpu_device), dev_leaf(e1, gpu_device), dev_leaf(e2, gpu_device), adj.to(gpu_device))]
+    cot = torch.ones(B, N, D, device=gpu_device)
+    snaps = []
+    orig = F_.rng_snapshot
+
+    def spy(dev, lazy=False):
+        s_ = orig(dev, lazy)
+        snaps.append(s_)
+        return s_
+    F_.rng_snapshot = spy
+    try:
+        bucket, fwd_bwd, graphs, results = _capture_step(hops, sets, cot)
+    finally:
+        F_.rng_snapshot = orig
+    assert len(snaps) == 12                    # 6 sites in the warm-up pass + 6 in the capture
+    snaps = snaps[6:]                          # the captured launches read these (views of the scope's buffer in the graph's pool)
+    HD = H * D
+    r = results[0]
+    seen_masks = []
+    for rep in range(2):
+        graphs[0].replay()
+        torch.cuda.synchronize()
+        k_gat = F_.dropout_keep_mask(snaps[0], _lib.SALT_GAT, 0.1, B * N * N).view(B, N, N).cpu()
+        k_cag = F_.dropout_keep_mask(snaps[1], _lib.SALT_GCN, 0.2, B * N * D).view(B, N, 1, L, D // L).cpu()
+        k_gl0 = F_.dropout_keep_mask(snaps[2], _lib.SALT_GLUE, 0.2, B * N * D).view(B, N, D).cpu()
+        k_mha = F_.dropout_keep_mask(snaps[3], _lib.SALT_MHA, 0.1, B * H * N * N).view(B, H, N, N).cpu()
+        k_mag = F_.dropout_keep_mask(snaps[4], _lib.SALT_GCN, 0.2, B * N * HD).view(B, N, H, L, D // L).cpu()
+        k_gl1 = F_.dropout_keep_mask(snaps[5], _lib.SALT_GLUE, 0.2, B * N * D).view(B, N, D).cpu()
+        seen_masks.append((k_gat, k_mag))
+        keeps = [{"gat": k_gat[b], "cag": [k_cag[b, :, 0, l] for l in range(L)], "glue.0": k_gl0[b],
+                  "mha.1": [k_mha[b, h] for h in range(H)],
+                  "mag.1": [[k_mag[b, :, h, l] for l in range(L)] for h in range(H)], "glue.1": k_gl1[b]} for b in range(B)]
+        outs, gx, ge1, ge2, sdl = _oracle_stack(x, e1, e2, adj, sd, L, H, keeps=keeps)
+        sum(outs[b][2].sum() for b in range(B)).backward()
+        for b in range(B):
+            close(r["x1"][b], outs[b][1], f"replay {rep} x1[{b}]")
+            close(r["x2"][b], outs[b][2], f"replay {rep} x2[{b}]")
+            close(r["dx"][b], gx[b].grad, f"replay {rep} dX[{b}]")
+            close(r["de1"][b], ge1[b].grad, f"replay {rep} dE1[{b}]")
+            close(r["de2"][b], ge2[b].grad, f"replay {rep} dE2[{b}]")
+        for p, g in r["pgrads"]:
+            p.grad = g                                                       # what bench.py does after a replay
+        _check_stack_param_grads(hops, sdl)
+    assert not torch.equal(seen_masks[0][0], seen_masks[1][0]) and not torch.equal(seen_masks[0][1], seen_masks[1][1])
+
+
+# ------------------------------------------------------------------------------------------------------
 # full-size properties (cfg 2: B=32, N=64, D=256, L=2, H=8)
 # ------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("cfg,B,N,D,L,H", [("c2", 32, 64, 256, 2, 8), ("c3", 32, 64, 768, 4, 4), ("c5", 32, 256, 512, 2, 8)])
@@ -463,6 +644,28 @@ def test_full_size_properties(gpu_device, cfg, B, N, D, L, H):
     close(dx[d], xr.grad, f"{cfg} dX[{d}]")
     close(de1[d], e1r.grad, f"{cfg} dE1[{d}]")
     close(de2[d], e2r.grad, f"{cfg} dE2[{d}]")
+    # The parameter gradients of the FULL batch (B = 32 launch: its split-K factors, carried weight-gradient tiles, group
+    # peeling) against the oracle summed over documents, relu decisions replayed (_relu_spy).  cfg 2 / cfg 3: all 32
+    # documents.  cfg 5 (the oracle needs ~10 s per document): the same B = 32 launch with a cotangent that is non-zero on
+    # 4 documents only -- the other 28 contribute exact zeros to every sum, the oracle runs those 4.
+    docs = list(range(B)) if cfg != "c5" else [0, 9, 18, 31]
+    w = torch.zeros(B, device=gpu_device)
+    w[docs] = 1.0
+    xg, a, b = (t.clone().requires_grad_() for t in (x, e1, e2))
+    hops.zero_grad()
+    with _relu_spy() as spy:
+        fw = hops(xg, [a, b])
+    (fw[2] * w[:, None, None]).sum().backward()
+    relus = spy.relus(docs)
+    traces = []
+    outs, gx, ge1, ge2, sdl = _oracle_stack(x, e1, e2, None, sd, L, H, relus=relus, docs=docs, traces=traces)
+    sum(o[2].sum() for o in outs).backward()
+    flips, total = _check_relu_decisions(relus, traces, docs)
+    print(f"{cfg}: {flips} of {total} relu decisions differ from the oracle's")
+    for k, d_ in enumerate(docs[:2]):
+        close(fw[2][d_], outs[k][2], f"{cfg} x2[{d_}] (relu decisions replayed)")
+        close(xg.grad[d_], gx[k].grad, f"{cfg} dX[{d_}]")
+    _check_stack_param_grads(hops, sdl)
 
 
 @pytest.mark.parametrize("B,N,D,L,H", [(16, 64, 768, 4, 4),     # cfg 3 shape: B H <= 64 and a long chain -- the CAGGC chain
@@ -477,22 +680,26 @@ def test_deferred_and_immediate_weight_gradients_agree_at_batch(gpu_device, B, N
     hops.load_state_dict(sd, strict=True)
     res = {}
     try:
-        for defer in (True, False):
+        for defer in (False, True):
             F_.defer_weight_grads = defer
             xs = [dev_leaf(t, gpu_device) for t in (x, e1, e2)]
             hops.zero_grad()
-            hops(xs[0], [xs[1], xs[2]])[-1].sum().backward()
+            with _relu_spy() as spy:
+                out = hops(xs[0], [xs[1], xs[2]])[-1]
+            out.sum().backward()
             assert not F_._passes
             res[defer] = [p.grad.clone() for p in hops.parameters() if p.grad is not None]
     finally:
         F_.defer_weight_grads = True
     for a_, b_ in zip(res[True], res[False]):
         torch.testing.assert_close(a_, b_, rtol=2e-5, atol=2e-5 * max(1.0, b_.abs().max().item()))
-    outs, gx, ge1, ge2, sdl = _oracle_stack(x, e1, e2, adj, sd, L, H)
+    # against the oracle with the HIP path's relu decisions replayed (the last run's: hops' gradients are the deferred ones)
+    docs = list(range(B))
+    relus, traces = spy.relus(docs), []
+    outs, gx, ge1, ge2, sdl = _oracle_stack(x, e1, e2, adj, sd, L, H, relus=relus, traces=traces)
     sum(o[2].sum() for o in outs).backward()
-    # (sums over up to 1024 rows of D = 768 features against a CPU reference with another summation order: 1e-3 of the
-    # largest entry; the deferred-vs-immediate comparison above is the tight one)
-    _check_stack_param_grads(hops, sdl, rtol=2e-3, atol=1e-3, relu_flips=True)
+    _check_relu_decisions(relus, traces, docs)
+    _check_stack_param_grads(hops, sdl)
 
 
 def test_edge_mean_handoff_is_used_and_safe(gpu_device):

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in gcgcn.h but missing from libgcgcn_hip.so"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.gcgcn_version() == _lib.ABI_VERSION == 3
+    assert lib.gcgcn_version() == _lib.ABI_VERSION == 4
 
 
 @pytest.mark.parametrize("D,L,H", [(8, 2, 2), (128, 2, 8), (768, 4, 4), (512, 2, 8), (12, 4, 4)])
@@ -142,3 +142,94 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(root, f)).read()
                 assert "oracle" not in src.replace("CPU oracle replay", ""), f"{f} mentions the oracle"
+
+
+def test_bench_self_launches_its_ranks():
+    """``python bench.py --gpus 2`` without a torch.distributed environment starts the two ranks itself (the driver may invoke
+    the scaling runs the way it invokes the 1-GPU run).  On a box without GPUs the failure must come from the CHILDREN
+    ("needs an MI355X"), not from a launcher hint, and the parent exits non-zero with their status."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the children would run the benchmark")
+    assert r.returncode != 0
+    assert "starting 2 ranks" in r.stderr
+    assert "needs an MI355X" in r.stderr and "launch with" not in r.stderr
+    assert r.stdout.strip() == ""                         # no JSON line from a failed run
+
+
+def test_deferral_is_switched_off_under_ddp():
+    """A forward that runs inside torch DistributedDataParallel's forward is recognised (its AccumulateGrad hooks need the
+    gradient during backward, which a parked gradient does not give them): functional._under_ddp() is what the blocks ask."""
+    import warnings
+    import torch.distributed as dist
+    from gcgcn_amd import functional as F_
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    seen = []
+
+    class Probe(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(2))
+
+        def forward(self, x):
+            with warnings.catch_warnings(record=True) as rec:
+                warnings.simplefilter("always")
+                seen.append((F_._under_ddp(), [str(w.message) for w in rec]))
+            return (x * self.w).sum()
+
+    assert F_._under_ddp() is False
+    m = Probe()
+    m(torch.ones(2))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        os.environ["MASTER_PORT"] = str(so.getsockname()[1])
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        F_._warned_ddp[0] = False
+        DDP(m)(torch.ones(2)).backward()
+    finally:
+        dist.destroy_process_group()
+    assert seen[0][0] is False and seen[1][0] is True
+    assert any("DistributedDataParallel" in w for w in seen[1][1])
+    assert F_._under_ddp() is False
+
+
+def test_tail_keys_as_root_and_as_submodule():
+    """GraphModelTail's state_dict carries the MODEL's key names (word_attention.{i}.*, dense_layer.*, ...) both as the root
+    module and nested in a parent (the documented integration: embeddings / encoder live in the parent), load_state_dict
+    accepts them in both positions, strict, and the dict's _metadata survives."""
+    torch.manual_seed(0)
+    tail = gcgcn_amd.GraphModelTail(hidden_size=16, layer_num=2, head_num=2, dis_size=4, entity_type_size=4, relation_num=5)
+
+    class Parent(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.dis_embed = torch.nn.Embedding(21, 4)
+            self.tail = gcgcn_amd.GraphModelTail(hidden_size=16, layer_num=2, head_num=2, dis_size=4, entity_type_size=4, relation_num=5)
+
+    root_sd = tail.state_dict()
+    assert hasattr(root_sd, "_metadata")
+    assert "word_attention.1.attention_sent.weight" in root_sd and "dense_layer.weight" in root_sd
+    assert not any(k.startswith(("producers.", "head.")) for k in root_sd)
+    par = Parent()
+    psd = par.state_dict()
+    assert "tail.word_attention.0.attention_all.bias" in psd and "tail.bili_layer_01.weight" in psd and "dis_embed.weight" in psd
+    assert not any(".producers." in k or ".head." in k for k in psd)
+    assert [k[len("tail."):] for k in psd if k.startswith("tail.")] == list(root_sd)          # same keys, same order
+    # round trips: root -> nested, nested -> root, strict
+    src = {("tail." + k): v + 1.0 for k, v in root_sd.items()}
+    src["dis_embed.weight"] = psd["dis_embed.weight"]
+    assert par.load_state_dict(src, strict=True).missing_keys == []
+    for k, v in par.tail.state_dict().items():
+        torch.testing.assert_close(v, root_sd[k] + 1.0)
+    tail.load_state_dict({k[len("tail."):]: v for k, v in par.state_dict().items() if k.startswith("tail.")}, strict=True)
+    for k, v in tail.state_dict().items():
+        torch.testing.assert_close(v, root_sd[k] + 1.0)
+    with pytest.raises(RuntimeError, match="Unexpected key"):
+        tail.load_state_dict({**root_sd, "word_attention.7.attention_sent.weight": torch.zeros(1)}, strict=True)

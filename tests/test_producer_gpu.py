@@ -166,6 +166,22 @@ def test_producer_ragged_capacities_and_empty(gpu_device):
         live[b, int(nv[b]):] = False
         live[b, :, int(nv[b]):] = False
     assert r == int(live.sum()) and q == int(live.any(-1).sum())
+    # capacities one short of what the batch holds (either one): nothing is computed, the device-side flag is set, every real
+    # pair of E is NaN (loud under a captured hipGraph, where nobody can raise) and check_capacity=True raises
+    for caps in ((r - 1, q), (r, q - 1), (r - 1, q - 1)):
+        e_bad = prod(dev(ctx), dev(sen), dev(ph), dev(pt), dev(node), dev(table), n_valid=dev(nv), max_live_slots=caps[0],
+                     max_live_pairs=caps[1])
+        assert prod.last_counts.tolist()[2] == 1
+        for b in range(B):
+            n = int(nv[b])
+            assert torch.isnan(e_bad[b, :n, :n]).all() and (e_bad[b, n:] == 0).all() and (e_bad[b, :, n:] == 0).all()
+        with pytest.raises(F_.ProducerCapacityError, match="max_live_slots"):
+            prod(dev(ctx), dev(sen), dev(ph), dev(pt), dev(node), dev(table), n_valid=dev(nv), max_live_slots=caps[0],
+                 max_live_pairs=caps[1], check_capacity=True)
+    e_ok = prod(dev(ctx), dev(sen), dev(ph), dev(pt), dev(node), dev(table), n_valid=dev(nv), max_live_slots=r, max_live_pairs=q,
+                check_capacity=True)                      # exactly enough
+    assert prod.last_counts.tolist()[:3] == [r, q, 0]
+    torch.testing.assert_close(e_ok, res[0][0], rtol=1e-5, atol=1e-6)
     # no live slot at all: every real pair gets linear_sentence_att's bias
     sen0 = sen.clone()
     sen0[..., 0] = False
