@@ -804,7 +804,11 @@ int gcn_chain_fwd(const GcnCtx& c, hipStream_t st) {
   dim3 grid(chain_grid(c, 1)), block(64 * CW);
   double fl = 0;
   for (int l = 0; l < c.L; ++l) fl += 2.0 * c.N * c.gh * (c.N + (double)l * c.gh);
-  if (chain_aligned(c, false) && chain_small_ok(c, false))
+  // option chain_t: 1 (default) = the column-strip kernels (chain_t.hip) wherever the default shape's own kernels do not
+  // apply, 2 = also there (A/B), 0 = never
+  const bool s_ok = chain_aligned(c, false) && chain_small_ok(c, false);
+  if (chain_t_ok(c, false) && !(s_ok && option("chain_t", 1) < 2)) return gcn_chain_t_fwd(c, grid, fl * c.B * c.H, st);
+  if (s_ok)
     GC_LAUNCH_TIMED("gcn_chain_fwd", fl * c.B * c.H, gcn_chain_s_fwd_kernel, grid, block, 0, st, c);
   else if (chain_aligned(c, false)) GC_LAUNCH_TIMED("gcn_chain_fwd", fl * c.B * c.H, gcn_chain_fwd_kernel<true>, grid, block, 0, st, c);
   else GC_LAUNCH_TIMED("gcn_chain_fwd", fl * c.B * c.H, gcn_chain_fwd_kernel<false>, grid, block, 0, st, c);
@@ -823,6 +827,9 @@ int gcn_chain_bwd(const GcnCtx& c, hipStream_t st, DeferQueue* carry) {
   // of the tile -- and occupies its compute unit alone (register footprint of this kernel).  As many tiles ride as fit
   // beside the chain's own duration (~8 us per dependent product and tile pass, measured at cfg 2 / cfg 3); a problem is
   // split at the budget, the rest of its tiles rides in GATAttention's edge pass.  K % 64 == 0 for equal halves.
+  const bool s_ok = chain_aligned(c, true) && chain_small_ok(c, true);
+  const bool use_t = !c.dout && chain_t_ok(c, true) && !(s_ok && option("chain_t", 1) < 2);
+  if (use_t) return gcn_chain_t_bwd(c, dim3(chain_grid(c, 2)), fl, st);   // (no parked tiles aboard: the edge pass carries them)
   int ng = 0;
   if (carry && carry->n > 0 && (long)c.B * c.H <= 64 && ((long)c.B * c.N) % 64 == 0 && chain_passengers()) {
     const int passes = (((c.N + 63) / 64) * ((c.gh + 63) / 64) + 1) / 2;

@@ -134,6 +134,11 @@ __host__ __device__ inline GemmArgs plan_bwd_dY(const GcnCtx& c, int l) {
   return g;
 }
 
+// chain_t.hip: LDS-resident chain kernels for N <= 64 and the instantiated (gh, L) pairs
+bool chain_t_ok(const GcnCtx& c, bool bwd);
+int gcn_chain_t_fwd(const GcnCtx& c, dim3 grid, double flops, hipStream_t st);
+int gcn_chain_t_bwd(const GcnCtx& c, dim3 grid, double flops, hipStream_t st);
+
 // chain.hip
 bool chain_can_carry(const EdgeRide& r);
 int gcn_chain_fwd(const GcnCtx& c, hipStream_t st);

@@ -769,6 +769,66 @@ def test_chain_and_per_product_paths_agree(gpu_device):
         _lib.call("gcgcn_set_option", b"bogus", 1)
 
 
+@pytest.mark.parametrize("B,N,D,L,H,ragged,train", [
+    (3, 64, 768, 4, 4, False, False),    # cfg 3 (bert-sized): gh = 192, four sub-layers, 12 waves
+    (2, 64, 768, 4, 4, True, True),      #   ... ragged, dropout on
+    (4, 42, 128, 2, 8, True, False),     # the reference's own model: hidden 128 -> gh = 64, N <= 42 ragged (glove:234, 250-251)
+    (3, 42, 128, 2, 8, True, True),
+    (8, 16, 128, 2, 8, False, True),     # cfg 1
+    (2, 64, 256, 2, 8, False, True),     # cfg 2's shape (served by gcn_chain_s_* by default; chain_t = 2 forces these kernels)
+    (2, 64, 512, 2, 8, True, False),     # gh = 256: 16 waves
+    (2, 30, 192, 3, 2, True, False),     # gh = 64, three sub-layers
+    (2, 64, 384, 2, 2, False, False),    # gh = 192, two sub-layers
+    (2, 7, 256, 4, 2, False, True),      # gh = 64, four sub-layers, one row block
+    (1, 1, 64, 1, 1, False, False),      # a single entity, a single sub-layer
+])
+def test_chain_t_matches_generic_chain(gpu_device, B, N, D, L, H, ragged, train):
+    """chain_t.hip (column strips, chained products, pushed dense connections; N <= 64) against the generic chain kernels on
+    the same inputs, same dropout snapshots: outputs, dX, dE and every parameter gradient.  (The generic kernels are tied to
+    the oracle by every other test in this file; at cfg 3 / the reference's shape those tests now run chain_t themselves.)"""
+    # (seed of the (2, 64, 384, 2, 2) case: with 7 N + L one pre-activation of document 0 lands within an ulp of zero, the two
+    # kernel generations round it to different sides and a whole gradient column legitimately differs -- see _check_relu_decisions)
+    sd = O.init_stack_params(D, L, H, seed=7 * N + L + (1 if D == 384 else 0))
+    x, e1, e2, adj = O.synth_docs(B, N, D, seed=N + D)
+    n_valid = None
+    if ragged:
+        n_valid = torch.randint(1, N + 1, (B,), generator=torch.Generator().manual_seed(N)).to(torch.int32)
+        n_valid[0] = N
+        x = x * (torch.arange(N)[None, :] < n_valid[:, None]).unsqueeze(-1).float()
+        n_valid = n_valid.to(gpu_device)
+    hops = gcgcn_amd.GraphHops(D, L, H).to(gpu_device)
+    hops.train(train)
+    hops.load_state_dict(sd, strict=True)
+    cot = torch.randn(B, N, D, generator=torch.Generator().manual_seed(5)).to(gpu_device)
+    res, masks = [], []
+    try:
+        for mode in (2, 0):
+            _lib.call("gcgcn_set_option", b"chain_t", mode)
+            gcgcn_amd.manual_seed(99, gpu_device)
+            xs = [dev_leaf(t, gpu_device) for t in (x, e1, e2)]
+            hops.zero_grad()
+            with _relu_spy() as spy:
+                f = hops(xs[0], [xs[1], xs[2]], n_valid=n_valid)
+            torch.autograd.backward(f[-1], cot)
+            res.append([f[1].detach(), f[2].detach(), xs[0].grad, xs[1].grad, xs[2].grad] +
+                       [p.grad.clone() for p in hops.parameters() if p.grad is not None])
+            masks.append([y.detach() > 0 for y in spy.Y])
+    finally:
+        _lib.call("gcgcn_set_option", b"chain_t", 1)
+    flips = sum(int((a != b_).sum()) for a, b_ in zip(*masks))
+    assert flips == 0, f"{flips} relu decisions differ between the two kernel generations on this seed (a pre-activation within " \
+                       "an ulp of zero): both are valid fp32 evaluations, but their gradients are not comparable -- pick another seed"
+    names = ["x1", "x2", "dX", "dE1", "dE2", "d gat", "d mha", "d caggc", "d maggc"]
+    assert len(res[0]) == len(res[1]) == 9
+    bad = []
+    for nm, a, b_ in zip(names, *res):
+        top = max(1.0, b_.abs().max().item())
+        err = (a - b_).abs()
+        if not bool((err <= 2e-5 * top + 2e-4 * b_.abs()).all()):
+            bad.append(f"{nm}: max |diff| {err.max().item():.3e} (largest entry {top:.3e}), {int((err > 2e-5 * top + 2e-4 * b_.abs()).sum())} of {err.numel()} off")
+    assert not bad, "; ".join(bad)
+
+
 @pytest.mark.parametrize("B,N,D,H,ragged", [(3, 64, 256, 8, False), (2, 42, 128, 4, True), (2, 7, 64, 4, False),
                                               (2, 64, 768, 4, True), (1, 13, 512, 2, False)])
 def test_mha_core_and_generic_paths_agree(gpu_device, B, N, D, H, ragged):
