@@ -55,7 +55,10 @@ constexpr int t_bwd_lds() { return 64 * T_LA + 2 * 64 * (GH + 4) + (GH / 16) * 6
 // forward:  rinv = 1 / rowsum(A_h);  for l:  Y_l = relu((G_l + A_h Pn_l) rinv),  HO_l = dropout(Y_l) + X_l,
 //           Pn_l' += Y_l Wd_{l'}[l gh : (l + 1) gh, :]  for l' > l   (Pn_l' starts as X Wn_l'[:D], written by the launch before)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int GH, int L>
+// FULL: every document fills all four 16-row blocks (N > 48, no n_valid): the row-block loops carry no branches, so the
+// LDS reads of one block overlap the MFMAs of another.  Otherwise blocks beyond ceil(n_valid / 16) are skipped (uniform
+// branches): a DocRED batch padded to 42 entities averages 20 real ones, two blocks instead of three.
+template <int GH, int L, bool FULL>
 __global__ __launch_bounds__(4 * GH) void gcn_chain_t_fwd_kernel(const GcnCtx c) {
   constexpr int W = GH / 16, NT = 4 * GH, P = GH + 4, NC = GH / 16;
   __shared__ __attribute__((aligned(16))) float lds[t_fwd_lds<GH, L>()];
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_fwd_kernel(const GcnCtx c)
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 15, g = lane >> 4;
   const int N = c.N;
   const int nv = c.n_valid ? min(max(c.n_valid[b], 0), N) : N;
-  const int nrb = (nv + 15) >> 4;                   // 16-row blocks that hold real entities (padding rows are zero everywhere)
+  const int nrb = FULL ? 4 : (nv + 15) >> 4;        // 16-row blocks that hold real entities (padding rows are zero everywhere)
   const unsigned HD = (unsigned)c.HD, D = (unsigned)c.D;
   const long zoff = (long)b * N * c.HD + (long)h * c.D;  // (b, row 0, h, l = 0, k = 0) in [B*N, H, L, gh]
   const float* __restrict__ Ag = c.A + (long)z * N * N;
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_fwd_kernel(const GcnCtx c)
 // dA: wave w accumulates rows 16 (w % 4) .. + 15, all 64 columns, over the k range [64 (w / 4), + 64) of every sub-layer in
 // registers; the gh / 64 partial sums meet in LDS at the end, in a fixed order (bitwise reproducible).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int GH, int L>
+template <int GH, int L, bool FULL>
 __global__ __launch_bounds__(4 * GH) void gcn_chain_t_bwd_kernel(const GcnCtx c) {
   constexpr int W = GH / 16, NT = 4 * GH, P = GH + 4, NC = GH / 16, SP = 20;   // SP: row pitch of a [gh][16 k] weight stage
   __shared__ __attribute__((aligned(16))) float lds[t_bwd_lds<GH>()];
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_bwd_kernel(const GcnCtx c)
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 15, g = lane >> 4;
   const int N = c.N;
   const int nv = c.n_valid ? min(max(c.n_valid[b], 0), N) : N;
-  const int nrb = (nv + 15) >> 4;
+  const int nrb = FULL ? 4 : (nv + 15) >> 4;
   const unsigned HD = (unsigned)c.HD;
   const long zoff = (long)b * N * c.HD + (long)h * c.D;
   const float* __restrict__ Ag = c.A + (long)z * N * N;
@@ -491,13 +494,16 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_bwd_kernel(const GcnCtx c)
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
+static bool chain_t_full(const GcnCtx& c) { return c.N > 48 && !c.n_valid; }
 template <int GH, int L>
 static void launch_fwd(const GcnCtx& c, dim3 grid, double fl, hipStream_t st) {
-  GC_LAUNCH_TIMED("gcn_chain_fwd", fl, (gcn_chain_t_fwd_kernel<GH, L>), grid, dim3(4 * GH), 0, st, c);
+  if (chain_t_full(c)) GC_LAUNCH_TIMED("gcn_chain_fwd", fl, (gcn_chain_t_fwd_kernel<GH, L, true>), grid, dim3(4 * GH), 0, st, c);
+  else GC_LAUNCH_TIMED("gcn_chain_fwd", fl, (gcn_chain_t_fwd_kernel<GH, L, false>), grid, dim3(4 * GH), 0, st, c);
 }
 template <int GH, int L>
 static void launch_bwd(const GcnCtx& c, dim3 grid, double fl, hipStream_t st) {
-  GC_LAUNCH_TIMED("gcn_chain_bwd", fl, (gcn_chain_t_bwd_kernel<GH, L>), grid, dim3(4 * GH), 0, st, c);
+  if (chain_t_full(c)) GC_LAUNCH_TIMED("gcn_chain_bwd", fl, (gcn_chain_t_bwd_kernel<GH, L, true>), grid, dim3(4 * GH), 0, st, c);
+  else GC_LAUNCH_TIMED("gcn_chain_bwd", fl, (gcn_chain_t_bwd_kernel<GH, L, false>), grid, dim3(4 * GH), 0, st, c);
 }
 
 // (gh, L) pairs the templates are instantiated for: the reference's model (64, 2), cfg 2's width (128, 2), cfg 3 (192, 4),
