@@ -678,25 +678,45 @@ class GraphModelTail(nn.Module):
         self._register_state_dict_hook(self._state_dict_hook)
         self._register_load_state_dict_pre_hook(self._load_pre_hook)
 
+    # Opt-in: do not compute the last hop at all.  The model's ``node_feats`` list records the PRE-update features (glove:338),
+    # so the last hop's output -- its edge-feature producer, attention and convolution -- never reaches the classifier and none
+    # of its parameters ever gets a gradient.  Logits and gradients are identical either way; the default (False)
+    # runs it like the reference does.
+    skip_dead_hop = False
+
     def forward(self, context_output: Tensor, node_feat: Tensor, adj_matrix: Optional[Tensor], sen_matrix: Tensor,
                 pos_matrix_h: Tensor, pos_matrix_t: Tensor, node_type: Tensor, node_relative_pos: Tensor,
-                dis_embed_weight: Tensor, ner_emb_weight: Tensor, n_valid: Optional[Tensor] = None) -> Tensor:
+                dis_embed_weight: Tensor, ner_emb_weight: Tensor, n_valid: Optional[Tensor] = None,
+                max_live_slots: Optional[int] = None, max_live_pairs: Optional[int] = None) -> Tensor:
         """Shapes as in the reference (one document: context_output ``[T,H]`` or ``[1,T,H]``, node_feat ``[N,H]``, ...) or with a
-        leading batch axis everywhere.  Returns ``relation_before_softmax_01``."""
+        leading batch axis everywhere.  Returns ``relation_before_softmax_01``.  ``max_live_slots`` / ``max_live_pairs``: capacities
+        of the edge-feature producers given up front (no host synchronisation; see EdgeFeatureProducer.forward)."""
         x = node_feat
         feats = [x]
         mask = None
-        for i in range(self.graph_hop):
-            e = self.producers[i](context_output, sen_matrix, pos_matrix_h, pos_matrix_t, x, dis_embed_weight, n_valid=n_valid)
-            if i < 1:
-                if self.get_weighted_adj_matrix.apply_mask and adj_matrix is not None:
-                    mask = torch.eq(adj_matrix, 0)                                              # glove:330
-                a = self.get_weighted_adj_matrix(x, e, mask, n_valid=n_valid)                  # glove:332
-                new = self.graphcnn[i](x, e, a, n_valid=n_valid)                               # glove:333
-            else:
-                al = self.get_adj_matrix[i - 1](x, e, n_valid=n_valid)                         # glove:336
-                new = self.graphcnn[i](x, e, al, n_valid=n_valid)                              # glove:337
-            feats.append(x)                                                                    # glove:338 (pre-update)
-            x = new if self.alpha == 1.0 else self.alpha * new + (1 - self.alpha) * x          # glove:339
-            x = F_.dropout(x, self.p, self.training)                                           # glove:341
+        hops = self.graph_hop - 1 if (self.skip_dead_hop and self.graph_hop > 0) else self.graph_hop
+        # alpha == 1 (the reference's setting): x <- dropout(new) is applied in the convolution's last epilogue (as GraphHops does)
+        fused_out = self.alpha == 1.0 and x.is_cuda
+        odrop = self.p if (fused_out and self.training) else 0.0
+        with F_.rng_scope(x.device, 3 * max(hops, 1), enabled=self.training and x.is_cuda):
+            for i in range(hops):
+                e = self.producers[i](context_output, sen_matrix, pos_matrix_h, pos_matrix_t, x, dis_embed_weight, n_valid=n_valid,
+                                      max_live_slots=max_live_slots, max_live_pairs=max_live_pairs)
+                if i < 1:
+                    if self.get_weighted_adj_matrix.apply_mask and adj_matrix is not None:
+                        mask = torch.eq(adj_matrix, 0)                                          # glove:330
+                    # (A, alias of x): the convolution's d(node_feat) is routed through the attention's own dX kernel
+                    a, xa = self.get_weighted_adj_matrix(x, e, mask, n_valid=n_valid, return_input_alias=True)   # glove:332
+                    new = self.graphcnn[i](xa, e, a, n_valid=n_valid, out_dropout=odrop)       # glove:333
+                else:
+                    al, xa = self.get_adj_matrix[i - 1](x, e, n_valid=n_valid, return_input_alias=True)         # glove:336
+                    new = self.graphcnn[i](xa, e, al, n_valid=n_valid, out_dropout=odrop)      # glove:337
+                feats.append(x)                                                                # glove:338 (pre-update)
+                if fused_out:
+                    x = new                                                                    # glove:339 + :341, inside the block
+                else:
+                    x = self.alpha * new + (1 - self.alpha) * x                                # glove:339
+                    x = F_.dropout(x, self.p, self.training)                                   # glove:341
+        if hops < self.graph_hop:
+            feats.append(x)                     # the skipped hop would have recorded its input: the feature list stays complete
         return self.head(feats, node_type, node_relative_pos, ner_emb_weight, dis_embed_weight, n_valid=n_valid)

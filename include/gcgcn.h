@@ -305,6 +305,14 @@ int gcgcn_gemm_dyn(int M, int N, int K, const float* A, int64_t lda, int a_kc, c
                    int64_t ldc, const float* bias, int accumulate, const int32_t* count, int dyn, int64_t cap, float* ws,
                    int64_t ws_elems, void* stream);
 
+/* ---- the trainer's optimiser step (config/Config.py:300, 372-373: torch.optim.Adam, no weight decay) -------------------
+ * ONE launch over n_tensors parameter tensors.  table (device memory): n_tensors records of 56 bytes
+ *   { float* p; const float* g; float* m; float* v; int64 numel; int64 block_begin; float step_size; float inv_bc2_sqrt; }
+ * sorted by block_begin, where a tensor owns ceil(numel / 1024) consecutive workgroups starting at block_begin,
+ * step_size = lr / (1 - beta1^t) and inv_bc2_sqrt = 1 / sqrt(1 - beta2^t) with t the tensor's own step count (torch skips a
+ * parameter whose .grad is None and does not advance its t).  Arithmetic as torch.optim.Adam's single-tensor path. */
+int gcgcn_adam_step(int n_tensors, const void* table, int64_t total_blocks, float beta1, float beta2, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

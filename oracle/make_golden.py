@@ -327,6 +327,81 @@ def tail_case(ref, docs=2, n=12, t=48, s=3, vocab=120):
     return "tail_c1", pk
 
 
+def model_step_case(ref, docs=2, n=10, t=40, s=3, vocab=90):
+    """The reference's model AND its trainer's step arithmetic, end to end: a real ``GCGCN_glove(config)`` (toy vocabulary) runs
+    ``docs`` synthetic documents from their RAW inputs (token / entity-type / coreference ids and the graph tensors of
+    ``Config.from_list_to_tensor``); every document's loss comes from the trainer's own statements (``config/Config.py:302,
+    355-364``, ``trainer_loss_lines``), the documents' losses are summed and divided by ``batch_size`` and ONE ``backward()``
+    runs, exactly as ``Config.py:366-372`` does with ``batch_size = docs``.  The fixture holds the full ``state_dict`` (the
+    6.4 MB bilinear weight as a seed), the raw inputs, logits, losses and the gradient of every parameter (``None`` for the
+    dead last hop).  eval() mode: the model's dropout draws come from torch's global generator and cannot be
+    replayed on another implementation; ``keep_prob = 1`` anyway switches the encoder's LockedDropout off."""
+    import contextlib, io
+    from torch.autograd import Variable
+    torch.manual_seed(777)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = ref.GCGCN_glove(_Cfg(vocab)).eval()
+    with torch.no_grad():
+        model.bili_layer_01.weight.copy_(head_bilinear_weight(777))
+    code = compile(trainer_loss_lines(), "Config.py:302,355-364", "exec")
+    g = torch.Generator().manual_seed(777)
+    pk = {"meta.docs": docs, "meta.bili_seed": np.int64(777), "meta.vocab": np.int64(vocab)}
+    for k, v in model.state_dict().items():
+        if k != "bili_layer_01.weight":
+            pk["sd." + k] = _np(v)
+    pk["meta.keys"] = np.array(list(model.state_dict().keys()))          # the reference's key order
+    total_loss = 0
+    for di in range(docs):
+        document = torch.randint(1, vocab, (t,), generator=g)
+        document[t - 6:] = 0                                              # padding tokens at the end, as from_list_to_tensor leaves them
+        ner = torch.randint(0, 7, (t,), generator=g)
+        pos = torch.randint(0, n + 1, (t,), generator=g)
+        adj = (torch.rand(n, n, generator=g) < 0.3).float() * (1 - torch.eye(n))
+        sen = torch.zeros(n, n, s, t, dtype=torch.bool)
+        for i in range(n):
+            for j in range(n):
+                if adj[i, j] > 0:
+                    for k in range(int(torch.randint(1, s + 1, (1,), generator=g))):
+                        ln = int(torch.randint(4, 12, (1,), generator=g))
+                        a0 = 0 if torch.rand(1, generator=g).item() < 0.5 else int(torch.randint(0, t - ln, (1,), generator=g))
+                        sen[i, j, k, a0:a0 + ln] = True
+        ph = torch.randint(0, 21, (n, n, s, t), generator=g)
+        pt = torch.randint(0, 21, (n, n, s, t), generator=g)
+        node_pos = torch.zeros(n, t)
+        for i in range(n):
+            a0 = int(torch.randint(0, t - 3, (1,), generator=g))
+            node_pos[i, a0:a0 + 3] = 1.0 / 3
+        node_type = torch.randint(0, 7, (n,), generator=g)
+        rel = torch.randint(-10, 11, (n, n), generator=g)
+        labels = (torch.rand(n, n, 97, generator=g) < 0.04).float()
+        logits = model(document, ner, pos, adj, sen, ph, pt, node_pos, node_type, rel)
+        ns = {"torch": torch, "nn": nn, "Variable": Variable, "predict_re": logits, "label_matrix": labels}
+        exec(code, ns)                                                     # Config.py:355-364
+        total_loss = total_loss + ns["temp_loss"]                          # Config.py:366
+        p = f"doc{di}."
+        pk[p + "document"], pk[p + "ner"], pk[p + "pos"] = _np(document), _np(ner), _np(pos)
+        pk[p + "node_pos"], pk[p + "adj"], pk[p + "sen"] = _np(node_pos), _np(adj), _np(sen)
+        pk[p + "pos_h"], pk[p + "pos_t"] = _np(ph.to(torch.uint8)), _np(pt.to(torch.uint8))
+        pk[p + "node_type"], pk[p + "rel"], pk[p + "labels"] = _np(node_type), _np(rel), _np(labels.to(torch.uint8))
+        pk[p + "logits"], pk[p + "loss"] = _np(logits), _np(ns["temp_loss"].squeeze(0))
+    total_loss = total_loss / docs                                         # Config.py:369 (batch_size = docs)
+    model.zero_grad()
+    total_loss.backward()                                                  # Config.py:371
+    pk["total_loss"] = _np(total_loss.squeeze(0))
+    none = []
+    for k, prm in model.named_parameters():
+        if prm.grad is None:
+            none.append(k)
+        elif k == "bili_layer_01.weight":
+            pk["gradpart.bili.r"] = np.array(HEAD_BILI_SLICES)
+            pk["gradpart.bili.slices"] = _np(prm.grad[HEAD_BILI_SLICES])
+            pk["gradpart.bili.sum_r"] = _np(prm.grad.sum(0))
+        else:
+            pk["grad.sd." + k] = _np(prm.grad)
+    pk["meta.grad_none"] = np.array(none)
+    return "model_step_c1", pk
+
+
 def tensorise_cases():
     """SURVEY 8 row f4, pinned on the reference's own function: ``Config.from_list_to_tensor`` (config/Config.py:162-233) and the
     ``dis2idx`` table (:106-116) are read as text and executed on synthetic documents (dicts with a networkx.DiGraph, the
@@ -504,9 +579,11 @@ def main():
         cases = tensorise_cases()
     elif "--tail-only" in sys.argv:
         cases = [tail_case(load_reference())]
+    elif "--model-only" in sys.argv:
+        cases = [model_step_case(load_reference())]
     else:
         ref = load_reference()
-        cases = list(block_cases(ref)) + [full_model_case(ref)] + list(loss_cases()) + list(producer_cases(ref)) + list(head_cases(ref)) + tensorise_cases() + [tail_case(ref)]
+        cases = list(block_cases(ref)) + [full_model_case(ref)] + list(loss_cases()) + list(producer_cases(ref)) + list(head_cases(ref)) + tensorise_cases() + [tail_case(ref), model_step_case(ref)]
     for name, pk in cases:
         path = os.path.join(OUT_DIR, name + ".npz")
         np.savez_compressed(path, **pk)
