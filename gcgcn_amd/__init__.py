@@ -7,8 +7,9 @@ gfx950 behind a C ABI (``include/gcgcn.h`` -> ``gcgcn_amd/lib/libgcgcn_hip.so``)
 from .modules import (ClassifierHead, EdgeFeatureProducer, GraphModelTail, GATAttention, GraphConv, GraphConvolution, GraphHops,  # noqa: F401
                       MultiGraphConvolution, MultiHeadAttention)
 from .functional import manual_seed, pair_bce_loss  # noqa: F401
-from . import functional, params  # noqa: F401
+from . import functional, models, optim, params  # noqa: F401
+from .optim import FusedAdam  # noqa: F401
 
 __all__ = ["GraphConv", "GATAttention", "MultiHeadAttention", "GraphConvolution", "MultiGraphConvolution", "GraphHops",
            "EdgeFeatureProducer", "ClassifierHead", "GraphModelTail",
-           "manual_seed", "pair_bce_loss", "functional", "params"]
+           "manual_seed", "pair_bce_loss", "FusedAdam", "functional", "models", "optim", "params"]

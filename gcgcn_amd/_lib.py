@@ -74,7 +74,7 @@ SIGNATURES = {
     "gcgcn_head_fwd": (I, [I, I, I, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P]),
     "gcgcn_head_bwd": (I, [I, I, I, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_tensorise": (I, [I, I, I, I, I, I, I, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P]),
-    "gcgcn_adam_step": (I, [I, P, L, F, F, F, P]),
+    "gcgcn_adam_step": (I, [I, P, L, ctypes.c_double, ctypes.c_double, ctypes.c_double, P]),
     "gcgcn_gemm": (I, [I, I, I, P, L, I, P, L, I, P, L, I, L, L, L, F, P, I, I, I, I, P, L, P]),
     "gcgcn_gemm_dyn": (I, [I, I, I, P, L, I, P, L, I, P, L, P, I, P, I, L, P, L, P]),
 }

@@ -30,7 +30,10 @@ __device__ __forceinline__ void adam1(float& p, const float g, float& m, float& 
   p = p - ss * (m / denom);              // param.addcdiv_(exp_avg, denom, value = -step_size)
 }
 
-__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamEntry* __restrict__ tab, int n, float b1, float b2, float eps) {
+// b1c = 1 - beta1 and b2c = 1 - beta2 arrive rounded from double, as torch passes them to lerp_ / addcmul_ (1.f - 0.999f is
+// 4.7e-5 away from 0.001f)
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamEntry* __restrict__ tab, int n, float b1c, float b2, float b2c,
+                                                         float eps) {
   int lo = 0, hi = n - 1;                // last entry whose block_begin <= blockIdx.x
   const long blk = blockIdx.x;
   while (lo < hi) {
@@ -41,7 +44,6 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamEntry* __rest
   const AdamEntry e = tab[lo];
   const long base = (blk - e.block_begin) * 1024 + threadIdx.x * 4;
   if (base >= e.numel) return;
-  const float b1c = 1.f - b1, b2c = 1.f - b2;
   const bool vec = base + 4 <= e.numel && ((((uintptr_t)e.p) | ((uintptr_t)e.g) | ((uintptr_t)e.m) | ((uintptr_t)e.v)) & 15) == 0;
   if (vec) {
     float4 p = *reinterpret_cast<const float4*>(e.p + base), m = *reinterpret_cast<const float4*>(e.m + base);
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamEntry* __rest
 
 using namespace gc;
 
-extern "C" int gcgcn_adam_step(int n_tensors, const void* table, int64_t total_blocks, float beta1, float beta2, float eps,
+extern "C" int gcgcn_adam_step(int n_tensors, const void* table, int64_t total_blocks, double beta1, double beta2, double eps,
                                void* stream) {
   GC_REQUIRE(n_tensors >= 0 && total_blocks >= 0, "adam_step: bad arguments");
   if (n_tensors == 0 || total_blocks == 0) return 0;
@@ -75,6 +77,6 @@ extern "C" int gcgcn_adam_step(int n_tensors, const void* table, int64_t total_b
   GC_REQUIRE(total_blocks <= 0x7fffffffL, "adam_step: too many elements for one launch");
   ProfScope ps("adam_step", (hipStream_t)stream);
   hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const AdamEntry*)table,
-                     n_tensors, beta1, beta2, eps);
+                     n_tensors, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps);
   return check_launch("adam_step");
 }

@@ -92,8 +92,6 @@ class _GraphRelationModel(GraphModelTail):
         rank = {name: i for i, name in enumerate(module._KEY_ORDER)}
         items = list(state_dict.items())
         mine = [(k, v) for k, v in items if k.startswith(prefix)]
-        if len(mine) != len(items) and prefix == "":
-            return
         keyed = sorted(range(len(mine)), key=lambda i: (rank.get(mine[i][0][len(prefix):].split(".", 1)[0], len(rank)), i))
         state_dict.clear()
         for k, v in items:
@@ -190,4 +188,10 @@ class GraphCNN_multihead_bert_gate_cls(_GraphRelationModel):
         logits = self._graph_forward(ctx, adj_matrix, sen_matrix, pos_matrix_h, pos_matrix_t, node_pos, node_type,
                                      node_relative_pos, n_valid, batched, **caps)
         cls = self.linear_cls(cls_feat)                                                      # bert:345
-        return logits + (cls[:, None, None, :] if batched else cls[0])
+        if not batched:
+            return logits + cls[0]
+        add = cls[:, None, None, :]
+        if n_valid is not None:                  # padding pairs of a ragged batch stay zero
+            ok = torch.arange(logits.shape[1], device=logits.device)[None, :] < n_valid[:, None]
+            add = add * (ok[:, :, None] & ok[:, None, :]).unsqueeze(-1).to(add.dtype)
+        return logits + add

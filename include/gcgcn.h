@@ -311,7 +311,7 @@ int gcgcn_gemm_dyn(int M, int N, int K, const float* A, int64_t lda, int a_kc, c
  * sorted by block_begin, where a tensor owns ceil(numel / 1024) consecutive workgroups starting at block_begin,
  * step_size = lr / (1 - beta1^t) and inv_bc2_sqrt = 1 / sqrt(1 - beta2^t) with t the tensor's own step count (torch skips a
  * parameter whose .grad is None and does not advance its t).  Arithmetic as torch.optim.Adam's single-tensor path. */
-int gcgcn_adam_step(int n_tensors, const void* table, int64_t total_blocks, float beta1, float beta2, float eps, void* stream);
+int gcgcn_adam_step(int n_tensors, const void* table, int64_t total_blocks, double beta1, double beta2, double eps, void* stream);
 
 #ifdef __cplusplus
 }

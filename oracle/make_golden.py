@@ -343,13 +343,18 @@ def model_step_case(ref, docs=2, n=10, t=40, s=3, vocab=90):
         model = ref.GCGCN_glove(_Cfg(vocab)).eval()
     with torch.no_grad():
         model.bili_layer_01.weight.copy_(head_bilinear_weight(777))
+        # the sentence-level weights are relu(score) (glove:211): with the default initialisation every score of these toy
+        # documents is negative, E is the bias everywhere and the producers' gradients are exactly zero -- lift the bias so
+        # that the fixture exercises them
+        for sa in model.sentence_attention:
+            sa.attention_all.bias.fill_(0.4)
     code = compile(trainer_loss_lines(), "Config.py:302,355-364", "exec")
     g = torch.Generator().manual_seed(777)
     pk = {"meta.docs": docs, "meta.bili_seed": np.int64(777), "meta.vocab": np.int64(vocab)}
     for k, v in model.state_dict().items():
         if k != "bili_layer_01.weight":
             pk["sd." + k] = _np(v)
-    pk["meta.keys"] = np.array(list(model.state_dict().keys()))          # the reference's key order
+    pk["names.keys"] = np.array(list(model.state_dict().keys()))          # the reference's key order
     total_loss = 0
     for di in range(docs):
         document = torch.randint(1, vocab, (t,), generator=g)
@@ -398,7 +403,7 @@ def model_step_case(ref, docs=2, n=10, t=40, s=3, vocab=90):
             pk["gradpart.bili.sum_r"] = _np(prm.grad.sum(0))
         else:
             pk["grad.sd." + k] = _np(prm.grad)
-    pk["meta.grad_none"] = np.array(none)
+    pk["names.grad_none"] = np.array(none)
     return "model_step_c1", pk
 
 
