@@ -125,8 +125,9 @@ def test_training_step_gradients_match_the_reference_trainer(gpu_device, batched
     want_none = set(str(k) for k in r["names.grad_none"])
     for k, want in g["grad_sd"].items():
         assert got.get(k) is not None, f"no gradient for {k}"
-        # relative to each tensor's own scale (the producers' gradients are ~1e-7 on these toy documents): 2e-3 of its largest entry
-        torch.testing.assert_close(got[k].cpu(), want, rtol=2e-3, atol=2e-3 * want.abs().max().item() + 1e-12, msg=lambda m: f"grad {k}: {m}")
+        # relative to each tensor's own scale (the producers' gradients are ~1e-7 on these toy documents): 2e-3 of its largest entry, + 1e-10 for the
+        # gradients that are rounding residue of an exact zero (the attention biases: a softmax ignores shifts)
+        torch.testing.assert_close(got[k].cpu(), want, rtol=2e-3, atol=2e-3 * want.abs().max().item() + 1e-10, msg=lambda m: f"grad {k}: {m}")
     gb = got["bili_layer_01.weight"].cpu()
     torch.testing.assert_close(gb[torch.from_numpy(r["gradpart.bili.r"])], torch.from_numpy(r["gradpart.bili.slices"]), rtol=2e-3, atol=1e-6)
     torch.testing.assert_close(gb.sum(0), torch.from_numpy(r["gradpart.bili.sum_r"]), rtol=2e-3, atol=1e-5)
