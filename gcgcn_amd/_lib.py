@@ -68,7 +68,12 @@ SIGNATURES = {
     "gcgcn_producer_count": (I, [I, I, I, I, P, P, P, P]),
     "gcgcn_producer_sizes": (I, [I, I, I, I, I, I, I, L, L, P]),
     "gcgcn_producer_fwd": (I, [I, I, I, I, I, I, I, P, P, P, P, I, P, P, P, P, L, L, P, P, P, L, P, P]),
-    "gcgcn_producer_bwd": (I, [I, I, I, I, I, I, I, P, P, P, P, I, P, P, P, P, L, L, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_producer_bwd": (I, [I, I, I, I, I, I, I, P, P, P, P, I, P, P, P, P, L, L, P, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_edge_mean_fwd_compact": (I, [I, I, I, P, P, P, P, P, P]),
+    "gcgcn_edge_mean_bwd_compact": (I, [I, I, I, P, P, P, P, P, P, P]),
+    "gcgcn_gat_fwd_compact": (I, [I, I, I, I, P, P, P, P, P, P, P, F, P, P, P, P, P, P, P, I, I, P]),
+    "gcgcn_gat_bwd_compact_scratch": (L, [I, I, I]),
+    "gcgcn_gat_bwd_compact": (I, [I, I, I, I, P, P, P, P, P, P, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_head_layout": (I, [I, I, I, I, I, P]),
     "gcgcn_head_sizes": (I, [I, I, I, I, P]),
     "gcgcn_head_fwd": (I, [I, I, I, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P]),

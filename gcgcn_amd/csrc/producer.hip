@@ -400,6 +400,15 @@ __global__ __launch_bounds__(256) void prod_expand_kernel(const float* __restric
   }
 }
 
+// Compact mode, capacities too small (counts[2]): nothing was computed.  Every real pair is pointed at row 0 of Ec and that row
+// is NaN, so the consumers' outputs are NaN -- as loud as the dense path's poisoned E, also under a captured hipGraph.
+__global__ __launch_bounds__(256) void prod_poison_kernel(ProdIdx ix, float* __restrict__ Ec, long BNN, int Hd) {
+  if (ix.counts[2] == 0) return;
+  const long pp = (long)blockIdx.x * 256 + threadIdx.x;
+  if (pp < BNN && ix.pair_div[pp] > 0.f) ix.pair_prow[pp] = 0;
+  if (pp < Hd) Ec[pp] = __builtin_nanf("");
+}
+
 // ---- backward: dEc[prow] = dE[pair];  wpair[pair] = 1 for real pairs (weights of the bias-gradient column sum) -----
 __global__ __launch_bounds__(64 * PW) void prod_gather_kernel(const float* __restrict__ dE, ProdIdx ix, float* __restrict__ dEc,
                                                               int Hd) {
@@ -939,11 +948,15 @@ int prod_fwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx
     GC_TRY(check_launch("prod_sent_fwd"));
   }
   GC_TRY(linear_fwd(w.CS, 0, 2 * Hd, flat + y.Wls, flat + y.bls, Hd, w.Ec, ws, wse, st, ix.counts + 1, cap_pairs));   // :329-330
-  {
+  if (E) {
     ProfScope ps("prod_expand", st, 4.0 * B * N * N * Hd);
     hipLaunchKernelGGL(prod_expand_kernel, dim3((unsigned)((long)B * N)), dim3(256), 0, st, w.Ec, flat + y.bls, n_valid, ix.pair_prow,
                        ix.counts, E, N, Hd);
     GC_TRY(check_launch("prod_expand"));
+  } else {  // compact consumers (compact.hip) read Ec / pair_prow themselves: E is never written
+    GC_REQUIRE(cap_pairs >= 1, "producer: compact rows need a capacity of at least one pair");
+    hipLaunchKernelGGL(prod_poison_kernel, dim3(cdiv((long)B * N * N, 256)), dim3(256), 0, st, ix, w.Ec, (long)B * N * N, Hd);
+    GC_TRY(check_launch("prod_poison"));
   }
   return 0;
 }
@@ -963,7 +976,7 @@ static int colsum_dyn(const float* X, const int* cnt, int C, float* part, float*
 int prod_bwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx, const unsigned char* sen, const void* pos_h,
              const void* pos_t, int pos_bytes, const float* node, const float* dis_table, const int* n_valid, const float* flat,
              ProdIdx ix, long cap_rows, long cap_pairs, ProdBufs w, const float* dE, ProdGrads g, float* dctx, float* dnode,
-             float* ddis_table, float* dflat, float* ws, long wse, hipStream_t st) {
+             float* ddis_table, float* dflat, float* ws, long wse, hipStream_t st, const float* dEc_in = nullptr) {
   const ProdLayout y = prod_layout(Hd, P);
   const long BT = (long)B * T, BN = (long)B * N, BNN = BN * N;
   const int* nrows = ix.counts;
@@ -973,13 +986,18 @@ int prod_bwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx
   GC_REQUIRE(hipMemsetAsync(g.dnterm, 0, sizeof(float) * BN * Hd, st) == hipSuccess, "producer: memset failed");
   GC_REQUIRE(hipMemsetAsync(g.dwb, 0, sizeof(float) * 2 * (Hd + 1), st) == hipSuccess, "producer: memset failed");
   // linear_sentence_att: E = CS W_ls^T + b_ls on live pairs, b_ls on every other real pair
-  {
-    ProfScope ps("prod_gather", st);
-    hipLaunchKernelGGL(prod_gather_kernel, dim3(PGRID), dim3(64 * PW), 0, st, dE, ix, g.dEc, Hd);
-    GC_TRY(check_launch("prod_gather"));
+  if (dE) {
+    {
+      ProfScope ps("prod_gather", st);
+      hipLaunchKernelGGL(prod_gather_kernel, dim3(PGRID), dim3(64 * PW), 0, st, dE, ix, g.dEc, Hd);
+      GC_TRY(check_launch("prod_gather"));
+    }
+    // d b_ls = sum over real pairs of dE (padding pairs hold a constant 0: their gradient is ignored)
+    GC_TRY(colsum(dE, n_valid ? g.wpair : nullptr, dflat + y.bls, BNN, Hd, Hd, 1, 0, 0, 0, 0, ws, st));
+  } else {  // compact consumers hand over dEc itself (rows beyond the live pairs zero); the bias gradient reached the caller
+            // through the consumers (compact.hip), dflat's b_ls slice stays as the caller initialised it
+    g.dEc = const_cast<float*>(dEc_in);
   }
-  // d b_ls = sum over real pairs of dE (padding pairs hold a constant 0: their gradient is ignored)
-  GC_TRY(colsum(dE, n_valid ? g.wpair : nullptr, dflat + y.bls, BNN, Hd, Hd, 1, 0, 0, 0, 0, ws, st));
   GC_TRY(linear_bwd_w(g.dEc, w.CS, 0, Hd, 2 * Hd, dflat + y.Wls, ws, wse, st, npairs, cap_pairs));
   GC_TRY(linear_bwd_x(g.dEc, 0, Hd, flat + y.Wls, 2 * Hd, g.dCS, 0, ws, wse, st, npairs, cap_pairs));
   {
@@ -1082,7 +1100,7 @@ __global__ __launch_bounds__(256) void prod_count_kernel(const unsigned char* __
   }
 }
 
-struct ProdBound { ProdIdx ix; ProdBufs w; ProdGrads g; float* scratch; long n_int, n_fwd, n_bwd, counts_off; };
+struct ProdBound { ProdIdx ix; ProdBufs w; ProdGrads g; float* scratch; long n_int, n_fwd, n_bwd, counts_off, prow_off, ec_off; };
 // Carve the caller's three buffers (every piece starts 16-byte aligned); with null bases this only measures them.
 static ProdBound prod_bind(int32_t* ibuf, float* fwd, float* bwd, bool want_bwd, int B, int N, int S, int T, int Hd, int P, int ND,
                            long cap_rows, long cap_pairs) {
@@ -1091,7 +1109,9 @@ static ProdBound prod_bind(int32_t* ibuf, float* fwd, float* bwd, bool want_bwd,
   memset(&o, 0, sizeof(o));
   long at = 0;
   auto ti = [&](long n) { int32_t* p = ibuf ? ibuf + at : nullptr; at += (n + 3) & ~3L; return p; };
-  o.ix.doc_counts = ti(2L * B), o.ix.pair_bits = ti(BNN), o.ix.pair_row0 = ti(BNN), o.ix.pair_prow = ti(BNN);
+  o.ix.doc_counts = ti(2L * B), o.ix.pair_bits = ti(BNN), o.ix.pair_row0 = ti(BNN);
+  o.prow_off = at;
+  o.ix.pair_prow = ti(BNN);
   o.ix.pair_div = (float*)ti(BNN), o.ix.row_slot = ti(R), o.ix.prow_pair = ti(Q);
   o.counts_off = at;
   o.ix.counts = ti(4);
@@ -1102,7 +1122,9 @@ static ProdBound prod_bind(int32_t* ibuf, float* fwd, float* bwd, bool want_bwd,
   auto tf = [&](long n) { float* p = base ? base + at : nullptr; at += (n + 3) & ~3L; return p; };
   o.w.sentF = tf((long)B * T * Hd), o.w.disF = tf((long)ND * Hd), o.w.table = tf((long)B * ND * T), o.w.CW = tf(R * 2 * Hd);
   o.w.stats = tf(4 * R), o.w.cwa = tf(R * Hd), o.w.sfeat = tf(R * Hd), o.w.nterm = tf((long)B * N * Hd), o.w.score = tf(2 * R);
-  o.w.CS = tf(Q * 2 * Hd), o.w.Ec = tf(Q * Hd);
+  o.w.CS = tf(Q * 2 * Hd);
+  o.ec_off = at;
+  o.w.Ec = tf(Q * Hd);
   o.n_fwd = at;
   if (want_bwd) {
     base = bwd, at = 0;
@@ -1148,13 +1170,15 @@ int gcgcn_producer_count(int B, int N, int S, int T, const uint8_t* sen, const i
   return check_launch("prod_count");
 }
 
-int gcgcn_producer_sizes(int B, int N, int S, int T, int Hd, int P, int ND, int64_t cap_rows, int64_t cap_pairs, int64_t* out4) {
+int gcgcn_producer_sizes(int B, int N, int S, int T, int Hd, int P, int ND, int64_t cap_rows, int64_t cap_pairs, int64_t* out7) {
+  int64_t* out4 = out7;
   int64_t* out3 = out4;
   GC_REQUIRE(B > 0 && N > 0 && S > 0 && T > 0 && Hd > 0 && P > 0 && ND > 0 && cap_rows >= 0 && cap_pairs >= 0 && out3,
              "producer_sizes: bad arguments");
   const ProdBound z = prod_bind(nullptr, nullptr, nullptr, true, B, N, S, T, Hd, P, ND, cap_rows, cap_pairs);
   out3[0] = z.n_int, out3[1] = z.n_fwd, out3[2] = z.n_bwd + prod_scratch_elems(B, N, T, Hd);
-  out4[3] = z.counts_off;   // offset (in int32) of {live rows, live pairs, over-capacity flag, 0} inside ibuf
+  out4[3] = z.counts_off;
+  out4[4] = z.prow_off, out4[5] = z.ec_off, out4[6] = up64(cap_pairs);   // pair_prow inside ibuf, Ec inside fbuf, its rows   // offset (in int32) of {live rows, live pairs, over-capacity flag, 0} inside ibuf
   return 0;
 }
 
@@ -1163,7 +1187,7 @@ int gcgcn_producer_fwd(int B, int N, int S, int T, int Hd, int P, int ND, const 
                        const float* flat, int64_t cap_rows, int64_t cap_pairs, int32_t* ibuf, float* fbuf, float* scratch,
                        int64_t scratch_elems, float* E, void* stream) {
   GC_REQUIRE(B > 0 && N > 0 && T > 0 && Hd > 0 && P > 0 && ND > 0, "producer_fwd: bad shape");
-  GC_REQUIRE(ctx && sen && pos_h && pos_t && node && dis_table && flat && ibuf && fbuf && E, "producer_fwd: null pointer");
+  GC_REQUIRE(ctx && sen && pos_h && pos_t && node && dis_table && flat && ibuf && fbuf, "producer_fwd: null pointer");   // E == NULL: compact
   GC_REQUIRE(cap_rows >= 0 && cap_pairs >= 0 && cap_rows < (1L << 30) && cap_pairs < (1L << 30), "producer_fwd: bad capacities");
   const ProdBound o = prod_bind(ibuf, fbuf, nullptr, false, B, N, S, T, Hd, P, ND, cap_rows, cap_pairs);
   return prod_fwd(B, N, S, T, Hd, P, ND, ctx, sen, pos_h, pos_t, pos_bytes, node, dis_table, n_valid, flat, o.ix, cap_rows, cap_pairs,
@@ -1173,16 +1197,16 @@ int gcgcn_producer_fwd(int B, int N, int S, int T, int Hd, int P, int ND, const 
 int gcgcn_producer_bwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx, const uint8_t* sen, const void* pos_h,
                        const void* pos_t, int pos_bytes, const float* node, const float* dis_table, const int32_t* n_valid,
                        const float* flat, int64_t cap_rows, int64_t cap_pairs, int32_t* ibuf, float* fbuf, float* bbuf,
-                       const float* dE, float* dctx, float* dnode, float* ddis_table, float* dflat, void* stream) {
+                       const float* dE, const float* dEc, float* dctx, float* dnode, float* ddis_table, float* dflat, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GC_REQUIRE(B > 0 && N > 0 && T > 0 && Hd > 0 && P > 0 && ND > 0, "producer_bwd: bad shape");
-  GC_REQUIRE(ctx && sen && pos_h && pos_t && node && dis_table && flat && ibuf && fbuf && bbuf && dE && dctx && dnode && ddis_table &&
-                 dflat,
+  GC_REQUIRE(ctx && sen && pos_h && pos_t && node && dis_table && flat && ibuf && fbuf && bbuf && (dE || dEc) && dctx && dnode &&
+                 ddis_table && dflat,
              "producer_bwd: null pointer");
   const ProdBound o = prod_bind(ibuf, fbuf, bbuf, true, B, N, S, T, Hd, P, ND, cap_rows, cap_pairs);
-  if (n_valid) GC_TRY(prod_wpair(n_valid, o.g.wpair, B, N, st));
+  if (n_valid && dE) GC_TRY(prod_wpair(n_valid, o.g.wpair, B, N, st));
   return prod_bwd(B, N, S, T, Hd, P, ND, ctx, sen, pos_h, pos_t, pos_bytes, node, dis_table, n_valid, flat, o.ix, cap_rows, cap_pairs,
-                  o.w, dE, o.g, dctx, dnode, ddis_table, dflat, o.scratch, prod_scratch_elems(B, N, T, Hd), st);
+                  o.w, dE, o.g, dctx, dnode, ddis_table, dflat, o.scratch, prod_scratch_elems(B, N, T, Hd), st, dE ? nullptr : dEc);
 }
 
 }  // extern "C"

@@ -540,43 +540,149 @@ class PairBceFn(torch.autograd.Function):
 class ProducerFn(torch.autograd.Function):
     """(ctx[B,T,Hd], node[B,N,Hd], dis_table[ND,P], flat; sen, pos_h, pos_t) -> E[B,N,N,Hd].  The edge-feature producer of
     one hop: WordAttention x2 + linear_word_att + SentenceAttention x2 + linear_sentence_att, GCGCN_glove.py:171-214 as
-    called at :300-330."""
+    called at :300-330.  ``compact``: E is never written; the outputs are the compact rows Ec[rows, Hd] (one per entity pair with
+    a live sentence slot) and the pair -> row index, for the consumers in csrc/compact.hip (CompactEdges)."""
 
     @staticmethod
-    def forward(ctx_, tok, node, dis_table, flat, sen, pos_h, pos_t, n_valid, cap_rows, cap_pairs):
+    def forward(ctx_, tok, node, dis_table, flat, sen, pos_h, pos_t, n_valid, cap_rows, cap_pairs, compact):
         B, T, Hd = tok.shape
         N, S = sen.shape[1], sen.shape[3]
         ND, P = dis_table.shape
         dev = tok.device
-        sizes = (ctypes.c_int64 * 4)()
+        if compact:
+            cap_pairs = max(int(cap_pairs), 1)
+        sizes = (ctypes.c_int64 * 7)()
         call("gcgcn_producer_sizes", B, N, S, T, Hd, P, ND, cap_rows, cap_pairs, ctypes.cast(sizes, ctypes.c_void_p))
         ibuf = torch.empty(sizes[0], dtype=torch.int32, device=dev)
         fbuf = torch.empty(sizes[1], device=dev)
-        E = torch.empty(B, N, N, Hd, device=dev)
+        E = None if compact else torch.empty(B, N, N, Hd, device=dev)
         pb = pos_h.element_size()
         call("gcgcn_producer_fwd", B, N, S, T, Hd, P, ND, _p(tok), _p(sen), _p(pos_h), _p(pos_t), pb, _p(node), _p(dis_table),
              _p(n_valid), _p(flat), cap_rows, cap_pairs, _p(ibuf), _p(fbuf), None, 0, _p(E), _stream())
         ctx_.save_for_backward(tok, node, dis_table, flat, sen, pos_h, pos_t, ibuf, fbuf)
-        ctx_.n_valid, ctx_.caps, ctx_.nbwd = n_valid, (cap_rows, cap_pairs), int(sizes[2])
+        ctx_.n_valid, ctx_.caps, ctx_.nbwd, ctx_.compact = n_valid, (cap_rows, cap_pairs), int(sizes[2]), bool(compact)
         counts = ibuf[int(sizes[3]):int(sizes[3]) + 4]      # {live rows, live pairs, over capacity, 0}, on the device
-        ctx_.mark_non_differentiable(counts)
-        return E, counts
+        if not compact:
+            ctx_.mark_non_differentiable(counts)
+            return E, counts
+        rows = int(sizes[6])
+        Ec = fbuf[int(sizes[5]):int(sizes[5]) + rows * Hd].view(rows, Hd)
+        prow = ibuf[int(sizes[4]):int(sizes[4]) + B * N * N].view(B, N, N)
+        ctx_.mark_non_differentiable(counts, prow)
+        return Ec, counts, prow
 
     @staticmethod
-    def backward(ctx_, dE, _dcounts=None):
+    def backward(ctx_, dE, _dcounts=None, _dprow=None):
         tok, node, dis_table, flat, sen, pos_h, pos_t, ibuf, fbuf = ctx_.saved_tensors
         B, T, Hd = tok.shape
         N, S = sen.shape[1], sen.shape[3]
         ND, P = dis_table.shape
         dev = tok.device
-        dE = dE.contiguous()
+        dE = dE.contiguous()                       # compact: the gradient of Ec (rows beyond the live pairs are zero)
         bbuf = torch.empty(ctx_.nbwd, device=dev)
         dtok, dnode = torch.empty_like(tok), torch.empty_like(node)
         dtab, dflat = torch.empty_like(dis_table), torch.zeros_like(flat)       # (zeros: the layout's alignment gaps)
         call("gcgcn_producer_bwd", B, N, S, T, Hd, P, ND, _p(tok), _p(sen), _p(pos_h), _p(pos_t), pos_h.element_size(), _p(node),
-             _p(dis_table), _p(ctx_.n_valid), _p(flat), ctx_.caps[0], ctx_.caps[1], _p(ibuf), _p(fbuf), _p(bbuf), _p(dE), _p(dtok),
-             _p(dnode), _p(dtab), _p(dflat), _stream())
-        return dtok, dnode, dtab, dflat, None, None, None, None, None, None
+             _p(dis_table), _p(ctx_.n_valid), _p(flat), ctx_.caps[0], ctx_.caps[1], _p(ibuf), _p(fbuf), _p(bbuf),
+             None if ctx_.compact else _p(dE), _p(dE) if ctx_.compact else None, _p(dtok), _p(dnode), _p(dtab), _p(dflat), _stream())
+        return dtok, dnode, dtab, dflat, None, None, None, None, None, None, None
+
+
+class CompactEdges:
+    """A hop's edge tensor without the tensor: ``Ec[rows, Hd]`` (one row per entity pair with a live sentence slot), ``prow[B,N,N]``
+    (row of a pair, -1 = none) and ``bias[Hd]`` -- every other real pair of ``context_sent_att`` equals the bias of
+    ``linear_sentence_att`` (EdgeFeatureProducer).  GATAttention / GraphConvolution / MultiGraphConvolution (and GraphHops,
+    GraphModelTail) accept it wherever they accept the dense ``edge_feat``; ``dense()`` expands it (tests, other consumers)."""
+
+    def __init__(self, Ec: Tensor, prow: Tensor, bias: Tensor, n_valid: Optional[Tensor], batched: bool = True):
+        self.Ec, self.prow, self.bias, self.n_valid, self.batched = Ec, prow, bias, n_valid, batched
+
+    @property
+    def _version(self):                       # (the edge-mean hand-off keys on it, like on a tensor's version counter)
+        return self.Ec._version
+
+    @property
+    def shape(self):
+        B, N, _ = self.prow.shape
+        return (B, N, N, self.Ec.shape[1]) if self.batched else (N, N, self.Ec.shape[1])
+
+    def dense(self) -> Tensor:
+        B, N, _ = self.prow.shape
+        live = (self.prow >= 0).unsqueeze(-1)
+        e = torch.where(live, self.Ec[self.prow.clamp_min(0).long()], self.bias.expand(B, N, N, -1))
+        if self.n_valid is not None:
+            ok = torch.arange(N, device=e.device)[None, :] < self.n_valid[:, None]
+            e = e * (ok[:, :, None] & ok[:, None, :]).unsqueeze(-1).to(e.dtype)
+        return e if self.batched else e[0]
+
+
+class GatCompactFn(torch.autograd.Function):
+    """GatFn on compact rows: (X[B,N,D], Ec[rows,D], bias[D], flat) -> (A[B,N,N], Ebar[B,N,D], X)."""
+
+    @staticmethod
+    def forward(ctx, x, Ec, bias, flat, prow, n_valid, p, snap, pending, Dh, uvc, uvc_valid):
+        B, N, D = x.shape
+        dev = x.device
+        st, sn, cnt = pending if pending is not None else (None, None, 0)
+        if uvc is None:
+            uvc, uvc_valid = torch.empty(2 * D + 1, device=dev), False
+        s = torch.empty(B, N, device=dev)
+        P = torch.empty(B, N, N, device=dev)
+        A = torch.empty(B, N, N, device=dev) if snap is not None else None
+        ebar = torch.empty(B, N, D, device=dev)
+        call("gcgcn_gat_fwd_compact", B, N, D, Dh, _p(x), _p(Ec), _p(prow), _p(bias), _p(n_valid), _p(flat), _p(snap), float(p),
+             _p(uvc), _p(s), _p(P), _p(A), _p(ebar), _p(st), _p(sn), cnt, 1 if uvc_valid else 0, _stream())
+        ctx.save_for_backward(x, Ec, bias, flat, uvc, P, prow)
+        ctx.n_valid, ctx.p, ctx.snap, ctx.Dh = n_valid, float(p), snap, Dh
+        return (P if A is None else A), ebar, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dA, dEbar, dXin):
+        x, Ec, bias, flat, uvc, P, prow = ctx.saved_tensors
+        B, N, D = x.shape
+        dev = x.device
+        dA = torch.zeros(B, N, N, device=dev) if dA is None else dA.contiguous()
+        dEbar = None if dEbar is None else dEbar.contiguous()
+        dXin = None if dXin is None else dXin.contiguous()
+        dX = torch.empty_like(x)
+        dEc = torch.zeros_like(Ec)                       # rows beyond the live pairs stay zero (the producer's GEMMs read them)
+        dbias = torch.empty_like(bias)
+        dflat = torch.empty_like(flat)
+        dlogit = torch.empty(B, N, N, device=dev)
+        ds = torch.empty(B, N, device=dev)
+        dvpart = torch.empty(B * N, D, device=dev)
+        duvc = torch.empty(2 * D + 1, device=dev)
+        scratch = torch.empty(max(_lib.lib().gcgcn_gat_bwd_compact_scratch(B, N, D), 1), device=dev)
+        call("gcgcn_gat_bwd_compact", B, N, D, ctx.Dh, _p(x), _p(Ec), _p(prow), _p(bias), _p(ctx.n_valid), _p(flat), _p(ctx.snap), ctx.p,
+             _p(uvc), _p(P), _p(dA), _p(dEbar), _p(dXin), _p(dX), _p(dEc), _p(dbias), _p(dflat), _p(dlogit), _p(ds), _p(dvpart), _p(duvc),
+             _p(scratch), _stream())
+        return dX, dEc, dbias, dflat, None, None, None, None, None, None, None, None
+
+
+class EdgeMeanCompactFn(torch.autograd.Function):
+    """EdgeMeanFn on compact rows: (Ec[rows,D], bias[D]; prow[B,N,N]) -> Ebar[B,N,D]."""
+
+    @staticmethod
+    def forward(ctx, Ec, bias, prow, n_valid):
+        B, N, _ = prow.shape
+        D = Ec.shape[1]
+        ebar = torch.empty(B, N, D, device=Ec.device)
+        call("gcgcn_edge_mean_fwd_compact", B, N, D, _p(Ec), _p(prow), _p(bias), _p(n_valid), _p(ebar), _stream())
+        ctx.save_for_backward(prow)
+        ctx.n_valid, ctx.rows = n_valid, Ec.shape[0]
+        return ebar
+
+    @staticmethod
+    def backward(ctx, dEbar):
+        prow, = ctx.saved_tensors
+        B, N, _ = prow.shape
+        dEbar = dEbar.contiguous()
+        D = dEbar.shape[-1]
+        dEc = torch.zeros(ctx.rows, D, device=dEbar.device)
+        dbias = torch.empty(D, device=dEbar.device)
+        rowbuf = torch.empty(2 * B * N, device=dEbar.device)
+        call("gcgcn_edge_mean_bwd_compact", B, N, D, _p(prow), _p(ctx.n_valid), _p(dEbar), _p(dEc), _p(dbias), _p(rowbuf), _stream())
+        return dEc, dbias, None, None
 
 
 class HeadFn(torch.autograd.Function):
@@ -678,7 +784,7 @@ class ProducerCapacityError(RuntimeError):
 
 
 def edge_features(tok, sen, pos_h, pos_t, node, dis_table, flat, n_valid=None, max_live_slots=None, max_live_pairs=None,
-                  check_capacity=False, return_counts=False):
+                  check_capacity=False, return_counts=False, compact=False):
     """E[B,N,N,Hd] of one hop from token states tok[B,T,Hd], sentence masks sen[B,N,N,S,T] (bool / uint8), distance ids
     pos_h / pos_t [B,N,N,S,T] (int64 as the reference passes them, or int32 / uint8), entity features node[B,N,Hd] and
     the distance-embedding table dis_table[ND,P].  Without ``max_live_*`` the live slots are counted first (one host
@@ -686,7 +792,8 @@ def edge_features(tok, sen, pos_h, pos_t, node, dis_table, flat, n_valid=None, m
     call can be captured in a hipGraph.  Capacities that turn out too small are never silent: the kernels compute nothing
     and write NaN into every real pair of E (so a captured graph fails loudly downstream); ``check_capacity=True`` reads the
     device-side flag back (one synchronisation) and raises :class:`ProducerCapacityError`; ``return_counts=True`` also returns
-    the device tensor ``int32[4] = {live slots, live pairs, over capacity, 0}`` for a check of the caller's own timing."""
+    the device tensor ``int32[4] = {live slots, live pairs, over capacity, 0}`` for a check of the caller's own timing.
+    ``compact=True``: returns ``(Ec[rows,Hd], prow[B,N,N])`` instead of E -- E is never written (see CompactEdges)."""
     tok, node, dis_table = _chk(tok, "context_output", 3), _chk(node, "node_feat", 3), _chk(dis_table, "dis_embed.weight", 2)
     B, T, Hd = tok.shape
     if sen.dim() != 5 or sen.shape[0] != B or sen.shape[4] != T or sen.shape[1] != sen.shape[2]:
@@ -714,8 +821,12 @@ def edge_features(tok, sen, pos_h, pos_t, node, dis_table, flat, n_valid=None, m
         r, q = producer_live_counts(sen, nv)
         max_live_slots = r if max_live_slots is None else max_live_slots
         max_live_pairs = q if max_live_pairs is None else max_live_pairs
-    E, counts = ProducerFn.apply(tok, node, dis_table, _chk(flat, "flat"), sen, pos_h.contiguous(), pos_t.contiguous(), nv,
-                                 int(max_live_slots), int(max_live_pairs))
+    out = ProducerFn.apply(tok, node, dis_table, _chk(flat, "flat"), sen, pos_h.contiguous(), pos_t.contiguous(), nv,
+                           int(max_live_slots), int(max_live_pairs), bool(compact))
+    if compact:
+        E, counts = (out[0], out[2]), out[1]          # (Ec, prow): the caller adds the bias and wraps them in CompactEdges
+    else:
+        E, counts = out
     if check_capacity and not torch.cuda.is_current_stream_capturing():
         if int(counts[2].item()) != 0:
             raise ProducerCapacityError(f"edge_features: max_live_slots={max_live_slots} / max_live_pairs={max_live_pairs} are "
@@ -747,7 +858,25 @@ def gat_attention(x, e, flat, n_valid=None, p=0.1, training=False, hidden_dim=No
                        D if hidden_dim is None else int(hidden_dim), mask, uvc, bool(uvc_valid))   # (A, Ebar, alias of x)
 
 
+def gat_attention_compact(x, ce: CompactEdges, flat, n_valid=None, p=0.1, training=False, hidden_dim=None, uvc=None, uvc_valid=False):
+    x = _chk(x, "node_feat", 3)
+    B, N, D = x.shape
+    if tuple(ce.prow.shape) != (B, N, N) or ce.Ec.shape[1] != D:
+        raise ValueError(f"compact edge_feat: pairs {tuple(ce.prow.shape)} / width {ce.Ec.shape[1]} do not match node_feat {tuple(x.shape)}")
+    nv = _nv(n_valid, B, N, x.device)
+    snap = rng_snapshot(x.device, lazy=True) if (training and p > 0.0) else None
+    return GatCompactFn.apply(x, _chk(ce.Ec, "Ec", 2), _chk(ce.bias, "bias", 1), _chk(flat, "flat"), ce.prow, nv, p, snap,
+                              _take_pending_rng(x.device), D if hidden_dim is None else int(hidden_dim), uvc, bool(uvc_valid))
+
+
+def edge_mean_compact(ce: CompactEdges, n_valid=None):
+    B, N, _ = ce.prow.shape
+    return EdgeMeanCompactFn.apply(_chk(ce.Ec, "Ec", 2), _chk(ce.bias, "bias", 1), ce.prow, _nv(n_valid, B, N, ce.Ec.device))
+
+
 def edge_mean(e, n_valid=None):
+    if isinstance(e, CompactEdges):
+        return edge_mean_compact(e, n_valid)
     e = _chk(e, "edge_feat", 4)
     B, N = e.shape[0], e.shape[1]
     return EdgeMeanFn.apply(e, _nv(n_valid, B, N, e.device))

@@ -146,7 +146,10 @@ class GATAttention(_FlatBlock):
     def forward(self, node_feat: Tensor, edge_feat: Tensor, mask: Optional[Tensor] = None,
                 n_valid: Optional[Tensor] = None, return_input_alias: bool = False) -> Tensor:
         x, batched = _batched(node_feat, 2)
-        e, _ = _batched(edge_feat, 3)
+        compact = isinstance(edge_feat, F_.CompactEdges)
+        if compact and self.apply_mask:
+            raise ValueError("GATAttention(apply_mask=True) needs the dense edge tensor (CompactEdges.dense())")
+        e = edge_feat if compact else _batched(edge_feat, 3)[0]
         mk = None
         if self.apply_mask and mask is not None:
             mk, _ = _batched(mask, 2)
@@ -166,8 +169,12 @@ class GATAttention(_FlatBlock):
             else:
                 uvc = torch.empty(2 * self.dim + 1, device=x.device)
                 self._uvc = (key, uvc)
-        a, ebar, xa = F_.gat_attention(x, e, self.flat, n_valid, self.p, self.training, hidden_dim=self.hidden_dim,
-                                       mask=mk, uvc=uvc, uvc_valid=valid)
+        if compact:      # the producer's compact rows: the edge pass reads Ec[prow] / the bias, E never exists (csrc/compact.hip)
+            a, ebar, xa = F_.gat_attention_compact(x, e, self.flat, n_valid, self.p, self.training, hidden_dim=self.hidden_dim,
+                                                   uvc=uvc, uvc_valid=valid)
+        else:
+            a, ebar, xa = F_.gat_attention(x, e, self.flat, n_valid, self.p, self.training, hidden_dim=self.hidden_dim,
+                                           mask=mk, uvc=uvc, uvc_valid=valid)
         F_.park_edge_mean(edge_feat, n_valid, ebar)
         a = a if batched else a.squeeze(0)
         # extension: (A, alias of node_feat).  Feeding the alias to the convolution of the same hop routes the
@@ -265,7 +272,7 @@ class _GcnBase(_FlatBlock):
         """mean_j E: taken from the GATAttention call that just streamed this tensor, else computed."""
         ebar = F_.take_edge_mean(edge_feat, n_valid)
         if ebar is None:
-            e, _ = _batched(edge_feat, 3)
+            e = edge_feat if isinstance(edge_feat, F_.CompactEdges) else _batched(edge_feat, 3)[0]
             ebar = F_.edge_mean(e, n_valid)
         return ebar
 
@@ -275,6 +282,9 @@ class _GcnBase(_FlatBlock):
         call (functional.GcnFn); ``out_dropout`` applies the hop's output dropout (glove:341) in the block's last
         epilogue."""
         if ride_edge is None:
+            return F_.gcn_stack(x, ebar, adj, self.flat, self.layer_num, self.head_num, n_valid, self.p, self.training,
+                                out_dropout=out_dropout)
+        if isinstance(ride_edge, F_.CompactEdges):     # nothing to stream: its mean is a segmented sum, computed when it is asked for
             return F_.gcn_stack(x, ebar, adj, self.flat, self.layer_num, self.head_num, n_valid, self.p, self.training,
                                 out_dropout=out_dropout)
         e_next, _ = _batched(ride_edge, 3)
@@ -416,14 +426,18 @@ class EdgeFeatureProducer(_FlatBlock):
     def forward(self, context_output: Tensor, sen_matrix: Tensor, pos_matrix_h: Tensor, pos_matrix_t: Tensor,
                 node_feat: Tensor, dis_embed_weight: Tensor, n_valid: Optional[Tensor] = None,
                 max_live_slots: Optional[int] = None, max_live_pairs: Optional[int] = None,
-                check_capacity: Optional[bool] = None) -> Tensor:
+                check_capacity: Optional[bool] = None, compact: bool = False):
         """context_output ``[T,H]`` / ``[1,T,H]`` (the reference's shapes, glove:292) or ``[B,T,H]``; sen_matrix / pos_matrix_*
         ``[N,N,S,T]`` or ``[B,N,N,S,T]``; node_feat ``[N,H]`` / ``[B,N,H]``; dis_embed_weight = ``model.dis_embed.weight``.
         Returns ``context_sent_att``: ``[N,N,H]`` or ``[B,N,N,H]``.
 
         ``max_live_slots`` / ``max_live_pairs`` (capacities given up front: no host synchronisation, capturable): if they are
         too small nothing is computed, every real pair of the result is NaN and ``self.last_counts[2]`` (a device tensor) is 1;
-        ``check_capacity`` (default: ``self.check_capacity``, off) reads that flag back and raises ``ProducerCapacityError``."""
+        ``check_capacity`` (default: ``self.check_capacity``, off) reads that flag back and raises ``ProducerCapacityError``.
+
+        ``compact=True``: returns a :class:`gcgcn_amd.functional.CompactEdges` handle instead of the tensor -- the rows of the
+        pairs with a live sentence slot, the pair index and the bias every other pair equals; the graph blocks take it wherever
+        they take ``edge_feat`` and the ``[N,N,hidden]`` tensor (and its gradient) is never written."""
         batched = sen_matrix.dim() == 5
         tok = context_output
         if tok.dim() == 2:
@@ -433,7 +447,12 @@ class EdgeFeatureProducer(_FlatBlock):
             node_feat = node_feat.unsqueeze(0)
         chk = self.check_capacity if check_capacity is None else check_capacity
         e, self.last_counts = F_.edge_features(tok, sen_matrix, pos_matrix_h, pos_matrix_t, node_feat, dis_embed_weight, self.flat,
-                                               n_valid, max_live_slots, max_live_pairs, check_capacity=chk, return_counts=True)
+                                               n_valid, max_live_slots, max_live_pairs, check_capacity=chk, return_counts=True,
+                                               compact=compact)
+        if compact:
+            o = P_.producer_layout(self.hidden, self.dis_size)[15]          # linear_sentence_att.bias inside flat
+            nv = None if n_valid is None else n_valid.to(device=tok.device, dtype=torch.int32)
+            return F_.CompactEdges(e[0], e[1], self.flat[o:o + self.hidden], nv, batched)
         return e if batched else e.squeeze(0)
 
     check_capacity = False      # read the over-capacity flag back after every call with caller-given capacities (one sync)
@@ -683,6 +702,10 @@ class GraphModelTail(nn.Module):
     # of its parameters ever gets a gradient.  Logits and gradients are identical either way; the default (False)
     # runs it like the reference does.
     skip_dead_hop = False
+    # Opt-in: the producers hand the graph blocks their compact rows (CompactEdges) instead of writing context_sent_att[N,N,hidden]
+    # per hop; same logits and gradients (tests/test_tail_gpu.py), no E / dE tensors.  Default: the dense tensor, the reference's
+    # own call pattern.
+    compact_edges = False
 
     def forward(self, context_output: Tensor, node_feat: Tensor, adj_matrix: Optional[Tensor], sen_matrix: Tensor,
                 pos_matrix_h: Tensor, pos_matrix_t: Tensor, node_type: Tensor, node_relative_pos: Tensor,
@@ -701,7 +724,8 @@ class GraphModelTail(nn.Module):
         with F_.rng_scope(x.device, 3 * max(hops, 1), enabled=self.training and x.is_cuda):
             for i in range(hops):
                 e = self.producers[i](context_output, sen_matrix, pos_matrix_h, pos_matrix_t, x, dis_embed_weight, n_valid=n_valid,
-                                      max_live_slots=max_live_slots, max_live_pairs=max_live_pairs)
+                                      max_live_slots=max_live_slots, max_live_pairs=max_live_pairs,
+                                      compact=self.compact_edges and not self.get_weighted_adj_matrix.apply_mask)
                 if i < 1:
                     if self.get_weighted_adj_matrix.apply_mask and adj_matrix is not None:
                         mask = torch.eq(adj_matrix, 0)                                          # glove:330

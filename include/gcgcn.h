@@ -233,8 +233,12 @@ int gcgcn_pair_bce_bwd(int B, int N, int R, const float* logits, const float* la
  * fp32 atomics (reproducible up to summation order). */
 int gcgcn_producer_layout(int Hd, int P, int64_t* out17);
 int gcgcn_producer_count(int B, int N, int S, int T, const uint8_t* sen, const int32_t* n_valid, int32_t* counts2, void* stream);
-int gcgcn_producer_sizes(int B, int N, int S, int T, int Hd, int P, int ND, int64_t cap_rows, int64_t cap_pairs, int64_t* out4);
-/* out4 = {ibuf elements, fbuf elements, bbuf elements, offset of int32 {live rows, live pairs, over capacity, 0} in ibuf} */
+int gcgcn_producer_sizes(int B, int N, int S, int T, int Hd, int P, int ND, int64_t cap_rows, int64_t cap_pairs, int64_t* out7);
+/* out7 = {ibuf elements, fbuf elements, bbuf elements, offset of int32 {live rows, live pairs, over capacity, 0} in ibuf,
+ *         offset of pair_prow int32[B,N,N] in ibuf, offset of the compact rows Ec[rows, Hd] in fbuf, rows of Ec}
+ * Compact mode: gcgcn_producer_fwd with E == NULL leaves E unwritten; the hop's graph blocks read Ec / pair_prow / the bias
+ * of linear_sentence_att directly (gcgcn_*_compact below) and hand gcgcn_producer_bwd dEc instead of dE (dE == NULL; rows
+ * of dEc beyond the live pairs must be zero; the bias gradient is produced by the consumers, not here). */
 int gcgcn_producer_fwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx, const uint8_t* sen, const void* pos_h,
                        const void* pos_t, int pos_bytes, const float* node, const float* dis_table, const int32_t* n_valid,
                        const float* flat, int64_t cap_rows, int64_t cap_pairs, int32_t* ibuf, float* fbuf, float* scratch,
@@ -243,7 +247,25 @@ int gcgcn_producer_fwd(int B, int N, int S, int T, int Hd, int P, int ND, const 
 int gcgcn_producer_bwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx, const uint8_t* sen, const void* pos_h,
                        const void* pos_t, int pos_bytes, const float* node, const float* dis_table, const int32_t* n_valid,
                        const float* flat, int64_t cap_rows, int64_t cap_pairs, int32_t* ibuf, float* fbuf, float* bbuf,
-                       const float* dE, float* dctx, float* dnode, float* ddis_table, float* dflat, void* stream);
+                       const float* dE, const float* dEc, float* dctx, float* dnode, float* ddis_table, float* dflat, void* stream);
+
+/* ---- consumers of the compact rows: a hop's graph blocks without a dense E (compact.hip) -------------------------------
+ * e_ij = Ec[prow[b,i,j]] where prow >= 0, else bias.  Mean-only hop (MultiGraphConvolution's edge term): Ebar = mean_j e_ij;
+ * backward dEc[prow] = dEbar_i / n, dbias = sum (dead pairs of row)/n dEbar_i.  Attention hop: gcgcn_gat_fwd / _bwd with the
+ * edge pass reading e_ij (no opt-in mask); dEc and dbias instead of dE.  rowbuf: float[2 B N]; scratch of the attention
+ * backward: gcgcn_gat_bwd_compact_scratch(B,N,D) floats.  D <= 512.  Every sum in a fixed order. */
+int gcgcn_edge_mean_fwd_compact(int B, int N, int D, const float* Ec, const int32_t* prow, const float* bias, const int32_t* n_valid,
+                                float* Ebar, void* stream);
+int gcgcn_edge_mean_bwd_compact(int B, int N, int D, const int32_t* prow, const int32_t* n_valid, const float* dEbar, float* dEc,
+                                float* dbias, float* rowbuf, void* stream);
+int gcgcn_gat_fwd_compact(int B, int N, int D, int Dh, const float* X, const float* Ec, const int32_t* prow, const float* bias,
+                          const int32_t* n_valid, const float* flat, const void* rng_snap, float p, float* uvc, float* s, float* P,
+                          float* A, float* Ebar, void* rng_state, void* rng_snaps, int rng_count, int uvc_valid, void* stream);
+int64_t gcgcn_gat_bwd_compact_scratch(int B, int N, int D);
+int gcgcn_gat_bwd_compact(int B, int N, int D, int Dh, const float* X, const float* Ec, const int32_t* prow, const float* bias,
+                          const int32_t* n_valid, const float* flat, const void* rng_snap, float p, const float* uvc, const float* P,
+                          const float* dA, const float* dEbar, const float* dX_in, float* dX, float* dEc, float* dbias, float* dflat,
+                          float* dlogit, float* ds, float* dvpart, float* duvc, float* scratch, void* stream);
 
 /* ---- classifier head  GCGCN_glove.py:306-307, 344-358 ------------------------------------------------ */
 /* logits[B,N,N,R] = bili_layer_01(eh, et) + classification_layer_01(cat(eh, et)) with

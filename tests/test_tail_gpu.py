@@ -91,3 +91,89 @@ def test_tail_trains_through_the_loss(gpu_device):
     dead = [k for k, v in sdl.items() if v.grad is None and not k.startswith(("get_adj_matrix.0.linears_k",))]
     assert any(k.startswith("graphcnn.1.") for k in dead) and any(k.startswith("word_attention.1.") for k in dead)
     assert tail.graphcnn[1].flat.grad is None and tail.producers[1].flat.grad is None
+
+
+def _compact_case(dev, B=3, N=11, S=3, T=40, Hd=128, P=20, seed=11):
+    """Synthetic batch for the compact-row consumers: ragged entity counts, some pairs with a live slot, one document with none."""
+    g = torch.Generator().manual_seed(seed)
+    ctx = torch.tanh(torch.randn(B, T, Hd, generator=g))
+    node = torch.rand(B, N, Hd, generator=g) * 2 - 1
+    table = torch.randn(21, P, generator=g) * 0.5
+    sen = torch.zeros(B, N, N, S, T, dtype=torch.bool)
+    live = torch.rand(B, N, N, S, generator=g) < 0.25
+    live[B - 1] = False                                          # a document without any live slot
+    for idx in live.nonzero().tolist():
+        b, i, j, s_ = idx
+        sen[b, i, j, s_, : int(torch.randint(3, 12, (1,), generator=g))] = True
+    other = (torch.rand(B, N, N, S, generator=g) < 0.3) & ~live   # slots that do not start at token 0: padded (glove:305)
+    for idx in other.nonzero().tolist():
+        b, i, j, s_ = idx
+        sen[b, i, j, s_, 5:15] = True
+    ph, pt = torch.randint(0, 21, (B, N, N, S, T), generator=g).to(torch.uint8), torch.randint(0, 21, (B, N, N, S, T), generator=g).to(torch.uint8)
+    nv = torch.tensor([N, N - 4, N - 1][:B], dtype=torch.int32)
+    node = node * (torch.arange(N)[None, :] < nv[:, None]).unsqueeze(-1).float()
+    return [t.to(dev) for t in (ctx, node, table, sen, ph, pt, nv)]
+
+
+def test_compact_rows_equal_the_dense_edge_tensor(gpu_device):
+    """EdgeFeatureProducer(compact=True): the handle's dense() is the dense call's E; GATAttention and the edge mean on the
+    handle equal the same blocks on the dense tensor, forward and every gradient (node features, token states, distance table,
+    producer parameters incl. linear_sentence_att's bias, GATAttention's parameters); capacities that are too small are loud."""
+    from gcgcn_amd import functional as F_
+    ctx, node, table, sen, ph, pt, nv = _compact_case(gpu_device)
+    B, N, Hd = node.shape
+    prod = gcgcn_amd.EdgeFeatureProducer(Hd, 20).to(gpu_device)
+    gat = gcgcn_amd.GATAttention(Hd, Hd).to(gpu_device).eval()
+    cotA = torch.randn(B, N, N, generator=torch.Generator().manual_seed(1)).to(gpu_device)
+    cotM = torch.randn(B, N, Hd, generator=torch.Generator().manual_seed(2)).to(gpu_device)
+    res = {}
+    for compact in (False, True):
+        prod.zero_grad(), gat.zero_grad()
+        c_, n_, t_ = (t.clone().requires_grad_() for t in (ctx, node, table))
+        e = prod(c_, sen, ph, pt, n_, t_, n_valid=nv, compact=compact)
+        if compact:
+            assert isinstance(e, F_.CompactEdges) and e.shape == (B, N, N, Hd)
+            torch.testing.assert_close(e.dense().detach(), res[False]["E"], rtol=1e-5, atol=1e-6)
+        a, xa = gat(n_, e, n_valid=nv, return_input_alias=True)
+        ebar = F_.take_edge_mean(e, nv)                                  # parked by GATAttention's pass
+        assert ebar is not None
+        ebar2 = F_.edge_mean(e if compact else e, nv)                    # the mean-only consumer (what a MAGGC hop runs)
+        ((a * cotA).sum() + (ebar * cotM).sum() + (ebar2 * cotM).sum() * 0.5 + (xa * 0.1).sum()).backward()
+        res[compact] = dict(E=(e.dense() if compact else e).detach(), A=a.detach(), ebar=ebar.detach(), ebar2=ebar2.detach(), dctx=c_.grad,
+                            dnode=n_.grad, dtable=t_.grad, dprod=prod.flat.grad.clone(), dgat=gat.flat.grad.clone())
+    for k in res[False]:
+        want = res[False][k]
+        torch.testing.assert_close(res[True][k], want, rtol=1e-4, atol=1e-5 * max(1.0, want.abs().max().item()), msg=lambda m: f"{k}: {m}")
+    assert res[True]["dprod"].abs().sum() > 0 and res[True]["dctx"].abs().sum() > 0
+    # capacities one short: NaN everywhere a real pair contributes, also through the compact consumers
+    r, q = F_.producer_live_counts(sen.view(torch.uint8), nv)
+    e_bad = prod(ctx, sen, ph, pt, node, table, n_valid=nv, max_live_slots=r, max_live_pairs=q - 1, compact=True)
+    assert prod.last_counts.tolist()[2] == 1
+    a_bad = gat(node, e_bad, n_valid=nv)
+    assert torch.isnan(a_bad[0, 0]).all() and torch.isnan(F_.edge_mean(e_bad, nv)[0, 0]).all()
+
+
+def test_tail_with_compact_edges(gpu_device):
+    """GraphModelTail(compact_edges=True): E and dE of both hops are never written; logits and every gradient equal the default
+    (dense) run, and the real model's logits of the fixture."""
+    g, sd, tail = _setup(gpu_device)
+    r = g["raw"]
+    docs = [_doc(r, di, gpu_device) for di in range(g["meta"]["docs"])]
+    batch = {k: torch.stack([d[k] for d in docs]) for k in docs[0]}
+    labels = (torch.rand(len(docs), batch["node_feat"].shape[1], batch["node_feat"].shape[1], 97, generator=torch.Generator().manual_seed(3)) < 0.05).float().to(gpu_device)
+    res = {}
+    for compact in (False, True):
+        tail.compact_edges = compact
+        tail.zero_grad()
+        dis, ner = sd["dis_embed.weight"].to(gpu_device).requires_grad_(), sd["ner_emb.weight"].to(gpu_device).requires_grad_()
+        b = {k: (v.clone().requires_grad_() if k in ("context_output", "node_feat") else v) for k, v in batch.items()}
+        out = tail(dis_embed_weight=dis, ner_emb_weight=ner, **b)
+        gcgcn_amd.pair_bce_loss(out, labels).sum().backward()
+        res[compact] = [out.detach(), b["context_output"].grad, b["node_feat"].grad, dis.grad, ner.grad] + \
+                       [p.grad.clone() for p in tail.parameters() if p.grad is not None]
+    tail.compact_edges = False
+    assert len(res[True]) == len(res[False])
+    for a, b_ in zip(res[True], res[False]):
+        torch.testing.assert_close(a, b_, rtol=1e-4, atol=1e-6 * max(1.0, b_.abs().max().item() * 10))
+    for di in range(len(docs)):
+        torch.testing.assert_close(res[True][0][di].cpu(), torch.from_numpy(r[f"doc{di}.logits"]), rtol=1e-4, atol=1e-4)
