@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--T", type=int, default=512)
     ap.add_argument("--live", type=float, default=0.15)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--compact", action="store_true", help="the producers hand over compact rows: E / dE of the hops are never written")
+    ap.add_argument("--skip-dead-hop", action="store_true", help="do not compute the hop whose output never reaches the classifier")
     a = ap.parse_args()
     import gcgcn_amd
     from gcgcn_amd import _lib
@@ -41,6 +43,7 @@ def main():
     rel = torch.randint(-10, 11, (B, N, N), generator=g, device=dev)
     labels = (torch.rand(B, N, N, R, generator=g, device=dev) < 0.03).float()
     tail = gcgcn_amd.GraphModelTail().to(dev).train()
+    tail.compact_edges, tail.skip_dead_hop = a.compact, a.skip_dead_hop
     gcgcn_amd.manual_seed(1337, dev)
 
     def step():
@@ -77,7 +80,8 @@ def main():
     print(json.dumps({"metric": "docs/sec fwd+bwd through the whole post-encoder model + loss", "value": round(B / dt, 1), "unit": "docs/s",
                       "ms_per_step": round(dt * 1e3, 3),
                       "config": {"workload": f"GraphModelTail (2 hops, hidden 128, L=2, H=8, R=97) + pair_bce_loss, train mode, B={B} N={N} "
-                                             f"S={S} T={T}, {a.live:.0%} of the sentence slots start at token 0, uint8 position ids, eager launches"},
+                                             f"S={S} T={T}, {a.live:.0%} of the sentence slots start at token 0, uint8 position ids, eager launches"
+                                             + (", compact edge rows (no E / dE tensors)" if a.compact else "") + (", dead last hop skipped" if a.skip_dead_hop else "")},
                       "gpu_ms_per_step_by_part": shares}))
 
 
