@@ -109,7 +109,8 @@ struct Opt {
 };
 static Opt g_opts[] = {{"head_v1", 0, false},   {"head_bil3", 0, false},  {"head_bil3_bwd", 0, false}, {"head_dw3", 0, false},
                        {"chain_s", 0, false},   {"chain_fuse", 0, false}, {"chain_carry", 0, false},   {"gat_ride", 0, false},
-                       {"chain_t", 0, false},   {"fwd_fuse", 0, false},   {"splitk_fuse", 0, false},   {"mha_ride", 0, false}};
+                       {"chain_t", 0, false},   {"fwd_fuse", 0, false},   {"splitk_fuse", 0, false},   {"mha_ride", 0, false},
+                       {"big_products", 0, false}, {"chain_carry_pct", 0, false}, {"chain_carry_rounds", 0, false}};
 int option(const char* name, int dflt) {
   for (Opt& o : g_opts) {
     if (strcmp(o.name, name) != 0) continue;
@@ -526,18 +527,48 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
   {  // the dependent per-(doc, head) sequence: normaliser, then per sub-layer dense connection + aggregation
     GcnCtx c = make_ctx(B, N, D, L, H, y, X, A, flat, n_valid, drop);
     c.G = G, c.Pn = Pn, c.Y = Y, c.HO = HO, c.rinv = rinv;
-    if (er.kind && !(use_chain() && chain_can_carry(er))) {  // the riding pass as its own launch
+    // Graphs of more than 64 entities: one batched launch per product (each is 256 x 256 x 256 per pair at cfg 5: big enough
+    // to fill the chip on its own) with the next hop's edge mean riding THROUGH those launches -- inside a chain launch the
+    // 512-thread passengers cannot share a compute unit with a chain workgroup (registers), so at B H >= 256 pairs they only
+    // ran after the chains (cfg 5: 1.05 ms per launch for 0.4 ms of products and 0.66 ms of streaming).
+    const bool big = N > 64 && option("big_products", 0) != 0;
+    const bool chain = use_chain() && !big;
+    GemmArgs plans[2 * 16];
+    int np = 0;
+    bool rideable = er.kind != 0 && !chain && L <= 16;
+    if (!chain && L <= 16) {
+      for (int l = 0; l < L; ++l) {
+        if (l > 0) plans[np++] = plan_fwd_dense(c, l);
+        plans[np++] = plan_fwd_agg(c, l);
+      }
+      for (int i = 0; i < np; ++i) rideable = rideable && gemm_ride_ok(plans[i], er);
+    }
+    if (er.kind && !(chain ? chain_can_carry(er) : rideable)) {  // the riding pass as its own launch
       GC_TRY(edge_fwd(er.in, nullptr, er.n_valid, er.out, nullptr, nullptr, nullptr, Drop(), er.B, er.N, er.D, st));
       er.kind = 0;
     }
     c.ride = er;
-    if (use_chain()) {
+    if (chain) {
       GC_TRY(gcn_chain_fwd(c, st));
     } else {
       GC_TRY(rowsum_inv(A, rinv, (long)B * H * N, N, st));  // glove:47-49
-      for (int l = 0; l < L; ++l) {
-        if (l > 0) GC_TRY(gemm(plan_fwd_dense(c, l), st, 0, 1));
-        GC_TRY(gemm(plan_fwd_agg(c, l), st, 0, 1));
+      if (er.kind && rideable) {  // passenger rows in proportion to each product's work
+        double tot = 0, w[2 * 16];
+        for (int i = 0; i < np; ++i) tot += (w[i] = (double)plans[i].M * plans[i].N * plans[i].K);
+        const long rows = (long)er.B * er.N;
+        long done = 0;
+        double acc = 0;
+        for (int i = 0; i < np; ++i) {
+          acc += w[i];
+          const long upto = (i == np - 1) ? rows : (long)(rows * (acc / tot));
+          GC_TRY(gemm_ride(plans[i], er, (int)done, (int)(upto - done), st));
+          done = upto;
+        }
+      } else {
+        for (int l = 0; l < L; ++l) {
+          if (l > 0) GC_TRY(gemm(plan_fwd_dense(c, l), st, 0, 1));
+          GC_TRY(gemm(plan_fwd_agg(c, l), st, 0, 1));
+        }
       }
     }
   }
@@ -639,19 +670,45 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
   }
 
   {  // the dependent per-(doc, head) sequence, last sub-layer first
-    if (er.kind && !(use_chain() && chain_can_carry(er))) {
+    const bool big = N > 64 && option("big_products", 0) != 0;   // see gcgcn_gcn_fwd
+    const bool chain = use_chain() && !big;
+    bool rideable = er.kind != 0 && !chain && L <= 16;
+    double tot = 0;
+    if (rideable)
+      for (int l = L - 1; l >= 0; --l) {
+        const GemmArgs a = plan_bwd_dP(c, l), b2 = plan_bwd_dA(c, l);
+        rideable = rideable && gemm_ride_ok(a, er) && gemm_ride_ok(b2, er);
+        tot += (double)a.M * a.N * a.K + (double)b2.M * b2.N * b2.K;
+        if (l > 0) {
+          const GemmArgs d = plan_bwd_dY(c, l);
+          rideable = rideable && gemm_ride_ok(d, er);
+          tot += (double)d.M * d.N * d.K;
+        }
+      }
+    if (er.kind && !(chain ? chain_can_carry(er) : rideable)) {
       GC_TRY(edge_bcast(er.in, er.n_valid, er.out, er.B, er.N, er.D, st));
       er.kind = 0;
     }
     c.ride = er;
-    if (use_chain()) {
+    if (chain) {
       GC_TRY(gcn_chain_bwd(c, st, dq));  // + parked weight gradients of earlier blocks where the chain leaves room
     } else {
+      const long rows = er.kind ? (long)er.B * er.N : 0;
+      long done = 0;
+      double acc = 0;
+      auto product = [&](const GemmArgs& g, bool last) -> int {   // one product, with its share of the riding dE broadcast
+        if (!er.kind) return gemm(g, st, 0, 1);
+        acc += (double)g.M * g.N * g.K;
+        const long upto = last ? rows : (long)(rows * (acc / tot));
+        const int e = gemm_ride(g, er, (int)done, (int)(upto - done), st);
+        done = upto;
+        return e;
+      };
       for (int l = L - 1; l >= 0; --l) {
         GC_TRY(relu_norm_bwd(dYa, Y, rinv, dM, drow, M, N, H, L, gh, l, l == L - 1, st));
-        GC_TRY(gemm(plan_bwd_dP(c, l), st, 0, 1));
-        GC_TRY(gemm(plan_bwd_dA(c, l), st, 0, 1));
-        if (l > 0) GC_TRY(gemm(plan_bwd_dY(c, l), st, 0, 1));
+        GC_TRY(product(plan_bwd_dP(c, l), false));
+        GC_TRY(product(plan_bwd_dA(c, l), l == 0));
+        if (l > 0) GC_TRY(product(plan_bwd_dY(c, l), false));
       }
     }
   }

@@ -829,7 +829,7 @@ int gcn_chain_bwd(const GcnCtx& c, hipStream_t st, DeferQueue* carry) {
   // split at the budget, the rest of its tiles rides in GATAttention's edge pass.  K % 64 == 0 for equal halves.
   const bool s_ok = chain_aligned(c, true) && chain_small_ok(c, true);
   const bool use_t = !c.dout && chain_t_ok(c, true) && !(s_ok && option("chain_t", 1) < 2);
-  if (use_t) return gcn_chain_t_bwd(c, dim3(chain_grid(c, 2)), fl, st);   // (no parked tiles aboard: the edge pass carries them)
+  if (use_t) return gcn_chain_t_bwd(c, fl, st, chain_passengers() ? carry : nullptr);
   int ng = 0;
   if (carry && carry->n > 0 && (long)c.B * c.H <= 64 && ((long)c.B * c.N) % 64 == 0 && chain_passengers()) {
     const int passes = (((c.N + 63) / 64) * ((c.gh + 63) / 64) + 1) / 2;

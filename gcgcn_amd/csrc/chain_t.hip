@@ -27,6 +27,7 @@
 
 #include "edge_body.hpp"
 #include "gcn_plan.hpp"
+#include "gemm_body.hpp"
 #include "rowops.hpp"
 
 namespace gc {
@@ -248,15 +249,52 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_fwd_kernel(const GcnCtx c)
 // dA: wave w accumulates rows 16 (w % 4) .. + 15, all 64 columns, over the k range [64 (w / 4), + 64) of every sub-layer in
 // registers; the gh / 64 partial sums meet in LDS at the end, in a fixed order (bitwise reproducible).
 // ---------------------------------------------------------------------------------------------------------------------
+// Parked weight-gradient tiles (gemm.hpp DeferQueue) as passengers of a chain launch that leaves compute units idle: a
+// passenger workgroup of NTEAM x 256 threads runs NTEAM consecutive 64 x 64 tiles of ONE problem side by side, one per team,
+// each over its whole K (all teams of a workgroup pass the same number of barriers: same problem, same K; a team beyond the
+// problem's last tile recomputes that tile without storing).  Workgroup pb -> problem by the prefix sums of ceil(take / NTEAM).
+constexpr int T_TEAM_LDS = lds_floats<1, 1, true, true>();
+template <int NTEAM>
+__device__ __forceinline__ void t_parked_tiles(const GemmGroup4& cg, int pb, float* __restrict__ lds) {
+  int i = 0, w = pb;
+  while (i + 1 < cg.nprob && w >= (cg.tile_take[i] + NTEAM - 1) / NTEAM) {
+    w -= (cg.tile_take[i] + NTEAM - 1) / NTEAM;
+    ++i;
+  }
+  const int team = threadIdx.x >> 8, t = threadIdx.x & 255;
+  int q = NTEAM * w + team;
+  const bool live = q < cg.tile_take[i];
+  if (!live) q = cg.tile_take[i] - 1;
+  q = xcd_remap(q + cg.tile_first[i], cg.tile_count[i]);
+  const GemmArgs& g = cg.p[i];
+  const int tn = g.N >> 6, tm = g.M >> 6;
+  const int zs = q / (tn * tm), r = q - zs * (tn * tm);
+  const int bx = (tm < tn) ? r / tm : r % tn, by = (tm < tn) ? r % tm : r / tn;   // same tile list as gemm_group_block
+  float* tl = lds + team * T_TEAM_LDS;
+  if (g.a_kc) {
+    if (g.b_kc) gemm_body<1, 1, true, true, true>(g, tl, bx, by, zs, t, live);
+    else gemm_body<1, 1, true, false, true>(g, tl, bx, by, zs, t, live);
+  } else {
+    if (g.b_kc) gemm_body<1, 1, false, true, true>(g, tl, bx, by, zs, t, live);
+    else gemm_body<1, 1, false, false, true>(g, tl, bx, by, zs, t, live);
+  }
+}
+
 template <int GH, int L, bool FULL>
-__global__ __launch_bounds__(4 * GH) void gcn_chain_t_bwd_kernel(const GcnCtx c) {
+__global__ __launch_bounds__(4 * GH) void gcn_chain_t_bwd_kernel(const GcnCtx c, const GemmGroup4 cg, const int npw) {
   constexpr int W = GH / 16, NT = 4 * GH, P = GH + 4, NC = GH / 16, SP = 20;   // SP: row pitch of a [gh][16 k] weight stage
   __shared__ __attribute__((aligned(16))) float lds[t_bwd_lds<GH>()];
   static_assert(2 * GH * SP <= 64 * P, "weight stages live in the Pn image");
   static_assert((W / 4 - 1) * 4096 <= 64 * P || W == 4, "dA exchange lives in the dM image");
-  if (blockIdx.x >= c.B * c.H) {  // passenger workgroup: one entity row of the riding dE broadcast
-    const EdgeRide& r = c.ride;
-    edge_bcast_row<4, W>(r.in, r.n_valid, r.out, r.N, r.D, 0, blockIdx.x - c.B * c.H);
+  static_assert((GH / 64) * T_TEAM_LDS <= t_bwd_lds<GH>(), "parked tiles use the chain kernel's LDS");
+  if (blockIdx.x >= c.B * c.H) {
+    const int pb = blockIdx.x - c.B * c.H;
+    if (pb < npw) {  // passenger workgroup: GH / 64 tiles of a parked weight-gradient product
+      t_parked_tiles<GH / 64>(cg, pb, lds);
+      return;
+    }
+    const EdgeRide& r = c.ride;  // passenger workgroup: one entity row of the riding dE broadcast
+    edge_bcast_row<4, W>(r.in, r.n_valid, r.out, r.N, r.D, 0, pb - npw);
     return;
   }
   float* const ATs = lds;                  // A_h transposed: [k = column of A][row of A]
@@ -501,9 +539,9 @@ static void launch_fwd(const GcnCtx& c, dim3 grid, double fl, hipStream_t st) {
   else GC_LAUNCH_TIMED("gcn_chain_fwd", fl, (gcn_chain_t_fwd_kernel<GH, L, false>), grid, dim3(4 * GH), 0, st, c);
 }
 template <int GH, int L>
-static void launch_bwd(const GcnCtx& c, dim3 grid, double fl, hipStream_t st) {
-  if (chain_t_full(c)) GC_LAUNCH_TIMED("gcn_chain_bwd", fl, (gcn_chain_t_bwd_kernel<GH, L, true>), grid, dim3(4 * GH), 0, st, c);
-  else GC_LAUNCH_TIMED("gcn_chain_bwd", fl, (gcn_chain_t_bwd_kernel<GH, L, false>), grid, dim3(4 * GH), 0, st, c);
+static void launch_bwd(const GcnCtx& c, const GemmGroup4& cg, int npw, dim3 grid, double fl, hipStream_t st) {
+  if (chain_t_full(c)) GC_LAUNCH_TIMED("gcn_chain_bwd", fl, (gcn_chain_t_bwd_kernel<GH, L, true>), grid, dim3(4 * GH), 0, st, c, cg, npw);
+  else GC_LAUNCH_TIMED("gcn_chain_bwd", fl, (gcn_chain_t_bwd_kernel<GH, L, false>), grid, dim3(4 * GH), 0, st, c, cg, npw);
 }
 
 // (gh, L) pairs the templates are instantiated for: the reference's model (64, 2), cfg 2's width (128, 2), cfg 3 (192, 4),
@@ -544,11 +582,29 @@ int gcn_chain_t_fwd(const GcnCtx& c, dim3 grid, double fl, hipStream_t st) {
   return 1;
 }
 
-int gcn_chain_t_bwd(const GcnCtx& c, dim3 grid, double fl, hipStream_t st) {
-#define X(gh_, l_)                                \
-  if (c.gh == gh_ && c.L == l_) {                 \
-    launch_bwd<gh_, l_>(c, grid, fl, st);         \
-    return check_launch("gcn_chain_t_bwd");       \
+// carry: parked weight-gradient products; as many of their tiles ride as fit on the compute units this launch leaves idle
+// in one round (a tile's whole K takes about as long as the chain itself), half of them when the dE broadcast rides as well
+int gcn_chain_t_bwd(const GcnCtx& c, double fl, hipStream_t st, DeferQueue* carry) {
+  GemmGroup4 cg;
+  cg.nprob = 0, cg.tile_begin[0] = 0;
+  const int nteam = c.gh / 64;
+  int npw = 0;
+  const long idle = 256 - (long)c.B * c.H;
+  if (carry && carry->n > 0 && idle > 0 && option("chain_carry", 1) != 0) {
+    bool ok = true;
+    for (int i = 0; i < carry->n; ++i) ok = ok && carry->p[i].K % BK == 0 && carry->p[i].splits <= 1;
+    long wgs = idle * option("chain_carry_rounds", 1);
+    if (c.ride.kind == 2) wgs = wgs * option("chain_carry_pct", 100) / 100;
+    if (ok && wgs > 0) {
+      gemm_take_deferred_pairs(carry, cg, &fl, wgs * nteam);
+      for (int i = 0; i < cg.nprob; ++i) npw += (cg.tile_take[i] + nteam - 1) / nteam;
+    }
+  }
+  const dim3 grid((unsigned)(c.B * c.H + npw) + (c.ride.kind == 2 ? (unsigned)(c.ride.B * c.ride.N) : 0u));
+#define X(gh_, l_)                                         \
+  if (c.gh == gh_ && c.L == l_) {                          \
+    launch_bwd<gh_, l_>(c, cg, npw, grid, fl, st);         \
+    return check_launch("gcn_chain_t_bwd");                \
   }
   GC_CHAIN_T_SHAPES(X)
 #undef X

@@ -22,10 +22,33 @@
 // separate instantiation with unconditional 16-byte loads; ragged shapes take the guarded one.
 #include <stdlib.h>
 
+#include "edge_body.hpp"
+#include "gcn_plan.hpp"
 #include "gemm_body.hpp"
 #include "rowops.hpp"
 
 namespace gc {
+
+// One batched product with an edge-tensor streaming pass riding in the SAME launch (graphs of more than 64 entities,
+// where a (doc, head) pair's working set does not fit a compute unit and the per-pair products are big enough -- 256 x 256
+// x 256 at cfg 5 -- to run as ordinary batched tile launches): `nrows` entity rows of the pass (EdgeRide, gcn_plan.hpp) are
+// spread EVENLY through the tile list, so the HBM-bound rows and the matrix-pipe-bound tiles share every compute unit for
+// the whole launch (4 workgroups per CU of either kind).  Behind the tiles they would only start once the tile list has
+// nearly drained.
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm_ride_kernel(const GemmArgs g, const EdgeRide r, int row0, int nrows, int tiles, int gx, int gy) {
+  __shared__ __attribute__((aligned(16))) float lds[lds_floats<1, 1, AKC, BKC>()];
+  const long x = blockIdx.x, total = gridDim.x;
+  const long before = x * nrows / total;                 // passenger workgroups among [0, x)
+  if ((x + 1) * nrows / total > before) {
+    const int row = row0 + (int)before;
+    if (r.kind == 1) edge_fwd_row<4, false, true, 4>(r.in, nullptr, r.n_valid, r.out, nullptr, nullptr, nullptr, Drop(), r.N, r.D, row, lds);
+    else edge_bcast_row<4, 4>(r.in, r.n_valid, r.out, r.N, r.D, 0, row);
+    return;
+  }
+  const int b = xcd_remap((int)(x - before), tiles);
+  gemm_body<1, 1, AKC, BKC, true>(g, lds, b % gx, (b / gx) % gy, b / (gx * gy));
+}
 
 template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
@@ -249,6 +272,30 @@ int gemm(const GemmArgs& g_in, hipStream_t stream, int tile, int splits) {
   const bool al = g.vecA && g.vecB && g.M % bm == 0 && g.N % bm == 0 && g.ksplit % BK == 0;
   if (tile == 2) return al ? launch<2, 2, true>(g, stream) : launch<2, 2, false>(g, stream);
   return al ? launch<1, 1, true>(g, stream) : launch<1, 1, false>(g, stream);
+}
+
+bool gemm_ride_ok(const GemmArgs& g, const EdgeRide& r) {
+  auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+  return r.kind != 0 && r.D % 4 == 0 && al(r.in) && al(r.out) && 4L * r.D <= lds_floats<1, 1, true, true>() && g.M % 64 == 0 &&
+         g.N % 64 == 0 && g.K % BK == 0 && al(g.A) && al(g.B) && g.lda % 4 == 0 && g.ldb % 4 == 0 && g.sA1 % 4 == 0 && g.sA2 % 4 == 0 &&
+         g.sB1 % 4 == 0 && g.sB2 % 4 == 0;
+}
+
+// unsplit interior product + rows [row0, row0 + nrows) of the riding pass; gemm_ride_ok(g, r) must hold
+int gemm_ride(const GemmArgs& g_in, const EdgeRide& r, int row0, int nrows, hipStream_t stream) {
+  GemmArgs g = g_in;
+  if (prepare(g, 1, 1, 0) < 0) return 1;
+  GC_REQUIRE(gemm_ride_ok(g, r) && g.vecA && g.vecB && nrows >= 0, "gemm_ride: not an interior problem / bad passenger");
+  const int gx = g.N / 64, gy = g.M / 64;
+  const long tiles = (long)gx * gy * g.batch1 * g.batch2;
+  GC_REQUIRE(tiles + nrows <= 0x7fffffffL, "gemm_ride: grid too large");
+  const dim3 grid((unsigned)(tiles + nrows)), block(256);
+  const double flops = 2.0 * g.M * g.N * g.K * g.batch1 * g.batch2;
+  if (g.a_kc && !g.b_kc) GC_LAUNCH_TIMED(g.tag, flops, (gemm_ride_kernel<true, false>), grid, block, 0, stream, g, r, row0, nrows, (int)tiles, gx, gy);
+  else if (g.a_kc && g.b_kc) GC_LAUNCH_TIMED(g.tag, flops, (gemm_ride_kernel<true, true>), grid, block, 0, stream, g, r, row0, nrows, (int)tiles, gx, gy);
+  else if (!g.a_kc && !g.b_kc) GC_LAUNCH_TIMED(g.tag, flops, (gemm_ride_kernel<false, false>), grid, block, 0, stream, g, r, row0, nrows, (int)tiles, gx, gy);
+  else GC_LAUNCH_TIMED(g.tag, flops, (gemm_ride_kernel<false, true>), grid, block, 0, stream, g, r, row0, nrows, (int)tiles, gx, gy);
+  return check_launch("gemm_ride");
 }
 
 // Independent problems in one launch (plus at most one reduce launch).  Problems that are not interior
