@@ -25,6 +25,12 @@ I = c_int
 F = c_float
 L = c_int64
 
+class MhaHook(ctypes.Structure):
+    """gcgcn_mha_hook: MultiHeadAttention's work riding inside the MultiGraphConvolution calls of the same hop (include/gcgcn.h)."""
+    _fields_ = [("flat_q", c_void_p), ("Q", c_void_p), ("P", c_void_p), ("A", c_void_p), ("dQ", c_void_p), ("rng_snap", c_void_p),
+                ("p", ctypes.c_float)]
+
+
 class EdgeRide(ctypes.Structure):
     """gcgcn_edge_ride: an edge-tensor pass riding along with a gcn_fwd / gcn_bwd call (include/gcgcn.h)."""
     _fields_ = [("B", ctypes.c_int32), ("N", ctypes.c_int32), ("D", ctypes.c_int32),
@@ -51,11 +57,12 @@ SIGNATURES = {
     "gcgcn_mha_layout": (I, [I, P]),
     "gcgcn_mha_scratch": (L, [I, I, I]),
     "gcgcn_mha_fwd": (I, [I, I, I, I, P, P, P, P, F, P, P, P, P, P]),
-    "gcgcn_mha_bwd": (I, [I, I, I, I, P, P, P, F, P, P, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_mha_bwd": (I, [I, I, I, I, P, P, P, F, P, P, P, P, P, P, P, P, P, P, I, P]),
+    "gcgcn_maggc_fusable": (I, [I, I, I]),
     "gcgcn_gcn_layout": (I, [I, I, I, P]),
     "gcgcn_gcn_scratch": (L, [I, I, I, I]),
-    "gcgcn_gcn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, F, P, P, P, P, P, P, P, P, P, P]),
-    "gcgcn_gcn_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_gcn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, F, P, P, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_gcn_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_defer_create": (P, []),
     "gcgcn_defer_destroy": (None, [P]),
     "gcgcn_defer_count": (I, [P]),

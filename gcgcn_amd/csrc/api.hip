@@ -110,7 +110,8 @@ struct Opt {
 static Opt g_opts[] = {{"head_v1", 0, false},   {"head_bil3", 0, false},  {"head_bil3_bwd", 0, false}, {"head_dw3", 0, false},
                        {"chain_s", 0, false},   {"chain_fuse", 0, false}, {"chain_carry", 0, false},   {"gat_ride", 0, false},
                        {"chain_t", 0, false},   {"fwd_fuse", 0, false},   {"splitk_fuse", 0, false},   {"mha_ride", 0, false},
-                       {"big_products", 0, false}, {"chain_carry_pct", 0, false}, {"chain_carry_rounds", 0, false}};
+                       {"big_products", 0, false}, {"chain_carry_pct", 0, false}, {"chain_carry_rounds", 0, false},
+                       {"maggc_fuse", 0, false}};
 int option(const char* name, int dflt) {
   for (Opt& o : g_opts) {
     if (strcmp(o.name, name) != 0) continue;
@@ -408,7 +409,7 @@ int64_t gcgcn_mha_scratch(int B, int N, int D) { return scratch_elems(B, N, D, 1
 
 int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat, const void* rng_snap, float p,
                   const float* Q, const float* P, const float* dA, const float* dX_in, float* dX, float* dflat, float* dS,
-                  float* dQ, float* scratch, void* defer_queue, void* stream) {
+                  float* dQ, float* scratch, void* defer_queue, int core_done, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("mha_bwd", B, N, D, 1, H));
   const long wse = scratch ? gemm_scratch_elems(B, N, D, 1) : 0;
@@ -417,7 +418,8 @@ int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat,
   const long M = (long)B * N;
   const int dh = D / H;
   const float alpha = 1.f / sqrtf((float)dh);
-  if (use_mha_core() && mha_core_ok(N, D, H, Q, dQ)) {
+  if (core_done) {  // dQ arrived with the call (computed as passengers of the convolution's backward, gcgcn_mha_hook)
+  } else if (use_mha_core() && mha_core_ok(N, D, H, Q, dQ)) {
     GC_TRY(mha_core_bwd(Q, P, dA, dQ, B, N, D, H, alpha, drop, st));
   } else {
     GC_TRY(softmax_bwd(P, dA, dS, M * H, N, drop, st));
@@ -496,9 +498,14 @@ int gcgcn_gcn_layout(int D, int L, int H, int64_t* o) {
 int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float* Ebar, const float* A,
                   const int32_t* n_valid, const float* flat, const void* rng_snap, float p, const void* out_rng_snap,
                   float out_p, float* out, float* Pn, float* Y, float* HO, float* rinv, float* G, float* wsum, float* scratch,
-                  const gcgcn_edge_ride* ride, void* stream) {
+                  const gcgcn_edge_ride* ride, const gcgcn_mha_hook* mha, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("gcn_fwd", B, N, D, L, H));
+  if (mha) {
+    GC_REQUIRE(gcgcn_maggc_fusable(N, D, H) && mha->flat_q && mha->Q && mha->P, "gcn_fwd: attention hook on a shape it does not serve");
+    GC_REQUIRE(mha_core_ok(N, D, H, mha->Q, nullptr), "gcn_fwd: attention hook: misaligned Q");
+    A = mha->A ? mha->A : mha->P;   // what the attention core below writes
+  }
   EdgeRide er;
   GC_TRY(make_ride("gcn_fwd", ride, 1, er));
   const long wse = scratch ? gemm_scratch_elems(B, N, D, H) : 0;
@@ -522,7 +529,22 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
     }
     ColRide hs;  // wsum = sum_h Wlin[:, h, :] (a by-product for gcgcn_gcn_bwd) in trailing workgroups of this launch
     if (wsum && H > 1) hs.X = flat + y.oWlin, hs.out = wsum, hs.R = H, hs.ld = D, hs.C = D * D, hs.ready_slices = -1;
-    GC_TRY(gemm_group(gs, 2, st, hs.X ? &hs : nullptr));
+    GemmArgs g3[3] = {gs[0], gs[1], GemmArgs()};
+    if (mha) {  // Q = X Wq^T + bq (glove:136, all heads at once): one more problem of this launch
+      GemmArgs& g = g3[2];
+      g.ws = scratch, g.ws_elems = wse;
+      g.A = X, g.lda = D, g.a_kc = 1;
+      g.B = mha->flat_q, g.ldb = D, g.b_kc = 1;
+      g.C = mha->Q, g.ldc = D;
+      g.M = (int)M, g.N = D, g.K = D;
+      g.bias = mha->flat_q + (long)D * D;
+    }
+    GC_TRY(gemm_group(g3, mha ? 3 : 2, st, hs.X ? &hs : nullptr));
+    if (mha) {  // the attention core: scores in LDS, P / A out (glove:137-140)
+      const Drop adrop = make_drop(mha->rng_snap, GCGCN_SALT_MHA, mha->p);
+      GC_REQUIRE(!adrop.snap || mha->A, "gcn_fwd: attention dropout on but A is NULL");
+      GC_TRY(mha_core_fwd(mha->Q, n_valid, mha->P, mha->A, B, N, D, H, 1.f / sqrtf((float)(D / H)), adrop, st));
+    }
   }
   {  // the dependent per-(doc, head) sequence: normaliser, then per sub-layer dense connection + aggregation
     GcnCtx c = make_ctx(B, N, D, L, H, y, X, A, flat, n_valid, drop);
@@ -599,8 +621,17 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
                   float out_p, const float* Pn, const float* Y, const float* HO, const float* rinv, const float* wsum_fwd,
                   const float* dout, float* dX, float* dEbar,
                   float* dA, float* dflat, float* W1, float* W2, float* W3, float* drow, float* dXres, float* dout_m,
-                  float* scratch, const gcgcn_edge_ride* ride, void* defer_queue, void* stream) {
+                  float* scratch, const gcgcn_edge_ride* ride, const gcgcn_mha_hook* mha, void* defer_queue, void* stream) {
   DeferQueue* dq = (DeferQueue*)defer_queue;
+  MhaPass mp;
+  if (mha) {
+    GC_REQUIRE(gcgcn_maggc_fusable(N, D, H) && mha->Q && mha->P && mha->dQ && mha_core_ok(N, D, H, mha->Q, mha->dQ),
+               "gcn_bwd: attention hook on a shape it does not serve");
+    mp.Q = mha->Q, mp.P = mha->P, mp.dA = dA, mp.dQ = mha->dQ;
+    mp.N = N, mp.D = D, mp.H = H, mp.dh = D / H, mp.kchunk = (D / H < 128) ? (D / H + 31) / 32 * 32 : 128, mp.count = B * H;
+    mp.alpha = 1.f / sqrtf((float)(D / H));
+    mp.drop = make_drop(mha->rng_snap, GCGCN_SALT_MHA, mha->p);
+  }
   const Drop odrop = make_drop(out_rng_snap, GCGCN_SALT_GLUE, out_p);
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("gcn_bwd", B, N, D, L, H));
@@ -779,9 +810,15 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
       g.batch2 = H;
       park();
     }
-    GC_TRY(gemm_group(gs, n, st, col_pending ? &cr : nullptr));
+    GC_TRY(gemm_group(gs, n, st, col_pending ? &cr : nullptr, nullptr, mha ? &mp : nullptr));   // + the attention core's backward
   }
   return 0;
+}
+
+int gcgcn_maggc_fusable(int N, int D, int H) {
+  if (N < 1 || N > 64 || H < 1 || D % H != 0) return 0;
+  const int dh = D / H;
+  return use_mha_core() && dh % 4 == 0 && D % 4 == 0 && gemm_group_can_carry_mha(dh) && option("maggc_fuse", 1) != 0 ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -25,6 +25,7 @@
 #include "edge_body.hpp"
 #include "gcn_plan.hpp"
 #include "gemm_body.hpp"
+#include "mha_body.hpp"
 #include "rowops.hpp"
 
 namespace gc {
@@ -90,46 +91,69 @@ __device__ __forceinline__ void col_ride_stage1(const ColRide& cr, int cb, float
 // that the XCD-contiguous remap can be applied PER PROBLEM: each XCD receives an equal, contiguous share of every
 // problem's tile list.  (One remap over the whole launch would hand XCD 0 the longest problem and XCD 7 the
 // shortest.)  The <= 7 padding workgroups per problem exit at once.
+// workgroup `idx` past the GEMM tiles (dispatched last, round-robin over the XCDs): the riding column sum
+__device__ __forceinline__ void group_tail(const GemmGroup& gg, const int idx, float* __restrict__ lds) {
+  const ColRide& cr = gg.col;
+  if (cr.ready_slices < 0) {  // sum over heads (sum_h Wlin[:, h, :] for the fused chain backward), eight loads in flight
+    const int e = idx * 256 + threadIdx.x;
+    if (e < cr.C) {
+      const int ld = (int)cr.ld, H = (int)cr.R, k = e / ld, c = e - k * ld;
+      float s = 0.f;
+      for (int h0 = 0; h0 < H; h0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = cr.X[((long)k * H + min(h0 + u, H - 1)) * ld + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (h0 + u < H) ? v[u] : 0.f;
+      }
+      cr.out[e] = s;
+    }
+    return;
+  }
+  if (cr.ready_slices > 0) {  // partial sums from an earlier launch: out[c] = their sum, slices in order
+    const int c = idx * 256 + threadIdx.x;
+    if (c < cr.C) {  // 16 independent loads in flight, summed in slice order
+      float s = 0.f;
+      for (int q0 = 0; q0 < cr.ready_slices; q0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = cr.part[(long)min(q0 + u, cr.ready_slices - 1) * cr.C + c];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += (q0 + u < cr.ready_slices) ? v[u] : 0.f;
+      }
+      cr.out[c] = s;
+    }
+    return;
+  }
+  col_ride_stage1(cr, idx, lds);
+}
+
 __global__ __launch_bounds__(256, 4) void gemm_group_kernel(const GemmGroup gg) {
   __shared__ __attribute__((aligned(16))) float lds[lds_floats<1, 1, true, true>()];
   const int tiles = gg.tile_begin[gg.nprob];
-  if ((int)blockIdx.x >= tiles) {  // past the GEMM tiles (dispatched last, round-robin over the XCDs): the riding column sum
-    const ColRide& cr = gg.col;
-    if (cr.ready_slices < 0) {  // sum over heads (sum_h Wlin[:, h, :] for the fused chain backward), eight loads in flight
-      const int e = (blockIdx.x - tiles) * 256 + threadIdx.x;
-      if (e < cr.C) {
-        const int ld = (int)cr.ld, H = (int)cr.R, k = e / ld, c = e - k * ld;
-        float s = 0.f;
-        for (int h0 = 0; h0 < H; h0 += 8) {
-          float v[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = cr.X[((long)k * H + min(h0 + u, H - 1)) * ld + c];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) s += (h0 + u < H) ? v[u] : 0.f;
-        }
-        cr.out[e] = s;
-      }
-      return;
-    }
-    if (cr.ready_slices > 0) {  // partial sums from an earlier launch: out[c] = their sum, slices in order
-      const int c = (blockIdx.x - tiles) * 256 + threadIdx.x;
-      if (c < cr.C) {  // 16 independent loads in flight, summed in slice order
-        float s = 0.f;
-        for (int q0 = 0; q0 < cr.ready_slices; q0 += 16) {
-          float v[16];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) v[u] = cr.part[(long)min(q0 + u, cr.ready_slices - 1) * cr.C + c];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) s += (q0 + u < cr.ready_slices) ? v[u] : 0.f;
-        }
-        cr.out[c] = s;
-      }
-      return;
-    }
-    col_ride_stage1(cr, blockIdx.x - tiles, lds);
+  if ((int)blockIdx.x >= tiles) {
+    group_tail(gg, blockIdx.x - tiles, lds);
     return;
   }
   gemm_group_block(gg, blockIdx.x, lds);
+}
+
+// The same launch with MultiHeadAttention's backward core aboard: mp.count (document, head) pairs spread EVENLY through the
+// tile list (behind the tiles they would start when the list has nearly drained and stretch the launch by their own latency).
+__global__ __launch_bounds__(256, 4) void gemm_group_pass_kernel(const GemmGroup gg, const MhaPass mp) {
+  __shared__ __attribute__((aligned(16))) float lds[lds_floats<1, 1, true, true>()];
+  const int tiles = gg.tile_begin[gg.nprob], inter = tiles + mp.count;
+  const int x = blockIdx.x;
+  if (x >= inter) {
+    group_tail(gg, x - inter, lds);
+    return;
+  }
+  const int before = (int)((long)x * mp.count / inter);   // pairs among the workgroups [0, x)
+  if ((int)((long)(x + 1) * mp.count / inter) > before) {
+    mha_core_bwd_body(lds, before, mp.Q, mp.P, mp.dA, mp.dQ, mp.N, mp.D, mp.H, mp.dh, mp.kchunk, mp.alpha, mp.drop);
+    return;
+  }
+  gemm_group_block(gg, x - before, lds);
 }
 
 // Split-K reduce: one thread sums the partials of 4 consecutive outputs (16-byte loads, split order => bitwise
@@ -300,7 +324,9 @@ int gemm_ride(const GemmArgs& g_in, const EdgeRide& r, int row0, int nrows, hipS
 
 // Independent problems in one launch (plus at most one reduce launch).  Problems that are not interior
 // 64x64 shapes fall back to their own launches.
-int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* col, bool* col_later) {
+bool gemm_group_can_carry_mha(int dh) { return mha_lds_bytes(dh) <= sizeof(float) * lds_floats<1, 1, true, true>(); }
+
+int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* col, bool* col_later, const MhaPass* mha) {
   if (col_later) *col_later = false;
   GemmGroup gg;
   gg.nprob = 0;
@@ -387,6 +413,9 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* 
   const bool ride = !ride2 && !ride3 && col && col->X && col->C > 0 && col->R > 0;
   if (ride || ride2) GC_REQUIRE(col->out && col->part, "gemm_group: column ride without out / part");
   if (ride3) GC_REQUIRE(col->X && col->out && col->R > 0 && col->ld > 0 && col->C == col->ld * col->ld, "gemm_group: bad head sum");
+  static_assert(sizeof(GemmGroup) + sizeof(MhaPass) + 32 <= 4096, "gemm_group_pass_kernel: kernel arguments exceed 4 KB");
+  if (gg.nprob == 0 && mha && mha->count > 0)   // nothing to ride on: the pairs get their launch
+    if (int e = mha_core_bwd(mha->Q, mha->P, mha->dA, mha->dQ, mha->count / mha->H, mha->N, mha->D, mha->H, mha->alpha, mha->drop, stream)) return e;
   if (gg.nprob == 0) {  // nothing to ride on
     if (ride3) return mask_rows(nullptr, nullptr, 0, (int)col->ld, 1, nullptr, make_drop(nullptr, 0, 0.f), stream, col->X, col->out, (int)col->R);
     if (ride2) return colsum(col->part, nullptr, col->out, col->ready_slices, col->C, col->C, 1, 0, 0, 0, 0, nullptr, stream);
@@ -402,7 +431,10 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* 
     gg.col = *col;
     col1 = cdiv(col->C, 256);
   }
-  GC_LAUNCH_TIMED("gemm_group", flops, gemm_group_kernel, dim3(tiles + col1), dim3(256), 0, stream, gg);
+  if (mha && mha->count > 0)
+    GC_LAUNCH_TIMED("gemm_group", flops, gemm_group_pass_kernel, dim3(tiles + mha->count + col1), dim3(256), 0, stream, gg, *mha);
+  else
+    GC_LAUNCH_TIMED("gemm_group", flops, gemm_group_kernel, dim3(tiles + col1), dim3(256), 0, stream, gg);
   if (int e = check_launch("gemm_group")) return e;
   if (ride && !any_split && col_later) {  // nothing to reduce: the caller folds stage 2 into a kernel of its own
     *col_later = true;

@@ -92,11 +92,24 @@ struct GemmGroupT {
   int nprob;
   ColRide col;  // col.X == nullptr: nothing rides
 };
+// MultiHeadAttention's backward core (mha_body.hpp: dA, P, Q -> dQ per (document, head)) riding in a group launch of the
+// convolution that follows the attention: `count` = B * H pairs, spread evenly through the launch's tile list.
+struct MhaPass {
+  const float* Q = nullptr;
+  const float* P = nullptr;
+  const float* dA = nullptr;
+  float* dQ = nullptr;
+  int N = 0, D = 0, H = 0, dh = 0, kchunk = 0, count = 0;
+  float alpha = 1.f;
+  Drop drop = {nullptr, 0, 0, 1.f};
+};
 using GemmGroup = GemmGroupT<9>;   // gemm_group launches and the edge pass carrying parked problems
 using GemmGroup4 = GemmGroupT<4>;  // passengers of a chain launch (kernel arguments stay small)
 // col_later (optional): if the launch needs no split-K reduce, stage 2 of the riding column sum is NOT launched on its own;
 // *col_later is set and the caller finishes it inside a later kernel of its own (col_ride_stage2_block).
-int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* col = nullptr, bool* col_later = nullptr);
+int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* col = nullptr, bool* col_later = nullptr,
+               const MhaPass* mha = nullptr);
+bool gemm_group_can_carry_mha(int dh);   // the pairs' LDS images fit the group kernel's
 
 // ---- deferred problems ------------------------------------------------------------------------------------------
 // Weight-gradient products are needed by nobody before the end of backward, while later launches of the same

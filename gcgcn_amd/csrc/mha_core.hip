@@ -6,49 +6,10 @@
 // dQ_h = alpha (dS + dS^T) Q_h without materialising dS; both products run on the fp32 MFMA from LDS operands.  Replaces three launches forward (batched score GEMM at
 // 64x64x32 per problem, softmax) and three backward (softmax gradient, two batched 64x32x64 GEMMs).
 // Larger graphs take the generic GEMM + row-softmax path in api.hip.
+#include "mha_body.hpp"
 #include "rowops.hpp"
 
 namespace gc {
-
-constexpr int MT = 64;       // padded graph size
-constexpr int MS = MT + 1;   // row stride of the score tile in LDS
-constexpr int MKC = 128;     // head-feature chunk held in LDS at a time
-
-static inline int mha_chunk(int dh) { return dh < MKC ? (dh + 31) / 32 * 32 : MKC; }
-static inline size_t mha_lds_bytes(int dh) { return sizeof(float) * (MT * MS + MT * (mha_chunk(dh) + 1)); }
-
-typedef float f16v __attribute__((ext_vector_type(16)));
-
-// Q_h chunk [N x kc] (row stride D in global) -> LDS rows of odd stride ld (conflict-free for both the k-contiguous
-// reads of the score product and the column-contiguous reads of the gradient product); rows >= N and columns
-// kc .. kpad are zero.
-__device__ __forceinline__ void load_q_chunk(float* qs, const float* __restrict__ q, int N, int D, int k0, int kc, int kpad,
-                                             int ld, int t) {
-  const int k4 = kpad >> 2;
-  for (int base = t; base < MT * k4; base += 4 * 256) {  // four independent loads in flight per thread
-    float4 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = base + u * 256, n = idx / k4, k = (idx - n * k4) << 2;
-      // clamped address + select instead of a guarded load: a load inside a branch is waited for at the branch's end,
-      // which serialises the four requests
-      v[u] = *reinterpret_cast<const float4*>(q + (long)min(n, N - 1) * D + k0 + min(k, kc - 4));
-      if (!(idx < MT * k4 && n < N && k < kc)) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = base + u * 256, n = idx / k4, k = (idx - n * k4) << 2;
-      if (idx < MT * k4) {
-        float* d = qs + n * ld + k;
-        d[0] = v[u].x, d[1] = v[u].y, d[2] = v[u].z, d[3] = v[u].w;
-      }
-    }
-  }
-}
-
-// v_mfma_f32_32x32x2_f32 operand / result mapping (wave of 64 lanes): A[row = lane & 31][k = lane >> 5],
-// B[k = lane >> 5][col = lane & 31], D[row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)][col = lane & 31].
-__device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 __global__ __launch_bounds__(256) void mha_core_fwd_kernel(const float* __restrict__ Q, const int* __restrict__ n_valid,
                                                            float* __restrict__ P, float* __restrict__ A, int N, int D, int H,
@@ -99,73 +60,11 @@ __global__ __launch_bounds__(256) void mha_core_fwd_kernel(const float* __restri
   }
 }
 
-// dQ_h = alpha (dS + dS^T) Q_h,  dS = P (dP - sum_j dP P),  dP = dropout_bwd(dA).   Padding entries have P == 0.
 __global__ __launch_bounds__(256) void mha_core_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ P,
                                                            const float* __restrict__ dA, float* __restrict__ dQ, int N, int D,
                                                            int H, int dh, int kchunk, float alpha, Drop drop) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* T = sm;             // [MT][MS]
-  float* qs = sm + MT * MS;  // [MT][kchunk + 1]
-  const int z = blockIdx.x, b = z / H, h = z - b * H;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const bool dd = drop.snap != nullptr;
-  const uint64_t key = dd ? drop_key(drop) : 0;
-  {  // all 16 rows of a wave are requested before the first one is reduced: one memory round trip, not sixteen
-    float p[MT / 4], g[MT / 4];
-#pragma unroll
-    for (int u = 0; u < MT / 4; ++u) {
-      const int i = wave + 4 * u;
-      const long oc = ((long)z * N + min(i, N - 1)) * N + min(lane, N - 1);  // clamped: unconditional loads
-      const bool ok = i < N && lane < N;
-      p[u] = P[oc], g[u] = dA[oc];
-      if (!ok) p[u] = 0.f, g[u] = 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < MT / 4; ++u) {
-      const int i = wave + 4 * u;
-      float gg = g[u];
-      if (dd) gg = (rng_u32(key, (uint64_t)(((long)z * N + i) * N + lane)) >= drop.thresh) ? gg * drop.scale : 0.f;
-      const float dot = wave_sum(gg * p[u]);
-      T[i * MS + lane] = p[u] * (gg - dot);
-    }
-  }
-  __syncthreads();
-  // symmetrise in place: the pair (i, j), (j, i) belongs to one thread
-  for (int idx = t; idx < MT * MT; idx += 256) {
-    const int i = idx >> 6, j = idx & 63;
-    if (i < j) {
-      const float s = T[i * MS + j] + T[j * MS + i];
-      T[i * MS + j] = s, T[j * MS + i] = s;
-    } else if (i == j) {
-      T[i * MS + i] *= 2.f;
-    }
-  }
-  const float* q = Q + (long)b * N * D + (long)h * dh;
-  float* dq = dQ + (long)b * N * D + (long)h * dh;
-  const int ld = kchunk + 1;
-  for (int k0 = 0; k0 < dh; k0 += kchunk) {
-    const int kc = min(kchunk, dh - k0), kpad = (kc + 31) & ~31;
-    __syncthreads();  // T symmetrised / previous chunk consumed
-    load_q_chunk(qs, q, N, D, k0, kc, kpad, ld, t);
-    __syncthreads();
-    // 32 x 32 output blocks (row block rb, column block cb) of the chunk, dealt round-robin to the waves
-    for (int blk = wave; blk < 2 * (kpad >> 5); blk += 4) {
-      const int rb = blk & 1, cb = blk >> 1;
-      const float* pa = T + (32 * rb + (lane & 31)) * MS + (lane >> 5);
-      const float* pb = qs + (lane >> 5) * ld + 32 * cb + (lane & 31);
-      f16v acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 4
-      for (int j = 0; j < MT; j += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[j], pb[j * ld], acc, 0, 0, 0);
-      const int c = 32 * cb + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = 32 * rb + mfma_row(r, lane);
-        if (i < N && c < kc) dq[(long)i * D + k0 + c] = acc[r] * alpha;
-      }
-    }
-  }
+  mha_core_bwd_body(sm, blockIdx.x, Q, P, dA, dQ, N, D, H, dh, kchunk, alpha, drop);
 }
 
 bool mha_core_ok(int N, int D, int H, const void* Q, const void* dQ) {

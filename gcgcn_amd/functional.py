@@ -250,7 +250,7 @@ class MhaFn(torch.autograd.Function):
         # longer side with the two convolutions' products (0.652 vs 0.648 ms) -- so it stays with its own group launch
         bp = _pass_for_parking(ctx, 1) if defer_mha_weight_grads else None
         call("gcgcn_mha_bwd", B, N, D, H, _p(x), _p(flat), _p(ctx.snap), ctx.p, _p(Q), _p(P), _p(dA), _p(dXin), _p(dX),
-             _p(dflat), _p(dS), _p(dQ), _p(scratch), None if bp is None else bp.queue, _stream())
+             _p(dflat), _p(dS), _p(dQ), _p(scratch), None if bp is None else bp.queue, 0, _stream())
         if bp is not None:
             bp.park(ctx.flat_leaf, dflat, (x, dQ))
             dflat = None                                # installed as .grad by the pass's end-of-backward callback
@@ -413,7 +413,7 @@ class GcnFn(torch.autograd.Function):
             ride, ride_p = _ride(e_next, n_valid, ebar_next, *ebar_next.shape)
         call("gcgcn_gcn_fwd", B, N, D, L, H, _p(x), _p(ebar), _p(adj), _p(n_valid), _p(flat), _p(snap), float(p),
              _p(out_snap), float(out_p), _p(out), _p(Pn), _p(Y), _p(HO), _p(rinv), _p(G), _p(wsum), _p(scratch), ride_p,
-             _stream())
+             None, _stream())
         del ride
         ctx.save_for_backward(x, ebar, adj, flat, Pn, Y, HO, rinv)
         ctx.wsum = wsum
@@ -450,13 +450,93 @@ class GcnFn(torch.autograd.Function):
         bp = _pass_for_parking(ctx, 3)
         call("gcgcn_gcn_bwd", B, N, D, L, H, _p(x), _p(ebar), _p(adj), _p(ctx.n_valid), _p(flat), _p(ctx.snap),
              ctx.p, _p(ctx.out_snap), ctx.out_p, _p(Pn), _p(Y), _p(HO), _p(rinv), _p(ctx.wsum), _p(dout), _p(dX), _p(dEbar), _p(dA),
-             _p(dflat), _p(W1), _p(W2), _p(W3), _p(drow), _p(dXres), _p(dout_m), _p(scratch), ride_p,
+             _p(dflat), _p(W1), _p(W2), _p(W3), _p(drow), _p(dXres), _p(dout_m), _p(scratch), ride_p, None,
              None if bp is None else bp.queue, _stream())
         del ride
         if bp is not None:
             bp.park(ctx.flat_leaf, dflat, (x, ebar, Y, HO, dout, dout_m, W2, W3))
             dflat = None                                # installed as .grad by the pass's end-of-backward callback
         return dX, dEbar, dA, dflat, None, None, None, None, None, dE_next, None, None
+
+
+class MaggcFn(torch.autograd.Function):
+    """One MAGGC hop as ONE autograd node: MultiHeadAttention.forward (glove:133-142) + MultiGraphConvolution.forward
+    (glove:97-120) on its adjacencies, (X[B,N,D], Ebar[B,N,D], flat_mha, flat_gcn[, E_next]) -> out[B,N,D][, mean_j E_next].
+    The attention's launches ride inside the convolution's (gcgcn_mha_hook, include/gcgcn.h): the query projection is one more
+    problem of the convolution's first group launch, the attention core's backward runs as passenger workgroups of its last
+    one -- two launches fewer per step than MhaFn + GcnFn, the same arithmetic (same kernels' bodies, same dropout draws)."""
+
+    @staticmethod
+    def forward(ctx, x, ebar, flat_mha, flat, n_valid, L, H, p_mha, snap_mha, p, snap, e_next, out_p, out_snap):
+        B, N, D = x.shape
+        dev = x.device
+        HD = H * D
+        Q = torch.empty(B, N, D, device=dev)
+        P = torch.empty(B, H, N, N, device=dev)
+        A = torch.empty(B, H, N, N, device=dev) if snap_mha is not None else None
+        out = torch.empty(B, N, D, device=dev)
+        Pn, Y, HO, G = (torch.empty(B, N, HD, device=dev) for _ in range(4))
+        rinv = torch.empty(B, H, N, device=dev)
+        wsum = torch.empty(D, D, device=dev) if (H > 1 and head_sum_in_forward and any(ctx.needs_input_grad[:4])) else None
+        scratch = torch.empty(max(_lib.lib().gcgcn_gcn_scratch(B, N, D, H), 1), device=dev)
+        ebar_next, ride, ride_p = None, None, None
+        if e_next is not None:
+            ebar_next = torch.empty(e_next.shape[0], e_next.shape[1], e_next.shape[3], device=dev)
+            ride, ride_p = _ride(e_next, n_valid, ebar_next, *ebar_next.shape)
+        hook = _lib.MhaHook(flat_mha.data_ptr(), Q.data_ptr(), P.data_ptr(), _p(A), None, _p(snap_mha), float(p_mha))
+        call("gcgcn_gcn_fwd", B, N, D, L, H, _p(x), _p(ebar), None, _p(n_valid), _p(flat), _p(snap), float(p), _p(out_snap), float(out_p),
+             _p(out), _p(Pn), _p(Y), _p(HO), _p(rinv), _p(G), _p(wsum), _p(scratch), ride_p,
+             ctypes.cast(ctypes.pointer(hook), ctypes.c_void_p), _stream())
+        del ride, hook
+        adj = P if A is None else A
+        ctx.save_for_backward(x, ebar, adj, flat, Pn, Y, HO, rinv, flat_mha, Q, P)
+        ctx.wsum = wsum
+        ctx.n_valid, ctx.L, ctx.H, ctx.p, ctx.snap = n_valid, L, H, float(p), snap
+        ctx.p_mha, ctx.snap_mha = float(p_mha), snap_mha
+        ctx.out_p, ctx.out_snap = float(out_p), out_snap
+        ctx.flat_leaf = flat if (flat.is_leaf and not _under_ddp()) else None
+        ctx.next_shape = None if e_next is None else tuple(e_next.shape)
+        return out, ebar_next
+
+    @staticmethod
+    def backward(ctx, dout, debar_next):
+        x, ebar, adj, flat, Pn, Y, HO, rinv, flat_mha, Q, P = ctx.saved_tensors
+        B, N, D = x.shape
+        L, H, dev = ctx.L, ctx.H, x.device
+        HD = H * D
+        dout = dout.contiguous()
+        dXc, dEbar = torch.empty_like(x), torch.empty_like(ebar)        # dXc: the convolution's share of dX
+        dA = torch.empty_like(adj)
+        dflat = torch.empty_like(flat)
+        W1, W2, W3 = (torch.empty(B, N, HD, device=dev) for _ in range(3))
+        drow = torch.empty(B, H, N, device=dev)
+        dXres = torch.empty(B, N, D, device=dev)
+        dout_m = torch.empty(B, N, D, device=dev) if (ctx.n_valid is not None or ctx.out_snap is not None) else None
+        scratch = torch.empty(max(_lib.lib().gcgcn_gcn_scratch(B, N, D, H), 1), device=dev)
+        dQ = torch.empty(B, N, D, device=dev)
+        dE_next, ride, ride_p = None, None, None
+        if ctx.next_shape is not None and ctx.needs_input_grad[11] and debar_next is not None:
+            debar_next = debar_next.contiguous()
+            dE_next = torch.empty(ctx.next_shape, device=dev)
+            ride, ride_p = _ride(debar_next, ctx.n_valid, dE_next, *debar_next.shape)
+        bp = _pass_for_parking(ctx, 3)
+        hook = _lib.MhaHook(None, Q.data_ptr(), P.data_ptr(), None, dQ.data_ptr(), _p(ctx.snap_mha), ctx.p_mha)
+        call("gcgcn_gcn_bwd", B, N, D, L, H, _p(x), _p(ebar), _p(adj), _p(ctx.n_valid), _p(flat), _p(ctx.snap), ctx.p, _p(ctx.out_snap),
+             ctx.out_p, _p(Pn), _p(Y), _p(HO), _p(rinv), _p(ctx.wsum), _p(dout), _p(dXc), _p(dEbar), _p(dA), _p(dflat), _p(W1), _p(W2),
+             _p(W3), _p(drow), _p(dXres), _p(dout_m), _p(scratch), ride_p, ctypes.cast(ctypes.pointer(hook), ctypes.c_void_p),
+             None if bp is None else bp.queue, _stream())
+        del ride, hook
+        if bp is not None:
+            bp.park(ctx.flat_leaf, dflat, (x, ebar, Y, HO, dout, dout_m, W2, W3))
+            dflat = None
+        # the rest of the attention's backward: dX = dQ Wq + dXc, dWq = dQ^T X, dbq (the core already ran, as passengers)
+        dX = torch.empty_like(x)
+        dflat_mha = torch.empty_like(flat_mha)
+        dS = torch.empty(1, device=dev)
+        scratch2 = torch.empty(max(_lib.lib().gcgcn_mha_scratch(B, N, D), 1), device=dev)
+        call("gcgcn_mha_bwd", B, N, D, H, _p(x), _p(flat_mha), _p(ctx.snap_mha), ctx.p_mha, _p(Q), _p(P), _p(dA), _p(dXc), _p(dX),
+             _p(dflat_mha), _p(dS), _p(dQ), _p(scratch2), None, 1, _stream())
+        return dX, dEbar, dflat_mha, dflat, None, None, None, None, None, None, None, dE_next, None, None
 
 
 class GraphConvFn(torch.autograd.Function):
@@ -904,6 +984,29 @@ def gcn_stack(x, ebar, adj, flat, L, H, n_valid=None, p=0.2, training=False, e_n
     out_snap = _snap_for(training, out_dropout, x.device)
     out, ebar_next = GcnFn.apply(x, ebar, adj, _chk(flat, "flat"), nv, L, H, p, snap, e_next,
                                  out_dropout if out_snap is not None else 0.0, out_snap)
+    return out if e_next is None else (out, ebar_next)
+
+
+def maggc_fusable(x: Tensor, H: int) -> bool:
+    """Can MultiHeadAttention + MultiGraphConvolution of one hop run as one fused call pair on this input?  (graph of at most 64
+    entities, narrow heads; gcgcn_maggc_fusable)"""
+    return x.is_cuda and x.dim() == 3 and bool(_lib.lib().gcgcn_maggc_fusable(x.shape[1], x.shape[2], int(H)))
+
+
+def maggc_hop(x, ebar, flat_mha, flat, L, H, n_valid=None, p_mha=0.1, p=0.2, training=False, e_next=None, out_dropout=0.0):
+    """MultiHeadAttention (its own draw first, like the separate modules) + MultiGraphConvolution of one hop, fused (MaggcFn)."""
+    x, ebar = _chk(x, "node_feat", 3), _chk(ebar, "edge_mean", 3)
+    B, N, D = x.shape
+    if ebar.shape != (B, N, D):
+        raise ValueError(f"maggc_hop: shapes x{tuple(x.shape)} ebar{tuple(ebar.shape)}")
+    nv = _nv(n_valid, B, N, x.device)
+    if e_next is not None:
+        e_next = _chk(e_next, "next edge_feat", 4)
+    snap_mha = _snap_for(training, p_mha, x.device)                 # draw order of the separate modules: attention, block, glue
+    snap = _snap_for(training, p, x.device)
+    out_snap = _snap_for(training, out_dropout, x.device)
+    out, ebar_next = MaggcFn.apply(x, ebar, _chk(flat_mha, "flat"), _chk(flat, "flat"), nv, L, H, p_mha, snap_mha, p, snap, e_next,
+                                   out_dropout if out_snap is not None else 0.0, out_snap)
     return out if e_next is None else (out, ebar_next)
 
 

@@ -368,6 +368,29 @@ class MultiGraphConvolution(_GcnBase):
         stacked = torch.stack(list(adj_list), dim=1 if batched else 0)
         return stacked if batched else stacked.unsqueeze(0)
 
+    def forward_with_attention(self, attention: "MultiHeadAttention", node_feat: Tensor, edge_feat: Tensor,
+                               n_valid: Optional[Tensor] = None, ride_edge: Optional[Tensor] = None, out_dropout: float = 0.0) -> Tensor:
+        """``self(node_feat, edge_feat, attention(node_feat, edge_feat))`` -- the whole MAGGC hop (glove:336-337) -- as one fused
+        call where the shape allows it (functional.maggc_fusable): the attention's launches ride inside the convolution's.  Same
+        results as the two separate module calls (same kernels' bodies, same dropout draws); two launches fewer per step."""
+        x, batched = _batched(node_feat, 2)
+        if not (F_.maggc_fusable(x, self.head_num) and attention.head_num == self.head_num and attention.dim == self.dim
+                and isinstance(attention, MultiHeadAttention)):
+            al, xa = attention(node_feat, edge_feat, n_valid=n_valid, return_input_alias=True)
+            return self(xa, edge_feat, al, n_valid=n_valid, ride_edge=ride_edge, out_dropout=out_dropout)
+        ebar = self._edge_mean(edge_feat, n_valid)
+        e_next = None
+        if ride_edge is not None and not isinstance(ride_edge, F_.CompactEdges):
+            e_next, _ = _batched(ride_edge, 3)
+        r = F_.maggc_hop(x, ebar, attention.flat, self.flat, self.layer_num, self.head_num, n_valid, attention.p, self.p,
+                         self.training, e_next=e_next, out_dropout=out_dropout)
+        if e_next is not None:
+            out, ebar_next = r
+            F_.park_edge_mean(ride_edge, n_valid, ebar_next)
+        else:
+            out = r
+        return out if batched else out.squeeze(0)
+
     def forward(self, node_feat: Tensor, edge_feat: Tensor, adj_matrix_list: Union[Tensor, Sequence[Tensor]],
                 n_valid: Optional[Tensor] = None, ride_edge: Optional[Tensor] = None,
                 out_dropout: float = 0.0) -> Tensor:
@@ -593,13 +616,17 @@ class GraphHops(nn.Module):
                     fork_edge_means()
                 new = self.graphcnn[i](xa, e, a, n_valid=n_valid, ride_edge=ride(i), out_dropout=odrop)  # glove:333
             else:
-                al, xa = self.get_adj_matrix[i - 1](x, e, n_valid=n_valid, return_input_alias=True)  # glove:336
                 if i in pre:
                     if self.overlap_edge_mean:
                         torch.cuda.current_stream().wait_stream(self._side_stream(x.device))
                         pre[i].record_stream(torch.cuda.current_stream())
                     F_.park_edge_mean(e, n_valid, pre.pop(i))
-                new = self.graphcnn[i](xa, e, al, n_valid=n_valid, ride_edge=ride(i), out_dropout=odrop)  # glove:337
+                if self.fuse_maggc:      # glove:336-337 as one fused call pair (falls back to the two module calls by itself)
+                    new = self.graphcnn[i].forward_with_attention(self.get_adj_matrix[i - 1], x, e, n_valid=n_valid,
+                                                                  ride_edge=ride(i), out_dropout=odrop)
+                else:
+                    al, xa = self.get_adj_matrix[i - 1](x, e, n_valid=n_valid, return_input_alias=True)  # glove:336
+                    new = self.graphcnn[i](xa, e, al, n_valid=n_valid, ride_edge=ride(i), out_dropout=odrop)  # glove:337
             if fused_out:
                 x = new                                                                      # glove:339 + :341, in the block
             else:
@@ -613,6 +640,8 @@ class GraphHops(nn.Module):
     overlap_edge_mean = False
     # the next hop's edge mean as a passenger of this hop's chain launch (chain.hip): on
     ride_edge_mean = True
+    # a MAGGC hop's attention rides inside its convolution's launches (functional.MaggcFn): on
+    fuse_maggc = True
     # measured: issuing the E2 mean before GATAttention evicts E1 from the Infinity Cache (left there by the previous
     # step's backward): edge_fwd_att 31 -> 52 us, step 0.883 -> 0.892 ms.  Off.
     early_edge_mean = False
@@ -732,9 +761,8 @@ class GraphModelTail(nn.Module):
                     # (A, alias of x): the convolution's d(node_feat) is routed through the attention's own dX kernel
                     a, xa = self.get_weighted_adj_matrix(x, e, mask, n_valid=n_valid, return_input_alias=True)   # glove:332
                     new = self.graphcnn[i](xa, e, a, n_valid=n_valid, out_dropout=odrop)       # glove:333
-                else:
-                    al, xa = self.get_adj_matrix[i - 1](x, e, n_valid=n_valid, return_input_alias=True)         # glove:336
-                    new = self.graphcnn[i](xa, e, al, n_valid=n_valid, out_dropout=odrop)      # glove:337
+                else:                                                                          # glove:336-337, fused where possible
+                    new = self.graphcnn[i].forward_with_attention(self.get_adj_matrix[i - 1], x, e, n_valid=n_valid, out_dropout=odrop)
                 feats.append(x)                                                                # glove:338 (pre-update)
                 if fused_out:
                     x = new                                                                    # glove:339 + :341, inside the block

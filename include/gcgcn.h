@@ -128,7 +128,8 @@ int gcgcn_mha_fwd(int B, int N, int D, int H, const float* X, const int32_t* n_v
  * dflat alive until the flush). */
 int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat, const void* rng_snap, float p,
                   const float* Q, const float* P, const float* dA, const float* dX_in, float* dX, float* dflat,
-                  float* dS, float* dQ, float* scratch, void* defer_queue, void* stream);
+                  float* dS, float* dQ, float* scratch, void* defer_queue, int core_done, void* stream);
+/* core_done = 1: dQ already holds the attention core's gradient (gcgcn_gcn_bwd with a gcgcn_mha_hook computed it) */
 
 /* ---- GraphConvolution (H = 1) / MultiGraphConvolution  GCGCN_glove.py:52-120 --------------- */
 /* flat = [WnX D x H*D | We D x H*D | Wd | Wlin D x H*D | blin D]
@@ -159,10 +160,27 @@ typedef struct gcgcn_edge_ride {
  * pair takes dout = gradient of the DROPPED output.
  * wsum[D,D] (may be NULL; H > 1 only): sum over heads of linear_layer.weight's column blocks, a function of the parameters
  * alone that rides in this call's first launch; gcgcn_gcn_bwd given the same buffer skips the launch that would sum it. */
+/* A whole MAGGC hop in one call pair (glove:336-337: MultiHeadAttention, then MultiGraphConvolution on its adjacencies).
+ * The attention's work rides inside the convolution's launches: forward, the query projection Q = X Wq^T + bq is one more
+ * problem of the first group launch (node / edge terms), the attention core (Q -> P, A) follows it and the chain reads
+ * A (or P when there is no dropout) -- the `A` argument of gcgcn_gcn_fwd is ignored; backward, the attention core
+ * (dA, P, Q -> dQ) runs as passenger workgroups of the convolution's last group launch, and gcgcn_mha_bwd is then called
+ * with core_done = 1 for the rest (dX = dQ Wq + dX_in, dWq, dbq).  Needs a graph of at most 64 entities and head width
+ * D / H <= 32 rounded to the score tile (gcgcn_maggc_fusable); results equal the separate calls bit for bit. */
+typedef struct gcgcn_mha_hook {
+  const float* flat_q;  /* MultiHeadAttention's flat parameters [Wq D*D | bq D] (gcgcn_mha_layout) */
+  float* Q;             /* [B,N,D]   forward: out; backward: in */
+  float* P;             /* [B,H,N,N] forward: out; backward: in */
+  float* A;             /* [B,H,N,N] forward: out (NULL without dropout) */
+  float* dQ;            /* [B,N,D]   backward: out */
+  const void* rng_snap; /* the attention's dropout snapshot (site GCGCN_SALT_MHA), NULL = eval */
+  float p;
+} gcgcn_mha_hook;
+int gcgcn_maggc_fusable(int N, int D, int H);
 int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float* Ebar, const float* A,
                   const int32_t* n_valid, const float* flat, const void* rng_snap, float p, const void* out_rng_snap,
                   float out_p, float* out, float* Pn, float* Y, float* HO, float* rinv, float* G, float* wsum, float* scratch,
-                  const gcgcn_edge_ride* ride, void* stream);
+                  const gcgcn_edge_ride* ride, const gcgcn_mha_hook* mha, void* stream);
 /* backward.  dout[B,N,D] -> dX, dEbar [B,N,D], dA[B,H,N,N], dflat.
  * Workspace: W1, W2, W3 (each [B,N,H*D]), drow[B,H,N], dXres[B,N,D], dout_m[B,N,D] (only used
  * when n_valid != NULL or out_rng_snap != NULL), scratch[gcgcn_gcn_scratch]. */
@@ -171,7 +189,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
                   float out_p, const float* Pn, const float* Y, const float* HO, const float* rinv, const float* wsum,
                   const float* dout, float* dX, float* dEbar,
                   float* dA, float* dflat, float* W1, float* W2, float* W3, float* drow, float* dXres, float* dout_m,
-                  float* scratch, const gcgcn_edge_ride* ride, void* defer_queue, void* stream);
+                  float* scratch, const gcgcn_edge_ride* ride, const gcgcn_mha_hook* mha, void* defer_queue, void* stream);
 /* defer_queue != NULL: the block's weight-gradient products (dWlin, dWnX, dWe, dWd: nobody needs them before the end
  * of backward) are not launched by this call but parked in that queue -- a small host-side object the caller creates
  * per backward pass (no process-wide state: concurrent passes, models and devices never share one).  A later

@@ -284,19 +284,23 @@ class _relu_spy:
 
     def __enter__(self):
         self.Y = []
-        self._orig = F_.GcnFn.forward
+        self._orig = {cls: cls.forward for cls in (F_.GcnFn, F_.MaggcFn)}     # (MaggcFn: a MAGGC hop with its attention fused in)
         spy = self
 
-        def fwd(ctx, x, ebar, adj, flat, n_valid, L, H, *rest):
-            out = spy._orig(ctx, x, ebar, adj, flat, n_valid, L, H, *rest)
-            B, N, D = x.shape
-            spy.Y.append(ctx.to_save[5].view(B, N, H, L, D // L))          # save_for_backward(x, ebar, adj, flat, Pn, Y, ...)
-            return out
-        F_.GcnFn.forward = staticmethod(fwd)
+        def wrap(cls):
+            def fwd(ctx, x, ebar, adj_or_flat_mha, flat, n_valid, L, H, *rest):
+                out = spy._orig[cls](ctx, x, ebar, adj_or_flat_mha, flat, n_valid, L, H, *rest)
+                B, N, D = x.shape
+                spy.Y.append(ctx.to_save[5].view(B, N, H, L, D // L))      # save_for_backward(x, ebar, adj, flat, Pn, Y, ...)
+                return out
+            return staticmethod(fwd)
+        for cls in self._orig:
+            cls.forward = wrap(cls)
         return self
 
     def __exit__(self, *exc):
-        F_.GcnFn.forward = staticmethod(self._orig)
+        for cls, f in self._orig.items():
+            cls.forward = staticmethod(f)
         return False
 
     def relus(self, docs):
@@ -700,6 +704,47 @@ def test_deferred_and_immediate_weight_gradients_agree_at_batch(gpu_device, B, N
     sum(o[2].sum() for o in outs).backward()
     _check_relu_decisions(relus, traces, docs)
     _check_stack_param_grads(hops, sdl)
+
+
+@pytest.mark.parametrize("B,N,D,L,H,ragged,train", [(3, 64, 256, 2, 8, False, True),     # cfg 2's shape: head width 32
+                                                     (4, 42, 128, 2, 8, True, True),      # the reference's model: head width 16
+                                                     (2, 16, 128, 2, 8, False, False),    # cfg 1
+                                                     (2, 64, 128, 2, 2, True, False)])    # head width 64: the widest that rides
+def test_fused_maggc_hop_equals_separate_modules(gpu_device, B, N, D, L, H, ragged, train):
+    """GraphHops.fuse_maggc: MultiHeadAttention + MultiGraphConvolution of a hop as ONE autograd node (functional.MaggcFn: the
+    query projection as a problem of the convolution's first group launch, the attention core's backward as passenger workgroups
+    of its last one) against the two separate module calls -- same dropout draws, outputs and every gradient."""
+    assert F_.maggc_fusable(torch.empty(B, N, D, device=gpu_device), H)
+    sd = O.init_stack_params(D, L, H, seed=3 * N + H)
+    x, e1, e2, adj = O.synth_docs(B, N, D, seed=N + H)
+    n_valid = None
+    if ragged:
+        n_valid = torch.randint(2, N + 1, (B,), generator=torch.Generator().manual_seed(N)).to(torch.int32)
+        n_valid[0] = N
+        x = x * (torch.arange(N)[None, :] < n_valid[:, None]).unsqueeze(-1).float()
+        n_valid = n_valid.to(gpu_device)
+    hops = gcgcn_amd.GraphHops(D, L, H).to(gpu_device)
+    hops.train(train)
+    hops.load_state_dict(sd, strict=True)
+    cot = torch.randn(B, N, D, generator=torch.Generator().manual_seed(6)).to(gpu_device)
+    res, nodes = [], []
+    try:
+        for fuse in (True, False):
+            hops.fuse_maggc = fuse
+            gcgcn_amd.manual_seed(123, gpu_device)
+            xs = [dev_leaf(t, gpu_device) for t in (x, e1, e2)]
+            hops.zero_grad()
+            f = hops(xs[0], [xs[1], xs[2]], n_valid=n_valid)
+            nodes.append(type(f[-1].grad_fn).__name__)
+            torch.autograd.backward(f[-1], cot)
+            res.append([f[1].detach(), f[2].detach(), xs[0].grad, xs[1].grad, xs[2].grad] +
+                       [p.grad.clone() for p in hops.parameters() if p.grad is not None])
+    finally:
+        hops.fuse_maggc = True
+    assert "Maggc" in nodes[0] and "Maggc" not in nodes[1], nodes
+    assert len(res[0]) == len(res[1]) == 9
+    for nm, a, b_ in zip(["x1", "x2", "dX", "dE1", "dE2", "d gat", "d mha", "d caggc", "d maggc"], *res):
+        torch.testing.assert_close(a, b_, rtol=1e-4, atol=1e-5 * max(1.0, b_.abs().max().item()), msg=lambda m: f"{nm}: {m}")
 
 
 def test_edge_mean_handoff_is_used_and_safe(gpu_device):
