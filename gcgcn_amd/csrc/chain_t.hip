@@ -592,11 +592,23 @@ int gcn_chain_t_bwd(const GcnCtx& c, double fl, hipStream_t st, DeferQueue* carr
   const long idle = 256 - (long)c.B * c.H;
   if (carry && carry->n > 0 && idle > 0 && option("chain_carry", 1) != 0) {
     bool ok = true;
-    for (int i = 0; i < carry->n; ++i) ok = ok && carry->p[i].K % BK == 0 && carry->p[i].splits <= 1;
+    int kmax = 0;
+    for (int i = 0; i < carry->n; ++i) {
+      ok = ok && carry->p[i].K % BK == 0 && carry->p[i].splits <= 1;
+      kmax = carry->p[i].K > kmax ? carry->p[i].K : kmax;
+    }
+    // A tile runs its whole K inside one workgroup (~1.1 us per 32-deep k-step, slower with several teams on the unit): it
+    // only pays where the chain itself runs that long.  Chain: MFMAs per wave x 32 cycles x waves per SIMD at ~0.55 of the
+    // matrix pipe (cfg 3: 138 us estimated, 132 measured), plus the riding dE broadcast at ~5 TB/s.
+    const double mfma = c.L * 128.0 + (c.L * (c.L - 1) / 2) * (double)c.gh;
+    double t_chain = mfma * 32.0 * (c.gh / 64) / 2100.0 / 0.55;
+    if (c.ride.kind == 2) t_chain += 4.0 * c.ride.B * c.ride.N * (double)c.ride.N * c.ride.D / 5.0e6;
+    const double t_tile = 1.1 * (kmax / 32.0) * (1.0 + 0.3 * (nteam - 1));
+    ok = ok && t_tile <= 1.25 * t_chain;
     long wgs = idle * option("chain_carry_rounds", 1);
     if (c.ride.kind == 2) wgs = wgs * option("chain_carry_pct", 100) / 100;
     if (ok && wgs > 0) {
-      gemm_take_deferred_pairs(carry, cg, &fl, wgs * nteam);
+      gemm_take_deferred_pairs(carry, cg, &fl, wgs * nteam, true);   // whole small problems first
       for (int i = 0; i < cg.nprob; ++i) npw += (cg.tile_take[i] + nteam - 1) / nteam;
     }
   }

@@ -560,9 +560,17 @@ bool gemm_defer(DeferQueue* q, const GemmArgs& g_in) {
   return true;
 }
 
-static void sort_parked(DeferQueue* q) {  // longest K first (they run the longest: start them first)
+static int tiles_of(const GemmArgs& g);
+// longest K first (they run the longest: start them first); small_first: among equal K the problems with the fewest tiles
+// lead -- a carrier with a tile budget then completes whole small problems instead of a slice of a big one, which keeps the
+// NUMBER of parked problems within what the last carrier's argument block holds (GemmGroup::MAXP)
+static void sort_parked(DeferQueue* q, bool small_first = false) {
+  auto before = [&](const GemmArgs& a, int da, const GemmArgs& b, int db) {
+    if (a.K != b.K) return a.K > b.K;
+    return small_first && tiles_of(a) - da < tiles_of(b) - db;
+  };
   for (int i = 1; i < q->n; ++i)
-    for (int j = i; j > 0 && q->p[j].K > q->p[j - 1].K; --j) {
+    for (int j = i; j > 0 && before(q->p[j], q->done[j], q->p[j - 1], q->done[j - 1]); --j) {
       const GemmArgs t = q->p[j];
       const int d = q->done[j];
       q->p[j] = q->p[j - 1], q->p[j - 1] = t;
@@ -576,11 +584,11 @@ static int tiles_of(const GemmArgs& g) { return (g.M >> 6) * (g.N >> 6) * g.batc
 // Move parked work into gg: up to G::MAXP problems, at most max_tiles tiles in all; a problem is split when the budget
 // ends inside it (its remaining tiles stay parked).  Returns the number of workgroups (one per tile, ranges 8-aligned).
 template <class G>
-static int take_parked(DeferQueue* q, G& gg, double* flops, long max_tiles) {
+static int take_parked(DeferQueue* q, G& gg, double* flops, long max_tiles, bool small_first = false) {
   gg.nprob = 0;
   gg.tile_begin[0] = 0;
   if (!q || q->n == 0 || max_tiles <= 0) return 0;
-  sort_parked(q);
+  sort_parked(q, small_first);
   int wgs = 0, np = 0, keep = 0;
   for (int i = 0; i < q->n; ++i) {
     const GemmArgs& g = q->p[i];
@@ -608,8 +616,8 @@ static int take_parked(DeferQueue* q, G& gg, double* flops, long max_tiles) {
 }
 
 int gemm_take_deferred(DeferQueue* q, GemmGroup& gg, double* flops) { return take_parked(q, gg, flops, 1L << 40); }
-int gemm_take_deferred_pairs(DeferQueue* q, GemmGroup4& gg, double* flops, long max_wgs) {
-  return take_parked(q, gg, flops, max_wgs);
+int gemm_take_deferred_pairs(DeferQueue* q, GemmGroup4& gg, double* flops, long max_wgs, bool small_first) {
+  return take_parked(q, gg, flops, max_wgs, small_first);
 }
 
 // tiles of parked problems, unsplit, as a launch of their own (what a carrying kernel would have run as passengers)

@@ -132,7 +132,7 @@ int gemm_take_deferred(DeferQueue* q, GemmGroup& gg, double* flops);
 // Same for a chain launch: a workgroup of 512 threads runs ONE tile, its two tile teams splitting K (the partial sums meet
 // in LDS).  Takes at most `max_wgs` tiles, longest problems first; a problem may be taken partially -- the rest of its
 // tiles waits for a later carrier.
-int gemm_take_deferred_pairs(DeferQueue* q, GemmGroup4& gg, double* flops, long max_wgs);
+int gemm_take_deferred_pairs(DeferQueue* q, GemmGroup4& gg, double* flops, long max_wgs, bool small_first = false);
 // Launch whatever is still parked as ordinary group launches (end of backward without a carrying launch).
 int gemm_flush_deferred(DeferQueue* q, hipStream_t stream);
 
