@@ -1,0 +1,49 @@
+"""bench.py's contract on a real GPU: one JSON line on stdout with the fields the driver reads, the roofline and CPU-baseline
+objects, the torch.distributed code path over a 1-rank RCCL group (GCGCN_FORCE_DIST=1: communicator, coalesced all-reduce of the
+four flat gradient tensors after every replayed step, barrier, MAX over ranks), and the strong-scaling flag.  Run as child
+processes, like the driver runs it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None, timeout=300):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=e, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"stdout must carry exactly one line, got {len(lines)}"
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract(gpu_device):
+    d = _run(["--config", "c1", "--steps", "6", "--warmup", "2"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["higher_is_better"] is True and d["unit"] == "docs/s"
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["mode"] == "graph"
+    assert abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3                 # docs/s = B / step time
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] in ("hbm", "mfma") and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 2e-3
+    assert "after" in rf["sampled_on"]                                                    # the timed region itself carries no events
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "documents" in cb["sample"]
+
+
+def test_bench_distributed_path_on_one_rank_and_strong_scaling_flag(gpu_device):
+    d = _run(["--config", "c1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--global-batch", "16"], env={"GCGCN_FORCE_DIST": "1"})
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["config"]["global_batch"] == 16 and "B=16/GPU" in d["config"]["workload"]
+    assert d["config"]["grad_allreduce"].startswith("one coalesced collective")
+    assert d["value"] > 0 and "cpu_baseline" not in d
