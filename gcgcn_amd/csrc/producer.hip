@@ -994,9 +994,11 @@ int prod_bwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx
     }
     // d b_ls = sum over real pairs of dE (padding pairs hold a constant 0: their gradient is ignored)
     GC_TRY(colsum(dE, n_valid ? g.wpair : nullptr, dflat + y.bls, BNN, Hd, Hd, 1, 0, 0, 0, 0, ws, st));
-  } else {  // compact consumers hand over dEc itself (rows beyond the live pairs zero); the bias gradient reached the caller
-            // through the consumers (compact.hip), dflat's b_ls slice stays as the caller initialised it
+  } else {  // compact consumers hand over dEc itself (rows beyond the live pairs are zero)
     g.dEc = const_cast<float*>(dEc_in);
+    // d b_ls: the live pairs' share is the column sum of dEc (Ec = CS W_ls^T + b_ls); the share of the pairs that ARE the bias
+    // reached the caller through the consumers (compact.hip) and is added by autograd
+    GC_TRY(colsum(dEc_in, nullptr, dflat + y.bls, up64(cap_pairs), Hd, Hd, 1, 0, 0, 0, 0, ws, st));
   }
   GC_TRY(linear_bwd_w(g.dEc, w.CS, 0, Hd, 2 * Hd, dflat + y.Wls, ws, wse, st, npairs, cap_pairs));
   GC_TRY(linear_bwd_x(g.dEc, 0, Hd, flat + y.Wls, 2 * Hd, g.dCS, 0, ws, wse, st, npairs, cap_pairs));

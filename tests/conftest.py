@@ -56,6 +56,20 @@ def gpu_device():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(autouse=True)
+def _poison_freed_gpu_memory(request):
+    """Before every GPU test: fill blocks of assorted sizes with NaN and hand them back to PyTorch's caching allocator, so that a
+    kernel reading memory nobody wrote sees NaN instead of whatever the previous test left there (fresh pages from the driver
+    are zero, and a stale gradient buffer of the right size can even hold the RIGHT numbers: round 3 had a missing bias-gradient
+    term that only showed once a NaN-filled block was recycled)."""
+    if request.node.get_closest_marker("gpu") is not None and torch.cuda.is_available():
+        dev = torch.device("cuda:0")
+        blocks = [torch.full((n,), float("nan"), device=dev) for n in (1 << 24, 1 << 22, 1 << 20) for _ in range(3)]
+        blocks += [torch.full((n,), float("nan"), device=dev) for n in (64, 1000, 4096, 20000, 65536, 200000, 500000) for _ in range(6)]
+        del blocks
+    yield
+
+
 def tail_oracle(r, sd, di):
     """The oracle's post-encoder chain on document di of the tail fixture: producer -> CAGGC -> producer -> MAGGC -> head,
     with the model's pre-update node_feats list (glove:338)."""
