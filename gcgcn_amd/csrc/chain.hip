@@ -129,13 +129,14 @@ template <bool ALIGNED>
 __global__ __launch_bounds__(64 * CW) void gcn_chain_bwd_kernel(const GcnCtx c, const GemmGroup4 cg) {
   __shared__ __attribute__((aligned(16))) float lds[CHAIN_LDS + XCHG_LDS];
   if (blockIdx.x >= c.B * c.H) {
-    const int pb = blockIdx.x - c.B * c.H, ng = cg.tile_begin[cg.nprob];
-    if (pb < ng) {  // passenger workgroup: one tile of a parked product, K split over the two tile teams
+    const int ng = cg.tile_begin[cg.nprob];
+    int pb;
+    if (spread_pick((int)blockIdx.x - c.B * c.H, c.carry, pb)) {  // passenger workgroup: one tile of a parked product, K split over the two tile teams
       gemm_group_splitk_block(cg, pb, lds, TEAM_LDS, lds + CHAIN_LDS);
       return;
     }
     const EdgeRide& r = c.ride;  // passenger workgroup: one entity row of the riding dE broadcast
-    edge_bcast_row<4, CW>(r.in, r.n_valid, r.out, r.N, r.D, 0, pb - ng);
+    edge_bcast_row<4, CW>(r.in, r.n_valid, r.out, r.N, r.D, 0, pb);
     return;
   }
   const int z = blockIdx.x;
@@ -385,13 +386,14 @@ template <bool FUSE>
 __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c, const GemmGroup4 cg) {
   __shared__ __attribute__((aligned(16))) float lds[S_BWD_LDS];
   if (blockIdx.x >= c.B * c.H) {
-    const int pb = blockIdx.x - c.B * c.H, ng = cg.tile_begin[cg.nprob];
-    if (pb < ng) {  // passenger workgroup: one tile of a parked product, K split over the two tile teams
+    const int ng = cg.tile_begin[cg.nprob];
+    int pb;
+    if (spread_pick((int)blockIdx.x - c.B * c.H, c.carry, pb)) {  // passenger workgroup: one tile of a parked product, K split over the two tile teams
       gemm_group_splitk_block(cg, pb, lds, TEAM_LDS, lds + CHAIN_LDS);
       return;
     }
     const EdgeRide& r = c.ride;  // passenger workgroup: one entity row of the riding dE broadcast
-    edge_bcast_row<4, CW>(r.in, r.n_valid, r.out, r.N, r.D, 0, pb - ng);
+    edge_bcast_row<4, CW>(r.in, r.n_valid, r.out, r.N, r.D, 0, pb);
     return;
   }
   float* const As = lds;
@@ -815,6 +817,8 @@ int gcn_chain_fwd(const GcnCtx& c, hipStream_t st) {
   return check_launch("gcn_chain_fwd");
 }
 
+static int chain_bwd_launch(const GcnCtx& c, const GemmGroup4& cg, dim3 grid, dim3 block, double fl, hipStream_t st);
+
 int gcn_chain_bwd(const GcnCtx& c, hipStream_t st, DeferQueue* carry) {
   GC_REQUIRE(c.ride.kind == 0 || (c.ride.kind == 2 && chain_can_carry(c.ride)), "gcn_chain_bwd: bad passenger");
   double fl = 0;
@@ -844,6 +848,21 @@ int gcn_chain_bwd(const GcnCtx& c, hipStream_t st, DeferQueue* carry) {
     if (rounds > 0 && halves && budget > 0) ng = gemm_take_deferred_pairs(carry, cg, &fl, budget);
   }
   dim3 grid(chain_grid(c, 2) + (unsigned)ng), block(64 * CW);
+  GcnCtx cc = c;
+  cc.carry = chain_carry_spread(c, ng);
+  return chain_bwd_launch(cc, cg, grid, block, fl, st);
+}
+
+Spread chain_carry_spread(const GcnCtx& c, int ng) {
+  // options chain_spread / chain_cohort / chain_spread_min: as carry_spread / carry_cohort / carry_spread_min (edge.hip) for
+  // the tile workgroups of a chain launch in which dE-broadcast rows ride as well; these tile workgroups take a compute
+  // unit each, so a cohort is half the idle units (cfg 5: 7.89 -> 7.78 ms; neutral at cfg 3; cfg 2 has too few tiles)
+  const long rows = c.ride.kind == 2 ? (long)c.ride.B * c.ride.N : 0;
+  const bool on = rows > 0 && ng >= option("chain_spread_min", 256);
+  return make_spread(ng, rows, option("chain_cohort", 128), on ? option("chain_spread", 85) : 0);
+}
+
+static int chain_bwd_launch(const GcnCtx& c, const GemmGroup4& cg, dim3 grid, dim3 block, double fl, hipStream_t st) {
   if (c.dout) {  // the caller asked for the fused output-projection gradient (after chain_bwd_fusable said yes)
     GC_REQUIRE(chain_aligned(c, true) && chain_bwd_fusable(c) && c.dXres && (c.H == 1 || c.Wsum), "gcn_chain_bwd: fused backward not available");
     fl += 2.0 * c.B * c.N * c.D * c.D * (c.H + (c.H > 1 ? 1 : 0));

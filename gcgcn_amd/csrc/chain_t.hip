@@ -288,13 +288,13 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_bwd_kernel(const GcnCtx c,
   static_assert((W / 4 - 1) * 4096 <= 64 * P || W == 4, "dA exchange lives in the dM image");
   static_assert((GH / 64) * T_TEAM_LDS <= t_bwd_lds<GH>(), "parked tiles use the chain kernel's LDS");
   if (blockIdx.x >= c.B * c.H) {
-    const int pb = blockIdx.x - c.B * c.H;
-    if (pb < npw) {  // passenger workgroup: GH / 64 tiles of a parked weight-gradient product
+    int pb;
+    if (spread_pick((int)blockIdx.x - c.B * c.H, c.carry, pb)) {  // passenger workgroup: GH / 64 tiles of a parked weight-gradient product
       t_parked_tiles<GH / 64>(cg, pb, lds);
       return;
     }
     const EdgeRide& r = c.ride;  // passenger workgroup: one entity row of the riding dE broadcast
-    edge_bcast_row<4, W>(r.in, r.n_valid, r.out, r.N, r.D, 0, pb - npw);
+    edge_bcast_row<4, W>(r.in, r.n_valid, r.out, r.N, r.D, 0, pb);
     return;
   }
   float* const ATs = lds;                  // A_h transposed: [k = column of A][row of A]
@@ -613,9 +613,11 @@ int gcn_chain_t_bwd(const GcnCtx& c, double fl, hipStream_t st, DeferQueue* carr
     }
   }
   const dim3 grid((unsigned)(c.B * c.H + npw) + (c.ride.kind == 2 ? (unsigned)(c.ride.B * c.ride.N) : 0u));
+  GcnCtx cc = c;
+  cc.carry = chain_carry_spread(c, npw);
 #define X(gh_, l_)                                         \
   if (c.gh == gh_ && c.L == l_) {                          \
-    launch_bwd<gh_, l_>(c, cg, npw, grid, fl, st);         \
+    launch_bwd<gh_, l_>(cc, cg, npw, grid, fl, st);        \
     return check_launch("gcn_chain_t_bwd");                \
   }
   GC_CHAIN_T_SHAPES(X)

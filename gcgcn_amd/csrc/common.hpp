@@ -110,6 +110,37 @@ inline Drop make_drop(const void* snap, uint64_t salt, float p) {
 // run-time A/B switch `name` (gcgcn_set_option > environment variable GCGCN_<NAME> > dflt); api.hip
 int option(const char* name, int dflt);
 
+// Two kinds of workgroup in one launch: `na` long-running ones (matrix tiles) and short ones (rows of a streaming pass).
+// The tiles go out in COHORTS of `cohort` consecutive workgroups, one cohort every `stride` indices (stride >= cohort;
+// stride == cohort: all tiles first).  A cohort starts together and runs in step, so its tiles find each other's operand
+// panels in L2 (tiles started one by one between rows each fetch their own: measured at cfg 5, 2 208 single tiles spread
+// through the edge pass took 4.0 ms against 2.6 ms tiles-first); between the cohorts every compute unit hosts rows next to
+// its tile.  Returns true and the ordinal among the tiles, or false and the ordinal among the others.
+struct Spread {
+  int na, cohort, stride;
+};
+__host__ inline Spread make_spread(long na, long others, long cohort, long pct) {
+  Spread s;
+  s.na = (int)na, s.cohort = (int)std::max<long>(1, cohort), s.stride = s.cohort;
+  const long nc = (na + s.cohort - 1) / s.cohort;
+  if (nc > 0 && pct > 0) s.stride = (int)std::max<long>(s.cohort, std::min<long>(na + others, pct * (na + others) / 100) / nc);
+  return s;
+}
+__device__ __forceinline__ bool spread_pick(int x, const Spread& s, int& idx) {
+  const int nc = (s.na + s.cohort - 1) / s.cohort;
+  if (nc == 0 || x >= nc * s.stride) {
+    idx = x - s.na;
+    return false;
+  }
+  const int c = x / s.stride, off = x - c * s.stride, size = min(s.cohort, s.na - c * s.cohort);
+  if (off < size) {
+    idx = c * s.cohort + off;
+    return true;
+  }
+  idx = x - (c * s.cohort + size);
+  return false;
+}
+
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- optional per-kernel timing (gcgcn_prof_start / gcgcn_prof_stop) ------------------------------

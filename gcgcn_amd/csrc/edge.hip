@@ -170,22 +170,24 @@ __global__ __launch_bounds__(64 * EW) void edge_bwd_kernel(const float* __restri
 
 // The same pass carrying deferred GEMM problems (gemm.hpp): the first gg.tile_begin[gg.nprob] workgroups each run one
 // 64x64 tile of a parked weight-gradient product over its whole K -- matrix-pipe work under an HBM-bound stream --
-// the rest are the entity rows.  The tiles come first in dispatch order: they run the longest.
+// the rest are the entity rows.  The tiles go out in cohorts spread through the launch (Spread, common.hpp): every compute
+// unit then hosts rows AND a tile for most of the launch, where tiles-first order fills the chip with tiles alone for
+// ntile / 1024 rounds before the first row starts (cfg 5: 1.5 rounds, no overlap at all).
 template <int VEC, bool NTL>
 __global__ __launch_bounds__(64 * EW) void edge_bwd_carry_kernel(const float* __restrict__ E, const float* __restrict__ v,
                                                                  const int* __restrict__ n_valid,
                                                                  const float* __restrict__ dlogit,
                                                                  const float* __restrict__ dEbar, float* __restrict__ dE,
                                                                  float* __restrict__ dvpart, int N, int D, int nt,
-                                                                 const GatTail gt, const GemmGroup gg) {
+                                                                 const Spread sp, const GatTail gt, const GemmGroup gg) {
   // one LDS image for both kinds of workgroup (the rows need N + EW * D floats of it): a fourth workgroup fits per CU
   __shared__ __attribute__((aligned(16))) float tile_lds[lds_floats<1, 1, true, true>()];
   const int ntile = gg.tile_begin[gg.nprob];
-  if ((int)blockIdx.x < ntile) {
-    gemm_group_block(gg, blockIdx.x, tile_lds);
+  int r;
+  if (spread_pick((int)blockIdx.x, sp, r)) {
+    gemm_group_block(gg, r, tile_lds);
     return;
   }
-  const int r = blockIdx.x - ntile;
   const int ngat = gt.P ? gt.B * gt.slices : 0;
   if (r < ngat) {
     const int b = r / gt.slices;
@@ -276,13 +278,17 @@ int edge_bwd(const float* E, const float* v, const int* n_valid, const float* dl
                         : 0;
   if (ntile > 0) {  // parked weight-gradient products ride along
     dim3 grid((unsigned)((long)B * N + ngat + ntile));
+    // options carry_spread: percentage of the launch the tile cohorts are spread over (0: all tiles first, the order until
+    // round 3), carry_cohort: tiles per cohort; launches of fewer than carry_spread_min tiles keep them in front
+    const Spread sp = make_spread(ntile, (long)B * N + ngat, option("carry_cohort", 256),
+                                  ntile >= option("carry_spread_min", 1024) ? option("carry_spread", 90) : 0);
     const double bytes = (dE ? 8.0 : 4.0) * B * N * N * D;
     if (nt_e1())
       GC_LAUNCH_TIMED("edge_bwd", bytes, (edge_bwd_carry_kernel<4, true>), grid, block, 0, st, E, v, n_valid, dlogit, dEbar, dE,
-                      dvpart, N, D, nt_store(), gt, gg);
+                      dvpart, N, D, nt_store(), sp, gt, gg);
     else
       GC_LAUNCH_TIMED("edge_bwd", bytes, (edge_bwd_carry_kernel<4, false>), grid, block, 0, st, E, v, n_valid, dlogit, dEbar, dE,
-                      dvpart, N, D, nt_store(), gt, gg);
+                      dvpart, N, D, nt_store(), sp, gt, gg);
     return check_launch("edge_bwd_carry");
   }
   dim3 grid((unsigned)((long)B * N + ngat));

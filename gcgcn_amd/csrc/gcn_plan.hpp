@@ -24,6 +24,7 @@ struct EdgeRide {
 struct GcnCtx {
   int B, N, D, L, H, gh;
   EdgeRide ride;
+  Spread carry;      // backward launches: how the tile passengers are placed among the riding rows (common.hpp)
   long HD, oWd, wd_head;
   const float* X;
   const float* A;
@@ -145,6 +146,7 @@ int gcn_chain_t_bwd(const GcnCtx& c, double flops, hipStream_t st, DeferQueue* c
 
 // chain.hip
 bool chain_can_carry(const EdgeRide& r);
+Spread chain_carry_spread(const GcnCtx& c, int n_tile_workgroups);
 int gcn_chain_fwd(const GcnCtx& c, hipStream_t st);
 int gcn_chain_bwd(const GcnCtx& c, hipStream_t st, DeferQueue* carry = nullptr);
 bool chain_bwd_fusable(const GcnCtx& c);   // c.dout / c.dXres / c.Wsum may be used instead of c.dYa
