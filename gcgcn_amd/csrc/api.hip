@@ -139,6 +139,13 @@ static bool set_opt(const char* name, int value) {
   return false;
 }
 
+// option big_products: 1 = graphs of more than 64 entities run one batched launch per product instead of the generic chain
+// kernels, 2 = only the blocks whose (document, head) pairs fill the chip by themselves (B H >= 256: nothing rides there)
+static bool big_products(int B, int N, int H) {
+  const int o = option("big_products", 0);
+  return N > 64 && (o == 1 || (o == 2 && (long)B * H >= 256));
+}
+
 // GCGCN_NO_CHAIN=1 (or gcgcn_set_option("chain", 0)) runs every per-(doc, head) product as its own batched
 // launch instead of inside the chain kernels (A/B testing of chain.hip).
 static int g_chain = -1;
@@ -555,7 +562,7 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
     // to fill the chip on its own) with the next hop's edge mean riding THROUGH those launches -- inside a chain launch the
     // 512-thread passengers cannot share a compute unit with a chain workgroup (registers), so at B H >= 256 pairs they only
     // ran after the chains (cfg 5: 1.05 ms per launch for 0.4 ms of products and 0.66 ms of streaming).
-    const bool big = N > 64 && option("big_products", 0) != 0;
+    const bool big = big_products(B, N, H);
     const bool chain = use_chain() && !big;
     GemmArgs plans[2 * 16];
     int np = 0;
@@ -703,7 +710,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
   }
 
   {  // the dependent per-(doc, head) sequence, last sub-layer first
-    const bool big = N > 64 && option("big_products", 0) != 0;   // see gcgcn_gcn_fwd
+    const bool big = big_products(B, N, H);   // see gcgcn_gcn_fwd
     const bool chain = use_chain() && !big;
     bool rideable = er.kind != 0 && !chain && L <= 16;
     double tot = 0;

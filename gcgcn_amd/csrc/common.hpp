@@ -124,6 +124,7 @@ __host__ inline Spread make_spread(long na, long others, long cohort, long pct) 
   s.na = (int)na, s.cohort = (int)std::max<long>(1, cohort), s.stride = s.cohort;
   const long nc = (na + s.cohort - 1) / s.cohort;
   if (nc > 0 && pct > 0) s.stride = (int)std::max<long>(s.cohort, std::min<long>(na + others, pct * (na + others) / 100) / nc);
+  if (s.cohort % 8 == 0) s.stride &= ~7;   // a tile's workgroup index keeps its low bits: xcd_remap (gemm_body.hpp) relies on them
   return s;
 }
 __device__ __forceinline__ bool spread_pick(int x, const Spread& s, int& idx) {

@@ -258,25 +258,32 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // Two register sets: while tile kt is multiplied from LDS, tile kt+1 waits in one set (it was requested a
-  // whole k-step ago) and tile kt+2 is being requested into the other.  Every global load therefore has two
-  // k-steps (~2 x 1024 MFMA cycles per wave) to land before its LDS store needs it.  Tile indices are clamped
-  // to the last tile so that all loads/stores are unconditional (a guarded prefetch makes hipcc keep the
-  // float4 sets in scratch); the clamped extra loads re-read the last tile from L2 and are never consumed.
+  // Two register sets, each requested TWO k-tiles before its LDS store: tile kt+1 waits in one set while tile kt is
+  // multiplied, tile kt+2 is in flight into the other.  A set is requested again right after its store (pinned there with
+  // sched_barrier: left alone, hipcc sinks the requests to the end of the NEXT k-tile, just in front of the stores, and then
+  // reuses their address registers so that the following k-tile starts with s_waitcnt vmcnt(0) -- every load's L2 round
+  // trip exposed once per k-tile and wave, which is what held these kernels at 0.6-0.75 of the matrix pipe).  Tile
+  // indices are clamped to the last tile so that all loads/stores are unconditional (a guarded prefetch makes hipcc keep
+  // the float4 sets in scratch); the clamped extra loads re-read the last tile from L2 and are never consumed.
   float ra0[BM / 32][4], rb0[BN / 32][4], ra1[BM / 32][4], rb1[BN / 32][4];
   const int nk = (kend - kbeg + BK - 1) / BK;
   auto kof = [&](int kt) { return kbeg + min(kt, nk - 1) * BK; };
   ops.template load_a<BM, AKC, ALIGNED>(ra0, g, A, m0, kof(0), kend, t);
   ops.template load_b<BN, BKC, ALIGNED>(rb0, g, B, n0, kof(0), kend, t);
+  ops.template load_a<BM, AKC, ALIGNED>(ra1, g, A, m0, kof(1), kend, t);
+  ops.template load_b<BN, BKC, ALIGNED>(rb1, g, B, n0, kof(1), kend, t);
+  __builtin_amdgcn_sched_barrier(0);
   store_tile<BM, AKC>(ra0, lds, t);
   store_tile<BN, BKC>(rb0, lds + OFFB, t);
-  ops.template load_a<BM, AKC, ALIGNED>(ra0, g, A, m0, kof(1), kend, t);
-  ops.template load_b<BN, BKC, ALIGNED>(rb0, g, B, n0, kof(1), kend, t);
+  __builtin_amdgcn_sched_barrier(0);
+  ops.template load_a<BM, AKC, ALIGNED>(ra0, g, A, m0, kof(2), kend, t);
+  ops.template load_b<BN, BKC, ALIGNED>(rb0, g, B, n0, kof(2), kend, t);
+  __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
 
   // One k-tile from LDS stage `cur`.  The operands of k-step kk+2 are read while the MFMAs of step kk
   // issue (register double buffer), so a wave does not serialise LDS latency with its matrix work.
-  auto compute = [&](const int cur) {
+  auto compute = [&](const int cur, auto&& mid) {
     const float* as = lds + cur * SA + wr * 32 * TM + l31 + lh * LDA;
     const float* bs = lds + OFFB + cur * SB + wc * 32 * TN + l31 + lh * LDB;
     float a[2][TM], b[2][TN];
@@ -305,22 +312,38 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      // half way through the k-tile: the staging work of the OTHER stage (LDS stores of the next tile, requests for the tile
+      // after next) goes out in the shadow of this wave's dependent MFMA chain instead of between the last MFMA and the barrier
+      if (kk == BK / 2 - 2) {
+        mid();
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
-  for (int kt = 0; kt < nk; kt += 2) {
-    ops.template load_a<BM, AKC, ALIGNED>(ra1, g, A, m0, kof(kt + 2), kend, t);
-    ops.template load_b<BN, BKC, ALIGNED>(rb1, g, B, n0, kof(kt + 2), kend, t);
-    compute(0);
-    store_tile<BM, AKC>(ra0, lds + SA, t);
-    store_tile<BN, BKC>(rb0, lds + OFFB + SB, t);
+  auto stage1 = [&](int kt) {                     // tile kt + 1 -> stage 1, then request tile kt + 3 into the freed set
+    store_tile<BM, AKC>(ra1, lds + SA, t);
+    store_tile<BN, BKC>(rb1, lds + OFFB + SB, t);
+    __builtin_amdgcn_sched_barrier(0);
+    ops.template load_a<BM, AKC, ALIGNED>(ra1, g, A, m0, kof(kt + 3), kend, t);
+    ops.template load_b<BN, BKC, ALIGNED>(rb1, g, B, n0, kof(kt + 3), kend, t);
+  };
+  auto stage0 = [&](int kt) {                     // tile kt + 2 -> stage 0, then request tile kt + 4
+    store_tile<BM, AKC>(ra0, lds, t);
+    store_tile<BN, BKC>(rb0, lds + OFFB, t);
+    __builtin_amdgcn_sched_barrier(0);
+    ops.template load_a<BM, AKC, ALIGNED>(ra0, g, A, m0, kof(kt + 4), kend, t);
+    ops.template load_b<BN, BKC, ALIGNED>(rb0, g, B, n0, kof(kt + 4), kend, t);
+  };
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {                  // whole pairs: no branch inside, the two register sets never meet in a phi
+    compute(0, [&] { stage1(kt); });              // tile kt
     __syncthreads();
-    if (kt + 1 >= nk) break;
-    ops.template load_a<BM, AKC, ALIGNED>(ra0, g, A, m0, kof(kt + 3), kend, t);
-    ops.template load_b<BN, BKC, ALIGNED>(rb0, g, B, n0, kof(kt + 3), kend, t);
-    compute(1);
-    store_tile<BM, AKC>(ra1, lds, t);
-    store_tile<BN, BKC>(rb1, lds + OFFB, t);
+    compute(1, [&] { stage0(kt); });              // tile kt + 1
     __syncthreads();
+  }
+  if (kt < nk) {                                  // odd count: the last tile sits in stage 0
+    compute(0, [] {});
+    __syncthreads();                              // (a chain kernel's next product restages these images at once)
   }
 
   // ---- two tile teams of one workgroup split K (role 1 gives, role 2 takes): the partial sums meet in LDS --------
