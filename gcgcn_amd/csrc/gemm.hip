@@ -246,9 +246,9 @@ static int launch(const GemmArgs& g, hipStream_t stream) {
 // (a K = 2048 tile next to K = 256 tiles would otherwise drain alone), and a launch that cannot fill
 // the slots at all is cut until its blocks are ~8 k-steps long.
 static int pick_splits(int K, long work) {
-  static const int thr_pct = [] {  // GCGCN_SPLIT_PCT: tuning knob (percent of the average slot load), default 150
+  static const int thr_pct = [] {  // GCGCN_SPLIT_PCT: tuning knob (percent of the average slot load), default 250
     const char* e = getenv("GCGCN_SPLIT_PCT");
-    return e ? atoi(e) : 150;
+    return e ? atoi(e) : 250;
   }();
   const long iters = cdiv(K, BK);
   long thr = work / 1024 * thr_pct / 100;
