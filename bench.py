@@ -270,11 +270,11 @@ def main():
     SMALL = ("gemm_splitk_reduce", "softmax", "mha_core", "head_sum", "dropout", "gat_fold", "gat_dlogit", "node_score",
              "colsum", "mask_rows", "rowsum", "relu_norm")
 
-    KERNEL_RE = {"gemm_group": r"gc::gemm_group_kernel", "gemm_single": r"gc::gemm_kernel<", "gcn_chain_fwd": r"gc::gcn_chain\w*_fwd_kernel",
+    KERNEL_RE = {"gemm_group": r"gc::gemm_group(_pass)?_kernel", "gemm_single": r"gc::gemm_kernel<", "gcn_chain_fwd": r"gc::gcn_chain\w*_fwd_kernel",
                  "gcn_chain_bwd": r"gc::gcn_chain\w*_bwd_kernel", "edge_bwd": r"gc::edge_bwd(_carry)?_kernel",
                  "edge_fwd_att": r"gc::edge_fwd_kernel<\d+, true", "edge_fwd_mean": r"gc::edge_fwd_kernel<\d+, false",
                  "edge_bcast": r"gc::edge_bcast"}
-    KERNEL_NAMES = {"gemm_group": "gc::gemm_group_kernel", "gemm_single": "gc::gemm_kernel<...>",
+    KERNEL_NAMES = {"gemm_group": "gc::gemm_group_kernel / gc::gemm_group_pass_kernel", "gemm_single": "gc::gemm_kernel<...>",
                     "gcn_chain_fwd": "gc::gcn_chain_fwd_kernel", "gcn_chain_bwd": "gc::gcn_chain_bwd_kernel",
                     "edge_bwd": "gc::edge_bwd_carry_kernel / gc::edge_bwd_kernel", "edge_fwd_att": "gc::edge_fwd_kernel<4,true,*>"}
 
@@ -366,10 +366,8 @@ def main():
                 r["pmc_source"] = os.path.relpath(pmcs[-1], ROOT)
                 tot = sum(v.get("launches", 1) for v in hit)
                 avg = lambda key: (sum(v[key] * v.get("launches", 1) for v in hit if key in v) / tot) if any(key in v for v in hit) else None
-                if bound == "hbm":
-                    r["traffic"] = avg("hbm_bytes_per_launch_corrected")
-                else:
-                    r["traffic_hbm_bytes_per_launch"] = avg("hbm_bytes_per_launch_corrected")
+                r["traffic"] = avg("hbm_bytes_per_launch_corrected")     # HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE)
+                r["traffic_unit"] = "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes"
                 if avg("mfma_busy") is not None:
                     r["mfma_busy"] = round(avg("mfma_busy"), 4)
         return r
