@@ -25,6 +25,7 @@
 #include "edge_body.hpp"
 #include "gcn_plan.hpp"
 #include "gemm_body.hpp"
+#include "gemm_big.hpp"
 #include "mha_body.hpp"
 #include "rowops.hpp"
 
@@ -52,12 +53,22 @@ __global__ __launch_bounds__(256) void gemm_ride_kernel(const GemmArgs g, const 
 }
 
 template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(256, (TM * TN == 4 ? 2 : 1)) void gemm_kernel(const GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float lds[lds_floats<TM, TN, AKC, BKC>()];
   const int gx = gridDim.x, gy = gridDim.y;
   const int nwg = gx * gy * gridDim.z;
   const int b = xcd_remap(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), nwg);
   gemm_body<TM, TN, AKC, BKC, ALIGNED>(g, lds, b % gx, (b / gx) % gy, b / (gx * gy));
+}
+
+// 128 x 128 tiles for big interior problems (gemm_big.hpp); two workgroups per compute unit
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[GB_LDS];
+  const int gx = gridDim.x, gy = gridDim.y;
+  const int nwg = gx * gy * gridDim.z;
+  const int b = xcd_remap(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), nwg);
+  gemm_big_body<AKC, BKC>(g, lds, b % gx, (b / gx) % gy, b / (gx * gy));
 }
 
 // Stage 1 of a riding column sum: workgroup cb sums one slice of rows for 64 columns (4 waves stride the rows,
@@ -241,6 +252,38 @@ static int launch(const GemmArgs& g, hipStream_t stream) {
   return 0;
 }
 
+bool gemm_big_ok(const GemmArgs& g) {
+  return g.vecA && g.vecB && g.M % 128 == 0 && g.N % 128 == 0 && g.ksplit % GB_BK == 0 && g.K % GB_BK == 0 &&
+         (g.splits == 1 || g.N % 4 == 0);
+}
+
+// option big_tiles: fewest 128 x 128 tiles of ONE unsplit problem for which it takes the gemm_big body by itself (0 = never,
+// the default: at cfg 5 the two forward projections that qualify at 2048 run 14 % faster alone and the step does not move,
+// 7.71 vs 7.75 ms -- out of the group launch they no longer share its tail with the other problems).
+// Two workgroups per compute unit = 512 slots: below a few full rounds the coarse tail costs more than the body gains
+// (2048 x 6144 x 768 = 768 tiles: 99 TF/s against 110-117 in 64 x 64 tiles; 8192 x 4096 x 512 = 2048 tiles: 128 against 112).
+static bool gemm_wants_big(const GemmArgs& g) {
+  const long min_tiles = option("big_tiles", 0);
+  return min_tiles > 0 && g.splits == 1 && gemm_big_ok(g) && (long)(g.M / 128) * (g.N / 128) * g.batch1 * g.batch2 >= min_tiles;
+}
+
+static int launch_big(const GemmArgs& g, hipStream_t stream) {
+  dim3 grid(g.N / 128, g.M / 128, g.batch1 * g.batch2 * g.splits), block(256);
+  const double flops = 2.0 * g.M * g.N * g.K * g.batch1 * g.batch2;
+  if (g.a_kc && !g.b_kc) GC_LAUNCH_TIMED(g.tag, flops, (gemm_big_kernel<true, false>), grid, block, 0, stream, g);
+  else if (g.a_kc && g.b_kc) GC_LAUNCH_TIMED(g.tag, flops, (gemm_big_kernel<true, true>), grid, block, 0, stream, g);
+  else if (!g.a_kc && !g.b_kc) GC_LAUNCH_TIMED(g.tag, flops, (gemm_big_kernel<false, false>), grid, block, 0, stream, g);
+  else GC_LAUNCH_TIMED(g.tag, flops, (gemm_big_kernel<false, true>), grid, block, 0, stream, g);
+  if (int e = check_launch("gemm_big")) return e;
+  if (g.splits > 1) {
+    ProfScope ps("gemm_splitk_reduce", stream);
+    dim3 rgrid(cdiv((long)g.M * g.N / 4, 256), g.batch1 * g.batch2);
+    hipLaunchKernelGGL(splitk_reduce_kernel, rgrid, dim3(256), 0, stream, g);
+    return check_launch("gemm_splitk_reduce");
+  }
+  return 0;
+}
+
 // Split factor of a problem inside a launch whose 64x64 tiles carry `work` tile-k-steps in total: no
 // workgroup should run much longer than the average load of one of the 256 x 4 resident slots
 // (a K = 2048 tile next to K = 256 tiles would otherwise drain alone), and a launch that cannot fill
@@ -287,11 +330,17 @@ static int prepare(GemmArgs& g, int tile, int splits, long group_work) {
 int gemm(const GemmArgs& g_in, hipStream_t stream, int tile, int splits) {
   GemmArgs g = g_in;
   if (g.M == 0 || g.N == 0) return 0;
+  const bool any_tile = tile == 0;
   tile = prepare(g, tile, splits, 0);
   if (tile < 0) return 1;
+  if (any_tile && gemm_wants_big(g)) tile = 3;
   const long nb = (long)g.batch1 * g.batch2;
   GC_REQUIRE(nb * g.splits <= 65535, "gemm: batch %ld x splits %d exceeds grid.z", nb, g.splits);
   GC_REQUIRE(cdiv(g.M, 64) <= 65535, "gemm: M %d exceeds grid.y", g.M);
+  if (tile == 3) {  // the 16x16x4 / ds_read_b128 body of gemm_big.hpp (interior problems only)
+    GC_REQUIRE(gemm_big_ok(g), "gemm: tile 3 needs M, N multiples of 128, K (and a split's share) of 32, 16-byte aligned rows");
+    return launch_big(g, stream);
+  }
   const int bm = (tile == 2) ? 128 : 64;
   const bool al = g.vecA && g.vecB && g.M % bm == 0 && g.N % bm == 0 && g.ksplit % BK == 0;
   if (tile == 2) return al ? launch<2, 2, true>(g, stream) : launch<2, 2, false>(g, stream);
@@ -350,7 +399,7 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* 
   // pass 1: fix every problem's split factor and count its workgroups
   GemmArgs prep[64];
   long blocks[64];
-  bool groupable[64];
+  bool groupable[64], big[64];
   long total_blocks = 0;
   int ng = 0;
   for (int oi = 0; oi < n; ++oi) {
@@ -360,7 +409,8 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* 
     if (g.M == 0 || g.N == 0) continue;
     if (prepare(g, 1, 0, work) < 0) return 1;
     const bool al = g.vecA && g.vecB && g.M % 64 == 0 && g.N % 64 == 0 && g.ksplit % BK == 0;
-    groupable[oi] = al && ng < GemmGroup::MAXP;
+    big[oi] = gemm_wants_big(g);   // enough 128 x 128 tiles for several rounds by itself: its own launch (gemm_big.hpp)
+    groupable[oi] = al && !big[oi] && ng < GemmGroup::MAXP;
     if (groupable[oi]) {
       ++ng;
       blocks[oi] = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * g.batch1 * g.batch2 * g.splits;
@@ -381,7 +431,7 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* 
   // pass 2: peeled / ungroupable problems first (own launches), then the group
   for (int oi = 0; oi < n; ++oi) {
     if (groupable[oi] || probs[order[oi]].M == 0 || probs[order[oi]].N == 0) continue;
-    if (int e = gemm(probs[order[oi]], stream, 0, 0)) return e;
+    if (int e = gemm(probs[order[oi]], stream, big[oi] ? 3 : 0, big[oi] ? 1 : 0)) return e;
   }
   for (int oi = 0; oi < n; ++oi) {
     if (!groupable[oi]) continue;

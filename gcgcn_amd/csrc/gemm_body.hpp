@@ -2,6 +2,7 @@
 // the design notes.
 #pragma once
 #include "gemm.hpp"
+#include <type_traits>
 
 namespace gc {
 
@@ -67,6 +68,32 @@ __device__ __forceinline__ void store_tile(const float (&r)[BMN / 32][4], float*
     }
   }
 }
+
+// Interior tiles of plain operands: each thread's load addresses differ from k-tile to k-tile by a wave-uniform step only.
+// Keeping the (BMN / 32) pointers in registers leaves one 64-bit add per load in the k-loop instead of a 64-bit
+// multiply-add chain per load (the 64 x 64 kernel issued more address instructions than MFMAs; on random data it is
+// clock-limited -- 10-28 % faster on all-zero operands -- and every instruction that is not an MFMA costs clock).
+template <int BMN, bool KC>
+struct TilePtr {
+  const float* p[BMN / 32];
+  long kstep;
+  __device__ __forceinline__ void init(const float* __restrict__ src, long ld, int mn0, int t) {
+#pragma unroll
+    for (int q = 0; q < BMN / 32; ++q) {
+      const int f = t + 256 * q;
+      p[q] = KC ? src + (long)(mn0 + (f >> 3)) * ld + ((f & 7) << 2) : src + (long)(f / (BMN / 4)) * ld + mn0 + ((f % (BMN / 4)) << 2);
+    }
+    kstep = KC ? 1 : ld;
+  }
+  __device__ __forceinline__ void load(float (&r)[BMN / 32][4], int k0) const {
+    const long o = (long)k0 * kstep;
+#pragma unroll
+    for (int q = 0; q < BMN / 32; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(p[q] + o);
+      r[q][0] = v.x, r[q][1] = v.y, r[q][2] = v.z, r[q][3] = v.w;
+    }
+  }
+};
 
 // How a tile body obtains its operands.  PlainOperands reads g.A / g.B; other policies (head.hip: operands that are
 // per-row outer products, never materialised) generate the same register tile instead.  Same k-loop for all of them.
@@ -268,16 +295,28 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
   float ra0[BM / 32][4], rb0[BN / 32][4], ra1[BM / 32][4], rb1[BN / 32][4];
   const int nk = (kend - kbeg + BK - 1) / BK;
   auto kof = [&](int kt) { return kbeg + min(kt, nk - 1) * BK; };
-  ops.template load_a<BM, AKC, ALIGNED>(ra0, g, A, m0, kof(0), kend, t);
-  ops.template load_b<BN, BKC, ALIGNED>(rb0, g, B, n0, kof(0), kend, t);
-  ops.template load_a<BM, AKC, ALIGNED>(ra1, g, A, m0, kof(1), kend, t);
-  ops.template load_b<BN, BKC, ALIGNED>(rb1, g, B, n0, kof(1), kend, t);
+  constexpr bool FASTP = ALIGNED && std::is_same<OPS, PlainOperands>::value;
+  TilePtr<BM, AKC> tpa;
+  TilePtr<BN, BKC> tpb;
+  if (FASTP) tpa.init(A, g.lda, m0, t), tpb.init(B, g.ldb, n0, t);
+  auto load_a = [&](float (&r)[BM / 32][4], int k0) {
+    if constexpr (FASTP) tpa.load(r, k0);
+    else ops.template load_a<BM, AKC, ALIGNED>(r, g, A, m0, k0, kend, t);
+  };
+  auto load_b = [&](float (&r)[BN / 32][4], int k0) {
+    if constexpr (FASTP) tpb.load(r, k0);
+    else ops.template load_b<BN, BKC, ALIGNED>(r, g, B, n0, k0, kend, t);
+  };
+  load_a(ra0, kof(0));
+  load_b(rb0, kof(0));
+  load_a(ra1, kof(1));
+  load_b(rb1, kof(1));
   __builtin_amdgcn_sched_barrier(0);
   store_tile<BM, AKC>(ra0, lds, t);
   store_tile<BN, BKC>(rb0, lds + OFFB, t);
   __builtin_amdgcn_sched_barrier(0);
-  ops.template load_a<BM, AKC, ALIGNED>(ra0, g, A, m0, kof(2), kend, t);
-  ops.template load_b<BN, BKC, ALIGNED>(rb0, g, B, n0, kof(2), kend, t);
+  load_a(ra0, kof(2));
+  load_b(rb0, kof(2));
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
 
@@ -324,15 +363,15 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
     store_tile<BM, AKC>(ra1, lds + SA, t);
     store_tile<BN, BKC>(rb1, lds + OFFB + SB, t);
     __builtin_amdgcn_sched_barrier(0);
-    ops.template load_a<BM, AKC, ALIGNED>(ra1, g, A, m0, kof(kt + 3), kend, t);
-    ops.template load_b<BN, BKC, ALIGNED>(rb1, g, B, n0, kof(kt + 3), kend, t);
+    load_a(ra1, kof(kt + 3));
+    load_b(rb1, kof(kt + 3));
   };
   auto stage0 = [&](int kt) {                     // tile kt + 2 -> stage 0, then request tile kt + 4
     store_tile<BM, AKC>(ra0, lds, t);
     store_tile<BN, BKC>(rb0, lds + OFFB, t);
     __builtin_amdgcn_sched_barrier(0);
-    ops.template load_a<BM, AKC, ALIGNED>(ra0, g, A, m0, kof(kt + 4), kend, t);
-    ops.template load_b<BN, BKC, ALIGNED>(rb0, g, B, n0, kof(kt + 4), kend, t);
+    load_a(ra0, kof(kt + 4));
+    load_b(rb0, kof(kt + 4));
   };
   int kt = 0;
   for (; kt + 1 < nk; kt += 2) {                  // whole pairs: no branch inside, the two register sets never meet in a phi

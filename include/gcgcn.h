@@ -330,7 +330,7 @@ int gcgcn_tensorise(int B, int N, int S, int T, int R, int dis_plus, int n_slots
 
 /* ---- raw batched GEMM (exposed for unit tests and benchmarks of the MFMA kernel) ----------- */
 /* C[z] = alpha * opA(A[z]) opB(B[z]);  a_kc: A stored [M][K] else [K][M];  b_kc: B stored [N][K]
- * else [K][N];  z < batch with element strides sA, sB, sC;  tile: 0 auto, 1 = 64x64, 2 = 128x128;
+ * else [K][N];  z < batch with element strides sA, sB, sC;  tile: 0 auto, 1 = 64x64, 2 = 128x128, 3 = 128x128 in 16x16x4 MFMAs with 16-byte LDS fragment reads (interior shapes only: M, N multiples of 128, K of 32, 16-byte aligned rows; refused otherwise);
  * splits: 0 auto, 1 none, n = split K n ways through ws[ws_elems] (>= n*batch*M*N floats);
  * bias[N] optional, relu/accumulate flags. */
 int gcgcn_gemm(int M, int N, int K, const float* A, int64_t lda, int a_kc, const float* B, int64_t ldb, int b_kc,

@@ -106,6 +106,51 @@ def test_gemm_split_k(gpu_device, M, N, K, batch, splits, a_kc, b_kc):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 0), (1, 1), (0, 0), (0, 1)])
+@pytest.mark.parametrize("M,N,K,batch,splits", [(128, 128, 32, 1, 1), (256, 384, 96, 2, 1), (512, 256, 1024, 1, 2), (128, 256, 160, 3, 1),
+                                                 (128, 256, 128, 1, 1)])
+def test_gemm_big_tile_body(gpu_device, M, N, K, batch, splits, a_kc, b_kc):
+    """tile = 3: the 128 x 128 body of gemm_big.hpp (16x16x4 MFMAs, ds_read_b128 fragments, swizzled k-contiguous images) in all
+    four operand layouts, with the fused epilogue (bias + relu, accumulate), split-K slabs, odd and even k-tile counts; A = I
+    with an asymmetric B must come back bitwise (row / column maps of the permuted accumulator blocks)."""
+    g = torch.Generator().manual_seed(M * 5 + N * 3 + K + a_kc * 2 + b_kc)
+    A = torch.randn(batch, M, K, generator=g)
+    B = torch.randn(batch, K, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    Ad = (A if a_kc else A.transpose(1, 2)).contiguous().to(gpu_device)
+    Bd = (B.transpose(1, 2) if b_kc else B).contiguous().to(gpu_device)
+    biasd = bias.to(gpu_device)
+    ws = torch.empty(max(1, splits * batch * M * N), device=gpu_device)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    lda, ldb = (K if a_kc else M), (K if b_kc else N)
+    C = torch.full((batch, M, N), float("nan"), device=gpu_device)
+    _lib.call("gcgcn_gemm", M, N, K, p(Ad), lda, a_kc, p(Bd), ldb, b_kc, p(C), N, batch, M * K, K * N, M * N,
+              0.5, p(biasd), 1, 0, 3, splits, p(ws), ws.numel(), None)
+    ref = torch.relu(0.5 * (A.double() @ B.double()) + bias.double()).float()
+    torch.testing.assert_close(C.cpu(), ref, rtol=1e-4, atol=2e-4 * math.sqrt(max(K, 256) / 256))
+    C2 = C.clone()
+    _lib.call("gcgcn_gemm", M, N, K, p(Ad), lda, a_kc, p(Bd), ldb, b_kc, p(C2), N, batch, M * K, K * N, M * N,
+              1.0, None, 0, 1, 3, splits, p(ws), ws.numel(), None)
+    torch.testing.assert_close(C2.cpu(), ref + (A.double() @ B.double()).float(), rtol=1e-4, atol=3e-4 * math.sqrt(max(K, 256) / 256))
+    if batch == 1 and splits == 1 and M == K:
+        eye = torch.eye(M)
+        Bi = torch.arange(K * N, dtype=torch.float32).view(K, N) % 1021.0
+        Ed = eye.to(gpu_device)                                      # symmetric: the same storage in both layouts
+        Bid = (Bi.t() if b_kc else Bi).contiguous().to(gpu_device)
+        Co = torch.empty(M, N, device=gpu_device)
+        _lib.call("gcgcn_gemm", M, N, K, p(Ed), K, a_kc, p(Bid), ldb, b_kc, p(Co), N, 1, 0, 0, 0, 1.0, None, 0, 0, 3, 1, None, 0, None)
+        assert torch.equal(Co.cpu(), Bi)
+
+
+def test_gemm_big_tile_body_refuses_ragged_shapes(gpu_device):
+    A = torch.randn(100, 64, device=gpu_device)
+    B = torch.randn(64, 128, device=gpu_device)
+    C = torch.empty(100, 128, device=gpu_device)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    with pytest.raises(RuntimeError, match="tile 3"):
+        _lib.call("gcgcn_gemm", 100, 128, 64, p(A), 64, 1, p(B), 128, 0, p(C), 128, 1, 0, 0, 0, 1.0, None, 0, 0, 3, 1, None, 0, None)
+
+
 # ------------------------------------------------------------------------------------------------------
 # blocks against the reference's golden vectors
 # ------------------------------------------------------------------------------------------------------
