@@ -9,6 +9,9 @@ namespace gc {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;
+#ifndef GC_GEMM_PF
+#define GC_GEMM_PF 3   // LDS read-ahead of the tile body in k-steps (A/B: -DGC_GEMM_PF=1 is the round-2 schedule)
+#endif
 
 template <int BMN, bool KC, bool ALIGNED>
 __device__ __forceinline__ void load_tile(float (&r)[BMN / 32][4], const float* __restrict__ src, long ld, int mn0, int k0,
@@ -256,6 +259,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
                                           const int zs, const int t = threadIdx.x, const bool do_store = true,
                                           const OPS& ops = OPS(), float* __restrict__ xchg = nullptr, const int role = 0) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int PF = GC_GEMM_PF;
   constexpr int LDA = AKC ? BM + 1 : BM;
   constexpr int LDB = BKC ? BN + 1 : BN;
   constexpr int SA = BK * LDA, SB = BK * LDB;  // floats per stage
@@ -325,19 +329,24 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
   auto compute = [&](const int cur, auto&& mid) {
     const float* as = lds + cur * SA + wr * 32 * TM + l31 + lh * LDA;
     const float* bs = lds + OFFB + cur * SB + wc * 32 * TN + l31 + lh * LDB;
-    float a[2][TM], b[2][TN];
+    // operand reads run PF k-steps (of 2) ahead of the MFMA that consumes them: one step is 64 cycles of matrix pipe per
+    // accumulator, less than an LDS round trip when the wave has its SIMD to itself (carried tiles, chain products)
+    float a[PF + 1][TM], b[PF + 1][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) a[0][i] = as[i * 32];
+    for (int p = 0; p < PF; ++p) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) b[0][j] = bs[j * 32];
+      for (int i = 0; i < TM; ++i) a[p][i] = as[(2 * p) * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[p][j] = bs[(2 * p) * LDB + j * 32];
+    }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
-      const int c = (kk >> 1) & 1, n = c ^ 1;
-      if (kk + 2 < BK) {
+      const int c = (kk >> 1) % (PF + 1), n = ((kk >> 1) + PF) % (PF + 1);
+      if (kk + 2 * PF < BK) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[n][i] = as[(kk + 2) * LDA + i * 32];
+        for (int i = 0; i < TM; ++i) a[n][i] = as[(kk + 2 * PF) * LDA + i * 32];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[n][j] = bs[(kk + 2) * LDB + j * 32];
+        for (int j = 0; j < TN; ++j) b[n][j] = bs[(kk + 2 * PF) * LDB + j * 32];
       }
       // Pin the read-ahead in front of the MFMAs it overlaps with.  Left to itself the compiler folds the register double
       // buffer away and sinks each pair of operand reads next to its use (read, wait, two MFMAs, read, ...): other waves
