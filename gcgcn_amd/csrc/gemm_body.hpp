@@ -10,7 +10,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;
 #ifndef GC_GEMM_PF
-#define GC_GEMM_PF 3   // LDS read-ahead of the tile body in k-steps (A/B: -DGC_GEMM_PF=1 is the round-2 schedule)
+#define GC_GEMM_PF 2   // LDS read-ahead of the tile body in k-steps (A/B: 1 is the round-2 schedule; 2, 3, 5 measure alike: cfg 3 1.796 / 1.803-1.814 / 1.820 ms)
 #endif
 
 template <int BMN, bool KC, bool ALIGNED>
