@@ -205,3 +205,83 @@ def test_model_trains_with_fused_adam(gpu_device):
     unmoved = sorted(k for k in a if torch.equal(a[k].cpu(), sd[k]) and k not in want_none)
     assert not unmoved, f"parameters with a gradient that did not move: {unmoved}"
     assert still >= len(want_none)                                               # the dead hop and linears_k stay where they were
+
+
+class _StubBert(torch.nn.Module):
+    """Stands in for pytorch_pretrained_bert.BertModel (third-party, absent here): same call contract as bert:275 --
+    ``bert(document, output_all_encoded_layers=False) -> (states[B,T,768], pooled[B,768])``."""
+
+    def __init__(self, vocab):
+        super().__init__()
+        self.emb = torch.nn.Embedding(vocab, 768)
+        self.mix = torch.nn.Linear(768, 768)
+
+    def forward(self, document, output_all_encoded_layers=True):
+        assert output_all_encoded_layers is False
+        h = torch.tanh(self.mix(self.emb(document)))
+        return h, h[:, 0]
+
+
+def _bert_oracle(sd, d, L=4, H=4):
+    """bert:275-346 restated on the CPU with the oracle's blocks (four sub-layers, four heads: bert:247-248)."""
+    from oracle import gcgcn_oracle as O
+    lin = lambda x, k: x @ sd[k + ".weight"].t() + sd[k + ".bias"]
+    states = torch.tanh(lin(sd["bert.emb.weight"][d["document"]], "bert.mix"))               # the stub encoder
+    cls_feat = states[0]
+    doc = torch.cat([states, sd["entity_embed.weight"][d["document_pos"]], sd["ner_emb.weight"][d["document_ner"]]], dim=-1)
+    ctx = torch.tanh(lin(doc, "linear_re"))                                                  # bert:283
+    x = d["node_pos"] @ ctx
+    feats = [x]
+    for i in range(2):
+        e = O.edge_features_folded(ctx, d["sen_matrix"], d["pos_matrix_h"].long(), d["pos_matrix_t"].long(), x, sd["dis_embed.weight"], sd, i)
+        if i == 0:
+            a = O.gat_attention(x, e, O.sub(sd, "get_weighted_adj_matrix"), torch.eq(d["adj_matrix"], 0))
+            new = O.graph_convolution(x, e, a, O.sub(sd, "graphcnn.0"), L)
+        else:
+            al = O.multi_head_attention(x, O.sub(sd, "get_adj_matrix.0"), H)
+            new = O.multi_graph_convolution(x, e, al, O.sub(sd, "graphcnn.1"), L, H)
+        feats.append(x)
+        x = new
+    return O.classifier_head(feats, d["node_type"], d["node_relative_pos"], sd) + lin(cls_feat, "linear_cls")   # bert:345-346
+
+
+def test_bert_variant_wiring_with_a_stub_encoder(gpu_device):
+    """GraphCNN_multihead_bert_gate_cls: constructor (bert:219-271: four sub-layers, four heads, 768 + 20 + 20 inputs to
+    linear_re, linear_cls), the ten-tensor forward and the [CLS] term on every pair, single document and ragged batch, against
+    the oracle's blocks chained as bert:275-346 chains them.  The encoder itself is third-party: a stub with BertModel's call
+    contract stands in (the reference class cannot be imported without pytorch_pretrained_bert)."""
+    g = load_golden(golden_files("model_step")[0])
+    r = g["raw"]
+    vocab = g["meta"]["vocab"]
+    torch.manual_seed(5)
+    model = M.GraphCNN_multihead_bert_gate_cls(Cfg(vocab), bert=_StubBert(vocab)).to(gpu_device).eval()
+    with torch.no_grad():
+        for n, p in model.named_parameters():                         # lift the near-zero default scores off the relu's edge
+            if n.endswith("attention_all.bias"):
+                p.fill_(0.4)
+    keys = list(model.state_dict().keys())
+    assert keys[0].startswith("bert.") and "linear_cls.weight" in keys and "graphcnn.1.graphconv.15.weights_node" in keys
+    assert not any(k.startswith("rnn.") for k in keys)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    docs = [_doc(r, di, gpu_device) for di in range(g["meta"]["docs"])]
+    order = ("document", "document_ner", "document_pos", "adj_matrix", "sen_matrix", "pos_matrix_h", "pos_matrix_t", "node_pos",
+             "node_type", "node_relative_pos")
+    refs = [_bert_oracle(sd, {k: v.cpu() for k, v in d.items()}) for d in docs]
+    with torch.no_grad():
+        for d, ref in zip(docs, refs):
+            out = model(*[d[k] for k in order])
+            torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=2e-4)
+        batch = {k: torch.stack([d[k] for d in docs]) for k in order}
+        out = model(**batch)
+        for di, ref in enumerate(refs):
+            torch.testing.assert_close(out[di].cpu(), ref, rtol=1e-4, atol=2e-4)
+    # one training step through the trainer's loss: every parameter of the path receives a finite gradient
+    model.train()
+    lab = torch.from_numpy(r["doc0.labels"]).to(gpu_device).float()
+    loss = gcgcn_amd.pair_bce_loss(model(*[docs[0][k] for k in order]), lab).sum()
+    loss.backward()
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), n
+    assert model.linear_cls.weight.grad is not None and model.graphcnn[0].flat.grad is not None
+    assert model.graphcnn[1].flat.grad is None         # the last hop's output never reaches the classifier (bert:333 as glove:338)
