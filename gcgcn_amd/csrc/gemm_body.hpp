@@ -9,6 +9,9 @@ namespace gc {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;
+#ifndef GC_GEMM_EG
+#define GC_GEMM_EG 4  // epilogue rows gathered at once by the plain kernels (A/B: 4 is the setting until round 3)
+#endif
 #ifndef GC_GEMM_PF
 #define GC_GEMM_PF 2   // LDS read-ahead of the tile body in k-steps (A/B: 1 is the round-2 schedule; 2, 3, 5 measure alike: cfg 3 1.796 / 1.803-1.814 / 1.820 ms)
 #endif
@@ -254,7 +257,7 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, const Epi& e, const 
   }
 }
 
-template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED, int EG = 4, int MASK = 0, int RT = EPI_ALL, class OPS = PlainOperands>
+template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED, int EG = GC_GEMM_EG, int MASK = 0, int RT = EPI_ALL, class OPS = PlainOperands>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__ lds, const int bx, const int by,
                                           const int zs, const int t = threadIdx.x, const bool do_store = true,
                                           const OPS& ops = OPS(), float* __restrict__ xchg = nullptr, const int role = 0) {
