@@ -113,7 +113,7 @@ static Opt g_opts[] = {{"head_v1", 0, false},   {"head_bil3", 0, false},  {"head
                        {"big_products", 0, false}, {"chain_carry_pct", 0, false}, {"chain_carry_rounds", 0, false},
                        {"maggc_fuse", 0, false}, {"carry_spread", 0, false}, {"chain_spread", 0, false},
                        {"carry_cohort", 0, false}, {"chain_cohort", 0, false}, {"carry_spread_min", 0, false},
-                       {"chain_spread_min", 0, false}, {"big_tiles", 0, false}};
+                       {"chain_spread_min", 0, false}, {"big_tiles", 0, false}, {"att_in_chain", 0, false}};
 int option(const char* name, int dflt) {
   for (Opt& o : g_opts) {
     if (strcmp(o.name, name) != 0) continue;
@@ -549,11 +549,6 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
       g.bias = mha->flat_q + (long)D * D;
     }
     GC_TRY(gemm_group(g3, mha ? 3 : 2, st, hs.X ? &hs : nullptr));
-    if (mha) {  // the attention core: scores in LDS, P / A out (glove:137-140)
-      const Drop adrop = make_drop(mha->rng_snap, GCGCN_SALT_MHA, mha->p);
-      GC_REQUIRE(!adrop.snap || mha->A, "gcn_fwd: attention dropout on but A is NULL");
-      GC_TRY(mha_core_fwd(mha->Q, n_valid, mha->P, mha->A, B, N, D, H, 1.f / sqrtf((float)(D / H)), adrop, st));
-    }
   }
   {  // the dependent per-(doc, head) sequence: normaliser, then per sub-layer dense connection + aggregation
     GcnCtx c = make_ctx(B, N, D, L, H, y, X, A, flat, n_valid, drop);
@@ -564,6 +559,17 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
     // ran after the chains (cfg 5: 1.05 ms per launch for 0.4 ms of products and 0.66 ms of streaming).
     const bool big = big_products(B, N, H);
     const bool chain = use_chain() && !big;
+    if (mha) {  // the attention core: scores in LDS, P / A out (glove:137-140) -- in the chain workgroups' prologue where the
+                // shape's chain kernel can do that (chain.hip), as a launch of its own otherwise
+      const Drop adrop = make_drop(mha->rng_snap, GCGCN_SALT_MHA, mha->p);
+      GC_REQUIRE(!adrop.snap || mha->A, "gcn_fwd: attention dropout on but A is NULL");
+      const float alpha = 1.f / sqrtf((float)(D / H));
+      if (chain && chain_fwd_computes_attention(c))
+        c.mha.Q = mha->Q, c.mha.P = mha->P, c.mha.A = mha->A, c.mha.alpha = alpha, c.mha.drop = adrop, c.mha.dh = D / H,
+        c.mha.kchunk = mha_chunk(D / H);
+      else
+        GC_TRY(mha_core_fwd(mha->Q, n_valid, mha->P, mha->A, B, N, D, H, alpha, adrop, st));
+    }
     GemmArgs plans[2 * 16];
     int np = 0;
     bool rideable = er.kind != 0 && !chain && L <= 16;

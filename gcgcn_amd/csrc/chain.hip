@@ -277,20 +277,25 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_fwd_kernel(const GcnCtx c
   const uint64_t key = dd ? drop_key(c.drop) : 0;
 
   // ---- requests, in the order their data is needed ---------------------------------------------------------------
+  const bool own_att = c.mha.Q != nullptr;   // the attention core runs here (uniform over the launch)
   f32x4 a[2], p[4];   // A_h and Pn_0 = X Wn_0 (written by the launch before): the first product's operands
   float s[8];          // A's rows once more for the normaliser (glove:47-49)
+  if (!own_att) {
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int idx = t + 512 * u;
-    a[u] = *reinterpret_cast<const f32x4*>(Ag + (idx >> 4) * 64 + (idx & 15) * 4);
+    for (int u = 0; u < 2; ++u) {
+      const int idx = t + 512 * u;
+      a[u] = *reinterpret_cast<const f32x4*>(Ag + (idx >> 4) * 64 + (idx & 15) * 4);
+    }
   }
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int idx = t + 512 * u;
     p[u] = *reinterpret_cast<const f32x4*>(Pg + (unsigned)(idx >> 5) * HD + (idx & 31) * 4);
   }
+  if (!own_att) {
 #pragma unroll
-  for (int u = 0; u < 8; ++u) s[u] = Ag[(wave * 8 + u) * 64 + lane];
+    for (int u = 0; u < 8; ++u) s[u] = Ag[(wave * 8 + u) * 64 + lane];
+  }
   float gv[2][16], xv[2][16], pv[16];   // epilogue operands of both sub-layers, Pn_1 = X Wn_1 as the dense product's start
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
@@ -298,10 +303,21 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_fwd_kernel(const GcnCtx c
     gv[0][q] = Gg[row * HD + (unsigned)col];
     xv[0][q] = Xg[row * D + (unsigned)col];
   }
+  if (own_att) {
+    // MultiHeadAttention's core for this (document, head) pair (mha_body.hpp; scratch: the Y image, free until the first
+    // product's epilogue): P / A to global memory for backward, the adjacency the chain uses into As; its rows again from
+    // there for the normaliser
+    mha_core_fwd_body(Ys, z, c.mha.Q, c.n_valid, c.mha.P, c.mha.A, 64, c.D, c.H, c.mha.dh, c.mha.kchunk, c.mha.alpha, c.mha.drop, t,
+                      t < 256, As, S_LA, CW);
+    __syncthreads();
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int idx = t + 512 * u;
-    *reinterpret_cast<f32x4*>(As + (idx >> 4) * S_LA + (idx & 15) * 4) = a[u];
+    for (int u = 0; u < 8; ++u) s[u] = As[(wave * 8 + u) * S_LA + lane];
+  } else {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = t + 512 * u;
+      *reinterpret_cast<f32x4*>(As + (idx >> 4) * S_LA + (idx & 15) * 4) = a[u];
+    }
   }
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -763,6 +779,11 @@ static bool chain_small_ok(const GcnCtx& c, bool bwd) {
 }
 
 static bool chain_aligned(const GcnCtx& c, bool bwd);
+// the dispatch rule of gcn_chain_fwd / _bwd: chain_t.hip takes the shape instead of the default shape's own kernels
+static bool chain_t_takes(const GcnCtx& c, bool bwd) {
+  const bool s_ok = chain_aligned(c, bwd) && chain_small_ok(c, bwd);
+  return chain_t_ok(c, bwd) && !(s_ok && option("chain_t", 1) < 2);
+}
 bool chain_bwd_fusable(const GcnCtx& c) {
   const bool on = option("chain_fuse", 1) != 0;
   auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
@@ -776,6 +797,11 @@ static bool chain_aligned(const GcnCtx& c, bool bwd) {
   if (bwd) ok = ok && (c.dout ? al(c.dout) && al(c.dXres) : al(c.dYa)) && al(c.dM) && al(c.dP) && al(c.dA);
   else ok = ok && al(c.G) && al(c.HO) && al(c.X);
   return ok;
+}
+
+bool chain_fwd_computes_attention(const GcnCtx& c) {   // before c.mha is set: a question about the shape and the options
+  return option("att_in_chain", 1) != 0 && chain_aligned(c, false) && chain_small_ok(c, false) && !chain_t_takes(c, false) &&
+         mha_lds_bytes(c.D / c.H) <= sizeof(float) * 64 * S_LP && (c.D / c.H) % 4 == 0;
 }
 
 // The riding pass uses the 16-byte row bodies and the chain kernel's static LDS for its per-wave column sums.

@@ -7,6 +7,7 @@
 // GraphConvolution.forward glove:70-76 / MultiGraphConvolution.forward glove:102-113.
 #pragma once
 #include "gemm.hpp"
+#include "mha_body.hpp"
 
 namespace gc {
 
@@ -24,6 +25,16 @@ struct EdgeRide {
 struct GcnCtx {
   int B, N, D, L, H, gh;
   EdgeRide ride;
+  // forward with MultiHeadAttention's core computed by the chain workgroup itself (LDS-resident kernels, gcgcn_mha_hook):
+  // A_h = dropout(softmax(alpha Q_h Q_h^T)) goes straight into the adjacency image; P and A are still written for backward
+  struct MhaFwd {
+    const float* Q;   // NULL: the adjacency comes from c.A
+    float* P;
+    float* A;         // NULL without dropout (the chain then uses P)
+    float alpha;
+    Drop drop;
+    int dh, kchunk;
+  } mha;
   Spread carry;      // backward launches: how the tile passengers are placed among the riding rows (common.hpp)
   long HD, oWd, wd_head;
   const float* X;
@@ -145,6 +156,7 @@ int gcn_chain_t_fwd(const GcnCtx& c, dim3 grid, double flops, hipStream_t st);
 int gcn_chain_t_bwd(const GcnCtx& c, double flops, hipStream_t st, DeferQueue* carry);
 
 // chain.hip
+bool chain_fwd_computes_attention(const GcnCtx& c);   // the forward chain kernel of this shape takes c.mha
 bool chain_can_carry(const EdgeRide& r);
 Spread chain_carry_spread(const GcnCtx& c, int n_tile_workgroups);
 int gcn_chain_fwd(const GcnCtx& c, hipStream_t st);

@@ -2,6 +2,7 @@
 // gemm.hip (the pairs of the backward ride as passenger workgroups of a group GEMM launch).  See mha_core.hip for the algorithm.
 #pragma once
 #include "common.hpp"
+#include "rowops.hpp"
 
 namespace gc {
 
@@ -44,6 +45,67 @@ __device__ __forceinline__ void load_q_chunk(float* qs, const float* __restrict_
 // v_mfma_f32_32x32x2_f32 operand / result mapping (wave of 64 lanes): A[row = lane & 31][k = lane >> 5],
 // B[k = lane >> 5][col = lane & 31], D[row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)][col = lane & 31].
 __device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// P = softmax(alpha Q_h Q_h^T) over the valid columns, A = dropout(P) for one (document, head) pair z (glove:136-140).
+// sm: MT * MS + MT * (kchunk + 1) floats of LDS.  The first 256 threads of the workgroup do the work (`t` their index, `on`
+// false for any further waves, which only keep the barriers company): a launch of its own runs it with 256 threads
+// (mha_core.hip), the LDS-resident chain kernels run it in their prologue (chain.hip: a_lds != NULL receives the adjacency the
+// chain will use -- A, or P when there is no dropout -- as an image of row pitch a_pitch, so that the chain reads it from LDS
+// and the attention core needs no launch).  Same arithmetic in both uses, bit for bit.
+__device__ __forceinline__ void mha_core_fwd_body(float* __restrict__ sm, const int z, const float* __restrict__ Q,
+                                                  const int* __restrict__ n_valid, float* __restrict__ P, float* __restrict__ A,
+                                                  int N, int D, int H, int dh, int kchunk, float alpha, const Drop& drop,
+                                                  const int t, const bool on, float* __restrict__ a_lds, const int a_pitch,
+                                                  const int nwaves) {
+  float* S = sm;             // [MT][MS]
+  float* qs = sm + MT * MS;  // [MT][kchunk + 1]
+  const int b = z / H, h = z - b * H;
+  const int lane = t & 63, wave = t >> 6;
+  const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
+  const float* q = Q + (long)b * N * D + (long)h * dh;
+  // scores: wave (wr, wc) owns the 32 x 32 quadrant S[32 wr .., 32 wc ..] = Q[32 wr ..] Q[32 wc ..]^T
+  const int wr = (wave >> 1) & 1, wc = wave & 1, ld = kchunk + 1;
+  f16v acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = 0; k0 < dh; k0 += kchunk) {
+    const int kc = min(kchunk, dh - k0);
+    if (k0) __syncthreads();
+    if (on) load_q_chunk(qs, q, N, D, k0, kc, (kc + 3) & ~3, ld, t);
+    __syncthreads();
+    if (on) {
+      const float* pa = qs + (32 * wr + (lane & 31)) * ld + (lane >> 5);
+      const float* pb = qs + (32 * wc + (lane & 31)) * ld + (lane >> 5);
+      for (int k = 0; k < kc; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k], pb[k], acc, 0, 0, 0);
+    }
+  }
+  if (on) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[(32 * wr + mfma_row(r, lane)) * MS + 32 * wc + (lane & 31)] = acc[r] * alpha;
+  }
+  __syncthreads();
+  // row softmax over the valid columns, dropout; lane = column; every wave of the workgroup takes rows
+  const bool dd = A && drop.snap;
+  const uint64_t key = dd ? drop_key(drop) : 0;
+  for (int i = wave; i < N; i += nwaves) {
+    const long r = (long)z * N + i;
+    float v = 0.f;
+    if (i < nv) {
+      const float s = (lane < nv) ? S[i * MS + lane] : -INFINITY;
+      const float m = wave_max(s);
+      const float e = (lane < nv) ? expf(s - m) : 0.f;
+      v = e / wave_sum(e);
+    }
+    if (lane < N) {
+      P[r * N + lane] = v;
+      if (A) {
+        if (dd) v = (rng_u32(key, (uint64_t)(r * N + lane)) >= drop.thresh) ? v * drop.scale : 0.f;
+        A[r * N + lane] = v;
+      }
+    }
+    if (a_lds && lane < MT) a_lds[i * a_pitch + lane] = (lane < N) ? v : 0.f;
+  }
+}
 
 // dQ_h = alpha (dS + dS^T) Q_h,  dS = P (dP - sum_j dP P),  dP = dropout_bwd(dA).   Padding entries have P == 0.
 // One (document, head) pair z; sm: MT * MS + MT * (kchunk + 1) floats of LDS; 256 threads.  A device function because two
