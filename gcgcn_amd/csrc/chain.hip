@@ -800,8 +800,10 @@ static bool chain_aligned(const GcnCtx& c, bool bwd) {
 }
 
 bool chain_fwd_computes_attention(const GcnCtx& c) {   // before c.mha is set: a question about the shape and the options
-  return option("att_in_chain", 1) != 0 && chain_aligned(c, false) && chain_small_ok(c, false) && !chain_t_takes(c, false) &&
-         mha_lds_bytes(c.D / c.H) <= sizeof(float) * 64 * S_LP && (c.D / c.H) % 4 == 0;
+  if (option("att_in_chain", 1) == 0) return false;
+  if (chain_t_takes(c, false)) return chain_t_fwd_att_ok(c);
+  return chain_aligned(c, false) && chain_small_ok(c, false) && mha_lds_bytes(c.D / c.H) <= sizeof(float) * 64 * S_LP &&
+         (c.D / c.H) % 4 == 0;
 }
 
 // The riding pass uses the 16-byte row bodies and the chain kernel's static LDS for its per-wave column sums.

@@ -92,7 +92,25 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_fwd_kernel(const GcnCtx c)
   const uint64_t key = dd ? drop_key(c.drop) : 0;
 
   // ---- the adjacency image (zero beyond N) and the row normaliser (glove:47-49) -----------------------------------------
-  {
+  if (c.mha.Q) {
+    // MultiHeadAttention's core for this pair runs here (mha_body.hpp; scratch: the Y image and the weight stages, all free
+    // until the first sub-layer): P / A to global memory for backward, the adjacency the chain uses straight into As
+    for (int idx = t; idx < (64 - N) * 16; idx += NT) {
+      const int row = N + (idx >> 4), c4 = (idx & 15) * 4;
+      *reinterpret_cast<t4*>(As + row * T_LA + c4) = t4{0.f, 0.f, 0.f, 0.f};
+    }
+    mha_core_fwd_body(Ys, z, c.mha.Q, c.n_valid, c.mha.P, c.mha.A, N, c.D, c.H, c.mha.dh, c.mha.kchunk, c.mha.alpha, c.mha.drop, t,
+                      t < 256, As, T_LA, W);
+    __syncthreads();
+    for (int i = w; i < 64; i += W) {
+      const float s = wave_sum(i < N ? As[i * T_LA + lane] : 0.f);
+      if (lane == 0) {
+        const float ri = i < N ? 1.f / (s + (s == 0.f ? 1.f : 0.f)) : 0.f;
+        Rs[i] = ri;
+        if (i < N) c.rinv[(long)z * N + i] = ri;
+      }
+    }
+  } else {
     const bool v4 = (N & 3) == 0;
     for (int idx = t; idx < 64 * 16; idx += NT) {
       const int row = idx >> 4, c4 = (idx & 15) * 4;
@@ -568,6 +586,14 @@ bool chain_t_ok(const GcnCtx& c, bool bwd) {
     ok = ok && c.ride.D % 4 == 0 && al(c.ride.in) && al(c.ride.out) && (bwd || (long)chain_t_waves(c.gh) * c.ride.D <= lds_fwd);
   }
   return ok;
+}
+
+// the forward kernel can run the attention core in its prologue: the core's scratch (score tile + one Q chunk) fits the Y image
+// and the weight stages
+bool chain_t_fwd_att_ok(const GcnCtx& c) {
+  const int dh = c.D / c.H;
+  const long room = 64L * (c.gh + 4) + 2L * (c.L - 1) * 16 * (c.gh + 4);
+  return c.N <= 64 && dh % 4 == 0 && (long)(mha_lds_bytes(dh) / sizeof(float)) <= room;
 }
 
 int gcn_chain_t_fwd(const GcnCtx& c, dim3 grid, double fl, hipStream_t st) {

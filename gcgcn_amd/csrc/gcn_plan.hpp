@@ -152,6 +152,7 @@ int gemm_ride(const GemmArgs& g, const EdgeRide& r, int row0, int nrows, hipStre
 
 // chain_t.hip: LDS-resident chain kernels for N <= 64 and the instantiated (gh, L) pairs
 bool chain_t_ok(const GcnCtx& c, bool bwd);
+bool chain_t_fwd_att_ok(const GcnCtx& c);
 int gcn_chain_t_fwd(const GcnCtx& c, dim3 grid, double flops, hipStream_t st);
 int gcn_chain_t_bwd(const GcnCtx& c, double flops, hipStream_t st, DeferQueue* carry);
 
