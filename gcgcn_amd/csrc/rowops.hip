@@ -588,7 +588,8 @@ int colsum3(const float* X0, const float* w0, float* o0, long R0, int C0, long l
   float* os[3] = {o0, o1, o2};
   const long Rs[3] = {R0, R1, R2}, lds[3] = {ld0, ld1, ld2};
   const int Cs[3] = {C0, C1, C2};
-  const int ns = stage2 ? 64 : 32;  // fewer slices when every consumer workgroup re-sums them
+  // fewer slices when every consumer workgroup re-sums them (option fold_slices, at most 64: the callers' scratch is sized for that)
+  const int ns = stage2 ? 64 : std::min(64, std::max(1, option("fold_slices", 32)));
   long off = 0;
   int maxC = 1;
   for (int i = 0; i < 3; ++i) {
