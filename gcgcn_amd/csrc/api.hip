@@ -825,7 +825,12 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
       g.batch2 = H;
       park();
     }
-    GC_TRY(gemm_group(gs, n, st, col_pending ? &cr : nullptr, nullptr, mha ? &mp : nullptr));   // + the attention core's backward
+    // + the attention core's backward: as passenger workgroups of this launch where a (document, head) pair's scratch fits
+    // the tile kernel's LDS (head width <= 32), as a launch of its own in front of it otherwise
+    const bool mha_rides = mha && gemm_group_can_carry_mha(D / H);
+    if (mha && !mha_rides)
+      GC_TRY(mha_core_bwd(mp.Q, mp.P, mp.dA, mp.dQ, B, N, D, H, mp.alpha, mp.drop, st));
+    GC_TRY(gemm_group(gs, n, st, col_pending ? &cr : nullptr, nullptr, mha_rides ? &mp : nullptr));
   }
   return 0;
 }
@@ -833,7 +838,9 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
 int gcgcn_maggc_fusable(int N, int D, int H) {
   if (N < 1 || N > 64 || H < 1 || D % H != 0) return 0;
   const int dh = D / H;
-  return use_mha_core() && dh % 4 == 0 && D % 4 == 0 && gemm_group_can_carry_mha(dh) && option("maggc_fuse", 1) != 0 ? 1 : 0;
+  // (the backward core rides in a group launch only for head widths up to 32; wider heads keep that launch, and still gain
+  // the query projection inside the forward group launch and the forward core inside the chain workgroups)
+  return use_mha_core() && dh % 4 == 0 && D % 4 == 0 && option("maggc_fuse", 1) != 0 ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------

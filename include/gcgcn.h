@@ -166,7 +166,9 @@ typedef struct gcgcn_edge_ride {
  * A (or P when there is no dropout) -- the `A` argument of gcgcn_gcn_fwd is ignored; backward, the attention core
  * (dA, P, Q -> dQ) runs as passenger workgroups of the convolution's last group launch, and gcgcn_mha_bwd is then called
  * with core_done = 1 for the rest (dX = dQ Wq + dX_in, dWq, dbq).  Needs a graph of at most 64 entities and head width
- * D / H <= 32 rounded to the score tile (gcgcn_maggc_fusable); results equal the separate calls bit for bit. */
+ * D / H a multiple of 4 (gcgcn_maggc_fusable); results equal the separate calls bit for bit.  Where a chain kernel that
+ * keeps its pair in LDS serves the shape, the forward core runs in that kernel's prologue instead of a launch; heads wider
+ * than 32 features keep the backward core as a launch of its own (its scratch does not fit a tile workgroup's LDS). */
 typedef struct gcgcn_mha_hook {
   const float* flat_q;  /* MultiHeadAttention's flat parameters [Wq D*D | bq D] (gcgcn_mha_layout) */
   float* Q;             /* [B,N,D]   forward: out; backward: in */

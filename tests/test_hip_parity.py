@@ -754,7 +754,11 @@ def test_deferred_and_immediate_weight_gradients_agree_at_batch(gpu_device, B, N
 @pytest.mark.parametrize("B,N,D,L,H,ragged,train", [(3, 64, 256, 2, 8, False, True),     # cfg 2's shape: head width 32
                                                      (4, 42, 128, 2, 8, True, True),      # the reference's model: head width 16
                                                      (2, 16, 128, 2, 8, False, False),    # cfg 1
-                                                     (2, 64, 128, 2, 2, True, False)])    # head width 64: the widest that rides
+                                                     (2, 64, 128, 2, 2, True, False),     # head width 64: backward core as its own launch
+                                                     (2, 64, 768, 4, 4, False, True),     # cfg 3: head width 192, the core's Q in two chunks
+                                                     (2, 40, 384, 2, 2, True, True),      # head width 192, ragged, N < 64
+                                                     (2, 32, 64, 1, 4, False, False)])    # one sub-layer: no room for the core in the chain
+                                                                                          # kernel's LDS -> the core keeps its launch
 def test_fused_maggc_hop_equals_separate_modules(gpu_device, B, N, D, L, H, ragged, train):
     """GraphHops.fuse_maggc: MultiHeadAttention + MultiGraphConvolution of a hop as ONE autograd node (functional.MaggcFn: the
     query projection as a problem of the convolution's first group launch, the attention core's backward as passenger workgroups
