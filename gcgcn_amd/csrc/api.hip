@@ -827,7 +827,8 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
     }
     // + the attention core's backward: as passenger workgroups of this launch where a (document, head) pair's scratch fits
     // the tile kernel's LDS (head width <= 32), as a launch of its own in front of it otherwise
-    const bool mha_rides = mha && gemm_group_can_carry_mha(D / H);
+    const bool mha_rides = mha && gemm_group_can_carry_mha(D / H) && option("mha_ride", 1) != 0;
+    if (mha_rides) mp.kchunk = gemm_group_mha_chunk(D / H);
     if (mha && !mha_rides)
       GC_TRY(mha_core_bwd(mp.Q, mp.P, mp.dA, mp.dQ, B, N, D, H, mp.alpha, mp.drop, st));
     GC_TRY(gemm_group(gs, n, st, col_pending ? &cr : nullptr, nullptr, mha_rides ? &mp : nullptr));

@@ -373,7 +373,16 @@ int gemm_ride(const GemmArgs& g_in, const EdgeRide& r, int row0, int nrows, hipS
 
 // Independent problems in one launch (plus at most one reduce launch).  Problems that are not interior
 // 64x64 shapes fall back to their own launches.
-bool gemm_group_can_carry_mha(int dh) { return mha_lds_bytes(dh) <= sizeof(float) * lds_floats<1, 1, true, true>(); }
+// The head-feature chunk with which a (document, head) pair's scratch (score tile + one chunk of Q_h) fits a tile workgroup's
+// LDS: the stand-alone kernel's chunk, or 0.  (A shorter chunk would fit wide heads too -- 32 features at a time for cfg 3's 192
+// -- but such passengers use two of their four waves and run six dependent passes: the group launch grew by 45 us to save a
+// 23 us launch.  Measured, not kept.)
+int gemm_group_mha_chunk(int dh) {
+  const size_t room = sizeof(float) * lds_floats<1, 1, true, true>();
+  const int c = mha_chunk(dh);
+  return sizeof(float) * (MT * MS + MT * (c + 1)) <= room ? c : 0;
+}
+bool gemm_group_can_carry_mha(int dh) { return gemm_group_mha_chunk(dh) > 0; }
 
 int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* col, bool* col_later, const MhaPass* mha) {
   if (col_later) *col_later = false;

@@ -110,6 +110,7 @@ using GemmGroup4 = GemmGroupT<4>;  // passengers of a chain launch (kernel argum
 int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* col = nullptr, bool* col_later = nullptr,
                const MhaPass* mha = nullptr);
 bool gemm_group_can_carry_mha(int dh);   // the pairs' LDS images fit the group kernel's
+int gemm_group_mha_chunk(int dh);        // ... with this head-feature chunk (MhaPass::kchunk)
 
 // ---- deferred problems ------------------------------------------------------------------------------------------
 // Weight-gradient products are needed by nobody before the end of backward, while later launches of the same
