@@ -128,6 +128,10 @@ __host__ inline Spread make_spread(long na, long others, long cohort, long pct) 
   return s;
 }
 __device__ __forceinline__ bool spread_pick(int x, const Spread& s, int& idx) {
+  if (s.na <= 0 || s.cohort <= 0) {  // nothing long-running aboard (also a zero-initialised Spread)
+    idx = x;
+    return false;
+  }
   const int nc = (s.na + s.cohort - 1) / s.cohort;
   if (nc == 0 || x >= nc * s.stride) {
     idx = x - s.na;
