@@ -42,6 +42,7 @@ SIGNATURES = {
     "gcgcn_version": (I, []),
     "gcgcn_last_error": (c_char_p, []),
     "gcgcn_set_option": (I, [c_char_p, I]),
+    "gcgcn_debug_spread": (I, [L, L, L, L, P, P]),
     "gcgcn_prof_start": (I, [c_char_p, I]),
     "gcgcn_prof_enable": (I, [I]),
     "gcgcn_prof_stop": (I, [P, P, P]),

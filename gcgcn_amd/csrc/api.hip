@@ -925,6 +925,20 @@ int gcgcn_graphconv_bwd(int B, int N, int Din, int De, int Dout, const float* X,
   return 0;
 }
 
+// The placement of tile passengers among the rows of a carrying launch (Spread, common.hpp), evaluated on the host with the
+// very function the kernels call: for every workgroup index x of a launch of n_tiles + n_others workgroups, kind[x] = 1 and
+// ordinal[x] = the tile's number, or kind[x] = 0 and ordinal[x] = the row's number.  Exposed for tests (no GPU needed).
+int gcgcn_debug_spread(int64_t n_tiles, int64_t n_others, int64_t cohort, int64_t pct, int32_t* kind, int32_t* ordinal) {
+  GC_REQUIRE(n_tiles >= 0 && n_others >= 0 && kind && ordinal, "debug_spread: bad arguments");
+  const Spread sp = make_spread(n_tiles, n_others, cohort, pct);
+  for (long x = 0; x < n_tiles + n_others; ++x) {
+    int idx = -1;
+    kind[x] = spread_pick((int)x, sp, idx) ? 1 : 0;
+    ordinal[x] = idx;
+  }
+  return 0;
+}
+
 int gcgcn_gemm(int M, int N, int K, const float* A, int64_t lda, int a_kc, const float* B, int64_t ldb, int b_kc,
                float* C, int64_t ldc, int batch, int64_t sA, int64_t sB, int64_t sC, float alpha, const float* bias,
                int relu, int accumulate, int tile, int splits, float* ws, int64_t ws_elems, void* stream) {

@@ -127,7 +127,7 @@ __host__ inline Spread make_spread(long na, long others, long cohort, long pct) 
   if (s.cohort % 8 == 0) s.stride &= ~7;   // a tile's workgroup index keeps its low bits: xcd_remap (gemm_body.hpp) relies on them
   return s;
 }
-__device__ __forceinline__ bool spread_pick(int x, const Spread& s, int& idx) {
+__host__ __device__ __forceinline__ bool spread_pick(int x, const Spread& s, int& idx) {
   if (s.na <= 0 || s.cohort <= 0) {  // nothing long-running aboard (also a zero-initialised Spread)
     idx = x;
     return false;
@@ -137,7 +137,7 @@ __device__ __forceinline__ bool spread_pick(int x, const Spread& s, int& idx) {
     idx = x - s.na;
     return false;
   }
-  const int c = x / s.stride, off = x - c * s.stride, size = min(s.cohort, s.na - c * s.cohort);
+  const int c = x / s.stride, off = x - c * s.stride, left = s.na - c * s.cohort, size = left < s.cohort ? left : s.cohort;
   if (off < size) {
     idx = c * s.cohort + off;
     return true;

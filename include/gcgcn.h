@@ -330,6 +330,10 @@ int gcgcn_tensorise(int B, int N, int S, int T, int R, int dis_plus, int n_slots
                     const int32_t* mention_node, const int32_t* n_valid, const int32_t* first_start, float* adj, uint8_t* sen, uint8_t* pos_h,
                     uint8_t* pos_t, float* node_pos, int64_t* node_relative_pos, float* label_matrix, void* stream);
 
+/* ---- test hook: how tile passengers are placed among the rows of a carrying launch (csrc/common.hpp Spread) ---------
+ * kind[x] / ordinal[x] for every workgroup index x < n_tiles + n_others: 1 / tile number or 0 / row number.  Host-only. */
+int gcgcn_debug_spread(int64_t n_tiles, int64_t n_others, int64_t cohort, int64_t pct, int32_t* kind, int32_t* ordinal);
+
 /* ---- raw batched GEMM (exposed for unit tests and benchmarks of the MFMA kernel) ----------- */
 /* C[z] = alpha * opA(A[z]) opB(B[z]);  a_kc: A stored [M][K] else [K][M];  b_kc: B stored [N][K]
  * else [K][N];  z < batch with element strides sA, sB, sC;  tile: 0 auto, 1 = 64x64, 2 = 128x128, 3 = 128x128 in 16x16x4 MFMAs with 16-byte LDS fragment reads (interior shapes only: M, N multiples of 128, K of 32, 16-byte aligned rows; refused otherwise);

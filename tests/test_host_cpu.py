@@ -233,3 +233,32 @@ def test_tail_keys_as_root_and_as_submodule():
         torch.testing.assert_close(v, root_sd[k] + 1.0)
     with pytest.raises(RuntimeError, match="Unexpected key"):
         tail.load_state_dict({**root_sd, "word_attention.7.attention_sent.weight": torch.zeros(1)}, strict=True)
+
+
+@pytest.mark.parametrize("tiles,others,cohort,pct", [(0, 100, 256, 90), (357, 2176, 256, 0), (1536, 8192, 256, 90), (2208, 8192, 256, 90),
+                                                      (2376, 2112, 256, 90), (336, 8192, 128, 85), (224, 2048, 128, 85), (7, 3, 8, 100),
+                                                      (1000, 10, 256, 90), (513, 4099, 64, 50), (1, 1, 1, 100)])
+def test_tile_passengers_and_rows_each_get_exactly_one_workgroup(tiles, others, cohort, pct):
+    """csrc/common.hpp Spread / spread_pick (the function the carrying kernels call, here run on the host): over the
+    tiles + others workgroup indices of a launch every tile ordinal and every row ordinal appears exactly once, tiles come in
+    cohorts of `cohort` consecutive workgroups, a cohort's first workgroup index is a multiple of 8 whenever the cohort is
+    (xcd_remap's low bits), and pct = 0 puts every tile in front."""
+    import ctypes
+    import numpy as np
+    from gcgcn_amd import _lib
+    n = tiles + others
+    kind = np.full(n, -1, np.int32)
+    ordinal = np.full(n, -1, np.int32)
+    _lib.call("gcgcn_debug_spread", tiles, others, cohort, pct, kind.ctypes.data_as(ctypes.c_void_p), ordinal.ctypes.data_as(ctypes.c_void_p))
+    t_idx = np.flatnonzero(kind == 1)
+    r_idx = np.flatnonzero(kind == 0)
+    assert len(t_idx) == tiles and len(r_idx) == others
+    assert np.array_equal(ordinal[t_idx], np.arange(tiles))            # in order, each exactly once
+    assert np.array_equal(ordinal[r_idx], np.arange(others))
+    if pct == 0 and tiles:
+        assert t_idx[-1] == tiles - 1
+    for c0 in range(0, tiles, cohort):                                 # a cohort is one run of consecutive workgroups
+        run = t_idx[c0:c0 + cohort]
+        assert np.array_equal(run, np.arange(run[0], run[0] + len(run)))
+        if cohort % 8 == 0:
+            assert run[0] % 8 == 0
