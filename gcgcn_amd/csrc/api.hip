@@ -113,7 +113,7 @@ static Opt g_opts[] = {{"head_v1", 0, false},   {"head_bil3", 0, false},  {"head
                        {"big_products", 0, false}, {"chain_carry_pct", 0, false}, {"chain_carry_rounds", 0, false},
                        {"maggc_fuse", 0, false}, {"carry_spread", 0, false}, {"chain_spread", 0, false},
                        {"carry_cohort", 0, false}, {"chain_cohort", 0, false}, {"carry_spread_min", 0, false},
-                       {"chain_spread_min", 0, false}, {"big_tiles", 0, false}, {"att_in_chain", 0, false}, {"fold_slices", 0, false}};
+                       {"chain_spread_min", 0, false}, {"big_tiles", 0, false}, {"att_in_chain", 0, false}, {"fold_slices", 0, false}, {"head_sum_fold", 0, false}};
 int option(const char* name, int dflt) {
   for (Opt& o : g_opts) {
     if (strcmp(o.name, name) != 0) continue;
@@ -691,9 +691,15 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
     cr.X = dout, cr.out = dflat + y.oblin, cr.part = scratch + wse, cr.R = M, cr.ld = D, cr.C = D, col_pending = true;
     if (2 * B <= COL_RIDE_SLICES) c.colpart = cr.part, cr.ready_slices = 2 * B;  // stage 1 inside the chain (it holds dout_b in LDS)
   } else {
+    // Small blocks (launch-bound: cfg 1, the reference's own model) fold the head-sum / dropout-backward kernel into this
+    // launch: dY = dropout_bwd(dHO) is the product's own epilogue (the forward mask: same site, same element offsets), and the
+    // residual gradient dXres = sum_h dHO_h = dout (sum_h Wlin_h) is one more small product (one head: dHO itself, written
+    // beside dY).  At cfg 3 the extra product and the second store cost more than the launch they save (round 2: +8 us).
+    const bool fold_hs = option("head_sum_fold", 1) != 0 && scratch && (H == 1 || wsum_fwd) && (long)M * HD <= (1L << 21) &&
+                         (((uintptr_t)dXres) & 15) == 0;
     {  // one launch: dHO = dout Wlin  and  dWlin = dout^T HO
-      GemmArgs gs[2];
-      gs[0].ws = gs[1].ws = scratch, gs[0].ws_elems = gs[1].ws_elems = wse;
+      GemmArgs gs[3];
+      gs[0].ws = gs[1].ws = gs[2].ws = scratch, gs[0].ws_elems = gs[1].ws_elems = gs[2].ws_elems = wse;
       gs[0].A = dout, gs[0].lda = D, gs[0].a_kc = 1;
       gs[0].B = flat + y.oWlin, gs[0].ldb = HD, gs[0].b_kc = 0;
       gs[0].C = dYa, gs[0].ldc = HD;
@@ -702,17 +708,41 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
       gs[1].B = HO, gs[1].ldb = HD, gs[1].b_kc = 0;
       gs[1].C = dflat + y.oWlin, gs[1].ldc = HD;
       gs[1].M = D, gs[1].N = (int)HD, gs[1].K = (int)M;
+      int np1 = 2;
+      if (fold_hs) {
+        if (H == 1) {
+          gs[0].C = dXres, gs[0].ldc = D;                                  // HD == D: the head sum is dHO
+          gs[0].C2 = dYa, gs[0].ldc2 = HD, gs[0].drop = drop, gs[0].drop_base = 0;
+        } else {
+          if (drop.snap) gs[0].C2 = dYa, gs[0].ldc2 = HD, gs[0].drop = drop, gs[0].drop_base = 0;   // over C: the dropped value stays
+          gs[2].A = dout, gs[2].lda = D, gs[2].a_kc = 1;
+          gs[2].B = wsum_fwd, gs[2].ldb = D, gs[2].b_kc = 0;
+          gs[2].C = dXres, gs[2].ldc = D;
+          gs[2].M = (int)M, gs[2].N = D, gs[2].K = D;
+          np1 = 3;
+        }
+      }
       // a weight gradient nobody needs before the end of backward: parked for a later launch with idle matrix pipes
-      const int ng1 = gemm_defer(dq, gs[1]) ? 1 : 2;
+      const bool parked = gemm_defer(dq, gs[1]);
+      GemmArgs run[3];
+      int nr = 0;
+      run[nr++] = gs[0];
+      if (!parked) run[nr++] = gs[1];
+      if (np1 == 3) run[nr++] = gs[2];
       if (scratch) {  // dblin = column sums of dout ride in this launch (stage 1) and in its reduce or the next kernel (stage 2)
         cr.X = dout, cr.out = dflat + y.oblin, cr.part = scratch + wse, cr.R = M, cr.ld = D, cr.C = D;
-        GC_TRY(gemm_group(gs, ng1, st, &cr, &col_later));
+        GC_TRY(gemm_group(run, nr, st, &cr, &col_later));
       } else {
-        GC_TRY(gemm_group(gs, ng1, st));
+        GC_TRY(gemm_group(run, nr, st));
         GC_TRY(colsum(dout, nullptr, dflat + y.oblin, M, D, D, 1, 0, 0, 0, 0, scratch, st));
       }
     }
-    GC_TRY(head_sum_drop_bwd(dYa, dYa, dXres, M, H, D, drop, st, col_later ? &cr : nullptr));  // residual + dropout backward
+    if (fold_hs) {  // stage 2 of the bias column sums (if this launch had no reduce pass to do it) joins the launch after the chain
+      col_pending = col_later;
+      if (col_later) cr.ready_slices = COL_RIDE_SLICES;
+    } else {
+      GC_TRY(head_sum_drop_bwd(dYa, dYa, dXres, M, H, D, drop, st, col_later ? &cr : nullptr));  // residual + dropout backward
+    }
   }
 
   {  // the dependent per-(doc, head) sequence, last sub-layer first
