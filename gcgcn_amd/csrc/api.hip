@@ -695,7 +695,8 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
     // launch: dY = dropout_bwd(dHO) is the product's own epilogue (the forward mask: same site, same element offsets), and the
     // residual gradient dXres = sum_h dHO_h = dout (sum_h Wlin_h) is one more small product (one head: dHO itself, written
     // beside dY).  At cfg 3 the extra product and the second store cost more than the launch they save (round 2: +8 us).
-    const bool fold_hs = option("head_sum_fold", 1) != 0 && scratch && (H == 1 || wsum_fwd) && (long)M * HD <= (1L << 21) &&
+    const long fold_opt = option("head_sum_fold", 1);   // 0 off, 1 up to 2 M elements of dHO, n > 1: up to n M elements (A/B)
+    const bool fold_hs = fold_opt != 0 && scratch && (H == 1 || wsum_fwd) && (long)M * HD <= (fold_opt > 1 ? fold_opt : 2) * (1L << 20) &&
                          (((uintptr_t)dXres) & 15) == 0;
     {  // one launch: dHO = dout Wlin  and  dWlin = dout^T HO
       GemmArgs gs[3];
