@@ -299,13 +299,14 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(const ColJobs j, floa
 // flat parameter layout: [W_h Dh*D | b_h Dh | W_t Dh*D | b_t Dh | W_r Dh*D | b_r Dh | wt 3Dh | wtb 1]
 // uvc output: [u D | v D | c 1]
 // ---------------------------------------------------------------------------------------------
-constexpr int FW = 16;  // waves per workgroup of the fold: all D/FW rows of a wave are in flight at once
+constexpr int FW = 16;  // waves per workgroup of the fold
+constexpr int FC = 16;  // columns per workgroup: 64 row lanes per column share the Dh rows (Dh / 64 dependent steps, not Dh / 16)
 // rng_state != NULL: workgroup 0 also advances the dropout generator (what rng_next_kernel does), so the first kernel
 // of a hop loop serves every dropout site of the step without a launch of its own.
 __global__ __launch_bounds__(64 * FW) void gat_fold_fwd_kernel(const float* __restrict__ flat, float* __restrict__ uvc, int D,
                                                                int Dh, uint64_t* rng_state, uint64_t* rng_snaps,
                                                                int rng_count) {
-  __shared__ float red[2][FW][64];
+  __shared__ float red[2][64][FC + 1];
   __shared__ float redc[FW];
   if (rng_state && blockIdx.x == 0 && threadIdx.x < 64) {  // one wave: reads of the state precede its update in program order
     const uint64_t seed = rng_state[0], ctr = rng_state[1];
@@ -321,24 +322,28 @@ __global__ __launch_bounds__(64 * FW) void gat_fold_fwd_kernel(const float* __re
   const float* br = Wr + DD;
   const float* wt = br + Dh;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int k = blockIdx.x * 64 + lane;
+  const int cl = threadIdx.x & (FC - 1), rl = threadIdx.x >> 4;   // column of this workgroup's FC, row lane 0..63
+  const int k = blockIdx.x * FC + cl;
   float au = 0.f, av = 0.f;
   if (k < D) {
-#pragma unroll 8
-    for (int d = wave; d < Dh; d += FW) {
+#pragma unroll 4
+    for (int d = rl; d < Dh; d += 64) {
       au = fmaf(Wh[(long)d * D + k], wt[d], au);
       au = fmaf(Wt[(long)d * D + k], wt[Dh + d], au);
       av = fmaf(Wr[(long)d * D + k], wt[2 * Dh + d], av);
     }
   }
-  red[0][wave][lane] = au;
-  red[1][wave][lane] = av;
+  red[0][rl][cl] = au;
+  red[1][rl][cl] = av;
   __syncthreads();
-  if (wave < 2 && k < D) {
-    float sacc = 0.f;
-#pragma unroll
-    for (int w = 0; w < FW; ++w) sacc += red[wave][w][lane];
-    uvc[wave * D + k] = sacc;
+  if (threadIdx.x < 2 * FC) {   // thread (which, column): the 64 row-lane partials in order
+    const int which = threadIdx.x / FC, c = threadIdx.x - which * FC, kk = blockIdx.x * FC + c;
+    if (kk < D) {
+      float sacc = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 64; ++r) sacc += red[which][r][c];
+      uvc[which * D + kk] = sacc;
+    }
   }
   if (blockIdx.x == 0) {
     float c = 0.f;
@@ -614,7 +619,7 @@ int colsum3(const float* X0, const float* w0, float* o0, long R0, int C0, long l
 int gat_fold_fwd(const float* flat, float* uvc, int D, int Dh, hipStream_t st, void* rng_state, void* rng_snaps,
                  int rng_count) {
   ProfScope ps("gat_fold_fwd", st);
-  hipLaunchKernelGGL(gat_fold_fwd_kernel, dim3(cdiv(D, 64)), dim3(64 * FW), 0, st, flat, uvc, D, Dh, (uint64_t*)rng_state,
+  hipLaunchKernelGGL(gat_fold_fwd_kernel, dim3(cdiv(D, FC)), dim3(64 * FW), 0, st, flat, uvc, D, Dh, (uint64_t*)rng_state,
                      (uint64_t*)rng_snaps, rng_count);
   return check_launch("gat_fold_fwd");
 }
