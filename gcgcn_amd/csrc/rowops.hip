@@ -362,23 +362,25 @@ __global__ __launch_bounds__(64 * FW) void gat_fold_fwd_kernel(const float* __re
 // backward of the fold; one wave per parameter row d.  duvc = [du D | dv D | dc 1].
 // ns > 0: duvc is not final yet -- `part` holds ns row-slice partials of du, dv, dc (colsum3 stage 1, jobs at
 // part_off[0..2]); every workgroup first sums them in slice order into LDS, which replaces the second-stage launch.
-__global__ __launch_bounds__(64 * RW) void gat_fold_bwd_kernel(const float* __restrict__ flat, const float* __restrict__ duvc,
+// (16 waves per workgroup: the slice sums are 32 (2 D + 1) dependent-latency loads per workgroup whatever its size -- at four
+// waves a thread ran 24 batches of eight loads one after the other, 20 us at cfg 3; at sixteen, with sixteen loads in flight, four)
+__global__ __launch_bounds__(64 * FW) void gat_fold_bwd_kernel(const float* __restrict__ flat, const float* __restrict__ duvc,
                                                                float* __restrict__ dflat, int D, int Dh,
                                                                const float* __restrict__ part, long off_dv, long off_dc,
                                                                int ns) {
   extern __shared__ float sduvc[];  // [2 D + 1] when ns > 0
   if (ns > 0) {
-    for (int k = threadIdx.x; k < 2 * D + 1; k += 64 * RW) {
+    for (int k = threadIdx.x; k < 2 * D + 1; k += 64 * FW) {
       const float* src = k < D ? part + k : (k < 2 * D ? part + off_dv + (k - D) : part + off_dc);
       const int C = k < 2 * D ? D : 1;
       float a = 0.f;
       int q = 0;
-      for (; q + 8 <= ns; q += 8) {  // eight independent loads in flight, summed in slice order
-        float v[8];
+      for (; q + 16 <= ns; q += 16) {  // sixteen independent loads in flight, summed in slice order
+        float v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = src[(long)(q + u) * C];
+        for (int u = 0; u < 16; ++u) v[u] = src[(long)(q + u) * C];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a += v[u];
+        for (int u = 0; u < 16; ++u) a += v[u];
       }
       for (; q < ns; ++q) a += src[(long)q * C];
       sduvc[k] = a;
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(64 * RW) void gat_fold_bwd_kernel(const float* __re
     __syncthreads();
     duvc = sduvc;
   }
-  const int d = blockIdx.x * RW + (threadIdx.x >> 6);
+  const int d = blockIdx.x * FW + (threadIdx.x >> 6);
   if (d >= Dh) return;
   const int lane = threadIdx.x & 63;
   const long DD = (long)Dh * D;
@@ -627,7 +629,7 @@ int gat_fold_bwd(const float* flat, const float* duvc, float* dflat, int D, int 
                  const long* part_off, int ns) {
   ProfScope ps("gat_fold_bwd", st);
   const size_t lds = ns > 0 ? sizeof(float) * (2 * (size_t)D + 1) : 0;
-  hipLaunchKernelGGL(gat_fold_bwd_kernel, dim3(cdiv(Dh, RW)), dim3(64 * RW), lds, st, flat, duvc, dflat, D, Dh, part,
+  hipLaunchKernelGGL(gat_fold_bwd_kernel, dim3(cdiv(Dh, FW)), dim3(64 * FW), lds, st, flat, duvc, dflat, D, Dh, part,
                      ns > 0 ? part_off[1] : 0L, ns > 0 ? part_off[2] : 0L, ns);
   return check_launch("gat_fold_bwd");
 }
