@@ -193,10 +193,7 @@ __device__ __forceinline__ void reduce4(const GemmArgs& g, int z, long idx4) {
     return;
   }
   const Epi e = make_epi(g, z1, z2);
-  epi_store(g, e, row, col, acc.x);
-  epi_store(g, e, row, col + 1, acc.y);
-  epi_store(g, e, row, col + 2, acc.z);
-  epi_store(g, e, row, col + 3, acc.w);
+  epi_store4(g, e, row, col, acc);
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const GemmGroup gg) {

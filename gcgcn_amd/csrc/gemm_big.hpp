@@ -183,8 +183,12 @@ __device__ __forceinline__ void gemm_big_body(const GemmArgs& g, float* __restri
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const int row = row_of(a, v);
+      if (BKC) {
 #pragma unroll
-      for (int b = 0; b < 4; ++b) epi_store(g, e, row, col_of(b), acc[a][b][v]);
+        for (int b = 0; b < 4; ++b) epi_store(g, e, row, col_of(b), acc[a][b][v]);
+      } else {  // four consecutive columns per lane
+        epi_store4(g, e, row, col_of(0), make_float4(acc[a][0][v], acc[a][1][v], acc[a][2][v], acc[a][3][v]));
+      }
     }
 }
 

@@ -178,6 +178,62 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, const Epi& e, int r
   }
 }
 
+// Four consecutive columns of one row through the fused epilogue with 16-byte accesses: the same arithmetic in the same
+// order as four epi_store calls (so either path gives the same bits), one round trip per operand instead of four.  The
+// caller guarantees col % 4 == 0; operands that are not 16-byte addressable send the element back to the scalar path.
+__device__ __forceinline__ void epi_store4(const GemmArgs& g, const Epi& e, int row, int col, const float4 a4) {
+  auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+  const bool vec = ((g.ldc | (e.add ? g.ldadd : 0) | (e.C2 ? g.ldc2 : 0) | (e.add2 ? g.ldadd2 : 0)) & 3) == 0 && al(e.C) &&
+                   (!e.add || al(e.add)) && (!g.bias || al(g.bias)) && (!e.C2 || al(e.C2)) && (!e.add2 || al(e.add2));
+  if (!vec) {
+    epi_store(g, e, row, col, a4.x);
+    epi_store(g, e, row, col + 1, a4.y);
+    epi_store(g, e, row, col + 2, a4.z);
+    epi_store(g, e, row, col + 3, a4.w);
+    return;
+  }
+  const long oc = (long)row * g.ldc + col;
+  // requests first
+  float4 addv = make_float4(0.f, 0.f, 0.f, 0.f), biasv = addv, cv = addv, a2v = addv;
+  if (e.add) addv = *reinterpret_cast<const float4*>(e.add + (long)row * g.ldadd + col);
+  if (g.bias) biasv = *reinterpret_cast<const float4*>(g.bias + col);
+  if (g.accumulate) cv = *reinterpret_cast<const float4*>(e.C + oc);
+  const long o2 = (long)row * g.ldc2 + col;
+  if (e.C2 && e.add2) a2v = *reinterpret_cast<const float4*>(e.add2 + (long)row * g.ldadd2 + col);
+  const float ra = e.rowadd ? e.rowadd[row] : 0.f;
+  const float rs = e.rowscale ? e.rowscale[row] : 1.f;
+  bool pad = false;
+  if (g.n_valid) {
+    const int doc = e.z1 * g.nv_zdoc + row / g.nv_rows;
+    pad = (row % g.nv_rows) >= g.n_valid[doc];
+  }
+  float v[4] = {g.alpha * a4.x, g.alpha * a4.y, g.alpha * a4.z, g.alpha * a4.w};
+  const float ad[4] = {addv.x, addv.y, addv.z, addv.w}, bi[4] = {biasv.x, biasv.y, biasv.z, biasv.w};
+  const float cc[4] = {cv.x, cv.y, cv.z, cv.w}, a2[4] = {a2v.x, a2v.y, a2v.z, a2v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (e.add) v[i] += ad[i];
+    if (g.bias) v[i] += bi[i];
+    if (e.rowadd) v[i] += ra;
+    if (e.rowscale) v[i] *= rs;
+    if (g.relu) v[i] = fmaxf(v[i], 0.f);
+    if (g.accumulate) v[i] += cc[i];
+    if (pad) v[i] = 0.f;
+  }
+  *reinterpret_cast<float4*>(e.C + oc) = make_float4(v[0], v[1], v[2], v[3]);
+  if (e.C2) {
+    float w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      w[i] = v[i];
+      if (e.dodrop) w[i] = (rng_u32(e.key, (uint64_t)(g.drop_base + e.offC2 + o2 + i)) >= g.drop.thresh) ? w[i] * g.drop.scale : 0.f;
+      if (e.add2) w[i] += a2[i];
+      if (pad) w[i] = 0.f;
+    }
+    *reinterpret_cast<float4*>(e.C2 + o2) = make_float4(w[0], w[1], w[2], w[3]);
+  }
+}
+
 // The 16 outputs a lane holds of one 32x32 accumulator tile (one column, 16 rows), EG rows at a
 // time: the epilogue operands of a row group are gathered first (all loads in flight together), then
 // the arithmetic, then the stores.  Element by element the loads are 16 dependent round trips.
