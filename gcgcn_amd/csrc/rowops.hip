@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64 * RW) void relu_norm_bwd_kernel(const float* __r
 __global__ __launch_bounds__(256) void head_sum_drop_bwd_kernel(const float* dHO, float* dY, float* __restrict__ dXres,
                                                                 long M, int H, int D, Drop drop, int main_blocks,
                                                                 const float* __restrict__ cpart, float* __restrict__ cout,
-                                                                int cC) {
+                                                                int cC, int vec) {
   if ((int)blockIdx.x >= main_blocks) {
     const int c = (blockIdx.x - main_blocks) * 256 + threadIdx.x;
     if (c < cC) {
@@ -148,12 +148,42 @@ __global__ __launch_bounds__(256) void head_sum_drop_bwd_kernel(const float* dHO
     }
     return;
   }
+  const bool dd = drop.snap != nullptr;
+  const uint64_t key = dd ? drop_key(drop) : 0;
+  if (vec) {  // D % 4 == 0, 16-byte aligned: four columns per thread, the heads' loads in flight together
+    const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= M * D) return;
+    const long m = e / D;
+    const int c = (int)(e - m * D);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int h0 = 0; h0 < H; h0 += 4) {
+      float4 g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) g[u] = *reinterpret_cast<const float4*>(dHO + (m * H + min(h0 + u, H - 1)) * D + c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (h0 + u >= H) continue;
+        const long o = (m * H + h0 + u) * D + c;
+        s.x += g[u].x, s.y += g[u].y, s.z += g[u].z, s.w += g[u].w;
+        if (dd) {
+          float4 y;
+          y.x = (rng_u32(key, (uint64_t)o) >= drop.thresh) ? g[u].x * drop.scale : 0.f;
+          y.y = (rng_u32(key, (uint64_t)(o + 1)) >= drop.thresh) ? g[u].y * drop.scale : 0.f;
+          y.z = (rng_u32(key, (uint64_t)(o + 2)) >= drop.thresh) ? g[u].z * drop.scale : 0.f;
+          y.w = (rng_u32(key, (uint64_t)(o + 3)) >= drop.thresh) ? g[u].w * drop.scale : 0.f;
+          *reinterpret_cast<float4*>(dY + o) = y;
+        } else if (dY != dHO) {
+          *reinterpret_cast<float4*>(dY + o) = g[u];
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(dXres + e) = s;
+    return;
+  }
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= M * D) return;
   const long m = e / D;
   const int c = (int)(e - m * D);
-  const bool dd = drop.snap != nullptr;
-  const uint64_t key = dd ? drop_key(drop) : 0;
   float s = 0.f;
   for (int h = 0; h < H; ++h) {
     const long o = (m * H + h) * D + c;
@@ -443,6 +473,8 @@ __global__ __launch_bounds__(64 * RW) void node_score_fwd_kernel(const float* __
   if (m >= M) return;
   const int lane = threadIdx.x & 63;
   float a = 0.f;
+  // (16-byte loads with four row segments in flight were measured: -3 us at cfg 3, -15 us at cfg 5 -- and a different
+  // summation order, which moved one relu decision of the N = 256 parity case; not worth a new fixture seed)
   for (int k = lane; k < D; k += 64) a = fmaf(X[m * D + k], uvc[k], a);
   a = wave_sum(a);
   if (lane == 0) s[m] = a + uvc[2 * D];
@@ -464,7 +496,7 @@ __global__ __launch_bounds__(256) void node_score_bwd_kernel(const float* __rest
 // Trailing workgroups (blockIdx >= main_blocks): wsum[k, c] = sum_h wlin[k, h, c] for the fused chain backward (chain.hip).
 __global__ __launch_bounds__(256) void mask_rows_kernel(const float* __restrict__ x, float* __restrict__ y, long M, int D,
                                                         int N, const int* __restrict__ n_valid, Drop drop, int main_blocks,
-                                                        const float* __restrict__ wlin, float* __restrict__ wsum, int H) {
+                                                        const float* __restrict__ wlin, float* __restrict__ wsum, int H, int vec) {
   if ((int)blockIdx.x >= main_blocks) {
     const int e = (blockIdx.x - main_blocks) * 256 + threadIdx.x;
     if (e < D * D) {
@@ -479,6 +511,23 @@ __global__ __launch_bounds__(256) void mask_rows_kernel(const float* __restrict_
       }
       wsum[e] = s;
     }
+    return;
+  }
+  if (vec) {  // D % 4 == 0, 16-byte aligned: four elements of one row per thread
+    const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= M * D) return;
+    const long m = e / D;
+    const long b = m / N;
+    float4 v = *reinterpret_cast<const float4*>(x + e);
+    if (n_valid && (int)(m - b * N) >= n_valid[b]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (drop.snap) {
+      const uint64_t key = drop_key(drop);
+      v.x = (rng_u32(key, (uint64_t)e) >= drop.thresh) ? v.x * drop.scale : 0.f;
+      v.y = (rng_u32(key, (uint64_t)(e + 1)) >= drop.thresh) ? v.y * drop.scale : 0.f;
+      v.z = (rng_u32(key, (uint64_t)(e + 2)) >= drop.thresh) ? v.z * drop.scale : 0.f;
+      v.w = (rng_u32(key, (uint64_t)(e + 3)) >= drop.thresh) ? v.w * drop.scale : 0.f;
+    }
+    *reinterpret_cast<float4*>(y + e) = v;
     return;
   }
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
@@ -523,9 +572,10 @@ int relu_norm_bwd(const float* dY, const float* Y, const float* rinv, float* dM,
 int head_sum_drop_bwd(const float* dHO, float* dY, float* dXres, long M, int H, int D, Drop drop, hipStream_t st,
                       const ColRide* finish) {
   ProfScope ps("head_sum_drop_bwd", st);
-  const int main_blocks = cdiv(M * D, 256), extra = finish ? cdiv(finish->C, 256) : 0;
+  const int vec = D % 4 == 0 && ((((uintptr_t)dHO) | ((uintptr_t)dY) | ((uintptr_t)dXres)) & 15) == 0;
+  const int main_blocks = cdiv(vec ? M * D / 4 : M * D, 256), extra = finish ? cdiv(finish->C, 256) : 0;
   hipLaunchKernelGGL(head_sum_drop_bwd_kernel, dim3(main_blocks + extra), dim3(256), 0, st, dHO, dY, dXres, M, H, D, drop,
-                     main_blocks, finish ? finish->part : nullptr, finish ? finish->out : nullptr, finish ? finish->C : 0);
+                     main_blocks, finish ? finish->part : nullptr, finish ? finish->out : nullptr, finish ? finish->C : 0, vec);
   return check_launch("head_sum_drop_bwd");
 }
 int dropout(const float* x, float* y, long n, Drop drop, hipStream_t st) {
@@ -657,10 +707,11 @@ int node_score_bwd(const float* ds, const float* uvc, const float* dXin, float* 
 int mask_rows(const float* x, float* y, long M, int D, int N, const int* n_valid, Drop drop, hipStream_t st, const float* wlin,
               float* wsum, int H) {
   ProfScope ps("mask_rows", st);
-  const int main_blocks = x ? cdiv(M * D, 256) : 0, extra = wsum ? cdiv((long)D * D, 256) : 0;
+  const int vec = x && D % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
+  const int main_blocks = x ? cdiv(vec ? M * D / 4 : M * D, 256) : 0, extra = wsum ? cdiv((long)D * D, 256) : 0;
   if (main_blocks + extra == 0) return 0;
   hipLaunchKernelGGL(mask_rows_kernel, dim3(main_blocks + extra), dim3(256), 0, st, x, y, M, D, N, n_valid, drop, main_blocks,
-                     wlin, wsum, H);
+                     wlin, wsum, H, vec);
   return check_launch("mask_rows");
 }
 
