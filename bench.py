@@ -91,16 +91,20 @@ def cpu_baseline(cfg, budget_s=20.0):
     warm = 2 if first < budget_s / 8 else 0
     for b in range(warm):
         one(1 + b)
-    n, t0 = 0, time.perf_counter()
-    while n < 20 and (time.perf_counter() - t0) < budget_s:
-        one(n % nd)
-        n += 1
-    dt = time.perf_counter() - t0
-    if n == 0:
-        n, dt = 1, first
-    return {"value": round(n / dt, 4), "unit": "docs/s", "cores": cores, "kind": "port",
-            "sample": f"{n} documents (N={N}, D={D}, L={L}, H={H}) forward+backward, one per call, train mode, "
-                      f"after {1 + warm} warm-up; PyTorch CPU kernels with {cores} threads (the host reports {ncpu} CPUs; a "
+    times, t0 = [], time.perf_counter()
+    while len(times) < 10 and (time.perf_counter() - t0) < budget_s:       # 10 timed documents, median
+        t1 = time.perf_counter()
+        one(len(times) % nd)
+        times.append(time.perf_counter() - t1)
+    if not times:
+        times = [first]
+    times.sort()
+    n = len(times)
+    med = times[n // 2] if n % 2 else 0.5 * (times[n // 2 - 1] + times[n // 2])
+    return {"value": round(1.0 / med, 4), "unit": "docs/s", "cores": cores, "kind": "port",
+            "sample": f"median of {n} documents (N={N}, D={D}, L={L}, H={H}) forward+backward, one per call, train mode, "
+                      f"after {1 + warm} warm-up (BASELINE.md 3's protocol; mean over the same documents: {n / sum(times):.3f} docs/s); "
+                      f"PyTorch CPU kernels with {cores} threads (the host reports {ncpu} CPUs; a "
                       "1-GPU lease of this pool owns a 16-core share, and more threads than that only oversubscribe these small "
                       "per-document tensors -- BASELINE.md 3 says os.cpu_count(), this is the deviation)"}
 
@@ -147,6 +151,10 @@ def main():
     ap.add_argument("--global-batch", type=int, default=None,
                     help="strong scaling: this many documents per step over ALL GPUs (per GPU: global / N; SURVEY 8d uses 256). "
                          "Default: weak scaling, the config's B per GPU")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (default) = RCCL over xGMI, one GPU per rank.  gloo: TEST ONLY -- the ranks may share one card "
+                         "(rank r uses GPU r mod device_count) and the collectives travel over gloo on the device tensors; "
+                         "exercises the whole N > 1 control flow of this script on a 1-GPU box")
     ap.add_argument("--overlap-grads", action="store_true",
                     help="all-reduce each block's gradient asynchronously from a backward hook (A/B; default: one "
                          "coalesced collective after backward)")
@@ -170,15 +178,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE=1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank
+    if args.dist_backend == "gloo":                              # test mode: ranks may share a card
+        dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     import torch.distributed as dist
     force_dist = os.environ.get("GCGCN_FORCE_DIST") == "1"      # 1-rank RCCL group: exercises the N > 1 code path
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import gcgcn_amd
     from gcgcn_amd import _lib
@@ -243,17 +257,21 @@ def main():
             torch.cuda.synchronize()
     counter = [0]
 
-    def step(eager=False, k=None):
+    def step(eager=False, k=None, collective=True):
+        """One forward + backward (+ the gradient all-reduce when there is more than one rank).  collective=False: the
+        profiling / sampling steps outside the timed region -- they may run on a subset of the ranks, or a different number
+        of times per rank, so they must not issue collectives (every rank has to issue the same collective sequence)."""
         if k is None:
             k = counter[0] % nsets
             counter[0] += 1
+        bucket.active = collective                             # (overlap mode all-reduces from backward hooks)
         if graphs and not eager:
             graphs[k].replay()
             for p, g in graph_grads[k]:                        # .grad = what this replay wrote
                 p.grad = g
         else:
             fwd_bwd(k)
-        if world > 1 or force_dist:
+        if collective and (world > 1 or force_dist):
             bucket.all_reduce()
 
     def sync():
@@ -282,7 +300,7 @@ def main():
         """HIP-event time of every launch whose kernel name starts with `prefix` over nsteps steps."""
         _lib.call("gcgcn_prof_start", prefix.encode(), nsteps * 64 + 64)
         for _ in range(nsteps):
-            step(eager=True)                                   # events cannot be recorded inside a graph replay
+            step(eager=True, collective=False)                 # events cannot be recorded inside a graph replay; no collective
         torch.cuda.synchronize()
         ms, n, w = ctypes.c_double(0), ctypes.c_int(0), ctypes.c_double(0)
         _lib.call("gcgcn_prof_stop", ctypes.byref(ms), ctypes.byref(n), ctypes.byref(w))
@@ -343,16 +361,30 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
 
+    # ragged batches: the host-side work counters of the launches assume full documents (they cannot see n_valid, which
+    # lives on the device); scale them to the rows / pairs that exist -- edge streams touch n_b^2 of N^2 pairs per document,
+    # the node-phase products n_b of N rows
+    rag_hbm = rag_mfma = 1.0
+    if n_valid is not None:
+        nvf = n_valid.double()
+        rag_hbm = float((nvf * nvf).sum().item()) / (B * N * N)
+        rag_mfma = float(nvf.sum().item()) / (B * N)
+
     def roof(fam, ms, n, work, samp):
         bound, peak = FAMILIES[fam]
         if n == 0 or ms <= 0:
             return None
+        if n_valid is not None:
+            work = work * (rag_hbm if bound == "hbm" else rag_mfma)
         ach = work / (ms * 1e-3)                           # work/s over the time those launches were running
         r = {"bound": bound, "kernel": KERNEL_NAMES.get(fam, fam + "*"), "achieved": round(ach / (1e9 if bound == "hbm" else 1e12), 2),
              "peak": peak / (1e9 if bound == "hbm" else 1e12), "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
              "frac": round(ach / peak, 4), "traffic": None, "avg_launch_us": round(ms / n * 1e3, 2),
              "launches": n, "work_per_launch": work / n, "sampled_steps": samp,
              "work": "executed fp32 flops (2MNK)" if bound == "mfma" else "algorithmic HBM bytes"}
+        if n_valid is not None:
+            r["work"] += (f" of the real entities only (x {rag_hbm:.4f} = sum n_b^2 / (B N^2))" if bound == "hbm" else
+                          f" on real rows only (x {rag_mfma:.4f} = sum n_b / (B N))")
         import glob
         import re
         # PMC summaries of this config (offline: separate rocprofv3 --pmc passes, tools/profile_config.sh), latest round
@@ -380,11 +412,11 @@ def main():
     warm = None
     if nsets > 1 and rank == 0 and world == 1 and not force_dist:
         for _ in range(3):
-            step(k=0)
+            step(k=0, collective=False)
         torch.cuda.synchronize()
         tw = time.perf_counter()
         for _ in range(args.steps):
-            step(k=0)
+            step(k=0, collective=False)
         torch.cuda.synchronize()
         warm = (time.perf_counter() - tw) / args.steps
     roofline_hbm = None
@@ -410,6 +442,11 @@ def main():
         docs = B * world * args.steps
         value = docs / dt
         flops = algorithmic_flops_per_doc(N, D, L, H)
+        bytes_doc = 20.0 * N * N * D
+        if n_valid is not None:                                # per-document work of the entities that exist
+            nl = [int(v) for v in n_valid.tolist()]
+            flops = sum(algorithmic_flops_per_doc(v, D, L, H) for v in nl) / len(nl)
+            bytes_doc = sum(20.0 * v * v * D for v in nl) / len(nl)
         line = {
             "metric": "docs/sec fwd+bwd through CAGGC+MAGGC", "value": round(value, 2), "unit": "docs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -426,9 +463,9 @@ def main():
                                                                        if args.overlap_grads else "one coalesced collective after backward")},
             "roofline": roofline,
             "roofline_hbm": roofline_hbm,
-            "whole_step": {"hbm_frac": round(value / world * 20 * N * N * D / HBM_PEAK, 4),
+            "whole_step": {"hbm_frac": round(value / world * bytes_doc / HBM_PEAK, 4),
                            "mfma_frac": round(value / world * flops / MFMA_F32_PEAK, 4),
-                           "algorithmic_bytes_per_doc": 20 * N * N * D, "algorithmic_flops_per_doc": flops},
+                           "algorithmic_bytes_per_doc": bytes_doc, "algorithmic_flops_per_doc": flops},
             "time_shares_ms_per_step": {k: v for k, v in shares.items() if v["launches_per_step"]},
         }
         if warm is not None:

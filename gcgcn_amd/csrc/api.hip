@@ -559,17 +559,6 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
     // ran after the chains (cfg 5: 1.05 ms per launch for 0.4 ms of products and 0.66 ms of streaming).
     const bool big = big_products(B, N, H);
     const bool chain = use_chain() && !big;
-    if (mha) {  // the attention core: scores in LDS, P / A out (glove:137-140) -- in the chain workgroups' prologue where the
-                // shape's chain kernel can do that (chain.hip), as a launch of its own otherwise
-      const Drop adrop = make_drop(mha->rng_snap, GCGCN_SALT_MHA, mha->p);
-      GC_REQUIRE(!adrop.snap || mha->A, "gcn_fwd: attention dropout on but A is NULL");
-      const float alpha = 1.f / sqrtf((float)(D / H));
-      if (chain && chain_fwd_computes_attention(c))
-        c.mha.Q = mha->Q, c.mha.P = mha->P, c.mha.A = mha->A, c.mha.alpha = alpha, c.mha.drop = adrop, c.mha.dh = D / H,
-        c.mha.kchunk = mha_chunk(D / H);
-      else
-        GC_TRY(mha_core_fwd(mha->Q, n_valid, mha->P, mha->A, B, N, D, H, alpha, adrop, st));
-    }
     GemmArgs plans[2 * 16];
     int np = 0;
     bool rideable = er.kind != 0 && !chain && L <= 16;
@@ -584,7 +573,18 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
       GC_TRY(edge_fwd(er.in, nullptr, er.n_valid, er.out, nullptr, nullptr, nullptr, Drop(), er.B, er.N, er.D, st));
       er.kind = 0;
     }
-    c.ride = er;
+    c.ride = er;   // BEFORE the question below: whether the column-strip kernels take this call depends on the passenger too
+    if (mha) {  // the attention core: scores in LDS, P / A out (glove:137-140) -- in the chain workgroups' prologue where the
+                // shape's chain kernel can do that (chain.hip), as a launch of its own otherwise
+      const Drop adrop = make_drop(mha->rng_snap, GCGCN_SALT_MHA, mha->p);
+      GC_REQUIRE(!adrop.snap || mha->A, "gcn_fwd: attention dropout on but A is NULL");
+      const float alpha = 1.f / sqrtf((float)(D / H));
+      if (chain && chain_fwd_computes_attention(c))
+        c.mha.Q = mha->Q, c.mha.P = mha->P, c.mha.A = mha->A, c.mha.alpha = alpha, c.mha.drop = adrop, c.mha.dh = D / H,
+        c.mha.kchunk = mha_chunk(D / H);
+      else
+        GC_TRY(mha_core_fwd(mha->Q, n_valid, mha->P, mha->A, B, N, D, H, alpha, adrop, st));
+    }
     if (chain) {
       GC_TRY(gcn_chain_fwd(c, st));
     } else {

@@ -129,7 +129,6 @@ template <bool ALIGNED>
 __global__ __launch_bounds__(64 * CW) void gcn_chain_bwd_kernel(const GcnCtx c, const GemmGroup4 cg) {
   __shared__ __attribute__((aligned(16))) float lds[CHAIN_LDS + XCHG_LDS];
   if (blockIdx.x >= c.B * c.H) {
-    const int ng = cg.tile_begin[cg.nprob];
     int pb;
     if (spread_pick((int)blockIdx.x - c.B * c.H, c.carry, pb)) {  // passenger workgroup: one tile of a parked product, K split over the two tile teams
       gemm_group_splitk_block(cg, pb, lds, TEAM_LDS, lds + CHAIN_LDS);
@@ -402,7 +401,6 @@ template <bool FUSE>
 __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c, const GemmGroup4 cg) {
   __shared__ __attribute__((aligned(16))) float lds[S_BWD_LDS];
   if (blockIdx.x >= c.B * c.H) {
-    const int ng = cg.tile_begin[cg.nprob];
     int pb;
     if (spread_pick((int)blockIdx.x - c.B * c.H, c.carry, pb)) {  // passenger workgroup: one tile of a parked product, K split over the two tile teams
       gemm_group_splitk_block(cg, pb, lds, TEAM_LDS, lds + CHAIN_LDS);
@@ -838,6 +836,9 @@ int gcn_chain_fwd(const GcnCtx& c, hipStream_t st) {
   // apply, 2 = also there (A/B), 0 = never
   const bool s_ok = chain_aligned(c, false) && chain_small_ok(c, false);
   if (chain_t_ok(c, false) && !(s_ok && option("chain_t", 1) < 2)) return gcn_chain_t_fwd(c, grid, fl * c.B * c.H, st);
+  // only the LDS-resident kernels run the attention core in their prologue: a caller that left it to the chain (c.mha) and ends
+  // up here would get a convolution over adjacencies nobody computed
+  GC_REQUIRE(!c.mha.Q || s_ok, "gcn_chain_fwd: the attention core was left to a chain kernel that does not run it");
   if (s_ok)
     GC_LAUNCH_TIMED("gcn_chain_fwd", fl * c.B * c.H, gcn_chain_s_fwd_kernel, grid, block, 0, st, c);
   else if (chain_aligned(c, false)) GC_LAUNCH_TIMED("gcn_chain_fwd", fl * c.B * c.H, gcn_chain_fwd_kernel<true>, grid, block, 0, st, c);

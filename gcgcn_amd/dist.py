@@ -49,6 +49,7 @@ class FlatGradBucket:
     def __init__(self, module: nn.Module, process_group=None, overlap: bool = False):
         self.pg = process_group
         self.overlap = overlap
+        self.active = True          # False: no collectives at all (steps that only some ranks run, e.g. profiling samples)
         self._pending = []
         self.params: List[nn.Parameter] = [p for n, p in module.named_parameters()
                                            if p.requires_grad and not n.endswith("flat_k")]
@@ -59,7 +60,7 @@ class FlatGradBucket:
 
     def _distributed(self) -> bool:
         # GCGCN_FORCE_DIST=1: issue the collectives even in a 1-rank group (exercises the RCCL path on one GPU)
-        if not (dist.is_available() and dist.is_initialized()):
+        if not (self.active and dist.is_available() and dist.is_initialized()):
             return False
         return dist.get_world_size(self.pg) > 1 or os.environ.get("GCGCN_FORCE_DIST") == "1"
 

@@ -168,6 +168,41 @@ def test_fused_adam_is_torch_adam(gpu_device):
         torch.testing.assert_close(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"], rtol=1e-5, atol=1e-12)
 
 
+def test_fused_adam_ring_wraps_and_checkpoints_move_both_ways(gpu_device):
+    """Round-3 ADVICE: step() must not drain the stream, and a checkpoint of torch's Adam that uses a feature FusedAdam lacks
+    must raise instead of training on with other arithmetic.  Eight steps back to back (the staging ring of three pinned
+    buffers wraps twice) against torch.optim.Adam; FusedAdam's state_dict loads into torch's Adam and continues identically."""
+    gen = torch.Generator().manual_seed(1)
+    base = [torch.randn(300, 7, generator=gen), torch.randn(129, generator=gen)]
+    pa = [b.clone().to(gpu_device).requires_grad_() for b in base]
+    pb = [b.clone().to(gpu_device).requires_grad_() for b in base]
+    oa, ob = FusedAdam(pa, lr=3e-3), torch.optim.Adam(pb, lr=3e-3)
+    grads = [[torch.randn(b.shape, generator=gen).to(gpu_device) for b in base] for _ in range(8)]
+    for gs in grads:                                  # no synchronisation between the steps: the ring hands out fresh staging
+        for a, b, g_ in zip(pa, pb, gs):
+            a.grad, b.grad = g_.clone(), g_.clone()
+        oa.step()
+        ob.step()
+    assert len(oa._ring) == FusedAdam._RING and oa._ring_next == 8
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(a.detach(), b.detach(), rtol=1e-5, atol=1e-6)
+    for key in ("weight_decay", "amsgrad", "maximize"):
+        assert key in oa.state_dict()["param_groups"][0]
+    oc = torch.optim.Adam(pa, lr=3e-3)                 # FusedAdam -> torch
+    oc.load_state_dict(oa.state_dict())
+    for a, b, g_ in zip(pa, pb, grads[0]):
+        a.grad, b.grad = g_.clone(), g_.clone()
+    oc.step()
+    ob.step()
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(a.detach(), b.detach(), rtol=1e-5, atol=1e-6)
+    od = torch.optim.Adam(pb, lr=3e-3, weight_decay=0.01)   # torch (with weight decay) -> FusedAdam: loud
+    oe = FusedAdam(pa, lr=3e-3)
+    oe.load_state_dict(od.state_dict())
+    with pytest.raises(RuntimeError, match="weight_decay"):
+        oe.step()
+
+
 def test_model_trains_with_fused_adam(gpu_device):
     """Three optimiser steps on the fixture's documents (eval-mode forward: no dropout noise).  FusedAdam over the model's own
     parameters (one flat tensor per block, the dead hop's without gradient) against torch.optim.Adam fed the SAME gradients
