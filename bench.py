@@ -146,8 +146,6 @@ def main():
                          "a training loop that feeds new documents every step).  1 = replay one batch (cache-warm)")
     ap.add_argument("--ragged", action="store_true",
                     help="secondary run (SURVEY 8d): DocRED-like entity counts n_valid ~ clip(round(N(19.5, 6^2)), 2, 42) padded to N")
-    ap.add_argument("--early-mean", action="store_true", help="issue the E2 mean before GATAttention (A/B; default off)")
-    ap.add_argument("--overlap", action="store_true", help="stream the E2 mean on a side stream (A/B; default off)")
     ap.add_argument("--global-batch", type=int, default=None,
                     help="strong scaling: this many documents per step over ALL GPUs (per GPU: global / N; SURVEY 8d uses 256). "
                          "Default: weak scaling, the config's B per GPU")
@@ -208,8 +206,6 @@ def main():
     hops = gcgcn_amd.GraphHops(D, L, H).to(dev).train()
     if args.eval_mode:
         hops.eval()
-    hops.overlap_edge_mean = args.overlap
-    hops.early_edge_mean = args.early_mean
     gcgcn_amd.manual_seed(1337 + rank, dev)
     bucket = FlatGradBucket(hops, overlap=args.overlap_grads)   # default: one coalesced all-reduce after backward
     n_valid = None

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GCGCN_LIB=<path> loads another build of the same ABI (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("GCGCN_LIB") or os.path.join(_HERE, "lib", "libgcgcn_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 SALT_GAT = 0x47415431
 SALT_MHA = 0x4D484131
@@ -57,13 +57,14 @@ SIGNATURES = {
     "gcgcn_edge_mean_bwd": (I, [I, I, I, P, P, P, P]),
     "gcgcn_mha_layout": (I, [I, P]),
     "gcgcn_mha_scratch": (L, [I, I, I]),
-    "gcgcn_mha_fwd": (I, [I, I, I, I, P, P, P, P, F, P, P, P, P, P]),
-    "gcgcn_mha_bwd": (I, [I, I, I, I, P, P, P, F, P, P, P, P, P, P, P, P, P, P, I, P]),
+    "gcgcn_row_blocks": (I, [I, I, P, P, P]),
+    "gcgcn_mha_fwd": (I, [I, I, I, I, P, P, P, P, F, P, P, P, P, P, P]),
+    "gcgcn_mha_bwd": (I, [I, I, I, I, P, P, P, F, P, P, P, P, P, P, P, P, P, P, I, P, P]),
     "gcgcn_maggc_fusable": (I, [I, I, I]),
     "gcgcn_gcn_layout": (I, [I, I, I, P]),
     "gcgcn_gcn_scratch": (L, [I, I, I, I]),
-    "gcgcn_gcn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, F, P, P, P, P, P, P, P, P, P, P, P]),
-    "gcgcn_gcn_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_gcn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, F, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_gcn_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, F, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_defer_create": (P, []),
     "gcgcn_defer_destroy": (None, [P]),
     "gcgcn_defer_count": (I, [P]),
@@ -84,8 +85,8 @@ SIGNATURES = {
     "gcgcn_gat_bwd_compact": (I, [I, I, I, I, P, P, P, P, P, P, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_head_layout": (I, [I, I, I, I, I, P]),
     "gcgcn_head_sizes": (I, [I, I, I, I, P]),
-    "gcgcn_head_fwd": (I, [I, I, I, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P]),
-    "gcgcn_head_bwd": (I, [I, I, I, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_head_fwd": (I, [I, I, I, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
+    "gcgcn_head_bwd": (I, [I, I, I, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_tensorise": (I, [I, I, I, I, I, I, I, P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P]),
     "gcgcn_adam_step": (I, [I, P, L, ctypes.c_double, ctypes.c_double, ctypes.c_double, P]),
     "gcgcn_gemm": (I, [I, I, I, P, L, I, P, L, I, P, L, I, L, L, L, F, P, I, I, I, I, P, L, P]),

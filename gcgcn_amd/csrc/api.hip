@@ -110,10 +110,11 @@ struct Opt {
 static Opt g_opts[] = {{"head_v1", 0, false},   {"head_bil3", 0, false},  {"head_bil3_bwd", 0, false}, {"head_dw3", 0, false},
                        {"chain_s", 0, false},   {"chain_fuse", 0, false}, {"chain_carry", 0, false},   {"gat_ride", 0, false},
                        {"chain_t", 0, false},   {"fwd_fuse", 0, false},   {"splitk_fuse", 0, false},   {"mha_ride", 0, false},
-                       {"big_products", 0, false}, {"chain_carry_pct", 0, false}, {"chain_carry_rounds", 0, false},
+                       {"chain_carry_pct", 0, false}, {"chain_carry_rounds", 0, false},
                        {"maggc_fuse", 0, false}, {"carry_spread", 0, false}, {"chain_spread", 0, false},
                        {"carry_cohort", 0, false}, {"chain_cohort", 0, false}, {"carry_spread_min", 0, false},
-                       {"chain_spread_min", 0, false}, {"big_tiles", 0, false}, {"att_in_chain", 0, false}, {"fold_slices", 0, false}, {"head_sum_fold", 0, false}};
+                       {"chain_spread_min", 0, false}, {"att_in_chain", 0, false}, {"fold_slices", 0, false}, {"head_sum_fold", 0, false},
+                       {"head_compact", 0, false}};
 int option(const char* name, int dflt) {
   for (Opt& o : g_opts) {
     if (strcmp(o.name, name) != 0) continue;
@@ -137,13 +138,6 @@ static bool set_opt(const char* name, int value) {
       return true;
     }
   return false;
-}
-
-// option big_products: 1 = graphs of more than 64 entities run one batched launch per product instead of the generic chain
-// kernels, 2 = only the blocks whose (document, head) pairs fill the chip by themselves (B H >= 256: nothing rides there)
-static bool big_products(int B, int N, int H) {
-  const int o = option("big_products", 0);
-  return N > 64 && (o == 1 || (o == 2 && (long)B * H >= 256));
 }
 
 // GCGCN_NO_CHAIN=1 (or gcgcn_set_option("chain", 0)) runs every per-(doc, head) product as its own batched
@@ -180,6 +174,12 @@ static int make_ride(const char* who, const gcgcn_edge_ride* ride, int kind, Edg
   return 0;
 }
 
+// Row blocks of a ragged batch (gcgcn_row_blocks) on one GEMM problem: mode 1 = M is the document-row dimension, 2 = K is.
+static void use_rows(GemmArgs& g, const int* rowblk, int mode, int zero_dead = 0) {
+  if (!rowblk) return;
+  g.rb = rowblk + ROWBLK_HDR, g.rb_n = rowblk, g.rb_mode = mode, g.rb_zero = zero_dead;
+}
+
 static GcnCtx make_ctx(int B, int N, int D, int L, int H, const GcnLayout& y, const float* X, const float* A,
                        const float* flat, const int* n_valid, Drop drop) {
   GcnCtx c;
@@ -196,7 +196,7 @@ using namespace gc;
 
 extern "C" {
 
-int gcgcn_version(void) { return 4; }
+int gcgcn_version(void) { return 5; }
 const char* gcgcn_last_error(void) { return g_err; }
 
 int gcgcn_set_option(const char* name, int value) {
@@ -212,6 +212,10 @@ int gcgcn_set_option(const char* name, int value) {
   if (set_opt(name, value)) return 0;
   set_error("set_option: unknown option '%s'", name);
   return 1;
+}
+
+int gcgcn_row_blocks(int B, int N, const int32_t* n_valid, int32_t* out, void* stream) {
+  return row_blocks(n_valid, B, N, out, (hipStream_t)stream);
 }
 
 int gcgcn_prof_start(const char* kernel_prefix, int capacity) {
@@ -377,7 +381,7 @@ int gcgcn_mha_layout(int D, int64_t* o) {
 }
 
 int gcgcn_mha_fwd(int B, int N, int D, int H, const float* X, const int32_t* n_valid, const float* flat,
-                  const void* rng_snap, float p, float* Q, float* P, float* A, float* scratch, void* stream) {
+                  const void* rng_snap, float p, float* Q, float* P, float* A, float* scratch, const int32_t* rowblk, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("mha_fwd", B, N, D, 1, H));
   const long wse = scratch ? gemm_scratch_elems(B, N, D, 1) : 0;
@@ -394,6 +398,7 @@ int gcgcn_mha_fwd(int B, int N, int D, int H, const float* X, const int32_t* n_v
     g.C = Q, g.ldc = D;
     g.M = (int)M, g.N = D, g.K = D;
     g.bias = flat + (long)D * D;
+    use_rows(g, (n_valid && N % 16 == 0 && N >= 32) ? rowblk : nullptr, 1, 1);
     GC_TRY(gemm(g, st));
   }
   const float alpha = 1.f / sqrtf((float)dh);
@@ -418,7 +423,7 @@ int64_t gcgcn_mha_scratch(int B, int N, int D) { return scratch_elems(B, N, D, 1
 
 int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat, const void* rng_snap, float p,
                   const float* Q, const float* P, const float* dA, const float* dX_in, float* dX, float* dflat, float* dS,
-                  float* dQ, float* scratch, void* defer_queue, int core_done, void* stream) {
+                  float* dQ, float* scratch, void* defer_queue, int core_done, const int32_t* rowblk, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("mha_bwd", B, N, D, 1, H));
   const long wse = scratch ? gemm_scratch_elems(B, N, D, 1) : 0;
@@ -457,6 +462,7 @@ int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat,
     gs[1].B = X, gs[1].ldb = D, gs[1].b_kc = 0;
     gs[1].C = dflat, gs[1].ldc = D;
     gs[1].M = D, gs[1].N = D, gs[1].K = (int)M;
+    if (N % 16 == 0 && N >= 32) use_rows(gs[0], rowblk, 1, 1), use_rows(gs[1], rowblk, 2);   // ragged batch: the rows that exist
     const int ng = gemm_defer((DeferQueue*)defer_queue, gs[1]) ? 1 : 2;  // dWq parked (see gcgcn_gcn_bwd)
     if (scratch) {  // dbq = column sums of dQ ride in the same two launches
       ColRide cr;
@@ -507,7 +513,7 @@ int gcgcn_gcn_layout(int D, int L, int H, int64_t* o) {
 int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float* Ebar, const float* A,
                   const int32_t* n_valid, const float* flat, const void* rng_snap, float p, const void* out_rng_snap,
                   float out_p, float* out, float* Pn, float* Y, float* HO, float* rinv, float* G, float* wsum, float* scratch,
-                  const gcgcn_edge_ride* ride, const gcgcn_mha_hook* mha, void* stream) {
+                  const gcgcn_edge_ride* ride, const gcgcn_mha_hook* mha, const int32_t* rowblk, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GC_TRY(check_dims("gcn_fwd", B, N, D, L, H));
   if (mha) {
@@ -524,6 +530,16 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
   const long M = (long)B * N;
   const long HD = (long)H * D;
   GC_REQUIRE(M <= 0x7fffffffL, "gcn_fwd: B*N too large");
+  // The per-(doc, head) context, with the passenger that will actually ride attached.  Ragged batch with a row-block list:
+  // the products around the chain run on the rows that exist; what they leave on the dead row blocks is ZERO (rb_zero), so the
+  // chain kernels -- whichever serves the shape -- see exactly what the dense products would have left there.
+  const bool chain = use_chain();
+  EdgeRide er_chain = er;
+  if (er.kind && !(chain && chain_can_carry(er))) er_chain.kind = 0;
+  GcnCtx c = make_ctx(B, N, D, L, H, y, X, A, flat, n_valid, drop);
+  c.G = G, c.Pn = Pn, c.Y = Y, c.HO = HO, c.rinv = rinv;
+  c.ride = er_chain;
+  const int* rows = (rowblk && n_valid && N % 16 == 0 && N >= 32) ? rowblk : nullptr;
 
   {  // one launch: Pn = X WnX (node term of every (head, sub-layer), X part of the dense input)
      //             G  = Ebar We (edge term, mean commuted with the projection, glove:40-41)
@@ -535,6 +551,7 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
       g.B = flat + (q ? y.oWe : y.oWnX), g.ldb = HD, g.b_kc = 0;
       g.C = q ? G : Pn, g.ldc = HD;
       g.M = (int)M, g.N = (int)HD, g.K = D;
+      use_rows(g, rows, 1, 1);
     }
     ColRide hs;  // wsum = sum_h Wlin[:, h, :] (a by-product for gcgcn_gcn_bwd) in trailing workgroups of this launch
     if (wsum && H > 1) hs.X = flat + y.oWlin, hs.out = wsum, hs.R = H, hs.ld = D, hs.C = D * D, hs.ready_slices = -1;
@@ -547,33 +564,15 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
       g.C = mha->Q, g.ldc = D;
       g.M = (int)M, g.N = D, g.K = D;
       g.bias = mha->flat_q + (long)D * D;
+      use_rows(g, rows, 1, 1);   // (the attention core stages all N rows of Q: zeros past the live blocks)
     }
     GC_TRY(gemm_group(g3, mha ? 3 : 2, st, hs.X ? &hs : nullptr));
   }
   {  // the dependent per-(doc, head) sequence: normaliser, then per sub-layer dense connection + aggregation
-    GcnCtx c = make_ctx(B, N, D, L, H, y, X, A, flat, n_valid, drop);
-    c.G = G, c.Pn = Pn, c.Y = Y, c.HO = HO, c.rinv = rinv;
-    // Graphs of more than 64 entities: one batched launch per product (each is 256 x 256 x 256 per pair at cfg 5: big enough
-    // to fill the chip on its own) with the next hop's edge mean riding THROUGH those launches -- inside a chain launch the
-    // 512-thread passengers cannot share a compute unit with a chain workgroup (registers), so at B H >= 256 pairs they only
-    // ran after the chains (cfg 5: 1.05 ms per launch for 0.4 ms of products and 0.66 ms of streaming).
-    const bool big = big_products(B, N, H);
-    const bool chain = use_chain() && !big;
-    GemmArgs plans[2 * 16];
-    int np = 0;
-    bool rideable = er.kind != 0 && !chain && L <= 16;
-    if (!chain && L <= 16) {
-      for (int l = 0; l < L; ++l) {
-        if (l > 0) plans[np++] = plan_fwd_dense(c, l);
-        plans[np++] = plan_fwd_agg(c, l);
-      }
-      for (int i = 0; i < np; ++i) rideable = rideable && gemm_ride_ok(plans[i], er);
-    }
-    if (er.kind && !(chain ? chain_can_carry(er) : rideable)) {  // the riding pass as its own launch
+    if (er.kind && !er_chain.kind) {  // the riding pass as its own launch
       GC_TRY(edge_fwd(er.in, nullptr, er.n_valid, er.out, nullptr, nullptr, nullptr, Drop(), er.B, er.N, er.D, st));
       er.kind = 0;
     }
-    c.ride = er;   // BEFORE the question below: whether the column-strip kernels take this call depends on the passenger too
     if (mha) {  // the attention core: scores in LDS, P / A out (glove:137-140) -- in the chain workgroups' prologue where the
                 // shape's chain kernel can do that (chain.hip), as a launch of its own otherwise
       const Drop adrop = make_drop(mha->rng_snap, GCGCN_SALT_MHA, mha->p);
@@ -589,23 +588,9 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
       GC_TRY(gcn_chain_fwd(c, st));
     } else {
       GC_TRY(rowsum_inv(A, rinv, (long)B * H * N, N, st));  // glove:47-49
-      if (er.kind && rideable) {  // passenger rows in proportion to each product's work
-        double tot = 0, w[2 * 16];
-        for (int i = 0; i < np; ++i) tot += (w[i] = (double)plans[i].M * plans[i].N * plans[i].K);
-        const long rows = (long)er.B * er.N;
-        long done = 0;
-        double acc = 0;
-        for (int i = 0; i < np; ++i) {
-          acc += w[i];
-          const long upto = (i == np - 1) ? rows : (long)(rows * (acc / tot));
-          GC_TRY(gemm_ride(plans[i], er, (int)done, (int)(upto - done), st));
-          done = upto;
-        }
-      } else {
-        for (int l = 0; l < L; ++l) {
-          if (l > 0) GC_TRY(gemm(plan_fwd_dense(c, l), st, 0, 1));
-          GC_TRY(gemm(plan_fwd_agg(c, l), st, 0, 1));
-        }
+      for (int l = 0; l < L; ++l) {
+        if (l > 0) GC_TRY(gemm(plan_fwd_dense(c, l), st, 0, 1));
+        GC_TRY(gemm(plan_fwd_agg(c, l), st, 0, 1));
       }
     }
   }
@@ -618,6 +603,7 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
     g.M = (int)M, g.N = D, g.K = (int)HD;
     g.bias = flat + y.oblin;
     g.n_valid = n_valid, g.nv_rows = N, g.nv_zdoc = 0;
+    use_rows(g, rows, 1, 1);   // the block's output: its padding rows are zero
     const Drop odrop = make_drop(out_rng_snap, GCGCN_SALT_GLUE, out_p);
     if (odrop.snap) {  // the hop's output dropout (glove:341) in the same epilogue: out = dropout(linear)
       g.C = G;         // the undropped values go to workspace that is free by now; nobody reads them
@@ -636,7 +622,8 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
                   float out_p, const float* Pn, const float* Y, const float* HO, const float* rinv, const float* wsum_fwd,
                   const float* dout, float* dX, float* dEbar,
                   float* dA, float* dflat, float* W1, float* W2, float* W3, float* drow, float* dXres, float* dout_m,
-                  float* scratch, const gcgcn_edge_ride* ride, const gcgcn_mha_hook* mha, void* defer_queue, void* stream) {
+                  float* scratch, const gcgcn_edge_ride* ride, const gcgcn_mha_hook* mha, void* defer_queue, const int32_t* rowblk,
+                  void* stream) {
   DeferQueue* dq = (DeferQueue*)defer_queue;
   MhaPass mp;
   if (mha) {
@@ -671,6 +658,13 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
   GcnCtx c = make_ctx(B, N, D, L, H, y, X, A, flat, n_valid, drop);
   c.Pn = const_cast<float*>(Pn), c.Y = const_cast<float*>(Y), c.rinv = const_cast<float*>(rinv);
   c.dYa = dYa, c.dM = dM, c.dP = dP, c.dA = dA, c.drow = drow, c.oWlin = y.oWlin;
+  // ragged batch with a row-block list: the products around the chain run on the rows that exist (see gcgcn_gcn_fwd)
+  {
+    EdgeRide er_chain = er;
+    if (er.kind && !(use_chain() && chain_can_carry(er))) er_chain.kind = 0;
+    c.ride = er_chain;
+  }
+  const int* rows = (rowblk && n_valid && N % 16 == 0 && N >= 32) ? rowblk : nullptr;
   const bool fuse = use_chain() && scratch && chain_bwd_fusable(c) && (((uintptr_t)dXres) & 15) == 0 &&
                     (((uintptr_t)dout) & 15) == 0 && (((uintptr_t)dout_m) & 15) == 0 && (long)M * HD >= (long)D * D;
   // sum_h Wlin_h: from the forward call if it left one, else summed here into dYa's buffer (free when the chain computes dHO)
@@ -709,6 +703,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
       gs[1].B = HO, gs[1].ldb = HD, gs[1].b_kc = 0;
       gs[1].C = dflat + y.oWlin, gs[1].ldc = HD;
       gs[1].M = D, gs[1].N = (int)HD, gs[1].K = (int)M;
+      use_rows(gs[0], rows, 1, 1), use_rows(gs[1], rows, 2);
       int np1 = 2;
       if (fold_hs) {
         if (H == 1) {
@@ -720,6 +715,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
           gs[2].B = wsum_fwd, gs[2].ldb = D, gs[2].b_kc = 0;
           gs[2].C = dXres, gs[2].ldc = D;
           gs[2].M = (int)M, gs[2].N = D, gs[2].K = D;
+          use_rows(gs[2], rows, 1, 1);
           np1 = 3;
         }
       }
@@ -747,45 +743,19 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
   }
 
   {  // the dependent per-(doc, head) sequence, last sub-layer first
-    const bool big = big_products(B, N, H);   // see gcgcn_gcn_fwd
-    const bool chain = use_chain() && !big;
-    bool rideable = er.kind != 0 && !chain && L <= 16;
-    double tot = 0;
-    if (rideable)
-      for (int l = L - 1; l >= 0; --l) {
-        const GemmArgs a = plan_bwd_dP(c, l), b2 = plan_bwd_dA(c, l);
-        rideable = rideable && gemm_ride_ok(a, er) && gemm_ride_ok(b2, er);
-        tot += (double)a.M * a.N * a.K + (double)b2.M * b2.N * b2.K;
-        if (l > 0) {
-          const GemmArgs d = plan_bwd_dY(c, l);
-          rideable = rideable && gemm_ride_ok(d, er);
-          tot += (double)d.M * d.N * d.K;
-        }
-      }
-    if (er.kind && !(chain ? chain_can_carry(er) : rideable)) {
+    const bool chain = use_chain();
+    if (er.kind && !c.ride.kind) {
       GC_TRY(edge_bcast(er.in, er.n_valid, er.out, er.B, er.N, er.D, st));
       er.kind = 0;
     }
-    c.ride = er;
     if (chain) {
       GC_TRY(gcn_chain_bwd(c, st, dq));  // + parked weight gradients of earlier blocks where the chain leaves room
     } else {
-      const long rows = er.kind ? (long)er.B * er.N : 0;
-      long done = 0;
-      double acc = 0;
-      auto product = [&](const GemmArgs& g, bool last) -> int {   // one product, with its share of the riding dE broadcast
-        if (!er.kind) return gemm(g, st, 0, 1);
-        acc += (double)g.M * g.N * g.K;
-        const long upto = last ? rows : (long)(rows * (acc / tot));
-        const int e = gemm_ride(g, er, (int)done, (int)(upto - done), st);
-        done = upto;
-        return e;
-      };
       for (int l = L - 1; l >= 0; --l) {
         GC_TRY(relu_norm_bwd(dYa, Y, rinv, dM, drow, M, N, H, L, gh, l, l == L - 1, st));
-        GC_TRY(product(plan_bwd_dP(c, l), false));
-        GC_TRY(product(plan_bwd_dA(c, l), l == 0));
-        if (l > 0) GC_TRY(product(plan_bwd_dY(c, l), false));
+        GC_TRY(gemm(plan_bwd_dP(c, l), st, 0, 1));
+        GC_TRY(gemm(plan_bwd_dA(c, l), st, 0, 1));
+        if (l > 0) GC_TRY(gemm(plan_bwd_dY(c, l), st, 0, 1));
       }
     }
   }
@@ -810,6 +780,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
       g.B = HO, g.ldb = HD, g.b_kc = 0;
       g.C = dflat + y.oWlin, g.ldc = HD;
       g.M = D, g.N = (int)HD, g.K = (int)M;
+      use_rows(g, rows, 2);
       park();
     }
     {
@@ -818,6 +789,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
       g.B = dP, g.ldb = HD, g.b_kc = 0;
       g.C = dflat + y.oWnX, g.ldc = HD;
       g.M = D, g.N = (int)HD, g.K = (int)M;
+      use_rows(g, rows, 2);
       park();
     }
     {
@@ -826,6 +798,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
       g.B = dM, g.ldb = HD, g.b_kc = 0;
       g.C = dflat + y.oWe, g.ldc = HD;
       g.M = D, g.N = (int)HD, g.K = (int)M;
+      use_rows(g, rows, 2);
       park();
     }
     {
@@ -835,6 +808,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
       g.C = dX, g.ldc = D;
       g.M = (int)M, g.N = D, g.K = (int)HD;
       g.add = dXres, g.ldadd = D;
+      use_rows(g, rows, 1, 1);   // the gradients that leave the block: zero on padding rows
     }
     {
       GemmArgs& g = next();
@@ -842,6 +816,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
       g.B = flat + y.oWe, g.ldb = HD, g.b_kc = 1;
       g.C = dEbar, g.ldc = D;
       g.M = (int)M, g.N = D, g.K = (int)HD;
+      use_rows(g, rows, 1, 1);
     }
     for (int l = 1; l < L; ++l) {
       if (n == GMAX) {  // many sub-layers and nothing parked: launch what has been described so far
@@ -854,6 +829,7 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
       g.C = dflat + y.wd_off(0, l), g.ldc = gh, g.sC2 = y.wd_head;
       g.M = l * gh, g.N = gh, g.K = (int)M;
       g.batch2 = H;
+      use_rows(g, rows, 2);
       park();
     }
     // + the attention core's backward: as passenger workgroups of this launch where a (document, head) pair's scratch fits

@@ -870,7 +870,7 @@ int gcn_chain_bwd(const GcnCtx& c, hipStream_t st, DeferQueue* carry) {
     const double t_tile = 0.47 * ((double)c.B * c.N / 32.0);              // us: weight gradients have K = B N
     const long rounds = t_tile > 0 ? (long)(t_chain / t_tile) : 0;
     bool halves = true;
-    for (int i = 0; i < carry->n; ++i) halves = halves && carry->p[i].K % 64 == 0;
+    for (int i = 0; i < carry->n; ++i) halves = halves && carry->p[i].K % 64 == 0 && !carry->p[i].rb;   // (row-block products ride elsewhere)
     // the riding dE broadcast needs its share of the idle compute units too: with it aboard only half of them take a tile
     long budget = rounds * (256 - (long)c.B * c.H);
     if (c.ride.kind == 2) budget = carry_budget_pct() * budget / 100;

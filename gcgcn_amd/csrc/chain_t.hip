@@ -1,4 +1,4 @@
-// LDS-resident chain kernels for every graph of up to 64 entities, any feature width gh in {64, 128, 192, 256} and any
+// LDS-resident chain kernels for every graph of up to 64 entities, any feature width gh in {32, 64, 128, 192, 256} and any
 // number of sub-layers the templates are instantiated for -- the generalisation of chain.hip's gcn_chain_s_* (which serve
 // one shape: 64 entities, two sub-layers of 128 features) to the reference's own model (hidden 128: gh = 64, L = 2, N <= 42
 // ragged; glove:234, 250-251), to cfg 3 (bert-sized: gh = 192, L = 4) and to anything in between.
@@ -144,7 +144,8 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_fwd_kernel(const GcnCtx c)
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int row = 16 * rb + 4 * g + v;
-        Pa[l][rb][v] = row < N ? Pg[(unsigned)row * HD + (unsigned)(l * GH + col)] : 0.f;
+        // (row blocks past the real entities' are neither read nor computed; everything this kernel leaves there is zero)
+        Pa[l][rb][v] = (row < N && rb < nrb) ? Pg[(unsigned)row * HD + (unsigned)(l * GH + col)] : 0.f;
       }
   t_barrier();
 
@@ -158,8 +159,8 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_fwd_kernel(const GcnCtx c)
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int row = 16 * rb + 4 * g + v;
-        gv[rb][v] = row < N ? Gg[(unsigned)row * HD + (unsigned)(l * GH + col)] : 0.f;
-        xv[rb][v] = row < N ? Xg[(unsigned)row * D + (unsigned)(l * GH + col)] : 0.f;
+        gv[rb][v] = (row < N && rb < nrb) ? Gg[(unsigned)row * HD + (unsigned)(l * GH + col)] : 0.f;
+        xv[rb][v] = (row < N && rb < nrb) ? Xg[(unsigned)row * D + (unsigned)(l * GH + col)] : 0.f;
       }
     t4 wr[2][NP > 0 ? NP : 1];
     const float* __restrict__ Wb = c.flat + c.oWd + (long)h * c.wd_head + (long)l * GH * GH + 4 * t;   // + wd_off(l') below
@@ -265,14 +266,15 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_fwd_kernel(const GcnCtx c)
 //   dS = dY_l [Y_l > 0];  dM_l = dS rinv;  drow -= rinv sum_c dS Y_l;  dPn_l = A_h^T dM_l;  dA += dM_l Pn_l^T;
 //   dY_l' += dPn_l Wd_l[l' gh : (l' + 1) gh, :]^T for l' < l   (dY_l' starts as dropout_bwd(dHO_l'), read from dYa)
 // dA: wave w accumulates rows 16 (w % 4) .. + 15, all 64 columns, over the k range [64 (w / 4), + 64) of every sub-layer in
-// registers; the gh / 64 partial sums meet in LDS at the end, in a fixed order (bitwise reproducible).
+// registers; the gh / 64 partial sums meet in LDS at the end, in a fixed order (bitwise reproducible).  gh = 32 (two waves: the
+// BERT model's width, hidden 128 over four sub-layers, bert:237,247-248): each wave takes two row blocks over the whole k range.
 // ---------------------------------------------------------------------------------------------------------------------
 // Parked weight-gradient tiles (gemm.hpp DeferQueue) as passengers of a chain launch that leaves compute units idle: a
 // passenger workgroup of NTEAM x 256 threads runs NTEAM consecutive 64 x 64 tiles of ONE problem side by side, one per team,
 // each over its whole K (all teams of a workgroup pass the same number of barriers: same problem, same K; a team beyond the
 // problem's last tile recomputes that tile without storing).  Workgroup pb -> problem by the prefix sums of ceil(take / NTEAM).
 constexpr int T_TEAM_LDS = lds_floats<1, 1, true, true>();
-template <int NTEAM>
+template <int NTEAM, bool RB>
 __device__ __forceinline__ void t_parked_tiles(const GemmGroup4& cg, int pb, float* __restrict__ lds) {
   int i = 0, w = pb;
   while (i + 1 < cg.nprob && w >= (cg.tile_take[i] + NTEAM - 1) / NTEAM) {
@@ -289,12 +291,13 @@ __device__ __forceinline__ void t_parked_tiles(const GemmGroup4& cg, int pb, flo
   const int zs = q / (tn * tm), r = q - zs * (tn * tm);
   const int bx = (tm < tn) ? r / tm : r % tn, by = (tm < tn) ? r % tm : r / tn;   // same tile list as gemm_group_block
   float* tl = lds + team * T_TEAM_LDS;
+  // (weight gradients: K-side problems, whose tile list does not depend on the row blocks)
   if (g.a_kc) {
     if (g.b_kc) gemm_body<1, 1, true, true, true>(g, tl, bx, by, zs, t, live);
     else gemm_body<1, 1, true, false, true>(g, tl, bx, by, zs, t, live);
   } else {
     if (g.b_kc) gemm_body<1, 1, false, true, true>(g, tl, bx, by, zs, t, live);
-    else gemm_body<1, 1, false, false, true>(g, tl, bx, by, zs, t, live);
+    else gemm_body<1, 1, false, false, true, GC_GEMM_EG, 0, EPI_ALL, PlainOperands, RB>(g, tl, bx, by, zs, t, live);
   }
 }
 
@@ -303,12 +306,15 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_bwd_kernel(const GcnCtx c,
   constexpr int W = GH / 16, NT = 4 * GH, P = GH + 4, NC = GH / 16, SP = 20;   // SP: row pitch of a [gh][16 k] weight stage
   __shared__ __attribute__((aligned(16))) float lds[t_bwd_lds<GH>()];
   static_assert(2 * GH * SP <= 64 * P, "weight stages live in the Pn image");
-  static_assert((W / 4 - 1) * 4096 <= 64 * P || W == 4, "dA exchange lives in the dM image");
+  static_assert(W <= 4 || (W / 4 - 1) * 4096 <= 64 * P, "dA exchange lives in the dM image");
   static_assert((GH / 64) * T_TEAM_LDS <= t_bwd_lds<GH>(), "parked tiles use the chain kernel's LDS");
+  constexpr int OBW = W >= 4 ? 1 : 4 / W;          // row blocks of dA per wave (fewer than four waves: several each)
+  constexpr int KS = GH >= 64 ? 4 : GH / 16;       // 16-deep k steps of a wave's k range (64 features, or all of a narrow sub-layer)
   if (blockIdx.x >= c.B * c.H) {
     int pb;
     if (spread_pick((int)blockIdx.x - c.B * c.H, c.carry, pb)) {  // passenger workgroup: GH / 64 tiles of a parked weight-gradient product
-      t_parked_tiles<GH / 64>(cg, pb, lds);
+      // (the host hands tiles to 256-thread teams only; a ragged launch -- !FULL -- may carry products on row blocks)
+      if constexpr (GH >= 64) t_parked_tiles<GH / 64, !FULL>(cg, pb, lds);
       return;
     }
     const EdgeRide& r = c.ride;  // passenger workgroup: one entity row of the riding dE broadcast
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_bwd_kernel(const GcnCtx c,
   float* __restrict__ Mg = c.dM + zoff;
   float* __restrict__ Qg = c.dP + zoff;
   const int col = 16 * w + j;
-  const int ob = w & 3, ks = w >> 2;       // dA: this wave's row block and k range
+  const int ob = w & 3, ks = w >> 2;       // dA: this wave's (first) row block and k range; further blocks: ob + W u
 
   {  // A_h^T image (zero beyond N), rinv
     const bool v4 = (N & 3) == 0;
@@ -361,9 +367,11 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_bwd_kernel(const GcnCtx c,
   for (int l = 0; l < L - 1; ++l)
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) Da[l][rb] = t4{0.f, 0.f, 0.f, 0.f};
-  t4 dacc[4];
+  t4 dacc[OBW][4];
 #pragma unroll
-  for (int jb = 0; jb < 4; ++jb) dacc[jb] = t4{0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < OBW; ++u)
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) dacc[u][jb] = t4{0.f, 0.f, 0.f, 0.f};
   constexpr int PV = (64 * (GH / 4)) / NT;  // 16-byte pieces of a 64 x gh image per thread (= 4)
   static_assert(PV * NT == 64 * (GH / 4), "image load mapping");
 
@@ -377,14 +385,14 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_bwd_kernel(const GcnCtx c,
       for (int v = 0; v < 4; ++v) {
         const int row = 16 * rb + 4 * g + v;
         const unsigned o = (unsigned)row * HD + (unsigned)(l * GH + col);
-        yv[rb][v] = row < N ? Yg[o] : 0.f;
-        dy[rb][v] = row < N ? Gy[o] : 0.f;
+        yv[rb][v] = (row < N && rb < nrb) ? Yg[o] : 0.f;      // (dYa's rows past the real entities' blocks may never have been written)
+        dy[rb][v] = (row < N && rb < nrb) ? Gy[o] : 0.f;
       }
     t4 pn[PV];
 #pragma unroll
     for (int u = 0; u < PV; ++u) {
       const int idx = t + NT * u, row = idx / (GH / 4), c4 = (idx - row * (GH / 4)) * 4;
-      pn[u] = row < N ? *reinterpret_cast<const t4*>(Pg + (unsigned)row * HD + (unsigned)(l * GH + c4)) : t4{0.f, 0.f, 0.f, 0.f};
+      pn[u] = (row < N && (row >> 4) < nrb) ? *reinterpret_cast<const t4*>(Pg + (unsigned)row * HD + (unsigned)(l * GH + c4)) : t4{0.f, 0.f, 0.f, 0.f};
     }
     // ---- through Y = relu(S), S = M rinv:  dS = dY [Y > 0];  dM = dS rinv;  drow -= rinv sum_c dS Y --------------------
     t4 dm[4];
@@ -452,16 +460,20 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_bwd_kernel(const GcnCtx c,
       gload(1, wr[1]);
     }
     // ---- dA += dM_l Pn_l^T: rows 16 ob .. + 15, k range [64 ks, 64 ks + 64) ------------------------------------------------
-    if (ob < nrb) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const t4 a = *reinterpret_cast<const t4*>(Ds + (16 * ob + j) * P + 64 * ks + 16 * s + 4 * g);
+    for (int u = 0; u < OBW; ++u) {
+      const int obu = ob + W * u;
+      if (obu < nrb) {
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb) {
-          if (jb < nrb) {
-            const t4 bq = *reinterpret_cast<const t4*>(Ps + (16 * jb + j) * P + 64 * ks + 16 * s + 4 * g);
+        for (int s = 0; s < KS; ++s) {
+          const t4 a = *reinterpret_cast<const t4*>(Ds + (16 * obu + j) * P + 64 * ks + 16 * s + 4 * g);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) dacc[jb] = mfma16(a[v], bq[v], dacc[jb]);
+          for (int jb = 0; jb < 4; ++jb) {
+            if (jb < nrb) {
+              const t4 bq = *reinterpret_cast<const t4*>(Ps + (16 * jb + j) * P + 64 * ks + 16 * s + 4 * g);
+#pragma unroll
+              for (int v = 0; v < 4; ++v) dacc[u][jb] = mfma16(a[v], bq[v], dacc[u][jb]);
+            }
           }
         }
       }
@@ -513,36 +525,39 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_bwd_kernel(const GcnCtx c,
   layer(std::integral_constant<int, 0>());
   // ---- dA = sum over the k ranges + drow (every column of a row); drow itself ---------------------------------------------
   t_barrier();   // sub-layer 0 is done with the images; Ts is final
-  if (ks > 0 && ob < nrb) {
+  if (ks > 0 && ob < nrb) {      // (only with more than four waves: OBW == 1)
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) Ds[((((ks - 1) * 4 + ob) * 4 + jb) * 4 + v) * 64 + lane] = dacc[jb][v];
+      for (int v = 0; v < 4; ++v) Ds[((((ks - 1) * 4 + ob) * 4 + jb) * 4 + v) * 64 + lane] = dacc[0][jb][v];
   }
   t_barrier();
-  if (ks == 0 && ob < nrb) {
-    float* __restrict__ dAg = c.dA + (long)z * N * N;
+  float* __restrict__ dAg = c.dA + (long)z * N * N;
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb)
+  for (int u = 0; u < OBW; ++u) {
+    const int obu = ob + W * u;
+    if (ks == 0 && obu < nrb) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int row = 16 * ob + 4 * g + v, cc = 16 * jb + j;
-        float s = dacc[jb][v];
+      for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
-        for (int k2 = 1; k2 < W / 4; ++k2) s += Ds[((((k2 - 1) * 4 + ob) * 4 + jb) * 4 + v) * 64 + lane];
-        if (row < N && cc < N) dAg[row * N + cc] = (jb < nrb ? s : 0.f) + Ts[row];
-      }
-  }
-  // rows of A beyond the real entities' blocks: dA = drow there (no product contributes), written by the wave that would own them
-  if (ks == 0 && ob >= nrb) {
-    float* __restrict__ dAg = c.dA + (long)z * N * N;
+        for (int v = 0; v < 4; ++v) {
+          const int row = 16 * obu + 4 * g + v, cc = 16 * jb + j;
+          float s = dacc[u][jb][v];
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb)
+          for (int k2 = 1; k2 < W / 4; ++k2) s += Ds[((((k2 - 1) * 4 + obu) * 4 + jb) * 4 + v) * 64 + lane];
+          if (row < N && cc < N) dAg[row * N + cc] = (jb < nrb ? s : 0.f) + Ts[row];
+        }
+    }
+    // rows of A beyond the real entities' blocks: dA = drow there (no product contributes), written by the wave that would own them
+    if (ks == 0 && obu >= nrb && obu < 4) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int row = 16 * ob + 4 * g + v, cc = 16 * jb + j;
-        if (row < N && cc < N) dAg[row * N + cc] = Ts[row];
-      }
+      for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int row = 16 * obu + 4 * g + v, cc = 16 * jb + j;
+          if (row < N && cc < N) dAg[row * N + cc] = Ts[row];
+        }
+    }
   }
   if (t < N) c.drow[(long)z * N + t] = Ts[t];
 }
@@ -564,7 +579,7 @@ static void launch_bwd(const GcnCtx& c, const GemmGroup4& cg, int npw, dim3 grid
 
 // (gh, L) pairs the templates are instantiated for: the reference's model (64, 2), cfg 2's width (128, 2), cfg 3 (192, 4),
 // and the neighbours a user is most likely to configure
-#define GC_CHAIN_T_SHAPES(X) X(64, 1) X(64, 2) X(64, 3) X(64, 4) X(128, 1) X(128, 2) X(128, 3) X(128, 4) X(192, 2) X(192, 4) X(256, 1) X(256, 2)
+#define GC_CHAIN_T_SHAPES(X) X(32, 2) X(32, 4) X(64, 1) X(64, 2) X(64, 3) X(64, 4) X(128, 1) X(128, 2) X(128, 3) X(128, 4) X(192, 2) X(192, 4) X(256, 1) X(256, 2)
 
 static int chain_t_waves(int gh) { return gh / 16; }
 
@@ -593,7 +608,8 @@ bool chain_t_ok(const GcnCtx& c, bool bwd) {
 bool chain_t_fwd_att_ok(const GcnCtx& c) {
   const int dh = c.D / c.H;
   const long room = 64L * (c.gh + 4) + 2L * (c.L - 1) * 16 * (c.gh + 4);
-  return c.N <= 64 && dh % 4 == 0 && (long)(mha_lds_bytes(dh) / sizeof(float)) <= room;
+  // (the core's body runs on the first four waves of the workgroup: widths of at least 64)
+  return c.N <= 64 && c.gh >= 64 && dh % 4 == 0 && (long)(mha_lds_bytes(dh) / sizeof(float)) <= room;
 }
 
 int gcn_chain_t_fwd(const GcnCtx& c, dim3 grid, double fl, hipStream_t st) {
@@ -616,11 +632,12 @@ int gcn_chain_t_bwd(const GcnCtx& c, double fl, hipStream_t st, DeferQueue* carr
   const int nteam = c.gh / 64;
   int npw = 0;
   const long idle = 256 - (long)c.B * c.H;
-  if (carry && carry->n > 0 && idle > 0 && option("chain_carry", 1) != 0) {
+  if (carry && carry->n > 0 && idle > 0 && nteam > 0 && option("chain_carry", 1) != 0) {   // (nteam == 0: a 128-thread workgroup hosts no tile team)
     bool ok = true;
     int kmax = 0;
     for (int i = 0; i < carry->n; ++i) {
       ok = ok && carry->p[i].K % BK == 0 && carry->p[i].splits <= 1;
+      ok = ok && !(carry->p[i].rb && (chain_t_full(c) || carry->p[i].rb_mode != 2));   // row-block products: the ragged instantiations only
       kmax = carry->p[i].K > kmax ? carry->p[i].K : kmax;
     }
     // A tile runs its whole K inside one workgroup (~1.1 us per 32-deep k-step, slower with several teams on the unit): it

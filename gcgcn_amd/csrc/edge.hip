@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64 * EW) void edge_bwd_kernel(const float* __restri
 // the rest are the entity rows.  The tiles go out in cohorts spread through the launch (Spread, common.hpp): every compute
 // unit then hosts rows AND a tile for most of the launch, where tiles-first order fills the chip with tiles alone for
 // ntile / 1024 rounds before the first row starts (cfg 5: 1.5 rounds, no overlap at all).
-template <int VEC, bool NTL>
+template <int VEC, bool NTL, bool RB>   // RB: a carried product runs on the row blocks of a ragged batch (GemmArgs::rb)
 __global__ __launch_bounds__(64 * EW) void edge_bwd_carry_kernel(const float* __restrict__ E, const float* __restrict__ v,
                                                                  const int* __restrict__ n_valid,
                                                                  const float* __restrict__ dlogit,
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64 * EW) void edge_bwd_carry_kernel(const float* __
   const int ntile = gg.tile_begin[gg.nprob];
   int r;
   if (spread_pick((int)blockIdx.x, sp, r)) {
-    gemm_group_block(gg, r, tile_lds);
+    gemm_group_block<RB>(gg, r, tile_lds);
     return;
   }
   const int ngat = gt.P ? gt.B * gt.slices : 0;
@@ -283,12 +283,14 @@ int edge_bwd(const float* E, const float* v, const int* n_valid, const float* dl
     const Spread sp = make_spread(ntile, (long)B * N + ngat, option("carry_cohort", 256),
                                   ntile >= option("carry_spread_min", 1024) ? option("carry_spread", 90) : 0);
     const double bytes = (dE ? 8.0 : 4.0) * B * N * N * D;
-    if (nt_e1())
-      GC_LAUNCH_TIMED("edge_bwd", bytes, (edge_bwd_carry_kernel<4, true>), grid, block, 0, st, E, v, n_valid, dlogit, dEbar, dE,
-                      dvpart, N, D, nt_store(), sp, gt, gg);
-    else
-      GC_LAUNCH_TIMED("edge_bwd", bytes, (edge_bwd_carry_kernel<4, false>), grid, block, 0, st, E, v, n_valid, dlogit, dEbar, dE,
-                      dvpart, N, D, nt_store(), sp, gt, gg);
+    bool any_rb = false;
+    for (int i = 0; i < gg.nprob; ++i) any_rb = any_rb || gg.p[i].rb != nullptr;
+#define GC_EDGE_CARRY(NT, RBV)                                                                                                  \
+  GC_LAUNCH_TIMED("edge_bwd", bytes, (edge_bwd_carry_kernel<4, NT, RBV>), grid, block, 0, st, E, v, n_valid, dlogit, dEbar, dE, \
+                  dvpart, N, D, nt_store(), sp, gt, gg)
+    if (nt_e1()) { if (any_rb) GC_EDGE_CARRY(true, true); else GC_EDGE_CARRY(true, false); }
+    else { if (any_rb) GC_EDGE_CARRY(false, true); else GC_EDGE_CARRY(false, false); }
+#undef GC_EDGE_CARRY
     return check_launch("edge_bwd_carry");
   }
   dim3 grid((unsigned)((long)B * N + ngat));

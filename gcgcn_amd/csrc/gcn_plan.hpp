@@ -146,10 +146,6 @@ __host__ __device__ inline GemmArgs plan_bwd_dY(const GcnCtx& c, int l) {
   return g;
 }
 
-// gemm.hip: one batched product with rows of an edge pass riding in the same launch
-bool gemm_ride_ok(const GemmArgs& g, const EdgeRide& r);
-int gemm_ride(const GemmArgs& g, const EdgeRide& r, int row0, int nrows, hipStream_t stream);
-
 // chain_t.hip: LDS-resident chain kernels for N <= 64 and the instantiated (gh, L) pairs
 bool chain_t_ok(const GcnCtx& c, bool bwd);
 bool chain_t_fwd_att_ok(const GcnCtx& c);

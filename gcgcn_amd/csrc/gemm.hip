@@ -25,50 +25,25 @@
 #include "edge_body.hpp"
 #include "gcn_plan.hpp"
 #include "gemm_body.hpp"
-#include "gemm_big.hpp"
 #include "mha_body.hpp"
 #include "rowops.hpp"
 
 namespace gc {
 
-// One batched product with an edge-tensor streaming pass riding in the SAME launch (graphs of more than 64 entities,
-// where a (doc, head) pair's working set does not fit a compute unit and the per-pair products are big enough -- 256 x 256
-// x 256 at cfg 5 -- to run as ordinary batched tile launches): `nrows` entity rows of the pass (EdgeRide, gcn_plan.hpp) are
-// spread EVENLY through the tile list, so the HBM-bound rows and the matrix-pipe-bound tiles share every compute unit for
-// the whole launch (4 workgroups per CU of either kind).  Behind the tiles they would only start once the tile list has
-// nearly drained.
-template <bool AKC, bool BKC>
-__global__ __launch_bounds__(256) void gemm_ride_kernel(const GemmArgs g, const EdgeRide r, int row0, int nrows, int tiles, int gx, int gy) {
-  __shared__ __attribute__((aligned(16))) float lds[lds_floats<1, 1, AKC, BKC>()];
-  const long x = blockIdx.x, total = gridDim.x;
-  const long before = x * nrows / total;                 // passenger workgroups among [0, x)
-  if ((x + 1) * nrows / total > before) {
-    const int row = row0 + (int)before;
-    if (r.kind == 1) edge_fwd_row<4, false, true, 4>(r.in, nullptr, r.n_valid, r.out, nullptr, nullptr, nullptr, Drop(), r.N, r.D, row, lds);
-    else edge_bcast_row<4, 4>(r.in, r.n_valid, r.out, r.N, r.D, 0, row);
-    return;
-  }
-  const int b = xcd_remap((int)(x - before), tiles);
-  gemm_body<1, 1, AKC, BKC, true>(g, lds, b % gx, (b / gx) % gy, b / (gx * gy));
-}
-
-template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED>
+template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED, bool RB = false>
 __global__ __launch_bounds__(256, (TM * TN == 4 ? 2 : 1)) void gemm_kernel(const GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float lds[lds_floats<TM, TN, AKC, BKC>()];
   const int gx = gridDim.x, gy = gridDim.y;
   const int nwg = gx * gy * gridDim.z;
-  const int b = xcd_remap(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), nwg);
-  gemm_body<TM, TN, AKC, BKC, ALIGNED>(g, lds, b % gx, (b / gx) % gy, b / (gx * gy));
-}
-
-// 128 x 128 tiles for big interior problems (gemm_big.hpp); two workgroups per compute unit
-template <bool AKC, bool BKC>
-__global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float lds[GB_LDS];
-  const int gx = gridDim.x, gy = gridDim.y;
-  const int nwg = gx * gy * gridDim.z;
-  const int b = xcd_remap(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), nwg);
-  gemm_big_body<AKC, BKC>(g, lds, b % gx, (b / gx) % gy, b / (gx * gy));
+  const int q = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  if (RB && g.rb && g.rb_mode == 1) {   // ragged batch: the live tile rows in XCD-balanced order, then the dead ones (gemm_body.hpp)
+    int bx, by, zs;
+    if (!tile_of_rows(g, q, gx, gy, bx, by, zs)) return;
+    gemm_body<TM, TN, AKC, BKC, ALIGNED, GC_GEMM_EG, 0, EPI_ALL, PlainOperands, RB>(g, lds, bx, by, zs);
+    return;
+  }
+  const int b = xcd_remap(q, nwg);
+  gemm_body<TM, TN, AKC, BKC, ALIGNED, GC_GEMM_EG, 0, EPI_ALL, PlainOperands, RB>(g, lds, b % gx, (b / gx) % gy, b / (gx * gy));
 }
 
 // Stage 1 of a riding column sum: workgroup cb sums one slice of rows for 64 columns (4 waves stride the rows,
@@ -139,6 +114,7 @@ __device__ __forceinline__ void group_tail(const GemmGroup& gg, const int idx, f
   col_ride_stage1(cr, idx, lds);
 }
 
+template <bool RB>
 __global__ __launch_bounds__(256, 4) void gemm_group_kernel(const GemmGroup gg) {
   __shared__ __attribute__((aligned(16))) float lds[lds_floats<1, 1, true, true>()];
   const int tiles = gg.tile_begin[gg.nprob];
@@ -146,11 +122,12 @@ __global__ __launch_bounds__(256, 4) void gemm_group_kernel(const GemmGroup gg) 
     group_tail(gg, blockIdx.x - tiles, lds);
     return;
   }
-  gemm_group_block(gg, blockIdx.x, lds);
+  gemm_group_block<RB>(gg, blockIdx.x, lds);
 }
 
 // The same launch with MultiHeadAttention's backward core aboard: mp.count (document, head) pairs spread EVENLY through the
 // tile list (behind the tiles they would start when the list has nearly drained and stretch the launch by their own latency).
+template <bool RB>
 __global__ __launch_bounds__(256, 4) void gemm_group_pass_kernel(const GemmGroup gg, const MhaPass mp) {
   __shared__ __attribute__((aligned(16))) float lds[lds_floats<1, 1, true, true>()];
   const int tiles = gg.tile_begin[gg.nprob], inter = tiles + mp.count;
@@ -164,7 +141,7 @@ __global__ __launch_bounds__(256, 4) void gemm_group_pass_kernel(const GemmGroup
     mha_core_bwd_body(lds, before, mp.Q, mp.P, mp.dA, mp.dQ, mp.N, mp.D, mp.H, mp.dh, mp.kchunk, mp.alpha, mp.drop);
     return;
   }
-  gemm_group_block(gg, x - before, lds);
+  gemm_group_block<RB>(gg, x - before, lds);
 }
 
 // Split-K reduce: one thread sums the partials of 4 consecutive outputs (16-byte loads, split order => bitwise
@@ -174,6 +151,26 @@ __device__ __forceinline__ void reduce4(const GemmArgs& g, int z, long idx4) {
   const long idx = idx4 * 4;
   if (idx >= mn) return;
   const long nb = (long)g.batch1 * g.batch2;
+  int row = (int)(idx / g.N);
+  const int col = (int)(idx - (long)row * g.N);
+  const int z1 = z / g.batch2, z2 = z - z1 * g.batch2;
+  if (g.rb && g.rb_mode == 1) {  // ragged batch: virtual row -> its place in the padded tensors; rows past the live blocks
+    const int bi = row >> 4;     // are zero-stored (outputs that leave the block) or left alone
+    const int prow = g.rb[bi] * 16 + (row & 15);
+    if (bi >= *g.rb_n) {
+      if (g.rb_zero) {
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        float* c = g.C + z1 * g.sC1 + z2 * g.sC2 + (long)prow * g.ldc + col;
+        c[0] = 0.f, c[1] = 0.f, c[2] = 0.f, c[3] = 0.f;
+        if (g.C2) {
+          float* c2 = g.C2 + z1 * g.sC21 + z2 * g.sC22 + (long)prow * g.ldc2 + col;
+          c2[0] = zero.x, c2[1] = zero.y, c2[2] = zero.z, c2[3] = zero.w;
+        }
+      }
+      return;
+    }
+    row = prow;
+  }
   const float4* w = reinterpret_cast<const float4*>(g.ws + (long)z * mn + idx);
   const long stride4 = nb * mn / 4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -181,8 +178,6 @@ __device__ __forceinline__ void reduce4(const GemmArgs& g, int z, long idx4) {
     const float4 v = w[(long)s * stride4];
     acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
   }
-  const int row = (int)(idx / g.N), col = (int)(idx - (long)row * g.N);
-  const int z1 = z / g.batch2, z2 = z - z1 * g.batch2;
   if (!(g.add || g.bias || g.rowadd || g.rowscale || g.relu || g.accumulate || g.n_valid || g.C2) && g.alpha == 1.f) {
     float* c = g.C + z1 * g.sC1 + z2 * g.sC2 + (long)row * g.ldc + col;
     if ((((uintptr_t)c) & 15) == 0) {
@@ -235,43 +230,26 @@ template <int TM, int TN, bool ALIGNED>
 static int launch(const GemmArgs& g, hipStream_t stream) {
   dim3 grid(cdiv(g.N, 64 * TN), cdiv(g.M, 64 * TM), g.batch1 * g.batch2 * g.splits), block(256);
   const double flops = 2.0 * g.M * g.N * g.K * g.batch1 * g.batch2;
+  if constexpr (ALIGNED) {
+    if (g.rb) {  // ragged batch: the instantiation with the row-block paths (prepare() kept rb only where they apply)
+      if (g.a_kc && !g.b_kc) GC_LAUNCH_TIMED(g.tag, flops, (gemm_kernel<TM, TN, true, false, true, true>), grid, block, 0, stream, g);
+      else if (g.a_kc && g.b_kc) GC_LAUNCH_TIMED(g.tag, flops, (gemm_kernel<TM, TN, true, true, true, true>), grid, block, 0, stream, g);
+      else GC_LAUNCH_TIMED(g.tag, flops, (gemm_kernel<TM, TN, false, false, true, true>), grid, block, 0, stream, g);
+      if (int e = check_launch("gemm")) return e;
+      if (g.splits > 1) {
+        ProfScope ps("gemm_splitk_reduce", stream);
+        dim3 rgrid(cdiv((long)g.M * g.N / 4, 256), g.batch1 * g.batch2);
+        hipLaunchKernelGGL(splitk_reduce_kernel, rgrid, dim3(256), 0, stream, g);
+        return check_launch("gemm_splitk_reduce");
+      }
+      return 0;
+    }
+  }
   if (g.a_kc && !g.b_kc) GC_LAUNCH_TIMED(g.tag, flops, (gemm_kernel<TM, TN, true, false, ALIGNED>), grid, block, 0, stream, g);
   else if (g.a_kc && g.b_kc) GC_LAUNCH_TIMED(g.tag, flops, (gemm_kernel<TM, TN, true, true, ALIGNED>), grid, block, 0, stream, g);
   else if (!g.a_kc && !g.b_kc) GC_LAUNCH_TIMED(g.tag, flops, (gemm_kernel<TM, TN, false, false, ALIGNED>), grid, block, 0, stream, g);
   else GC_LAUNCH_TIMED(g.tag, flops, (gemm_kernel<TM, TN, false, true, ALIGNED>), grid, block, 0, stream, g);
   if (int e = check_launch("gemm")) return e;
-  if (g.splits > 1) {
-    ProfScope ps("gemm_splitk_reduce", stream);
-    dim3 rgrid(cdiv((long)g.M * g.N / 4, 256), g.batch1 * g.batch2);
-    hipLaunchKernelGGL(splitk_reduce_kernel, rgrid, dim3(256), 0, stream, g);
-    return check_launch("gemm_splitk_reduce");
-  }
-  return 0;
-}
-
-bool gemm_big_ok(const GemmArgs& g) {
-  return g.vecA && g.vecB && g.M % 128 == 0 && g.N % 128 == 0 && g.ksplit % GB_BK == 0 && g.K % GB_BK == 0 &&
-         (g.splits == 1 || g.N % 4 == 0);
-}
-
-// option big_tiles: fewest 128 x 128 tiles of ONE unsplit problem for which it takes the gemm_big body by itself (0 = never,
-// the default: at cfg 5 the two forward projections that qualify at 2048 run 14 % faster alone and the step does not move,
-// 7.71 vs 7.75 ms -- out of the group launch they no longer share its tail with the other problems).
-// Two workgroups per compute unit = 512 slots: below a few full rounds the coarse tail costs more than the body gains
-// (2048 x 6144 x 768 = 768 tiles: 99 TF/s against 110-117 in 64 x 64 tiles; 8192 x 4096 x 512 = 2048 tiles: 128 against 112).
-static bool gemm_wants_big(const GemmArgs& g) {
-  const long min_tiles = option("big_tiles", 0);
-  return min_tiles > 0 && g.splits == 1 && gemm_big_ok(g) && (long)(g.M / 128) * (g.N / 128) * g.batch1 * g.batch2 >= min_tiles;
-}
-
-static int launch_big(const GemmArgs& g, hipStream_t stream) {
-  dim3 grid(g.N / 128, g.M / 128, g.batch1 * g.batch2 * g.splits), block(256);
-  const double flops = 2.0 * g.M * g.N * g.K * g.batch1 * g.batch2;
-  if (g.a_kc && !g.b_kc) GC_LAUNCH_TIMED(g.tag, flops, (gemm_big_kernel<true, false>), grid, block, 0, stream, g);
-  else if (g.a_kc && g.b_kc) GC_LAUNCH_TIMED(g.tag, flops, (gemm_big_kernel<true, true>), grid, block, 0, stream, g);
-  else if (!g.a_kc && !g.b_kc) GC_LAUNCH_TIMED(g.tag, flops, (gemm_big_kernel<false, false>), grid, block, 0, stream, g);
-  else GC_LAUNCH_TIMED(g.tag, flops, (gemm_big_kernel<false, true>), grid, block, 0, stream, g);
-  if (int e = check_launch("gemm_big")) return e;
   if (g.splits > 1) {
     ProfScope ps("gemm_splitk_reduce", stream);
     dim3 rgrid(cdiv((long)g.M * g.N / 4, 256), g.batch1 * g.batch2);
@@ -314,58 +292,35 @@ static int prepare(GemmArgs& g, int tile, int splits, long group_work) {
   g.vecB = aligned16(g.B) && g.ldb % 4 == 0 && g.sB1 % 4 == 0 && g.sB2 % 4 == 0;
   const long t64 = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * nb;
   (void)t64;
-  if (tile == 0) tile = 1;  // measured: 64x64 tiles beat 128x128 at every size up to 4096^3 (117 vs 104 TF/s)
-  if (splits == 0) splits = (tile == 2) ? 1 : pick_splits(g.K, group_work > 0 ? group_work : t64 * cdiv(g.K, BK));
+  tile = 1;  // measured: 64x64 tiles beat both 128x128 bodies on every product of this path (dropped experiments)
+  if (splits == 0) splits = pick_splits(g.K, group_work > 0 ? group_work : t64 * cdiv(g.K, BK));
   if (splits > 1 && (!g.ws || (long)splits * nb * g.M * g.N > g.ws_elems || g.K % (splits * BK) != 0 || g.N % 4 != 0 ||
                      (((uintptr_t)g.ws) & 15) != 0))
     splits = 1;
   g.splits = splits;
   g.ksplit = (splits > 1) ? g.K / splits : g.K;
+  if (g.rb) {  // row blocks of a ragged batch: only what the gathering tile body serves, anything else runs dense (equally correct)
+    const bool interior = g.vecA && g.vecB && g.M % 64 == 0 && g.N % 64 == 0 && g.K % BK == 0 && g.ksplit % BK == 0 && g.rb_n;
+    const bool ok = interior && ((g.rb_mode == 1 && g.a_kc && nb == 1) || (g.rb_mode == 2 && !g.a_kc && !g.b_kc && g.K % 64 == 0));
+    // M-side: a launch that does not fill the chip anyway gains nothing from skipping tiles and pays the list's lookups in
+    // its latency-bound prologue (128-tile output projection: 21 vs 16 us measured) -- dense below one tile per compute unit
+    // and slot (a problem inside a group launch shares the launch: group_work > 0 keeps it)
+    const bool small = g.rb_mode == 1 && group_work <= 0 && (long)cdiv(g.M, 64) * cdiv(g.N, 64) * splits <= 256;
+    if (!ok || small) g.rb = nullptr, g.rb_n = nullptr, g.rb_mode = 0, g.rb_zero = 0;
+  }
   return tile;
 }
 
 int gemm(const GemmArgs& g_in, hipStream_t stream, int tile, int splits) {
   GemmArgs g = g_in;
   if (g.M == 0 || g.N == 0) return 0;
-  const bool any_tile = tile == 0;
-  tile = prepare(g, tile, splits, 0);
-  if (tile < 0) return 1;
-  if (any_tile && gemm_wants_big(g)) tile = 3;
+  GC_REQUIRE(tile == 0 || tile == 1, "gemm: tile %d (64 x 64 tiles are the only body; 128 x 128 bodies lost every A/B on this path)", tile);
+  if (prepare(g, 1, splits, 0) < 0) return 1;
   const long nb = (long)g.batch1 * g.batch2;
   GC_REQUIRE(nb * g.splits <= 65535, "gemm: batch %ld x splits %d exceeds grid.z", nb, g.splits);
   GC_REQUIRE(cdiv(g.M, 64) <= 65535, "gemm: M %d exceeds grid.y", g.M);
-  if (tile == 3) {  // the 16x16x4 / ds_read_b128 body of gemm_big.hpp (interior problems only)
-    GC_REQUIRE(gemm_big_ok(g), "gemm: tile 3 needs M, N multiples of 128, K (and a split's share) of 32, 16-byte aligned rows");
-    return launch_big(g, stream);
-  }
-  const int bm = (tile == 2) ? 128 : 64;
-  const bool al = g.vecA && g.vecB && g.M % bm == 0 && g.N % bm == 0 && g.ksplit % BK == 0;
-  if (tile == 2) return al ? launch<2, 2, true>(g, stream) : launch<2, 2, false>(g, stream);
+  const bool al = g.vecA && g.vecB && g.M % 64 == 0 && g.N % 64 == 0 && g.ksplit % BK == 0;
   return al ? launch<1, 1, true>(g, stream) : launch<1, 1, false>(g, stream);
-}
-
-bool gemm_ride_ok(const GemmArgs& g, const EdgeRide& r) {
-  auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
-  return r.kind != 0 && r.D % 4 == 0 && al(r.in) && al(r.out) && 4L * r.D <= lds_floats<1, 1, true, true>() && g.M % 64 == 0 &&
-         g.N % 64 == 0 && g.K % BK == 0 && al(g.A) && al(g.B) && g.lda % 4 == 0 && g.ldb % 4 == 0 && g.sA1 % 4 == 0 && g.sA2 % 4 == 0 &&
-         g.sB1 % 4 == 0 && g.sB2 % 4 == 0;
-}
-
-// unsplit interior product + rows [row0, row0 + nrows) of the riding pass; gemm_ride_ok(g, r) must hold
-int gemm_ride(const GemmArgs& g_in, const EdgeRide& r, int row0, int nrows, hipStream_t stream) {
-  GemmArgs g = g_in;
-  if (prepare(g, 1, 1, 0) < 0) return 1;
-  GC_REQUIRE(gemm_ride_ok(g, r) && g.vecA && g.vecB && nrows >= 0, "gemm_ride: not an interior problem / bad passenger");
-  const int gx = g.N / 64, gy = g.M / 64;
-  const long tiles = (long)gx * gy * g.batch1 * g.batch2;
-  GC_REQUIRE(tiles + nrows <= 0x7fffffffL, "gemm_ride: grid too large");
-  const dim3 grid((unsigned)(tiles + nrows)), block(256);
-  const double flops = 2.0 * g.M * g.N * g.K * g.batch1 * g.batch2;
-  if (g.a_kc && !g.b_kc) GC_LAUNCH_TIMED(g.tag, flops, (gemm_ride_kernel<true, false>), grid, block, 0, stream, g, r, row0, nrows, (int)tiles, gx, gy);
-  else if (g.a_kc && g.b_kc) GC_LAUNCH_TIMED(g.tag, flops, (gemm_ride_kernel<true, true>), grid, block, 0, stream, g, r, row0, nrows, (int)tiles, gx, gy);
-  else if (!g.a_kc && !g.b_kc) GC_LAUNCH_TIMED(g.tag, flops, (gemm_ride_kernel<false, false>), grid, block, 0, stream, g, r, row0, nrows, (int)tiles, gx, gy);
-  else GC_LAUNCH_TIMED(g.tag, flops, (gemm_ride_kernel<false, true>), grid, block, 0, stream, g, r, row0, nrows, (int)tiles, gx, gy);
-  return check_launch("gemm_ride");
 }
 
 // Independent problems in one launch (plus at most one reduce launch).  Problems that are not interior
@@ -405,7 +360,7 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* 
   // pass 1: fix every problem's split factor and count its workgroups
   GemmArgs prep[64];
   long blocks[64];
-  bool groupable[64], big[64];
+  bool groupable[64];
   long total_blocks = 0;
   int ng = 0;
   for (int oi = 0; oi < n; ++oi) {
@@ -415,8 +370,7 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* 
     if (g.M == 0 || g.N == 0) continue;
     if (prepare(g, 1, 0, work) < 0) return 1;
     const bool al = g.vecA && g.vecB && g.M % 64 == 0 && g.N % 64 == 0 && g.ksplit % BK == 0;
-    big[oi] = gemm_wants_big(g);   // enough 128 x 128 tiles for several rounds by itself: its own launch (gemm_big.hpp)
-    groupable[oi] = al && !big[oi] && ng < GemmGroup::MAXP;
+    groupable[oi] = al && ng < GemmGroup::MAXP;
     if (groupable[oi]) {
       ++ng;
       blocks[oi] = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * g.batch1 * g.batch2 * g.splits;
@@ -437,7 +391,7 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* 
   // pass 2: peeled / ungroupable problems first (own launches), then the group
   for (int oi = 0; oi < n; ++oi) {
     if (groupable[oi] || probs[order[oi]].M == 0 || probs[order[oi]].N == 0) continue;
-    if (int e = gemm(probs[order[oi]], stream, big[oi] ? 3 : 0, big[oi] ? 1 : 0)) return e;
+    if (int e = gemm(probs[order[oi]], stream)) return e;
   }
   for (int oi = 0; oi < n; ++oi) {
     if (!groupable[oi]) continue;
@@ -487,10 +441,15 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* 
     gg.col = *col;
     col1 = cdiv(col->C, 256);
   }
-  if (mha && mha->count > 0)
-    GC_LAUNCH_TIMED("gemm_group", flops, gemm_group_pass_kernel, dim3(tiles + mha->count + col1), dim3(256), 0, stream, gg, *mha);
-  else
-    GC_LAUNCH_TIMED("gemm_group", flops, gemm_group_kernel, dim3(tiles + col1), dim3(256), 0, stream, gg);
+  bool any_rb = false;
+  for (int i = 0; i < gg.nprob; ++i) any_rb = any_rb || gg.p[i].rb != nullptr;
+  if (mha && mha->count > 0) {
+    if (any_rb) GC_LAUNCH_TIMED("gemm_group", flops, gemm_group_pass_kernel<true>, dim3(tiles + mha->count + col1), dim3(256), 0, stream, gg, *mha);
+    else GC_LAUNCH_TIMED("gemm_group", flops, gemm_group_pass_kernel<false>, dim3(tiles + mha->count + col1), dim3(256), 0, stream, gg, *mha);
+  } else {
+    if (any_rb) GC_LAUNCH_TIMED("gemm_group", flops, gemm_group_kernel<true>, dim3(tiles + col1), dim3(256), 0, stream, gg);
+    else GC_LAUNCH_TIMED("gemm_group", flops, gemm_group_kernel<false>, dim3(tiles + col1), dim3(256), 0, stream, gg);
+  }
   if (int e = check_launch("gemm_group")) return e;
   if (ride && !any_split && col_later) {  // nothing to reduce: the caller folds stage 2 into a kernel of its own
     *col_later = true;
@@ -677,9 +636,10 @@ int gemm_take_deferred_pairs(DeferQueue* q, GemmGroup4& gg, double* flops, long 
 }
 
 // tiles of parked problems, unsplit, as a launch of their own (what a carrying kernel would have run as passengers)
+template <bool RB>
 __global__ __launch_bounds__(256, 4) void gemm_parked_kernel(const GemmGroup gg) {
   __shared__ __attribute__((aligned(16))) float lds[lds_floats<1, 1, true, true>()];
-  gemm_group_block(gg, blockIdx.x, lds);
+  gemm_group_block<RB>(gg, blockIdx.x, lds);
 }
 
 int gemm_flush_deferred(DeferQueue* q, hipStream_t stream) {
@@ -691,7 +651,10 @@ int gemm_flush_deferred(DeferQueue* q, hipStream_t stream) {
       double fl = 0;
       const int wgs = gemm_take_deferred(q, gg, &fl);
       if (wgs > 0) {
-        GC_LAUNCH_TIMED("gemm_group", fl, gemm_parked_kernel, dim3(wgs), dim3(256), 0, stream, gg);
+        bool any_rb = false;
+        for (int i = 0; i < gg.nprob; ++i) any_rb = any_rb || gg.p[i].rb != nullptr;
+        if (any_rb) GC_LAUNCH_TIMED("gemm_group", fl, gemm_parked_kernel<true>, dim3(wgs), dim3(256), 0, stream, gg);
+        else GC_LAUNCH_TIMED("gemm_group", fl, gemm_parked_kernel<false>, dim3(wgs), dim3(256), 0, stream, gg);
         if (int e = check_launch("gemm_parked")) return e;
       }
       continue;

@@ -50,6 +50,19 @@ struct GemmArgs {
   const int* n_valid = nullptr;
   int nv_rows = 1, nv_zdoc = 0;
   const char* tag = "gemm_single";  // name seen by the per-kernel timer (gemm_kernel launches; groups: "gemm_group")
+  // Ragged batches: run on the entity rows that exist.  The [B N]-row tensors stay padded in memory; `rb` lists their 16-row
+  // blocks, LIVE blocks first (block r of document b is live iff 16 r < n_valid[b]), then the dead ones; *rb_n = number of
+  // live blocks (device).  Interior, 16-byte aligned problems only (the launcher drops rb otherwise: the dense product is
+  // equally correct, padding rows hold zeros).
+  //   rb_mode 1: M is the document-row dimension -- virtual row m of this problem is row rb[m / 16] * 16 + m % 16 of A
+  //              ([M][K], a_kc = 1) and of every row-indexed epilogue operand and output.  Tiles past the live blocks do no
+  //              arithmetic; they store zeros when rb_zero is set (outputs that leave the block: their padding rows must be
+  //              zero) and nothing otherwise (workspaces whose dead rows nobody reads).
+  //   rb_mode 2: K is the document-row dimension (weight gradients; both operands [K][.], a_kc = b_kc = 0): only the live
+  //              blocks are summed over.
+  const int* rb = nullptr;
+  const int* rb_n = nullptr;
+  int rb_mode = 0, rb_zero = 0;
   // split-K workspace (optional): partial sums [splits][batch][M][N]
   float* ws = nullptr;
   long ws_elems = 0;
@@ -58,7 +71,8 @@ struct GemmArgs {
   int splits = 1, ksplit = 0;
 };
 
-// Enqueue on `stream`.  tile: 0 = pick by residency, 1 = 64x64 block, 2 = 128x128 block.
+// Enqueue on `stream`.  tile: 0 or 1 = the 64x64 block body (the only one; the two 128x128 bodies of earlier rounds lost every
+// A/B on this path's products and are gone).
 // splits: 0 = pick (needs g.ws), 1 = none, n = split K n ways (partials in g.ws, then one
 // deterministic reduce + epilogue kernel).
 int gemm(const GemmArgs& g, hipStream_t stream, int tile = 0, int splits = 0);

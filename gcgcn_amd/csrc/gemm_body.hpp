@@ -99,6 +99,36 @@ struct TilePtr {
       r[q][0] = v.x, r[q][1] = v.y, r[q][2] = v.z, r[q][3] = v.w;
     }
   }
+  // ---- ragged batches (GemmArgs::rb): the document rows that exist, through the list of live 16-row blocks -------------
+  // rb_mode 1, KC operand [rows][k]: this thread's rows are fixed for the whole k-loop, so the list is read once, here.
+  // Blocks of the tile past the live ones (only the last live tile has any) read a live block instead: their results are
+  // never stored as computed.
+  __device__ __forceinline__ void init_rows(const float* __restrict__ src, long ld, int mn0, int t, const int* __restrict__ rb, int nl) {
+    static_assert(KC, "row-gathered operands are stored [rows][k]");
+#pragma unroll
+    for (int q = 0; q < BMN / 32; ++q) {
+      const int f = t + 256 * q, vr = mn0 + (f >> 3);
+      const int bid = rb[min(vr >> 4, nl - 1)];
+      p[q] = src + ((long)bid * 16 + (vr & 15)) * ld + ((f & 7) << 2);
+    }
+    kstep = 1;
+  }
+  // rb_mode 2, operand [k][cols] with k the document rows: a k-tile is BMN / 32 blocks of 16 rows; the thread keeps its row
+  // INSIDE a block and its columns, the block comes with every request (id[q]; -1: past the live blocks, contributes zeros).
+  __device__ __forceinline__ void init_k(const float* __restrict__ src, long ld, int mn0, int t) {
+    static_assert(!KC && BMN == 64, "k-gathered operands are stored [k][cols], 64 columns per tile");
+#pragma unroll
+    for (int q = 0; q < BMN / 32; ++q) p[q] = src + (long)(t >> 4) * ld + mn0 + ((t & 15) << 2);
+    kstep = ld;
+  }
+  __device__ __forceinline__ void load_k(float (&r)[BMN / 32][4], const int (&id)[2]) const {
+#pragma unroll
+    for (int q = 0; q < BMN / 32; ++q) {
+      float4 v = *reinterpret_cast<const float4*>(p[q] + (long)max(id[q], 0) * 16 * kstep);
+      if (id[q] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      r[q][0] = v.x, r[q][1] = v.y, r[q][2] = v.z, r[q][3] = v.w;
+    }
+  }
 };
 
 // How a tile body obtains its operands.  PlainOperands reads g.A / g.B; other policies (head.hip: operands that are
@@ -244,8 +274,12 @@ __device__ __forceinline__ void epi_store4(const GemmArgs& g, const Epi& e, int 
 // MASK: features the caller guarantees are present (no run-time test, no branch: the operand gathers of a row
 // group then really are one straight block of loads).  RT: features tested at run time.  Everything else is
 // compiled out.
+// rb0 / rb1: rows of the tile's first / second 16 rows in the output and in every row-indexed operand (dense: row0, row0 + 16;
+// ragged batches: the two row blocks' places in the padded tensors).  dead: bit h set = half h lies past the live row blocks:
+// it stores zeros (zero_dead) or nothing, and gathers nothing.
 template <bool ALIGNED, int EG, int MASK, int RT>
-__device__ __forceinline__ void epi_tile(const GemmArgs& g, const Epi& e, const int row0, const int col, const f32x16& acc) {
+__device__ __forceinline__ void epi_tile(const GemmArgs& g, const Epi& e, const int rb0, const int rb1, const int lh4, const int col,
+                                         const f32x16& acc, const int dead = 0, const bool zero_dead = false) {
   if (!ALIGNED && col >= g.N) return;
   const bool hadd = (MASK & EPI_ADD) || ((RT & EPI_ADD) && e.add);
   const bool hra = (MASK & EPI_ROWADD) || ((RT & EPI_ROWADD) && e.rowadd);
@@ -265,10 +299,11 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, const Epi& e, const 
 #pragma unroll
     for (int u = 0; u < EG; ++u) {
       const int r = q0 + u;
-      const unsigned row = (unsigned)(row0 + (r & 3) + 8 * (r >> 2));
-      ok[u] = ALIGNED || (int)row < g.M;
-      addv[u] = 0.f, accv[u] = 0.f, a2v[u] = 0.f, rsv[u] = 1.f, rav[u] = 0.f, pad[u] = false;
-      if (ok[u]) {
+      const unsigned row = (unsigned)((r < 8 ? rb0 : rb1) + lh4 + (r & 3) + 8 * ((r >> 2) & 1));
+      const bool dd = (dead >> (r >> 3)) & 1;
+      ok[u] = (ALIGNED || (int)row < g.M) && (!dd || zero_dead);
+      addv[u] = 0.f, accv[u] = 0.f, a2v[u] = 0.f, rsv[u] = 1.f, rav[u] = 0.f, pad[u] = dd;
+      if (ok[u] && !dd) {
         if (hadd) addv[u] = e.add[row * ldadd + (unsigned)col];
         if (hra) rav[u] = e.rowadd[row];
         if (hrs) rsv[u] = e.rowscale[row];
@@ -281,7 +316,7 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, const Epi& e, const 
     for (int u = 0; u < EG; ++u) {
       if (!ok[u]) continue;
       const int r = q0 + u;
-      const unsigned row = (unsigned)(row0 + (r & 3) + 8 * (r >> 2));
+      const unsigned row = (unsigned)((r < 8 ? rb0 : rb1) + lh4 + (r & 3) + 8 * ((r >> 2) & 1));
       float v = (alpha * acc[r] + addv[u] + bias + rav[u]) * rsv[u];
       if (hrelu) v = fmaxf(v, 0.f);
       v += accv[u];
@@ -295,7 +330,7 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, const Epi& e, const 
         for (int u = 0; u < EG; ++u) {
           if (!ok[u]) continue;
           const int r = q0 + u;
-          const unsigned o2 = (unsigned)(row0 + (r & 3) + 8 * (r >> 2)) * ldc2 + (unsigned)col;
+          const unsigned o2 = (unsigned)((r < 8 ? rb0 : rb1) + lh4 + (r & 3) + 8 * ((r >> 2) & 1)) * ldc2 + (unsigned)col;
           float w = (rng_u32(e.key, (uint64_t)(g.drop_base + e.offC2 + (long)o2)) >= g.drop.thresh) ? accv[u] * g.drop.scale : 0.f;
           w += a2v[u];
           e.C2[o2] = pad[u] ? 0.f : w;
@@ -305,7 +340,7 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, const Epi& e, const 
         for (int u = 0; u < EG; ++u) {
           if (!ok[u]) continue;
           const int r = q0 + u;
-          const unsigned o2 = (unsigned)(row0 + (r & 3) + 8 * (r >> 2)) * ldc2 + (unsigned)col;
+          const unsigned o2 = (unsigned)((r < 8 ? rb0 : rb1) + lh4 + (r & 3) + 8 * ((r >> 2) & 1)) * ldc2 + (unsigned)col;
           e.C2[o2] = pad[u] ? 0.f : accv[u] + a2v[u];
         }
       }
@@ -313,7 +348,10 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, const Epi& e, const 
   }
 }
 
-template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED, int EG = GC_GEMM_EG, int MASK = 0, int RT = EPI_ALL, class OPS = PlainOperands>
+// RB: the row-block paths of a ragged batch (GemmArgs::rb) are compiled in.  A separate instantiation, chosen by the launcher:
+// with them in every body the DENSE launches lost 3-9 % (cfg 2 / cfg 1: more registers, a longer prologue) -- A/B of round 4.
+template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED, int EG = GC_GEMM_EG, int MASK = 0, int RT = EPI_ALL, class OPS = PlainOperands,
+          bool RB = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__ lds, const int bx, const int by,
                                           const int zs, const int t = threadIdx.x, const bool do_store = true,
                                           const OPS& ops = OPS(), float* __restrict__ xchg = nullptr, const int role = 0) {
@@ -334,8 +372,21 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
   const int z = zs / g.splits, sp = zs - z * g.splits;
   const int z1 = z / g.batch2, z2 = z - z1 * g.batch2;
   const int m0 = by * BM, n0 = bx * BN;
-  const int kbeg = sp * g.ksplit;
-  const int kend = min(g.K, kbeg + g.ksplit);
+  constexpr bool FASTP = ALIGNED && std::is_same<OPS, PlainOperands>::value;
+  // ragged batches (GemmArgs::rb): the live 16-row blocks of the document-row dimension
+  const bool rbm = RB && FASTP && AKC && g.rb && g.rb_mode == 1;             // M = document rows: A rows gathered, C rows scattered
+  const bool rbk = RB && FASTP && !AKC && !BKC && g.rb && g.rb_mode == 2;    // K = document rows: both operands gathered
+  const int nl = (rbm || rbk) ? __builtin_amdgcn_readfirstlane(*g.rb_n) : 0;
+  int kbeg = sp * g.ksplit;
+  int kend = min(g.K, kbeg + g.ksplit);
+  if (rbk) {
+    // K = the live rows.  Every slice runs the SAME number of k-tiles (two tile teams of one workgroup share its barriers):
+    // ceil(k-tiles / splits), at least one; blocks past the live ones load zeros (ids() below), so a slice that reaches
+    // past the end -- or lies wholly behind it -- just adds zeros.
+    const int kt_all = (nl * 16 + BK - 1) / BK;
+    const int ks = max((kt_all + g.splits - 1) / g.splits, 1) * BK;
+    kbeg = sp * ks, kend = kbeg + ks;
+  }
 
   const float* __restrict__ A = g.A + z1 * g.sA1 + z2 * g.sA2;
   const float* __restrict__ B = g.B + z1 * g.sB1 + z2 * g.sB2;
@@ -357,29 +408,83 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
   // the float4 sets in scratch); the clamped extra loads re-read the last tile from L2 and are never consumed.
   float ra0[BM / 32][4], rb0[BN / 32][4], ra1[BM / 32][4], rb1[BN / 32][4];
   const int nk = (kend - kbeg + BK - 1) / BK;
+  // rb_mode 1: a tile whose rows all lie past the live blocks does no arithmetic: it stores zeros where the output leaves
+  // the block (rb_zero), nothing otherwise.  (Split problems: the reduce pass does the same per row, gemm.hip.)
+  if (rbm && (m0 >> 4) >= nl && !xchg) {
+    if (g.rb_zero && do_store && g.splits <= 1) {
+      const Epi e = make_epi(g, z1, z2);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int bi = (m0 >> 4) + 2 * (wr * TM + i);
+          epi_tile<ALIGNED, EG, MASK, RT>(g, e, g.rb[bi] * 16, g.rb[bi + 1] * 16, 4 * lh, n0 + (wc * TN + j) * 32 + l31, acc[i][j], 3, true);
+        }
+    }
+    return;
+  }
   auto kof = [&](int kt) { return kbeg + min(kt, nk - 1) * BK; };
-  constexpr bool FASTP = ALIGNED && std::is_same<OPS, PlainOperands>::value;
   TilePtr<BM, AKC> tpa;
   TilePtr<BN, BKC> tpb;
-  if (FASTP) tpa.init(A, g.lda, m0, t), tpb.init(B, g.ldb, n0, t);
-  auto load_a = [&](float (&r)[BM / 32][4], int k0) {
-    if constexpr (FASTP) tpa.load(r, k0);
-    else ops.template load_a<BM, AKC, ALIGNED>(r, g, A, m0, k0, kend, t);
+  if constexpr (FASTP) {
+    if constexpr (AKC) {
+      if (rbm) tpa.init_rows(A, g.lda, m0, t, g.rb, max(nl, 1));
+      else tpa.init(A, g.lda, m0, t);
+      tpb.init(B, g.ldb, n0, t);
+    } else if constexpr (!BKC && BM == 64 && BN == 64) {
+      if (rbk) tpa.init_k(A, g.lda, m0, t), tpb.init_k(B, g.ldb, n0, t);
+      else tpa.init(A, g.lda, m0, t), tpb.init(B, g.ldb, n0, t);
+    } else {
+      tpa.init(A, g.lda, m0, t), tpb.init(B, g.ldb, n0, t);
+    }
+  }
+  // rb_mode 2: the two 16-row blocks of a set's NEXT request, fetched one request ahead (scalar loads that have long
+  // landed when the request is issued: a request must not wait for its own addresses in the middle of a k-tile's MFMAs)
+  int id0[2] = {0, 0}, id1[2] = {0, 0};
+  auto ids = [&](int (&id)[2], int kt) {
+    // (wave-uniform by construction; readfirstlane makes the compiler see it, so these are scalar loads -- as vector loads
+    // their wait would also drain the operand requests in flight and take the two-tile prefetch apart)
+    const int bi = __builtin_amdgcn_readfirstlane(kof(kt) >> 4);
+    id[0] = bi < nl ? g.rb[bi] : -1;
+    id[1] = bi + 1 < nl ? g.rb[bi + 1] : -1;
   };
-  auto load_b = [&](float (&r)[BN / 32][4], int k0) {
-    if constexpr (FASTP) tpb.load(r, k0);
-    else ops.template load_b<BN, BKC, ALIGNED>(r, g, B, n0, k0, kend, t);
+  auto load_a = [&](float (&r)[BM / 32][4], int k0, const int (&id)[2]) {
+    if constexpr (FASTP) {
+      if constexpr (!AKC && !BKC && BM == 64 && BN == 64) {
+        if (rbk) tpa.load_k(r, id);
+        else tpa.load(r, k0);
+      } else {
+        tpa.load(r, k0);
+      }
+    } else {
+      ops.template load_a<BM, AKC, ALIGNED>(r, g, A, m0, k0, kend, t);
+    }
   };
-  load_a(ra0, kof(0));
-  load_b(rb0, kof(0));
-  load_a(ra1, kof(1));
-  load_b(rb1, kof(1));
+  auto load_b = [&](float (&r)[BN / 32][4], int k0, const int (&id)[2]) {
+    if constexpr (FASTP) {
+      if constexpr (!AKC && !BKC && BM == 64 && BN == 64) {
+        if (rbk) tpb.load_k(r, id);
+        else tpb.load(r, k0);
+      } else {
+        tpb.load(r, k0);
+      }
+    } else {
+      ops.template load_b<BN, BKC, ALIGNED>(r, g, B, n0, k0, kend, t);
+    }
+  };
+  if (rbk) ids(id0, 0), ids(id1, 1);
+  load_a(ra0, kof(0), id0);
+  load_b(rb0, kof(0), id0);
+  load_a(ra1, kof(1), id1);
+  load_b(rb1, kof(1), id1);
+  if (rbk) ids(id0, 2), ids(id1, 3);
   __builtin_amdgcn_sched_barrier(0);
   store_tile<BM, AKC>(ra0, lds, t);
   store_tile<BN, BKC>(rb0, lds + OFFB, t);
   __builtin_amdgcn_sched_barrier(0);
-  load_a(ra0, kof(2));
-  load_b(rb0, kof(2));
+  load_a(ra0, kof(2), id0);
+  load_b(rb0, kof(2), id0);
+  if (rbk) ids(id0, 4);
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
 
@@ -431,15 +536,17 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
     store_tile<BM, AKC>(ra1, lds + SA, t);
     store_tile<BN, BKC>(rb1, lds + OFFB + SB, t);
     __builtin_amdgcn_sched_barrier(0);
-    load_a(ra1, kof(kt + 3));
-    load_b(rb1, kof(kt + 3));
+    load_a(ra1, kof(kt + 3), id1);
+    load_b(rb1, kof(kt + 3), id1);
+    if (rbk) ids(id1, kt + 5);
   };
   auto stage0 = [&](int kt) {                     // tile kt + 2 -> stage 0, then request tile kt + 4
     store_tile<BM, AKC>(ra0, lds, t);
     store_tile<BN, BKC>(rb0, lds + OFFB, t);
     __builtin_amdgcn_sched_barrier(0);
-    load_a(ra0, kof(kt + 4));
-    load_b(rb0, kof(kt + 4));
+    load_a(ra0, kof(kt + 4), id0);
+    load_b(rb0, kof(kt + 4), id0);
+    if (rbk) ids(id0, kt + 6);
   };
   int kt = 0;
   for (; kt + 1 < nk; kt += 2) {                  // whole pairs: no branch inside, the two register sets never meet in a phi
@@ -485,21 +592,38 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
     return;
   }
   const Epi e = make_epi(g, z1, z2);
+  // rows of this wave's sub-tile(s) in the output: dense = the tile's own rows; rb_mode 1 = the two row blocks' places in
+  // the padded tensors (blocks past the live ones: zero-stored or skipped, see epi_tile)
+  auto rows_of = [&](const int i, int& r0, int& r1, int& dead) {
+    const int ms = m0 + (wr * TM + i) * 32;
+    r0 = ms, r1 = ms + 16, dead = 0;
+    if (rbm) {
+      const int bi = ms >> 4;
+      r0 = g.rb[bi] * 16, r1 = g.rb[bi + 1] * 16;
+      dead = (bi >= nl ? 1 : 0) | (bi + 1 >= nl ? 2 : 0);
+    }
+  };
   if (RT == EPI_ALL && !(g.add || g.bias || g.rowadd || g.rowscale || g.relu || g.accumulate || g.n_valid || g.C2) &&
       g.alpha == 1.f) {
     // the common case of the stand-alone kernels (weight / data gradients): a bare store
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+      int r0, r1, dead;
+      rows_of(i, r0, r1, dead);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        epi_tile<ALIGNED, EG, 0, 0>(g, e, m0 + (wr * TM + i) * 32 + 4 * lh, n0 + (wc * TN + j) * 32 + l31, acc[i][j]);
+        epi_tile<ALIGNED, EG, 0, 0>(g, e, r0, r1, 4 * lh, n0 + (wc * TN + j) * 32 + l31, acc[i][j], dead, g.rb_zero != 0);
+    }
     return;
   }
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TM; ++i) {
+    int r0, r1, dead;
+    rows_of(i, r0, r1, dead);
 #pragma unroll
     for (int j = 0; j < TN; ++j)
-      epi_tile<ALIGNED, EG, MASK, RT>(g, e, m0 + (wr * TM + i) * 32 + 4 * lh, n0 + (wc * TN + j) * 32 + l31, acc[i][j]);
+      epi_tile<ALIGNED, EG, MASK, RT>(g, e, r0, r1, 4 * lh, n0 + (wc * TN + j) * 32 + l31, acc[i][j], dead, g.rb_zero != 0);
+  }
 }
 
 // Workgroups are dealt round-robin over the 8 XCDs (ids b and b + 8 share an XCD and its 4 MiB L2).
@@ -514,25 +638,52 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 // Workgroup hb of a multi-problem launch (GemmGroup): find its problem by the prefix sums of (8-aligned) tile ranges,
 // remap inside the problem, run one interior 64x64 tile.  Shared by gemm_group_kernel and by kernels that carry
 // deferred problems as passengers (edge.hip).
-template <class G>
+// A problem's tile (bx, by, zs) for position q of its tile list (tn x tm tiles, zs slices; q < tn tm zs): the XCD-contiguous
+// order, the short side walked fastest -- the tiles that are neighbours in the list (and therefore on one XCD) then share BOTH
+// operand panels (weight gradients are [D x H*D] with K = B*N: 4 x 32 tiles, each reading two 512 KiB panels).
+__device__ __forceinline__ void tile_of(int q, const int count, const int tn, const int tm, int& bx, int& by, int& zs) {
+  q = xcd_remap(q, count);
+  zs = q / (tn * tm);
+  const int r = q - zs * (tn * tm);
+  bx = (tm < tn) ? r / tm : r % tn, by = (tm < tn) ? r % tm : r / tn;
+}
+// rb_mode 1 (ragged batch, M = document rows): only the first ceil(live blocks / 4) tile rows hold entities.  The list is
+// re-cut on the device: positions [0, live tiles) are the live tiles in the usual XCD-balanced order (leaving them where
+// they are would hand the XCDs that own the front of the list all the work), the positions behind them are the dead tile
+// rows -- zero-stored where the output leaves the block, left at once otherwise.  False: nothing to do for this position.
+__device__ __forceinline__ bool tile_of_rows(const GemmArgs& g, const int q, const int tn, const int tm, int& bx, int& by, int& zs) {
+  const int nl = __builtin_amdgcn_readfirstlane(*g.rb_n);
+  const int tml = min((nl + 3) >> 2, tm), live = tml * tn * g.splits;
+  if (q < live) {
+    tile_of(q, live, tn, tml, bx, by, zs);
+    return true;
+  }
+  if (!g.rb_zero || g.splits > 1) return false;     // (split problems: the reduce pass zero-stores the dead rows)
+  const int d = q - live;
+  by = tml + d / tn, bx = d - (d / tn) * tn, zs = 0;
+  return by < tm;
+}
+
+template <bool RB = false, class G>
 __device__ __forceinline__ void gemm_group_block(const G& gg, int hb, float* __restrict__ lds) {
   int i = 0;
   while (i + 1 < gg.nprob && hb >= gg.tile_begin[i + 1]) ++i;
   int b = hb - gg.tile_begin[i];
   if (b >= gg.tile_take[i]) return;
-  b = xcd_remap(b + gg.tile_first[i], gg.tile_count[i]);
   const GemmArgs& g = gg.p[i];
   const int tn = g.N >> 6, tm = g.M >> 6;
-  // walk the short side fastest: the tiles that are neighbours in the list (and therefore on one XCD) then share BOTH
-  // operand panels (weight gradients are [D x H*D] with K = B*N: 4 x 32 tiles, each reading two 512 KiB panels)
-  const int zs = b / (tn * tm), r = b - zs * (tn * tm);
-  const int bx = (tm < tn) ? r / tm : r % tn, by = (tm < tn) ? r % tm : r / tn;
-  if (g.a_kc) {
-    if (g.b_kc) gemm_body<1, 1, true, true, true>(g, lds, bx, by, zs);
-    else gemm_body<1, 1, true, false, true>(g, lds, bx, by, zs);
+  int bx, by, zs;
+  if (RB && g.rb && g.rb_mode == 1) {
+    if (!tile_of_rows(g, b + gg.tile_first[i], tn, tm, bx, by, zs)) return;
   } else {
-    if (g.b_kc) gemm_body<1, 1, false, true, true>(g, lds, bx, by, zs);
-    else gemm_body<1, 1, false, false, true>(g, lds, bx, by, zs);
+    tile_of(b + gg.tile_first[i], gg.tile_count[i], tn, tm, bx, by, zs);
+  }
+  if (g.a_kc) {
+    if (g.b_kc) gemm_body<1, 1, true, true, true, GC_GEMM_EG, 0, EPI_ALL, PlainOperands, RB>(g, lds, bx, by, zs);
+    else gemm_body<1, 1, true, false, true, GC_GEMM_EG, 0, EPI_ALL, PlainOperands, RB>(g, lds, bx, by, zs);
+  } else {
+    if (g.b_kc) gemm_body<1, 1, false, true, true, GC_GEMM_EG, 0, EPI_ALL, PlainOperands, RB>(g, lds, bx, by, zs);
+    else gemm_body<1, 1, false, false, true, GC_GEMM_EG, 0, EPI_ALL, PlainOperands, RB>(g, lds, bx, by, zs);
   }
 }
 

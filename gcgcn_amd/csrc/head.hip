@@ -124,6 +124,11 @@ struct Bil2 {
   const float* P; const float* Q; const float* W; const float* W2; const float* bias;
   float* C;
   int rows, nA, ncol, ldc, accumulate_unused;
+  // compacted pair rows (ragged batches, head_fwd / head_bwd): the number of rows lives on the device (workgroups past it exit
+  // at once), and output row r goes to row crow[r] of C (the pair's slot in the padded [B, N, N, .] tensor); NULL = dense
+  const int* rows_dev; const int* crow;
+  int sel_lo, sel_hi;   // with rows_dev: this launch runs only when sel_lo <= *rows_dev < sel_hi (two tile sizes are launched for a
+                        // device-side count; the one whose range does not hold the count leaves at once)
 };
 
 // position in the k-step sequence: for bc in 0..3: aa in 0..per_bc-1 (aa == nA: the Linear's et half, MODE 1), then tail steps
@@ -140,7 +145,9 @@ __global__ __launch_bounds__(256, 3) void head_bil2_kernel(const Bil2 a) {
   __shared__ __attribute__((aligned(16))) float lds[2 * SB];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1, l31 = lane & 31, lh = lane >> 5;
   const int m0 = blockIdx.x * 64;
-  const long row = min(m0 + wr * 32 + l31, a.rows - 1);   // this lane's A row (clamped: rows past the end are never stored)
+  const int nrows = a.rows_dev ? *a.rows_dev : a.rows;
+  if (m0 >= nrows || (a.rows_dev && (nrows < a.sel_lo || nrows >= a.sel_hi))) return;
+  const long row = min(m0 + wr * 32 + l31, nrows - 1);   // this lane's A row (clamped: rows past the end are never stored)
   const float* __restrict__ prow = a.P + row * HW;
   const float* __restrict__ qrow = a.Q + row * HW;
   const int per_bc = a.nA + (MODE == 1 ? 1 : 0), nsteps = 4 * per_bc + (MODE == 1 ? 4 : 0);
@@ -266,7 +273,7 @@ __global__ __launch_bounds__(256, 3) void head_bil2_kernel(const Bil2 a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const long rw = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (rw < a.rows) a.C[rw * a.ldc + col] = (j ? acc1[r] : acc0[r]) + bias;
+      if (rw < nrows) a.C[(a.crow ? (long)a.crow[rw] : rw) * a.ldc + col] = (j ? acc1[r] : acc0[r]) + bias;
     }
   }
 }
@@ -284,7 +291,9 @@ __global__ __launch_bounds__(256, 2) void head_bil3_kernel(const Bil2 a) {
   __shared__ __attribute__((aligned(16))) float lds[2 * SB];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, lh = lane >> 5;
   const int m0 = blockIdx.x * 128;
-  const long row = min(m0 + wave * 32 + l31, a.rows - 1);   // this lane's A row (clamped: rows past the end are never stored)
+  const int nrows = a.rows_dev ? *a.rows_dev : a.rows;
+  if (m0 >= nrows || (a.rows_dev && (nrows < a.sel_lo || nrows >= a.sel_hi))) return;
+  const long row = min(m0 + wave * 32 + l31, nrows - 1);   // this lane's A row (clamped: rows past the end are never stored)
   const float* __restrict__ prow = a.P + row * HW;
   const float* __restrict__ qrow = a.Q + row * HW;
   const int per_bc = a.nA + (MODE == 1 ? 1 : 0), nsteps = 4 * per_bc + (MODE == 1 ? 4 : 0);
@@ -417,12 +426,12 @@ __global__ __launch_bounds__(256, 2) void head_bil3_kernel(const Bil2 a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const long rw = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (rw < a.rows) a.C[rw * a.ldc + col] = (j == 0 ? acc0[r] : j == 1 ? acc1[r] : j == 2 ? acc2[r] : acc3[r]) + bias;
+      if (rw < nrows) a.C[(a.crow ? (long)a.crow[rw] : rw) * a.ldc + col] = (j == 0 ? acc0[r] : j == 1 ? acc1[r] : j == 2 ? acc2[r] : acc3[r]) + bias;
     }
   }
   if (MODE == 1 && a.ncol > 96 && lh == 0) {
     const long rw = m0 + wave * 32 + l31;
-    if (rw < a.rows) a.C[rw * a.ldc + 96] = a96 + (a.bias ? a.bias[96] : 0.f);
+    if (rw < nrows) a.C[(a.crow ? (long)a.crow[rw] : rw) * a.ldc + 96] = a96 + (a.bias ? a.bias[96] : 0.f);
   }
 }
 
@@ -437,6 +446,7 @@ struct HeadDw {
   const float* doutp; const float* EH; const float* ET;
   float* out;      // [splits][R][16384] partials, or dW_b itself when splits == 1
   long pairs; int R, ksteps_per_split;
+  const int* pairs_dev;   // compacted pair rows: K lives on the device (NULL = pairs); the split's share is derived from it
 };
 __global__ __launch_bounds__(256, 3) void head_dw_kernel(const HeadDw a) {
   constexpr int LA = 132;                        // A image [32 k][132]: dout[p, 0..127]
@@ -444,8 +454,10 @@ __global__ __launch_bounds__(256, 3) void head_dw_kernel(const HeadDw a) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, lh = lane >> 5;
   const int ca = blockIdx.x, sp = blockIdx.y;    // column tile = the index a; K split
   const int bcol = wave * 32 + l31;              // this lane's b
-  const long k_begin = (long)sp * a.ksteps_per_split * 32;
-  const long k_end = min(a.pairs, k_begin + (long)a.ksteps_per_split * 32);
+  const long npairs = a.pairs_dev ? (long)*a.pairs_dev : a.pairs;
+  const int kps = a.pairs_dev ? (int)((((npairs + 31) >> 5) + gridDim.y - 1) / gridDim.y) : a.ksteps_per_split;
+  const long k_begin = (long)sp * kps * 32;
+  const long k_end = min(npairs, k_begin + (long)kps * 32);
   const int nk = (int)((k_end - k_begin + 31) / 32);
   f32x16 acc0, acc1, acc2;
 #pragma unroll
@@ -459,14 +471,14 @@ __global__ __launch_bounds__(256, 3) void head_dw_kernel(const HeadDw a) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int idx = t + 256 * u, row = idx >> 5, c4 = idx & 31;
-      const long p = min(p0 + row, a.pairs - 1);
+      const long p = min(p0 + row, npairs - 1);
       float4 v = ld4(a.doutp + p * HW + c4 * 4);
       if (p0 + row >= k_end) v = make_float4(0.f, 0.f, 0.f, 0.f);   // past the split's end: contributes nothing
       ra[u] = v;
     }
-    if (t < 32) re = a.EH[min(p0 + t, a.pairs - 1) * HW + ca];
+    if (t < 32) re = a.EH[min(p0 + t, npairs - 1) * HW + ca];
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) rq[kk] = a.ET[min(p0 + 2 * kk + lh, a.pairs - 1) * HW + bcol];
+    for (int kk = 0; kk < 16; ++kk) rq[kk] = a.ET[min(p0 + 2 * kk + lh, npairs - 1) * HW + bcol];
   };
   auto sstore = [&](float* __restrict__ st) {
 #pragma unroll
@@ -533,25 +545,44 @@ static bool head_v1(long pairs) {
 // the forward pass's 128-pair tile with column 96 on the vector ALU (GCGCN_HEAD_BIL3=0 / set_option("head_bil3", 0): A/B knob)
 static bool head_bil3_ok(int ncol) { return option("head_bil3", 1) != 0 && ncol > 64 && ncol <= 97; }
 
+constexpr int HEAD_TILE128_MIN_ROWS = 32768;   // one 128-pair tile per compute unit (the rule head_v1 applies to host-side counts)
 static int head_bil2(int mode, const float* P, const float* Q, const float* W, const float* W2, const float* bias, float* C, long rows,
-                     int nA, int ncol, int ldc, hipStream_t st) {
+                     int nA, int ncol, int ldc, hipStream_t st, const int* rows_dev = nullptr, const int* crow = nullptr) {
   Bil2 a;
   a.P = P, a.Q = Q, a.W = W, a.W2 = W2, a.bias = bias, a.C = C, a.rows = (int)rows, a.nA = nA, a.ncol = ncol, a.ldc = ldc, a.accumulate_unused = 0;
-  const dim3 grid((unsigned)cdiv(rows, 64)), block(256);
+  a.rows_dev = rows_dev, a.crow = crow;   // (rows = the capacity the grid is sized for)
+  a.sel_lo = 0, a.sel_hi = 0x7fffffff;
+  const dim3 grid((unsigned)cdiv(rows, 64)), grid128((unsigned)cdiv(rows, 128)), block(256);
   const double flops = 2.0 * rows * ncol * (double)(nA * HW + (mode == 1 ? 2 * HW : 0));
-  if (mode == 1 && head_bil3_ok(ncol)) {  // 3 MFMA column blocks + column 96 on the vector ALU, 128 pairs per workgroup
-    GC_LAUNCH_TIMED("head_bilinear", flops, head_bil3_kernel<1>, dim3((unsigned)cdiv(rows, 128)), block, 0, st, a);
-    return check_launch("head_bil3");
-  }
   const bool wide = option("head_bil3_bwd", 1) != 0;
-  if (mode != 1 && wide && ncol == 128) {  // 128-pair tiles, four accumulators per wave
-    if (mode == 2) GC_LAUNCH_TIMED("head_bilinear", flops, head_bil3_kernel<2>, dim3((unsigned)cdiv(rows, 128)), block, 0, st, a);
-    else GC_LAUNCH_TIMED("head_bilinear", flops, head_bil3_kernel<3>, dim3((unsigned)cdiv(rows, 128)), block, 0, st, a);
+  const bool tile128 = (mode == 1 && head_bil3_ok(ncol)) || (mode != 1 && wide && ncol == 128);
+  auto launch128 = [&](const Bil2& b, const double flops) {   // 128 pairs per workgroup: 3 MFMA column blocks + column 96 on the vector ALU (mode 1), four accumulators (2 / 3)
+    if (mode == 1) GC_LAUNCH_TIMED("head_bilinear", flops, head_bil3_kernel<1>, grid128, block, 0, st, b);
+    else if (mode == 2) GC_LAUNCH_TIMED("head_bilinear", flops, head_bil3_kernel<2>, grid128, block, 0, st, b);
+    else GC_LAUNCH_TIMED("head_bilinear", flops, head_bil3_kernel<3>, grid128, block, 0, st, b);
+  };
+  auto launch64 = [&](const Bil2& b, const double flops) {
+    if (mode == 1) GC_LAUNCH_TIMED("head_bilinear", flops, (head_bil2_kernel<1>), grid, block, 0, st, b);
+    else if (mode == 2) GC_LAUNCH_TIMED("head_bilinear", flops, (head_bil2_kernel<2>), grid, block, 0, st, b);
+    else GC_LAUNCH_TIMED("head_bilinear", flops, (head_bil2_kernel<3>), grid, block, 0, st, b);
+  };
+  if (rows_dev && tile128) {
+    // The count is on the device, the better tile depends on it: 128-pair tiles (each generated operand value feeds 3-4 MFMAs)
+    // once there is a tile per compute unit, 64-pair tiles below that (a DocRED batch of 32 documents: 14 k real pairs = 109
+    // big tiles on 256 compute units: 4.14 ms per step against 3.39 with the small ones).  Both are launched; the one whose range
+    // does not hold the count leaves at once (a few microseconds of a millisecond-sized pass).
+    Bil2 big = a, small = a;
+    big.sel_lo = HEAD_TILE128_MIN_ROWS, small.sel_hi = HEAD_TILE128_MIN_ROWS;
+    launch128(big, 0.5 * flops);    // (the host-side work counter: one of the two runs, the timer sees both)
+    if (int e = check_launch("head_bil3")) return e;
+    launch64(small, 0.5 * flops);
+    return check_launch("head_bil2");
+  }
+  if (tile128) {
+    launch128(a, flops);
     return check_launch("head_bil3");
   }
-  if (mode == 1) GC_LAUNCH_TIMED("head_bilinear", flops, (head_bil2_kernel<1>), grid, block, 0, st, a);
-  else if (mode == 2) GC_LAUNCH_TIMED("head_bilinear", flops, (head_bil2_kernel<2>), grid, block, 0, st, a);
-  else GC_LAUNCH_TIMED("head_bilinear", flops, (head_bil2_kernel<3>), grid, block, 0, st, a);
+  launch64(a, flops);
   return check_launch("head_bil2");
 }
 
@@ -593,13 +624,73 @@ __global__ __launch_bounds__(256) void head_node_kernel(const float* __restrict_
   UT[e] = U[e] + Tt[ty * HW + c];
 }
 
+// ---- compacted pair rows for ragged batches ---------------------------------------------------------------------------
+// The reference runs the head on ONE unpadded document (glove:344-358: n x n pairs).  A padded batch has B N^2 pair slots of
+// which sum_b n_b^2 exist (a DocRED batch padded to 42 entities averages 20: a quarter); the bilinear passes -- 2 x 128 x 128 x
+// 97 flops per pair and pass -- run on the existing pairs only: row q = off[b] + i n_b + j of EH / ET / dout / dEH / dET is pair
+// (b, i, j), off = exclusive prefix sums of n_b^2.  idx = [count | - | off[0..B] | prow[capacity]], prow[q] = the pair's slot
+// b N^2 + i N + j in the padded tensors.  Everything stays on the device (no host read: capturable); the kernels below size
+// their grids for the capacity and leave at once past the count.
+__global__ __launch_bounds__(256) void head_index_kernel(const int* __restrict__ n_valid, int B, int N, int* __restrict__ idx) {
+  __shared__ int part[256];
+  // exclusive scan of n_b^2 over B documents: thread t owns documents [t chunk, (t + 1) chunk)
+  const int t = threadIdx.x, chunk = (B + 255) / 256;
+  int s = 0;
+  for (int b = t * chunk; b < min(B, (t + 1) * chunk); ++b) {
+    const int nv = min(max(n_valid[b], 0), N);
+    s += nv * nv;
+  }
+  part[t] = s;
+  __syncthreads();
+  if (t == 0) {
+    int run = 0;
+    for (int k = 0; k < 256; ++k) {
+      const int v = part[k];
+      part[k] = run;
+      run += v;
+    }
+    idx[0] = run, idx[1] = 0;
+  }
+  __syncthreads();
+  int run = part[t];
+  for (int b = t * chunk; b < min(B, (t + 1) * chunk); ++b) {
+    idx[2 + b] = run;
+    const int nv = min(max(n_valid[b], 0), N);
+    run += nv * nv;
+    if (b == B - 1) idx[2 + B] = run;
+  }
+}
+__global__ __launch_bounds__(256) void head_prow_kernel(const int* __restrict__ n_valid, const int* __restrict__ off,
+                                                        int* __restrict__ prow, long pairs, int N) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= pairs) return;
+  const long b = p / ((long)N * N);
+  const int ij = (int)(p - b * N * N), i = ij / N, j = ij - i * N, nv = min(max(n_valid[b], 0), N);
+  if (i < nv && j < nv) prow[off[b] + i * nv + j] = (int)p;
+}
+
 // ---- eh[p] = tanh(UT[b, j] + Rt[dis_plus + rel[p]]),  et[p] = tanh(UT[b, i] + Rt[dis_plus - rel[p]])   (one wave per pair)
+// cnt / prow != NULL: compacted rows -- row q holds pair prow[q]; rows [count, roundup128(count)) are zero (the tile kernels
+// clamp their reads to the last row, the K-side products read up to the next multiple of 64)
 __global__ __launch_bounds__(256) void head_feat_fwd_kernel(const float* __restrict__ UT, const float* __restrict__ Rt,
                                                             const long long* __restrict__ rel, float* __restrict__ EH,
-                                                            float* __restrict__ ET, long pairs, int N, int dis_plus, int ND) {
-  const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (p >= pairs) return;
+                                                            float* __restrict__ ET, long pairs, int N, int dis_plus, int ND,
+                                                            const int* __restrict__ cnt, const int* __restrict__ prow) {
+  const long q = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
+  long p = q;
+  if (cnt) {
+    const long n = *cnt;
+    if (q >= ((n + 127) & ~127L)) return;
+    if (q >= n) {
+      *reinterpret_cast<float2*>(EH + q * HW + 2 * lane) = make_float2(0.f, 0.f);
+      *reinterpret_cast<float2*>(ET + q * HW + 2 * lane) = make_float2(0.f, 0.f);
+      return;
+    }
+    p = prow[q];
+  } else if (q >= pairs) {
+    return;
+  }
   const long b = p / ((long)N * N);
   const int ij = (int)(p - b * N * N), i = ij / N, j = ij - i * N;
   const int d = (int)rel[p];
@@ -608,19 +699,23 @@ __global__ __launch_bounds__(256) void head_feat_fwd_kernel(const float* __restr
   const float2 ui = *reinterpret_cast<const float2*>(UT + (b * N + i) * HW + 2 * lane);
   const float2 rh = *reinterpret_cast<const float2*>(Rt + (long)kh * HW + 2 * lane);
   const float2 rt = *reinterpret_cast<const float2*>(Rt + (long)kt * HW + 2 * lane);
-  *reinterpret_cast<float2*>(EH + p * HW + 2 * lane) = make_float2(tanhf(uj.x + rh.x), tanhf(uj.y + rh.y));
-  *reinterpret_cast<float2*>(ET + p * HW + 2 * lane) = make_float2(tanhf(ui.x + rt.x), tanhf(ui.y + rt.y));
+  *reinterpret_cast<float2*>(EH + q * HW + 2 * lane) = make_float2(tanhf(uj.x + rh.x), tanhf(uj.y + rh.y));
+  *reinterpret_cast<float2*>(ET + q * HW + 2 * lane) = make_float2(tanhf(ui.x + rt.x), tanhf(ui.y + rt.y));
 }
 
 // ---- doutp[p, 0..127] = dout[p, 0..R) (zero padding), pairs of padding entities zeroed ---------------------------------
+// cnt / prow != NULL: compacted rows -- doutp[q] = dout[prow[q]] for q < count, zero up to the capacity (`pairs` rows)
 __global__ __launch_bounds__(256) void head_pad_kernel(const float* __restrict__ dout, const int* __restrict__ n_valid,
-                                                       float* __restrict__ doutp, long pairs, int N, int R) {
+                                                       float* __restrict__ doutp, long pairs, int N, int R,
+                                                       const int* __restrict__ cnt, const int* __restrict__ prow) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= pairs * HW) return;
   const long p = e / HW;
   const int c = (int)(e - p * HW);
   float v = 0.f;
-  if (c < R) {
+  if (cnt) {
+    if (c < R && p < *cnt) v = dout[(long)prow[p] * R + c];
+  } else if (c < R) {
     bool ok = true;
     if (n_valid) {
       const long b = p / ((long)N * N);
@@ -634,9 +729,10 @@ __global__ __launch_bounds__(256) void head_pad_kernel(const float* __restrict__
 
 // ---- through the tanh, in place: dEH <- dEH (1 - eh^2), dET <- dET (1 - et^2) -----------------------------------------
 __global__ __launch_bounds__(256) void head_tanh_bwd_kernel(const float* __restrict__ EH, const float* __restrict__ ET,
-                                                            float* __restrict__ dEH, float* __restrict__ dET, long n4) {
+                                                            float* __restrict__ dEH, float* __restrict__ dET, long n4,
+                                                            const int* __restrict__ cnt) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= n4) return;
+  if (e >= n4 || (cnt && e >= (long)*cnt * (HW / 4))) return;
   const float4 h = ld4(EH + 4 * e), t = ld4(ET + 4 * e);
   float4 a = ld4(dEH + 4 * e), b = ld4(dET + 4 * e);
   a.x *= 1.f - h.x * h.x, a.y *= 1.f - h.y * h.y, a.z *= 1.f - h.z * h.z, a.w *= 1.f - h.w * h.w;
@@ -646,19 +742,33 @@ __global__ __launch_bounds__(256) void head_tanh_bwd_kernel(const float* __restr
 }
 
 // ---- dUT[b, n, :] = sum_i dEH[b, i, n, :] + sum_j dET[b, n, j, :]   (one workgroup per entity, rows in order) ----------
+// off != NULL: compacted rows -- pair (b, i, j) is row off[b] + i n_b + j; padding entities get zero
 __global__ __launch_bounds__(256) void head_node_bwd_kernel(const float* __restrict__ dEH, const float* __restrict__ dET,
-                                                            float* __restrict__ dUT, int N) {
+                                                            float* __restrict__ dUT, int N, const int* __restrict__ off,
+                                                            const int* __restrict__ n_valid) {
   __shared__ float red[2][HW];
   const long bn = blockIdx.x;
   const long b = bn / N;
   const int n = (int)(bn - b * N);
   const int c = threadIdx.x & (HW - 1), half = threadIdx.x >> 7;   // 2 x 128 threads: half 0 sums the head side, half 1 the tail side
   float a = 0.f;
-  const long base = b * N * N;
-  if (half == 0) {
-    for (int i = 0; i < N; ++i) a += dEH[(base + (long)i * N + n) * HW + c];
+  if (off) {
+    const int nv = min(max(n_valid[b], 0), N);
+    const long base = off[b];
+    if (n < nv) {
+      if (half == 0) {
+        for (int i = 0; i < nv; ++i) a += dEH[(base + (long)i * nv + n) * HW + c];
+      } else {
+        for (int j = 0; j < nv; ++j) a += dET[(base + (long)n * nv + j) * HW + c];
+      }
+    }
   } else {
-    for (int j = 0; j < N; ++j) a += dET[(base + (long)n * N + j) * HW + c];
+    const long base = b * N * N;
+    if (half == 0) {
+      for (int i = 0; i < N; ++i) a += dEH[(base + (long)i * N + n) * HW + c];
+    } else {
+      for (int j = 0; j < N; ++j) a += dET[(base + (long)n * N + j) * HW + c];
+    }
   }
   red[half][c] = a;
   __syncthreads();
@@ -668,15 +778,23 @@ __global__ __launch_bounds__(256) void head_node_bwd_kernel(const float* __restr
 // ---- partial gradient of a gathered table: part[b, k, :] = sum over the items of document b whose id == k --------------
 //   rel mode : items = pairs, two contributions per pair (dEH at dis_plus + rel, dET at dis_plus - rel); grid (B, ND)
 //   type mode: items = entities (X2 == nullptr), ids = type; grid (B, 7)
+//   off / prow != NULL (rel mode): compacted rows -- the document's items are rows [off[b], off[b + 1]), their ids at prow[row]
 __global__ __launch_bounds__(256) void head_table_bwd_kernel(const long long* __restrict__ ids, const float* __restrict__ X1,
                                                              const float* __restrict__ X2, float* __restrict__ part, long per_doc,
-                                                             int dis_plus, int nk) {
+                                                             int dis_plus, int nk, const int* __restrict__ off,
+                                                             const int* __restrict__ prow) {
   __shared__ float red[2][HW];
   const int b = blockIdx.x, k = blockIdx.y;
   const int c = threadIdx.x & (HW - 1), half = threadIdx.x >> 7;
   const float* X = half ? X2 : X1;
   float a = 0.f;
-  if (X) {
+  if (X && off) {
+    for (long q = off[b]; q < off[b + 1]; ++q) {
+      const int d = (int)ids[prow[q]];
+      const int id = half ? dis_plus - d : dis_plus + d;
+      if (min(max(id, 0), nk - 1) == k) a += X[q * HW + c];
+    }
+  } else if (X) {
     const long base = (long)b * per_doc;
     for (long q = 0; q < per_doc; ++q) {
       const int d = (int)ids[base + q];
@@ -715,7 +833,19 @@ struct HeadBufs {
   float *U, *Tt, *Rt, *UT, *bsum, *EH, *ET;                                  // forward (EH / ET saved for backward)
   float *doutp, *dEH, *dET, *dUT, *partR, *partT, *dRt, *dTt, *dW, *scratch;  // backward
   long scratch_elems;
+  int* idx;   // compacted pair rows of a ragged batch: [count | - | off[0..B] | prow[B N^2]] (head_index_kernel); NULL = dense
 };
+static long head_idx_ints(int B, int N) { return ((2 + (long)B + 1 + 3) & ~3L) + (long)B * N * N; }
+static const int* idx_cnt(const HeadBufs& w) { return w.idx; }
+static const int* idx_off(const HeadBufs& w) { return w.idx ? w.idx + 2 : nullptr; }
+static int* idx_prow(const HeadBufs& w, int B) { return w.idx ? w.idx + ((2 + (long)B + 1 + 3) & ~3L) : nullptr; }
+
+// option head_compact (default 1): ragged batches run the pair passes on the pairs that exist (compacted rows).  Served by the
+// register-generated kernels with the relation count just past 96 (the reference's 97; head_bil3 / head_dw); anything else keeps
+// the dense path, which computes every pair slot of the padded batch.
+static bool head_compacts(const int* n_valid, int R) {
+  return n_valid && option("head_compact", 1) != 0 && R > 64 && R <= 97;
+}
 
 static int small_gemm(const float* A, long lda, int a_kc, const float* B, long ldb, int b_kc, float* C, long ldc, int M, int N, int K,
                       const float* bias, int accumulate, float* ws, long wse, hipStream_t st) {
@@ -727,11 +857,13 @@ static int small_gemm(const float* A, long lda, int a_kc, const float* B, long l
 }
 
 int head_fwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int dis_plus, const float* const* feats, const long long* type,
-             const long long* rel, const float* ner_emb, const float* dis_table, const float* flat, HeadBufs w, float* logits,
-             hipStream_t st) {
+             const long long* rel, const float* ner_emb, const float* dis_table, const int* n_valid, const float* flat, HeadBufs w,
+             float* logits, hipStream_t st) {
   const HeadLayout y = head_layout(Hd, nf, Pt, Pr, R);
   const long BN = (long)B * N, pairs = BN * N;
   GC_REQUIRE(pairs < (1L << 31) / 2 && R >= 1 && R <= HW, "head: %ld pairs / %d relations out of range", pairs, R);
+  const bool compact = head_compacts(n_valid, R);
+  GC_REQUIRE(!compact || w.idx, "head_fwd: n_valid given without the index workspace");
   for (int k = 0; k < nf; ++k)  // U = sum_k feats_k W_k^T + b           (glove:354-355, the entity part of the dense layer)
     GC_TRY(small_gemm(feats[k], Hd, 1, flat + y.Wd + (long)k * Hd, y.Fin, 1, w.U, HW, (int)BN, HW, Hd, k == 0 ? flat + y.bd : nullptr,
                       k > 0, nullptr, 0, st));
@@ -742,8 +874,20 @@ int head_fwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int di
     hipLaunchKernelGGL(head_node_kernel, dim3(cdiv(BN * HW, 256)), dim3(256), 0, st, w.U, w.Tt, type, w.UT, BN, flat + y.bb, flat + y.bc,
                        w.bsum, R);
     GC_TRY(check_launch("head_node"));
-    hipLaunchKernelGGL(head_feat_fwd_kernel, dim3(cdiv(pairs, 4)), dim3(256), 0, st, w.UT, w.Rt, rel, w.EH, w.ET, pairs, N, dis_plus, ND);
+    if (compact) {   // which pairs exist, and where their rows go
+      hipLaunchKernelGGL(head_index_kernel, dim3(1), dim3(256), 0, st, n_valid, B, N, w.idx);
+      GC_TRY(check_launch("head_index"));
+      hipLaunchKernelGGL(head_prow_kernel, dim3(cdiv(pairs, 256)), dim3(256), 0, st, n_valid, idx_off(w), idx_prow(w, B), pairs, N);
+      GC_TRY(check_launch("head_prow"));
+    }
+    const long frows = compact ? ((pairs + 127) & ~127L) : pairs;
+    hipLaunchKernelGGL(head_feat_fwd_kernel, dim3(cdiv(frows, 4)), dim3(256), 0, st, w.UT, w.Rt, rel, w.EH, w.ET, pairs, N, dis_plus, ND,
+                       compact ? idx_cnt(w) : nullptr, compact ? idx_prow(w, B) : nullptr);
     GC_TRY(check_launch("head_feat_fwd"));
+  }
+  if (compact) {   // the pairs that exist, scattered into the padded tensor; every other slot is zero
+    GC_REQUIRE(hipMemsetAsync(logits, 0, sizeof(float) * pairs * R, st) == hipSuccess, "head: memset failed");
+    return head_bil2(1, w.EH, w.ET, flat + y.Wb, flat + y.Wc, w.bsum, logits, pairs, HW, R, R, st, idx_cnt(w), idx_prow(w, B));
   }
   GemmArgs g;   // logits = [eh (x) et | eh | et] [W_b ; W_c]^T + (b_b + b_c)                     (glove:358)
   g.A = w.EH, g.B = flat + y.Wb, g.C = logits, g.ldc = R;
@@ -763,11 +907,28 @@ int head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int di
   const long BN = (long)B * N, pairs = BN * N;
   float* ws = w.scratch;
   const long wse = w.scratch_elems;
+  // ragged batch: the rows of EH / ET (written by head_fwd), dout, dEH, dET are the pairs that exist, compacted (head_fwd built
+  // the index); their count is on the device
+  const bool compact = head_compacts(n_valid, R);
+  GC_REQUIRE(!compact || w.idx, "head_bwd: n_valid given without the index workspace");
+  const int* cnt = compact ? idx_cnt(w) : nullptr;
+  const int* prow = compact ? idx_prow(w, B) : nullptr;
   {
     ProfScope ps("head_feat", st);
-    hipLaunchKernelGGL(head_pad_kernel, dim3(cdiv(pairs * HW, 256)), dim3(256), 0, st, dlogits, n_valid, w.doutp, pairs, N, R);
+    const long prows = compact ? ((pairs + 127) & ~127L) : pairs;   // compacted: zero up to the last row any tile or k-step reads
+    hipLaunchKernelGGL(head_pad_kernel, dim3(cdiv(prows * HW, 256)), dim3(256), 0, st, dlogits, n_valid, w.doutp, prows, N, R, cnt, prow);
     GC_TRY(check_launch("head_pad"));
   }
+  // (products over the pair rows: M or K = the device-side count on the compacted path)
+  auto rows_gemm = [&](const float* A, long lda, int a_kc, const float* Bm, long ldb, int b_kc, float* C, long ldc, int M, int Nn, int K,
+                       int accumulate, int dyn) -> int {
+    if (!compact) return small_gemm(A, lda, a_kc, Bm, ldb, b_kc, C, ldc, M, Nn, K, nullptr, accumulate, dyn == 2 ? ws : nullptr, dyn == 2 ? wse : 0, st);
+    GemmArgs g;
+    g.A = A, g.lda = lda, g.a_kc = a_kc, g.B = Bm, g.ldb = ldb, g.b_kc = b_kc, g.C = C, g.ldc = ldc;
+    g.M = M, g.N = Nn, g.K = K, g.accumulate = accumulate, g.ws = ws, g.ws_elems = wse;
+    g.tag = "head_gemm";
+    return gemm_dyn(g, cnt, dyn, pairs, st);
+  };
   // bias gradients: both biases see the column sums of dlogits
   GC_TRY(colsum(w.doutp, nullptr, w.dW, pairs, R, HW, 1, 0, 0, 0, 0, ws, st));
   GC_REQUIRE(hipMemcpyAsync(dflat + y.bb, w.dW, sizeof(float) * R, hipMemcpyDeviceToDevice, st) == hipSuccess, "head: copy failed");
@@ -779,17 +940,17 @@ int head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int di
     GemmArgs g;
     g.A = w.doutp, g.B = flat + y.Wb, g.C = w.dEH, g.ldc = HW, g.M = (int)pairs, g.N = HW, g.K = R * HW;
     o.P = w.doutp, o.Q = w.ET;
-    if (!head_v1(pairs)) GC_TRY(head_bil2(2, w.doutp, w.ET, flat + y.Wb, nullptr, nullptr, w.dEH, pairs, R, HW, HW, st));
+    if (compact || !head_v1(pairs)) GC_TRY(head_bil2(2, w.doutp, w.ET, flat + y.Wb, nullptr, nullptr, w.dEH, pairs, R, HW, HW, st, cnt));
     else GC_TRY(head_gemm(2, g, o, st));
-    GC_TRY(small_gemm(w.doutp, HW, 1, flat + y.Wc, 2 * HW, 0, w.dEH, HW, (int)pairs, HW, HW, nullptr, 1, nullptr, 0, st));
+    GC_TRY(rows_gemm(w.doutp, HW, 1, flat + y.Wc, 2 * HW, 0, w.dEH, HW, (int)pairs, HW, HW, 1, 1));
   }
   {  // d et = sum_(r,a) dout[p,r] eh[p,a] W_b[r,a,b]  + dout W_c[:, 128:]
     GemmArgs g;
     g.A = w.doutp, g.B = flat + y.Wb, g.C = w.dET, g.ldc = HW, g.M = (int)pairs, g.N = HW, g.K = R * HW;
     o.P = w.doutp, o.Q = w.EH;
-    if (!head_v1(pairs)) GC_TRY(head_bil2(3, w.doutp, w.EH, flat + y.Wb, nullptr, nullptr, w.dET, pairs, R, HW, HW, st));
+    if (compact || !head_v1(pairs)) GC_TRY(head_bil2(3, w.doutp, w.EH, flat + y.Wb, nullptr, nullptr, w.dET, pairs, R, HW, HW, st, cnt));
     else GC_TRY(head_gemm(3, g, o, st));
-    GC_TRY(small_gemm(w.doutp, HW, 1, flat + y.Wc + HW, 2 * HW, 0, w.dET, HW, (int)pairs, HW, HW, nullptr, 1, nullptr, 0, st));
+    GC_TRY(rows_gemm(w.doutp, HW, 1, flat + y.Wc + HW, 2 * HW, 0, w.dET, HW, (int)pairs, HW, HW, 1, 1));
   }
   {  // d W_b[r, (a, b)] = sum_p dout[p, r] eh[p, a] et[p, b]
     GemmArgs g;
@@ -797,12 +958,13 @@ int head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int di
     g.ws = ws, g.ws_elems = wse;
     o.P = w.EH, o.Q = w.ET, o.KB = 0;
     const bool dw3 = option("head_dw3", 1) != 0;
-    if (dw3 && R > 64 && R <= 97 && !head_v1(pairs)) {  // all R rows per workgroup, row 96 on the vector ALU (head_dw_kernel)
+    if (compact || (dw3 && R > 64 && R <= 97 && !head_v1(pairs))) {  // all R rows per workgroup, row 96 on the vector ALU (head_dw_kernel)
       const long ksteps = cdiv(pairs, 32);
       int splits = 1;
       while (splits < 16 && (long)HW * splits < 2048 && ksteps / (splits * 2) >= 64 && (long)(splits * 2) * R * HW * HW <= wse) splits *= 2;
       HeadDw d;
       d.doutp = w.doutp, d.EH = w.EH, d.ET = w.ET, d.pairs = pairs, d.R = R, d.ksteps_per_split = (int)cdiv(ksteps, splits);
+      d.pairs_dev = cnt;   // compacted: K = the device-side count (the split factor stays the capacity's)
       d.out = splits > 1 ? ws : dflat + y.Wb;
       GC_LAUNCH_TIMED("head_bilinear", 2.0 * R * HW * HW * (double)pairs, head_dw_kernel, dim3(HW, splits), dim3(256), 0, st, d);
       GC_TRY(check_launch("head_dw"));
@@ -815,20 +977,23 @@ int head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int di
     }
   }
   // d W_c = dout^T [eh | et]    (computed 128 rows deep into a workspace, the R real rows copied out)
-  GC_TRY(small_gemm(w.doutp, HW, 0, w.EH, HW, 0, w.dW, 2 * HW, HW, HW, (int)pairs, nullptr, 0, ws, wse, st));
-  GC_TRY(small_gemm(w.doutp, HW, 0, w.ET, HW, 0, w.dW + HW, 2 * HW, HW, HW, (int)pairs, nullptr, 0, ws, wse, st));
+  GC_TRY(rows_gemm(w.doutp, HW, 0, w.EH, HW, 0, w.dW, 2 * HW, HW, HW, (int)pairs, 0, 2));
+  GC_TRY(rows_gemm(w.doutp, HW, 0, w.ET, HW, 0, w.dW + HW, 2 * HW, HW, HW, (int)pairs, 0, 2));
   GC_REQUIRE(hipMemcpyAsync(dflat + y.Wc, w.dW, sizeof(float) * R * 2 * HW, hipMemcpyDeviceToDevice, st) == hipSuccess, "head: copy failed");
   {
     ProfScope ps("head_feat", st);
-    hipLaunchKernelGGL(head_tanh_bwd_kernel, dim3(cdiv(pairs * HW / 4, 256)), dim3(256), 0, st, w.EH, w.ET, w.dEH, w.dET, pairs * HW / 4);
+    hipLaunchKernelGGL(head_tanh_bwd_kernel, dim3(cdiv(pairs * HW / 4, 256)), dim3(256), 0, st, w.EH, w.ET, w.dEH, w.dET, pairs * HW / 4, cnt);
     GC_TRY(check_launch("head_tanh_bwd"));
-    hipLaunchKernelGGL(head_node_bwd_kernel, dim3((unsigned)BN), dim3(256), 0, st, w.dEH, w.dET, w.dUT, N);
+    hipLaunchKernelGGL(head_node_bwd_kernel, dim3((unsigned)BN), dim3(256), 0, st, w.dEH, w.dET, w.dUT, N, compact ? idx_off(w) : nullptr,
+                       n_valid);
     GC_TRY(check_launch("head_node_bwd"));
-    hipLaunchKernelGGL(head_table_bwd_kernel, dim3(B, ND), dim3(256), 0, st, rel, w.dEH, w.dET, w.partR, (long)N * N, dis_plus, ND);
+    hipLaunchKernelGGL(head_table_bwd_kernel, dim3(B, ND), dim3(256), 0, st, rel, w.dEH, w.dET, w.partR, (long)N * N, dis_plus, ND,
+                       compact ? idx_off(w) : nullptr, prow);
     GC_TRY(check_launch("head_table_bwd/rel"));
     hipLaunchKernelGGL(head_table_fin_kernel, dim3(cdiv((long)ND * HW, 256)), dim3(256), 0, st, w.partR, w.dRt, B, ND * HW);
     GC_TRY(check_launch("head_table_fin/rel"));
-    hipLaunchKernelGGL(head_table_bwd_kernel, dim3(B, 7), dim3(256), 0, st, type, w.dUT, (const float*)nullptr, w.partT, (long)N, 0, 7);
+    hipLaunchKernelGGL(head_table_bwd_kernel, dim3(B, 7), dim3(256), 0, st, type, w.dUT, (const float*)nullptr, w.partT, (long)N, 0, 7,
+                       (const int*)nullptr, (const int*)nullptr);
     GC_TRY(check_launch("head_table_bwd/type"));
     hipLaunchKernelGGL(head_table_fin_kernel, dim3(cdiv(7L * HW, 256)), dim3(256), 0, st, w.partT, w.dTt, B, 7 * HW);
     GC_TRY(check_launch("head_table_fin/type"));
@@ -849,7 +1014,8 @@ int head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int di
 }
 
 static HeadBufs head_bind(float* fwd, float* bwd, int B, int N, int R, int ND, long* n_fwd, long* n_bwd) {
-  const long BN = (long)B * N, pairs = BN * N;
+  const long BN = (long)B * N, pairs = (BN * N + 127) & ~127L;   // pair rows: a whole number of 128-row tiles (compacted rows are
+                                                                // zero-filled / read that far)
   HeadBufs w;
   memset(&w, 0, sizeof(w));
   float* base = fwd;
@@ -884,34 +1050,38 @@ int gcgcn_head_layout(int Hd, int nf, int Pt, int Pr, int R, int64_t* o) {
   return 0;
 }
 
-int gcgcn_head_sizes(int B, int N, int R, int ND, int64_t* out2) {
-  GC_REQUIRE(B > 0 && N > 0 && R > 0 && R <= HW && ND > 0 && out2, "head_sizes: bad arguments");
+int gcgcn_head_sizes(int B, int N, int R, int ND, int64_t* out3) {
+  GC_REQUIRE(B > 0 && N > 0 && R > 0 && R <= HW && ND > 0 && out3, "head_sizes: bad arguments");
   long a = 0, b = 0;
   head_bind(nullptr, nullptr, B, N, R, ND, &a, &b);
-  out2[0] = a, out2[1] = b;
+  out3[0] = a, out3[1] = b, out3[2] = head_idx_ints(B, N);
   return 0;
 }
 
 int gcgcn_head_fwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int dis_plus, const float* const* feats,
                    const int64_t* node_type, const int64_t* node_relative_pos, const float* ner_emb, const float* dis_table,
-                   const float* flat, float* fbuf, float* logits, void* stream) {
+                   const int32_t* n_valid, const float* flat, float* fbuf, int32_t* ibuf, float* logits, void* stream) {
   GC_REQUIRE(B > 0 && N > 0 && Hd > 0 && nf > 0 && nf <= 8 && Pt > 0 && Pr > 0 && R > 0 && ND > 0, "head_fwd: bad shape");
   GC_REQUIRE(Hd % 4 == 0 && Pt % 4 == 0 && Pr % 4 == 0, "head_fwd: feature widths must be multiples of 4 (16-byte rows)");
   GC_REQUIRE(feats && node_type && node_relative_pos && ner_emb && dis_table && flat && fbuf && logits, "head_fwd: null pointer");
-  const HeadBufs w = head_bind(fbuf, nullptr, B, N, R, ND, nullptr, nullptr);
+  GC_REQUIRE(!n_valid || ibuf, "head_fwd: n_valid given without ibuf");
+  HeadBufs w = head_bind(fbuf, nullptr, B, N, R, ND, nullptr, nullptr);
+  w.idx = ibuf;
   return head_fwd(B, N, Hd, nf, Pt, Pr, R, ND, dis_plus, feats, (const long long*)node_type, (const long long*)node_relative_pos, ner_emb,
-                  dis_table, flat, w, logits, (hipStream_t)stream);
+                  dis_table, n_valid, flat, w, logits, (hipStream_t)stream);
 }
 
 int gcgcn_head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int dis_plus, const float* const* feats,
                    const int64_t* node_type, const int64_t* node_relative_pos, const float* ner_emb, const float* dis_table,
-                   const int32_t* n_valid, const float* flat, float* fbuf, float* bbuf, const float* dlogits, float* const* dfeats,
-                   float* dner_emb, float* ddis_table, float* dflat, void* stream) {
+                   const int32_t* n_valid, const float* flat, float* fbuf, int32_t* ibuf, float* bbuf, const float* dlogits,
+                   float* const* dfeats, float* dner_emb, float* ddis_table, float* dflat, void* stream) {
   GC_REQUIRE(B > 0 && N > 0 && Hd > 0 && nf > 0 && nf <= 8 && Pt > 0 && Pr > 0 && R > 0 && ND > 0, "head_bwd: bad shape");
   GC_REQUIRE(feats && node_type && node_relative_pos && ner_emb && dis_table && flat && fbuf && bbuf && dlogits && dfeats && dner_emb &&
                  ddis_table && dflat,
              "head_bwd: null pointer");
-  const HeadBufs w = head_bind(fbuf, bbuf, B, N, R, ND, nullptr, nullptr);
+  GC_REQUIRE(!n_valid || ibuf, "head_bwd: n_valid given without ibuf");
+  HeadBufs w = head_bind(fbuf, bbuf, B, N, R, ND, nullptr, nullptr);
+  w.idx = ibuf;
   return head_bwd(B, N, Hd, nf, Pt, Pr, R, ND, dis_plus, feats, (const long long*)node_type, (const long long*)node_relative_pos, ner_emb,
                   dis_table, n_valid, flat, w, dlogits, dfeats, dner_emb, ddis_table, dflat, (hipStream_t)stream);
 }

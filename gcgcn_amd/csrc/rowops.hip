@@ -542,6 +542,43 @@ __global__ __launch_bounds__(256) void mask_rows_kernel(const float* __restrict_
 // =============================================================================================
 // launchers
 // =============================================================================================
+// ---- row blocks of a ragged batch ----------------------------------------------------------------------------------------
+// One workgroup: per-document live-block counts, exclusive scans over the documents (live and dead lists), then every
+// document writes its blocks.  B N / 16 is a few hundred entries; this is launch latency, nothing else.
+__global__ __launch_bounds__(256) void row_blocks_kernel(const int* __restrict__ n_valid, int B, int N, int* __restrict__ out) {
+  __shared__ int part[256];
+  const int t = threadIdx.x, chunk = (B + 255) / 256, per = N / 16;
+  int s = 0;
+  for (int b = t * chunk; b < min(B, (t + 1) * chunk); ++b) s += (min(max(n_valid[b], 0), N) + 15) >> 4;
+  part[t] = s;
+  __syncthreads();
+  if (t == 0) {
+    int run = 0;
+    for (int k = 0; k < 256; ++k) {
+      const int v = part[k];
+      part[k] = run;
+      run += v;
+    }
+    out[0] = run, out[1] = 0, out[2] = 0, out[3] = 0;
+  }
+  __syncthreads();
+  const int total_live = out[0];
+  int live_at = part[t];
+  for (int b = t * chunk; b < min(B, (t + 1) * chunk); ++b) {
+    const int nl = (min(max(n_valid[b], 0), N) + 15) >> 4;
+    int dead_at = total_live + b * per - live_at;      // dead blocks of the documents before b: b per - live_at
+    for (int r = 0; r < per; ++r) {
+      if (r < nl) out[ROWBLK_HDR + live_at++] = b * per + r;
+      else out[ROWBLK_HDR + dead_at++] = b * per + r;
+    }
+  }
+}
+int row_blocks(const int* n_valid, int B, int N, int* out, hipStream_t st) {
+  GC_REQUIRE(n_valid && out && B > 0 && N > 0 && N % 16 == 0, "row_blocks: needs n_valid and N a multiple of 16 (N = %d)", N);
+  hipLaunchKernelGGL(row_blocks_kernel, dim3(1), dim3(256), 0, st, n_valid, B, N, out);
+  return check_launch("row_blocks");
+}
+
 int softmax_fwd(const float* S, const float* coladd, const int* n_valid, float* P, float* A, long rows, int N, int heads,
                 Drop drop, hipStream_t st) {
   if (rows == 0) return 0;

@@ -44,6 +44,11 @@ int edge_bwd(const float* E, const float* v, const int* n_valid, const float* dl
              float* dvpart, int B, int N, int D, hipStream_t st, DeferQueue* carry = nullptr, const GatTail* tail = nullptr);
 int edge_bcast(const float* dEbar, const int* n_valid, float* dE, int B, int N, int D, hipStream_t st);
 
+// Row blocks of a ragged batch (GemmArgs::rb): out = [live count | 0 | 0 | 0 | block list], the list = all B N / 16 blocks of
+// 16 entity rows, the LIVE ones first (block r of document b is live iff 16 r < n_valid[b]), each group in ascending order.
+int row_blocks(const int* n_valid, int B, int N, int* out, hipStream_t st);
+constexpr int ROWBLK_HDR = 4;
+
 // mha_core.hip: fused attention core of MultiHeadAttention for N <= 64
 bool mha_core_ok(int N, int D, int H, const void* Q, const void* dQ);
 int mha_core_fwd(const float* Q, const int* n_valid, float* P, float* A, int B, int N, int D, int H, float alpha, Drop drop,

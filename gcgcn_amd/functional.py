@@ -56,6 +56,26 @@ def _nv(n_valid: Optional[Tensor], B: int, N: int, dev) -> Optional[Tensor]:
     return nv
 
 
+# ---- ragged batches: the entity rows that exist ------------------------------------------------------------------------
+# With n_valid the node-phase products of a block (X WnX, Ebar We, the output projection, every data and weight gradient) run
+# on the LIVE 16-row blocks of the [B N]-row tensors only (block r of document b is live iff 16 r < n_valid[b]); the tensors
+# stay padded in memory, so nothing else changes.  The list is built on the device from n_valid (one tiny launch, no host
+# read, captured with the step) once per hop loop and handed to every block call.  N must be a multiple of 16; the blocks fall
+# back to the dense products by themselves where the column-strip chain kernels do not serve the shape.
+row_block_launches = os.environ.get("GCGCN_ROW_BLOCKS", "1") != "0"      # GCGCN_ROW_BLOCKS=0: A/B knob (every padded row computed)
+
+
+def row_blocks(n_valid: Optional[Tensor], B: int, N: int) -> Optional[Tensor]:
+    """int32[4 + B N / 16] for gcgcn_gcn_fwd / _bwd / gcgcn_mha_fwd / _bwd (``rowblk``), or None (dense products)."""
+    # (N = 16 is one block per document: nothing to skip but whole empty documents, and the list's lookups cost cfg 1 10 %)
+    if n_valid is None or not row_block_launches or N % 16 != 0 or N < 32 or not n_valid.is_cuda:
+        return None
+    nv = n_valid.to(dtype=torch.int32).contiguous()
+    out = torch.empty(4 + B * N // 16, dtype=torch.int32, device=nv.device)
+    call("gcgcn_row_blocks", B, N, _p(nv), _p(out), _stream())
+    return out
+
+
 # ---- dropout RNG state -----------------------------------------------------------------------------
 # One generator per DEVICE, like torch's own default CUDA generator behind nn.Dropout (which the reference uses): a
 # device-resident {seed, counter} pair advanced by the kernels themselves.  This is the one piece of process-wide state of the
@@ -220,7 +240,7 @@ class MhaFn(torch.autograd.Function):
     is the alias of X described at GatFn."""
 
     @staticmethod
-    def forward(ctx, x, flat, n_valid, H, p, snap):
+    def forward(ctx, x, flat, n_valid, H, p, snap, rowblk=None):
         B, N, D = x.shape
         dev = x.device
         Q = torch.empty(B, N, D, device=dev)
@@ -228,9 +248,9 @@ class MhaFn(torch.autograd.Function):
         A = torch.empty(B, H, N, N, device=dev) if snap is not None else None
         scratch = torch.empty(max(_lib.lib().gcgcn_mha_scratch(B, N, D), 1), device=dev)
         call("gcgcn_mha_fwd", B, N, D, H, _p(x), _p(n_valid), _p(flat), _p(snap), float(p), _p(Q), _p(P), _p(A),
-             _p(scratch), _stream())
+             _p(scratch), _p(rowblk), _stream())
         ctx.save_for_backward(x, flat, Q, P)
-        ctx.H, ctx.p, ctx.snap = H, float(p), snap
+        ctx.H, ctx.p, ctx.snap, ctx.rowblk = H, float(p), snap, rowblk
         ctx.flat_leaf = flat if (flat.is_leaf and not _under_ddp()) else None
         return (P if A is None else A), x.view_as(x)
 
@@ -250,11 +270,11 @@ class MhaFn(torch.autograd.Function):
         # longer side with the two convolutions' products (0.652 vs 0.648 ms) -- so it stays with its own group launch
         bp = _pass_for_parking(ctx, 1) if defer_mha_weight_grads else None
         call("gcgcn_mha_bwd", B, N, D, H, _p(x), _p(flat), _p(ctx.snap), ctx.p, _p(Q), _p(P), _p(dA), _p(dXin), _p(dX),
-             _p(dflat), _p(dS), _p(dQ), _p(scratch), None if bp is None else bp.queue, 0, _stream())
+             _p(dflat), _p(dS), _p(dQ), _p(scratch), None if bp is None else bp.queue, 0, _p(ctx.rowblk), _stream())
         if bp is not None:
-            bp.park(ctx.flat_leaf, dflat, (x, dQ))
+            bp.park(ctx.flat_leaf, dflat, (x, dQ, ctx.rowblk))
             dflat = None                                # installed as .grad by the pass's end-of-backward callback
-        return dX, dflat, None, None, None, None
+        return dX, dflat, None, None, None, None, None
 
 
 # ---- deferred weight gradients ---------------------------------------------------------------------------------
@@ -394,7 +414,7 @@ class GcnFn(torch.autograd.Function):
     latency-bound chain launch, and so does its backward."""
 
     @staticmethod
-    def forward(ctx, x, ebar, adj, flat, n_valid, L, H, p, snap, e_next, out_p, out_snap):
+    def forward(ctx, x, ebar, adj, flat, n_valid, L, H, p, snap, e_next, out_p, out_snap, rowblk=None):
         B, N, D = x.shape
         dev = x.device
         HD = H * D
@@ -413,10 +433,10 @@ class GcnFn(torch.autograd.Function):
             ride, ride_p = _ride(e_next, n_valid, ebar_next, *ebar_next.shape)
         call("gcgcn_gcn_fwd", B, N, D, L, H, _p(x), _p(ebar), _p(adj), _p(n_valid), _p(flat), _p(snap), float(p),
              _p(out_snap), float(out_p), _p(out), _p(Pn), _p(Y), _p(HO), _p(rinv), _p(G), _p(wsum), _p(scratch), ride_p,
-             None, _stream())
+             None, _p(rowblk), _stream())
         del ride
         ctx.save_for_backward(x, ebar, adj, flat, Pn, Y, HO, rinv)
-        ctx.wsum = wsum
+        ctx.wsum, ctx.rowblk = wsum, rowblk
         ctx.n_valid, ctx.L, ctx.H, ctx.p, ctx.snap = n_valid, L, H, float(p), snap
         ctx.out_p, ctx.out_snap = float(out_p), out_snap
         # to see in backward whether .grad will be installed or added to (never parked under DDP: see _under_ddp)
@@ -451,12 +471,12 @@ class GcnFn(torch.autograd.Function):
         call("gcgcn_gcn_bwd", B, N, D, L, H, _p(x), _p(ebar), _p(adj), _p(ctx.n_valid), _p(flat), _p(ctx.snap),
              ctx.p, _p(ctx.out_snap), ctx.out_p, _p(Pn), _p(Y), _p(HO), _p(rinv), _p(ctx.wsum), _p(dout), _p(dX), _p(dEbar), _p(dA),
              _p(dflat), _p(W1), _p(W2), _p(W3), _p(drow), _p(dXres), _p(dout_m), _p(scratch), ride_p, None,
-             None if bp is None else bp.queue, _stream())
+             None if bp is None else bp.queue, _p(ctx.rowblk), _stream())
         del ride
         if bp is not None:
-            bp.park(ctx.flat_leaf, dflat, (x, ebar, Y, HO, dout, dout_m, W2, W3))
+            bp.park(ctx.flat_leaf, dflat, (x, ebar, Y, HO, dout, dout_m, W2, W3, ctx.rowblk))
             dflat = None                                # installed as .grad by the pass's end-of-backward callback
-        return dX, dEbar, dA, dflat, None, None, None, None, None, dE_next, None, None
+        return dX, dEbar, dA, dflat, None, None, None, None, None, dE_next, None, None, None
 
 
 class MaggcFn(torch.autograd.Function):
@@ -467,7 +487,7 @@ class MaggcFn(torch.autograd.Function):
     one -- two launches fewer per step than MhaFn + GcnFn, the same arithmetic (same kernels' bodies, same dropout draws)."""
 
     @staticmethod
-    def forward(ctx, x, ebar, flat_mha, flat, n_valid, L, H, p_mha, snap_mha, p, snap, e_next, out_p, out_snap):
+    def forward(ctx, x, ebar, flat_mha, flat, n_valid, L, H, p_mha, snap_mha, p, snap, e_next, out_p, out_snap, rowblk=None):
         B, N, D = x.shape
         dev = x.device
         HD = H * D
@@ -486,11 +506,11 @@ class MaggcFn(torch.autograd.Function):
         hook = _lib.MhaHook(flat_mha.data_ptr(), Q.data_ptr(), P.data_ptr(), _p(A), None, _p(snap_mha), float(p_mha))
         call("gcgcn_gcn_fwd", B, N, D, L, H, _p(x), _p(ebar), None, _p(n_valid), _p(flat), _p(snap), float(p), _p(out_snap), float(out_p),
              _p(out), _p(Pn), _p(Y), _p(HO), _p(rinv), _p(G), _p(wsum), _p(scratch), ride_p,
-             ctypes.cast(ctypes.pointer(hook), ctypes.c_void_p), _stream())
+             ctypes.cast(ctypes.pointer(hook), ctypes.c_void_p), _p(rowblk), _stream())
         del ride, hook
         adj = P if A is None else A
         ctx.save_for_backward(x, ebar, adj, flat, Pn, Y, HO, rinv, flat_mha, Q, P)
-        ctx.wsum = wsum
+        ctx.wsum, ctx.rowblk = wsum, rowblk
         ctx.n_valid, ctx.L, ctx.H, ctx.p, ctx.snap = n_valid, L, H, float(p), snap
         ctx.p_mha, ctx.snap_mha = float(p_mha), snap_mha
         ctx.out_p, ctx.out_snap = float(out_p), out_snap
@@ -524,10 +544,10 @@ class MaggcFn(torch.autograd.Function):
         call("gcgcn_gcn_bwd", B, N, D, L, H, _p(x), _p(ebar), _p(adj), _p(ctx.n_valid), _p(flat), _p(ctx.snap), ctx.p, _p(ctx.out_snap),
              ctx.out_p, _p(Pn), _p(Y), _p(HO), _p(rinv), _p(ctx.wsum), _p(dout), _p(dXc), _p(dEbar), _p(dA), _p(dflat), _p(W1), _p(W2),
              _p(W3), _p(drow), _p(dXres), _p(dout_m), _p(scratch), ride_p, ctypes.cast(ctypes.pointer(hook), ctypes.c_void_p),
-             None if bp is None else bp.queue, _stream())
+             None if bp is None else bp.queue, _p(ctx.rowblk), _stream())
         del ride, hook
         if bp is not None:
-            bp.park(ctx.flat_leaf, dflat, (x, ebar, Y, HO, dout, dout_m, W2, W3))
+            bp.park(ctx.flat_leaf, dflat, (x, ebar, Y, HO, dout, dout_m, W2, W3, ctx.rowblk))
             dflat = None
         # the rest of the attention's backward: dX = dQ Wq + dXc, dWq = dQ^T X, dbq (the core already ran, as passengers)
         dX = torch.empty_like(x)
@@ -535,8 +555,8 @@ class MaggcFn(torch.autograd.Function):
         dS = torch.empty(1, device=dev)
         scratch2 = torch.empty(max(_lib.lib().gcgcn_mha_scratch(B, N, D), 1), device=dev)
         call("gcgcn_mha_bwd", B, N, D, H, _p(x), _p(flat_mha), _p(ctx.snap_mha), ctx.p_mha, _p(Q), _p(P), _p(dA), _p(dXc), _p(dX),
-             _p(dflat_mha), _p(dS), _p(dQ), _p(scratch2), None, 1, _stream())
-        return dX, dEbar, dflat_mha, dflat, None, None, None, None, None, None, None, dE_next, None, None
+             _p(dflat_mha), _p(dS), _p(dQ), _p(scratch2), None, 1, _p(ctx.rowblk), _stream())
+        return dX, dEbar, dflat_mha, dflat, None, None, None, None, None, None, None, dE_next, None, None, None
 
 
 class GraphConvFn(torch.autograd.Function):
@@ -774,15 +794,17 @@ class HeadFn(torch.autograd.Function):
         B, N, Hd = feats[0].shape
         nf, Pt, (ND, Pr) = len(feats), ner_emb.shape[1], dis_table.shape
         dev = flat.device
-        sizes = (ctypes.c_int64 * 2)()
+        sizes = (ctypes.c_int64 * 3)()
         call("gcgcn_head_sizes", B, N, R, ND, ctypes.cast(sizes, ctypes.c_void_p))
         fbuf = torch.empty(sizes[0], device=dev)
+        # ragged batch: the pair passes run on the pairs that exist (compacted rows; the index lives in ibuf, on the device)
+        ibuf = torch.empty(sizes[2], dtype=torch.int32, device=dev) if n_valid is not None else None
         logits = torch.empty(B, N, N, R, device=dev)
         fp = (ctypes.c_void_p * nf)(*[f.data_ptr() for f in feats])
         call("gcgcn_head_fwd", B, N, Hd, nf, Pt, Pr, R, ND, dis_plus, ctypes.cast(fp, ctypes.c_void_p), _p(node_type), _p(rel),
-             _p(ner_emb), _p(dis_table), _p(flat), _p(fbuf), _p(logits), _stream())
+             _p(ner_emb), _p(dis_table), _p(n_valid), _p(flat), _p(fbuf), _p(ibuf), _p(logits), _stream())
         ctx.save_for_backward(flat, ner_emb, dis_table, node_type, rel, fbuf, *feats)
-        ctx.n_valid, ctx.R, ctx.dis_plus, ctx.nbwd = n_valid, R, dis_plus, int(sizes[1])
+        ctx.n_valid, ctx.R, ctx.dis_plus, ctx.nbwd, ctx.ibuf = n_valid, R, dis_plus, int(sizes[1]), ibuf
         return logits
 
     @staticmethod
@@ -798,7 +820,7 @@ class HeadFn(torch.autograd.Function):
         fp = (ctypes.c_void_p * nf)(*[f.data_ptr() for f in feats])
         dp = (ctypes.c_void_p * nf)(*[f.data_ptr() for f in dfeats])
         call("gcgcn_head_bwd", B, N, Hd, nf, Pt, Pr, ctx.R, ND, ctx.dis_plus, ctypes.cast(fp, ctypes.c_void_p), _p(node_type),
-             _p(rel), _p(ner_emb), _p(dis_table), _p(ctx.n_valid), _p(flat), _p(fbuf), _p(bbuf), _p(dlogits),
+             _p(rel), _p(ner_emb), _p(dis_table), _p(ctx.n_valid), _p(flat), _p(fbuf), _p(ctx.ibuf), _p(bbuf), _p(dlogits),
              ctypes.cast(dp, ctypes.c_void_p), _p(dner), _p(dtab), _p(dflat), _stream())
         return (dflat, dner, dtab, None, None, None, None, None, *dfeats)
 
@@ -962,13 +984,13 @@ def edge_mean(e, n_valid=None):
     return EdgeMeanFn.apply(e, _nv(n_valid, B, N, e.device))
 
 
-def multi_head_adjacency(x, flat, H, n_valid=None, p=0.1, training=False):
+def multi_head_adjacency(x, flat, H, n_valid=None, p=0.1, training=False, rowblk=None):
     x = _chk(x, "node_feat", 3)
     B, N, D = x.shape
-    return MhaFn.apply(x, _chk(flat, "flat"), _nv(n_valid, B, N, x.device), H, p, _snap_for(training, p, x.device))
+    return MhaFn.apply(x, _chk(flat, "flat"), _nv(n_valid, B, N, x.device), H, p, _snap_for(training, p, x.device), rowblk)
 
 
-def gcn_stack(x, ebar, adj, flat, L, H, n_valid=None, p=0.2, training=False, e_next=None, out_dropout=0.0):
+def gcn_stack(x, ebar, adj, flat, L, H, n_valid=None, p=0.2, training=False, e_next=None, out_dropout=0.0, rowblk=None):
     """Returns ``out`` -- or ``(out, mean_j e_next)`` when the next hop's edge tensor ``e_next[B,N,N,D']`` is given.
     ``out_dropout`` > 0 (training only): the hop's ``x <- dropout(out)`` (glove:341) applied inside the block."""
     x, ebar, adj = _chk(x, "node_feat", 3), _chk(ebar, "edge_mean", 3), _chk(adj, "adjacency", 4)
@@ -982,8 +1004,10 @@ def gcn_stack(x, ebar, adj, flat, L, H, n_valid=None, p=0.2, training=False, e_n
             raise ValueError(f"gcn_stack: next edge tensor {tuple(e_next.shape)} does not match B={B} N={N}")
     snap = _snap_for(training, p, x.device)                       # draw order: block, then the hop's output dropout
     out_snap = _snap_for(training, out_dropout, x.device)
+    if rowblk is None:                                            # a block called on its own: its own list
+        rowblk = row_blocks(nv, B, N)
     out, ebar_next = GcnFn.apply(x, ebar, adj, _chk(flat, "flat"), nv, L, H, p, snap, e_next,
-                                 out_dropout if out_snap is not None else 0.0, out_snap)
+                                 out_dropout if out_snap is not None else 0.0, out_snap, rowblk)
     return out if e_next is None else (out, ebar_next)
 
 
@@ -993,7 +1017,7 @@ def maggc_fusable(x: Tensor, H: int) -> bool:
     return x.is_cuda and x.dim() == 3 and bool(_lib.lib().gcgcn_maggc_fusable(x.shape[1], x.shape[2], int(H)))
 
 
-def maggc_hop(x, ebar, flat_mha, flat, L, H, n_valid=None, p_mha=0.1, p=0.2, training=False, e_next=None, out_dropout=0.0):
+def maggc_hop(x, ebar, flat_mha, flat, L, H, n_valid=None, p_mha=0.1, p=0.2, training=False, e_next=None, out_dropout=0.0, rowblk=None):
     """MultiHeadAttention (its own draw first, like the separate modules) + MultiGraphConvolution of one hop, fused (MaggcFn)."""
     x, ebar = _chk(x, "node_feat", 3), _chk(ebar, "edge_mean", 3)
     B, N, D = x.shape
@@ -1005,8 +1029,10 @@ def maggc_hop(x, ebar, flat_mha, flat, L, H, n_valid=None, p_mha=0.1, p=0.2, tra
     snap_mha = _snap_for(training, p_mha, x.device)                 # draw order of the separate modules: attention, block, glue
     snap = _snap_for(training, p, x.device)
     out_snap = _snap_for(training, out_dropout, x.device)
+    if rowblk is None:
+        rowblk = row_blocks(nv, B, N)
     out, ebar_next = MaggcFn.apply(x, ebar, _chk(flat_mha, "flat"), _chk(flat, "flat"), nv, L, H, p_mha, snap_mha, p, snap, e_next,
-                                   out_dropout if out_snap is not None else 0.0, out_snap)
+                                   out_dropout if out_snap is not None else 0.0, out_snap, rowblk)
     return out if e_next is None else (out, ebar_next)
 
 

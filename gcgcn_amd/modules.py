@@ -229,9 +229,9 @@ class MultiHeadAttention(_FlatBlock):
         return P_.unpack_mha(self.flat.grad, self.dim, self.head_num, "q")
 
     def forward(self, node_feat: Tensor, mask: Optional[Tensor] = None, n_valid: Optional[Tensor] = None,
-                return_input_alias: bool = False) -> List[Tensor]:
+                return_input_alias: bool = False, rowblk: Optional[Tensor] = None) -> List[Tensor]:
         x, batched = _batched(node_feat, 2)
-        a, xa = F_.multi_head_adjacency(x, self.flat, self.head_num, n_valid, self.p, self.training)  # [B,H,N,N]
+        a, xa = F_.multi_head_adjacency(x, self.flat, self.head_num, n_valid, self.p, self.training, rowblk=rowblk)  # [B,H,N,N]
         heads = list(a.unbind(1)) if batched else list(a.squeeze(0).unbind(0))
         return (heads, xa if batched else xa.squeeze(0)) if return_input_alias else heads   # see GATAttention
 
@@ -276,20 +276,20 @@ class _GcnBase(_FlatBlock):
             ebar = F_.edge_mean(e, n_valid)
         return ebar
 
-    def _stack(self, x, ebar, adj, n_valid, ride_edge, out_dropout):
+    def _stack(self, x, ebar, adj, n_valid, ride_edge, out_dropout, rowblk=None):
         """The fused block.  Extensions used by GraphHops: ``ride_edge`` is the edge tensor the NEXT hop's
         convolution will be called with -- its mean is computed inside this block's chain launch and parked for that
         call (functional.GcnFn); ``out_dropout`` applies the hop's output dropout (glove:341) in the block's last
-        epilogue."""
+        epilogue; ``rowblk``: the hop loop's row-block list of a ragged batch (functional.row_blocks; None: built here)."""
         if ride_edge is None:
             return F_.gcn_stack(x, ebar, adj, self.flat, self.layer_num, self.head_num, n_valid, self.p, self.training,
-                                out_dropout=out_dropout)
+                                out_dropout=out_dropout, rowblk=rowblk)
         if isinstance(ride_edge, F_.CompactEdges):     # nothing to stream: its mean is a segmented sum, computed when it is asked for
             return F_.gcn_stack(x, ebar, adj, self.flat, self.layer_num, self.head_num, n_valid, self.p, self.training,
-                                out_dropout=out_dropout)
+                                out_dropout=out_dropout, rowblk=rowblk)
         e_next, _ = _batched(ride_edge, 3)
         out, ebar_next = F_.gcn_stack(x, ebar, adj, self.flat, self.layer_num, self.head_num, n_valid, self.p,
-                                      self.training, e_next=e_next, out_dropout=out_dropout)
+                                      self.training, e_next=e_next, out_dropout=out_dropout, rowblk=rowblk)
         F_.park_edge_mean(ride_edge, n_valid, ebar_next)
         return out
 
@@ -338,11 +338,11 @@ class GraphConvolution(_GcnBase):
 
     def forward(self, node_feat: Tensor, edge_feat: Tensor, adj_matrix: Tensor,
                 n_valid: Optional[Tensor] = None, ride_edge: Optional[Tensor] = None,
-                out_dropout: float = 0.0) -> Tensor:
+                out_dropout: float = 0.0, rowblk: Optional[Tensor] = None) -> Tensor:
         x, batched = _batched(node_feat, 2)
         adj, _ = _batched(adj_matrix, 2)
         ebar = self._edge_mean(edge_feat, n_valid)
-        out = self._stack(x, ebar, adj.unsqueeze(1), n_valid, ride_edge, out_dropout)
+        out = self._stack(x, ebar, adj.unsqueeze(1), n_valid, ride_edge, out_dropout, rowblk)
         return out if batched else out.squeeze(0)
 
 
@@ -369,21 +369,22 @@ class MultiGraphConvolution(_GcnBase):
         return stacked if batched else stacked.unsqueeze(0)
 
     def forward_with_attention(self, attention: "MultiHeadAttention", node_feat: Tensor, edge_feat: Tensor,
-                               n_valid: Optional[Tensor] = None, ride_edge: Optional[Tensor] = None, out_dropout: float = 0.0) -> Tensor:
+                               n_valid: Optional[Tensor] = None, ride_edge: Optional[Tensor] = None, out_dropout: float = 0.0,
+                               rowblk: Optional[Tensor] = None) -> Tensor:
         """``self(node_feat, edge_feat, attention(node_feat, edge_feat))`` -- the whole MAGGC hop (glove:336-337) -- as one fused
         call where the shape allows it (functional.maggc_fusable): the attention's launches ride inside the convolution's.  Same
         results as the two separate module calls (same kernels' bodies, same dropout draws); two launches fewer per step."""
         x, batched = _batched(node_feat, 2)
         if not (F_.maggc_fusable(x, self.head_num) and attention.head_num == self.head_num and attention.dim == self.dim
                 and isinstance(attention, MultiHeadAttention)):
-            al, xa = attention(node_feat, edge_feat, n_valid=n_valid, return_input_alias=True)
-            return self(xa, edge_feat, al, n_valid=n_valid, ride_edge=ride_edge, out_dropout=out_dropout)
+            al, xa = attention(node_feat, edge_feat, n_valid=n_valid, return_input_alias=True, rowblk=rowblk)
+            return self(xa, edge_feat, al, n_valid=n_valid, ride_edge=ride_edge, out_dropout=out_dropout, rowblk=rowblk)
         ebar = self._edge_mean(edge_feat, n_valid)
         e_next = None
         if ride_edge is not None and not isinstance(ride_edge, F_.CompactEdges):
             e_next, _ = _batched(ride_edge, 3)
         r = F_.maggc_hop(x, ebar, attention.flat, self.flat, self.layer_num, self.head_num, n_valid, attention.p, self.p,
-                         self.training, e_next=e_next, out_dropout=out_dropout)
+                         self.training, e_next=e_next, out_dropout=out_dropout, rowblk=rowblk)
         if e_next is not None:
             out, ebar_next = r
             F_.park_edge_mean(ride_edge, n_valid, ebar_next)
@@ -393,11 +394,11 @@ class MultiGraphConvolution(_GcnBase):
 
     def forward(self, node_feat: Tensor, edge_feat: Tensor, adj_matrix_list: Union[Tensor, Sequence[Tensor]],
                 n_valid: Optional[Tensor] = None, ride_edge: Optional[Tensor] = None,
-                out_dropout: float = 0.0) -> Tensor:
+                out_dropout: float = 0.0, rowblk: Optional[Tensor] = None) -> Tensor:
         x, batched = _batched(node_feat, 2)
         adj = self._stack_heads(adj_matrix_list, batched)
         ebar = self._edge_mean(edge_feat, n_valid)
-        out = self._stack(x, ebar, adj, n_valid, ride_edge, out_dropout)
+        out = self._stack(x, ebar, adj, n_valid, ride_edge, out_dropout, rowblk)
         return out if batched else out.squeeze(0)
 
 
@@ -568,39 +569,18 @@ class GraphHops(nn.Module):
             return self._hops(x, feats, edge_feats, adj_matrix, n_valid)
 
     def _hops(self, x, feats, edge_feats, adj_matrix, n_valid):
-        # The MAGGC hops use their edge tensor only through mean_j E (glove:40-41), which does not depend on
-        # anything computed here: stream those HBM-bound passes on a side stream while the CAGGC hop's
-        # matrix work runs (autograd replays the same placement for the dE broadcast in backward).
-        pre = {}
-
-        def fork_edge_means():
-            # side stream (lowest priority): starts after everything enqueued so far, i.e. after GATAttention's own
-            # pass over E1, so the two HBM streams do not compete
-            cur = torch.cuda.current_stream()
-            side = self._side_stream(x.device)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                for i in range(1, self.graph_hop):
-                    eb, _ = _batched(edge_feats[i], 3)
-                    pre[i] = F_.edge_mean(eb, n_valid)
-
-        if x.is_cuda and self.graph_hop > 1 and self.early_edge_mean and not self.overlap_edge_mean:
-            # Same stream, just earlier: the E means of the MAGGC hops depend on nothing computed here.  Issued first,
-            # they run back to back with GATAttention's own pass over E1 (HBM clocks already up), and their autograd
-            # nodes are the oldest of the step, so the dE broadcasts run last in backward, next to the dE1 kernel.
-            for i in range(1, self.graph_hop):
-                eb, _ = _batched(edge_feats[i], 3)
-                pre[i] = F_.edge_mean(eb, n_valid)
-
         def ride(i):
             # hop i + 1 needs its edge tensor only as mean_j E: let that HBM-bound pass ride in hop i's chain launch
-            on = self.ride_edge_mean and x.is_cuda and i + 1 < self.graph_hop and (i + 1) not in pre \
-                and not self.overlap_edge_mean
+            on = self.ride_edge_mean and x.is_cuda and i + 1 < self.graph_hop
             return edge_feats[i + 1] if on else None
 
         # alpha == 1 (the reference's setting): x <- dropout(new) is applied in the convolution's last epilogue
         fused_out = self.alpha == 1.0 and x.is_cuda
         odrop = self.p if (fused_out and self.training) else 0.0
+        # ragged batch: the list of entity-row blocks that exist, built once (on the device) for every block of the loop
+        rb = None
+        if n_valid is not None and x.is_cuda and x.dim() == 3:
+            rb = F_.row_blocks(n_valid, x.shape[0], x.shape[1])
 
         for i in range(self.graph_hop):
             e = edge_feats[i]
@@ -612,21 +592,14 @@ class GraphHops(nn.Module):
                 if self.get_weighted_adj_matrix.apply_mask and adj_matrix is not None:
                     mask = torch.eq(adj_matrix, 0)                                                          # glove:330
                 a, xa = self.get_weighted_adj_matrix(x, e, mask, n_valid=n_valid, return_input_alias=True)  # glove:332
-                if x.is_cuda and self.graph_hop > 1 and self.overlap_edge_mean:
-                    fork_edge_means()
-                new = self.graphcnn[i](xa, e, a, n_valid=n_valid, ride_edge=ride(i), out_dropout=odrop)  # glove:333
+                new = self.graphcnn[i](xa, e, a, n_valid=n_valid, ride_edge=ride(i), out_dropout=odrop, rowblk=rb)  # glove:333
             else:
-                if i in pre:
-                    if self.overlap_edge_mean:
-                        torch.cuda.current_stream().wait_stream(self._side_stream(x.device))
-                        pre[i].record_stream(torch.cuda.current_stream())
-                    F_.park_edge_mean(e, n_valid, pre.pop(i))
                 if self.fuse_maggc:      # glove:336-337 as one fused call pair (falls back to the two module calls by itself)
                     new = self.graphcnn[i].forward_with_attention(self.get_adj_matrix[i - 1], x, e, n_valid=n_valid,
-                                                                  ride_edge=ride(i), out_dropout=odrop)
+                                                                  ride_edge=ride(i), out_dropout=odrop, rowblk=rb)
                 else:
-                    al, xa = self.get_adj_matrix[i - 1](x, e, n_valid=n_valid, return_input_alias=True)  # glove:336
-                    new = self.graphcnn[i](xa, e, al, n_valid=n_valid, ride_edge=ride(i), out_dropout=odrop)  # glove:337
+                    al, xa = self.get_adj_matrix[i - 1](x, e, n_valid=n_valid, return_input_alias=True, rowblk=rb)  # glove:336
+                    new = self.graphcnn[i](xa, e, al, n_valid=n_valid, ride_edge=ride(i), out_dropout=odrop, rowblk=rb)  # glove:337
             if fused_out:
                 x = new                                                                      # glove:339 + :341, in the block
             else:
@@ -635,25 +608,11 @@ class GraphHops(nn.Module):
             feats.append(x)
         return feats
 
-    # measured on MI355X (cfg 2): 1.005 ms/step with the side stream vs 0.935 without -- the HBM stream slows the
-    # latency-bound kernels it overlaps and the cross-stream waits cost more than the 40 us they hide.  Off.
-    overlap_edge_mean = False
-    # the next hop's edge mean as a passenger of this hop's chain launch (chain.hip): on
+    # The next hop's edge mean rides as passenger workgroups of this hop's chain launch (chain.hip): on.  (Streaming it on a
+    # side stream, or issuing it before GATAttention, were measured and dropped: DESIGN.md, dropped experiments.)
     ride_edge_mean = True
     # a MAGGC hop's attention rides inside its convolution's launches (functional.MaggcFn): on
     fuse_maggc = True
-    # measured: issuing the E2 mean before GATAttention evicts E1 from the Infinity Cache (left there by the previous
-    # step's backward): edge_fwd_att 31 -> 52 us, step 0.883 -> 0.892 ms.  Off.
-    early_edge_mean = False
-    _streams = {}
-
-    @classmethod
-    def _side_stream(cls, dev):
-        key = (dev.type, dev.index)
-        if key not in cls._streams:
-            lo, _hi = torch.cuda.Stream.priority_range()
-            cls._streams[key] = torch.cuda.Stream(device=dev, priority=lo)
-        return cls._streams[key]
 
 
 # ======================================================================================================
@@ -750,6 +709,7 @@ class GraphModelTail(nn.Module):
         # alpha == 1 (the reference's setting): x <- dropout(new) is applied in the convolution's last epilogue (as GraphHops does)
         fused_out = self.alpha == 1.0 and x.is_cuda
         odrop = self.p if (fused_out and self.training) else 0.0
+        rb = F_.row_blocks(n_valid, x.shape[0], x.shape[1]) if (n_valid is not None and x.is_cuda and x.dim() == 3) else None
         with F_.rng_scope(x.device, 3 * max(hops, 1), enabled=self.training and x.is_cuda):
             for i in range(hops):
                 e = self.producers[i](context_output, sen_matrix, pos_matrix_h, pos_matrix_t, x, dis_embed_weight, n_valid=n_valid,
@@ -760,9 +720,10 @@ class GraphModelTail(nn.Module):
                         mask = torch.eq(adj_matrix, 0)                                          # glove:330
                     # (A, alias of x): the convolution's d(node_feat) is routed through the attention's own dX kernel
                     a, xa = self.get_weighted_adj_matrix(x, e, mask, n_valid=n_valid, return_input_alias=True)   # glove:332
-                    new = self.graphcnn[i](xa, e, a, n_valid=n_valid, out_dropout=odrop)       # glove:333
+                    new = self.graphcnn[i](xa, e, a, n_valid=n_valid, out_dropout=odrop, rowblk=rb)       # glove:333
                 else:                                                                          # glove:336-337, fused where possible
-                    new = self.graphcnn[i].forward_with_attention(self.get_adj_matrix[i - 1], x, e, n_valid=n_valid, out_dropout=odrop)
+                    new = self.graphcnn[i].forward_with_attention(self.get_adj_matrix[i - 1], x, e, n_valid=n_valid, out_dropout=odrop,
+                                                                  rowblk=rb)
                 feats.append(x)                                                                # glove:338 (pre-update)
                 if fused_out:
                     x = new                                                                    # glove:339 + :341, inside the block

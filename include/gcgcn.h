@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-int gcgcn_version(void);            /* ABI version, currently 4 */
+int gcgcn_version(void);            /* ABI version, currently 5 */
 const char* gcgcn_last_error(void); /* message of the last failing call on this thread */
 
 /* Run-time switches for A/B tests.  "chain": 1 (default) = the per-(doc, head) products of a conv run inside the
@@ -42,6 +42,19 @@ const char* gcgcn_last_error(void); /* message of the last failing call on this 
  * "head_dw3", "chain_s", "chain_fuse", "chain_carry", "gat_ride", ... -- select kernel generations; each also reads the
  * environment variable GCGCN_<NAME> once when nobody set it (DESIGN.md section 6 lists them). */
 int gcgcn_set_option(const char* name, int value);
+
+/* ---- ragged batches: the entity rows that exist (ABI v5) -------------------------------------------------------------- */
+/* The reference runs one UNPADDED document per call (config/Config.py:339-354): its products have n rows.  A padded batch
+ * [B, N, .] with n_valid has sum_b n_b real rows of B N.  gcgcn_row_blocks lists the 16-row blocks of the [B N]-row tensors,
+ * the LIVE ones first (block r of document b is live iff 16 r < n_valid[b]): out = int32[4 + B N / 16] = {live count, 0, 0, 0,
+ * list}; N must be a multiple of 16.  Given as `rowblk` to gcgcn_gcn_fwd / _bwd and gcgcn_mha_fwd / _bwd (NULL = dense), the
+ * node-phase products of the block -- X WnX, Ebar We, X Wq, the output projection, every data gradient and every weight
+ * gradient (K = the live rows) -- run on the live blocks only; the tensors keep their padded layout, outputs that leave the
+ * block (out, dX, dEbar, Q) are zero on padding rows as always.  Everything stays on the device (no host read; the list is
+ * rebuilt by every replay of a captured step).  A block whose shape the column-strip chain kernels do not serve (N > 64, or
+ * a width they are not instantiated for) ignores the list and computes every row, as does a forward / backward pair without
+ * n_valid.  The SAME list must be given to a block's forward and backward. */
+int gcgcn_row_blocks(int B, int N, const int32_t* n_valid, int32_t* out, void* stream);
 
 /* ---- per-kernel timing for roofline reports (bench.py) ------------------------------------------- */
 /* While active, every kernel launch whose name starts with kernel_prefix ("edge_bwd", "edge_fwd",
@@ -122,13 +135,13 @@ int gcgcn_mha_layout(int D, int64_t* out3);
  * (then no GEMM is split). */
 int64_t gcgcn_mha_scratch(int B, int N, int D);
 int gcgcn_mha_fwd(int B, int N, int D, int H, const float* X, const int32_t* n_valid, const float* flat,
-                  const void* rng_snap, float p, float* Q, float* P, float* A, float* scratch, void* stream);
+                  const void* rng_snap, float p, float* Q, float* P, float* A, float* scratch, const int32_t* rowblk, void* stream);
 /* backward.  dX_in[B,N,D] (NULL = zero) as in gcgcn_gat_bwd.  Workspace: dS[B,H,N,N], dQ[B,N,D],
  * scratch[gcgcn_mha_scratch].  defer_queue (may be NULL): dWq is parked as described at gcgcn_gcn_bwd (keep X, dQ and
  * dflat alive until the flush). */
 int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat, const void* rng_snap, float p,
                   const float* Q, const float* P, const float* dA, const float* dX_in, float* dX, float* dflat,
-                  float* dS, float* dQ, float* scratch, void* defer_queue, int core_done, void* stream);
+                  float* dS, float* dQ, float* scratch, void* defer_queue, int core_done, const int32_t* rowblk, void* stream);
 /* core_done = 1: dQ already holds the attention core's gradient (gcgcn_gcn_bwd with a gcgcn_mha_hook computed it) */
 
 /* ---- GraphConvolution (H = 1) / MultiGraphConvolution  GCGCN_glove.py:52-120 --------------- */
@@ -182,7 +195,7 @@ int gcgcn_maggc_fusable(int N, int D, int H);
 int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float* Ebar, const float* A,
                   const int32_t* n_valid, const float* flat, const void* rng_snap, float p, const void* out_rng_snap,
                   float out_p, float* out, float* Pn, float* Y, float* HO, float* rinv, float* G, float* wsum, float* scratch,
-                  const gcgcn_edge_ride* ride, const gcgcn_mha_hook* mha, void* stream);
+                  const gcgcn_edge_ride* ride, const gcgcn_mha_hook* mha, const int32_t* rowblk, void* stream);
 /* backward.  dout[B,N,D] -> dX, dEbar [B,N,D], dA[B,H,N,N], dflat.
  * Workspace: W1, W2, W3 (each [B,N,H*D]), drow[B,H,N], dXres[B,N,D], dout_m[B,N,D] (only used
  * when n_valid != NULL or out_rng_snap != NULL), scratch[gcgcn_gcn_scratch]. */
@@ -191,7 +204,8 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
                   float out_p, const float* Pn, const float* Y, const float* HO, const float* rinv, const float* wsum,
                   const float* dout, float* dX, float* dEbar,
                   float* dA, float* dflat, float* W1, float* W2, float* W3, float* drow, float* dXres, float* dout_m,
-                  float* scratch, const gcgcn_edge_ride* ride, const gcgcn_mha_hook* mha, void* defer_queue, void* stream);
+                  float* scratch, const gcgcn_edge_ride* ride, const gcgcn_mha_hook* mha, void* defer_queue, const int32_t* rowblk,
+                  void* stream);
 /* defer_queue != NULL: the block's weight-gradient products (dWlin, dWnX, dWe, dWd: nobody needs them before the end
  * of backward) are not launched by this call but parked in that queue -- a small host-side object the caller creates
  * per backward pass (no process-wide state: concurrent passes, models and devices never share one).  A later
@@ -298,18 +312,23 @@ int gcgcn_gat_bwd_compact(int B, int N, int D, int Dh, const float* X, const flo
  *         bili_layer_01 W [R,128,128]], pieces 16-byte aligned; out7 = 6 offsets + total.
  * The bilinear form runs on the fp32 MFMA with the per-pair outer product eh (x) et generated in registers: no
  * [pairs, 16384] operand and no [N,N,F] concatenations exist.  Buffers: fbuf float[sizes[0]] (forward, kept for backward),
- * bbuf float[sizes[1]] (backward workspace) from gcgcn_head_sizes.  Deterministic (no atomics). */
+ * bbuf float[sizes[1]] (backward workspace), ibuf int32[sizes[2]] (pair index of a ragged batch; only touched when n_valid is
+ * given) from gcgcn_head_sizes.  Deterministic (no atomics).
+ * n_valid (ABI v5): the reference runs these lines on ONE unpadded document (n x n pairs).  With n_valid the pair passes run on
+ * the pairs that exist only -- rows of eh / et / their gradients compacted on the device (row off[b] + i n_b + j, off = prefix
+ * sums of n_b^2; no host read, capturable), 2 x 128 x 128 x R flops per existing pair and pass instead of per pair slot of the
+ * padded batch -- and logits of pairs with a padding entity are exactly zero.  n_valid == NULL: every slot is computed. */
 int gcgcn_head_layout(int Hd, int nf, int Pt, int Pr, int R, int64_t* out7);
-int gcgcn_head_sizes(int B, int N, int R, int ND, int64_t* out2);
+int gcgcn_head_sizes(int B, int N, int R, int ND, int64_t* out3);
 int gcgcn_head_fwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int dis_plus, const float* const* feats,
                    const int64_t* node_type, const int64_t* node_relative_pos, const float* ner_emb, const float* dis_table,
-                   const float* flat, float* fbuf, float* logits, void* stream);
+                   const int32_t* n_valid, const float* flat, float* fbuf, int32_t* ibuf, float* logits, void* stream);
 /* dlogits[B,N,N,R] (entries of padding entities ignored when n_valid is given) -> dfeats (nf pointers, [B,N,Hd] each),
- * dner_emb[7,Pt], ddis_table[ND,Pr], dflat. */
+ * dner_emb[7,Pt], ddis_table[ND,Pr], dflat.  n_valid / fbuf / ibuf: the forward call's. */
 int gcgcn_head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int dis_plus, const float* const* feats,
                    const int64_t* node_type, const int64_t* node_relative_pos, const float* ner_emb, const float* dis_table,
-                   const int32_t* n_valid, const float* flat, float* fbuf, float* bbuf, const float* dlogits, float* const* dfeats,
-                   float* dner_emb, float* ddis_table, float* dflat, void* stream);
+                   const int32_t* n_valid, const float* flat, float* fbuf, int32_t* ibuf, float* bbuf, const float* dlogits,
+                   float* const* dfeats, float* dner_emb, float* ddis_table, float* dflat, void* stream);
 
 /* ---- device-side tensorisation of packed documents  config/Config.py:162-233 -------------------------- */
 /* Expands the packed records of a batch (gcgcn_amd/data.py; all int32, device memory) into the dense inputs of the
@@ -336,7 +355,7 @@ int gcgcn_debug_spread(int64_t n_tiles, int64_t n_others, int64_t cohort, int64_
 
 /* ---- raw batched GEMM (exposed for unit tests and benchmarks of the MFMA kernel) ----------- */
 /* C[z] = alpha * opA(A[z]) opB(B[z]);  a_kc: A stored [M][K] else [K][M];  b_kc: B stored [N][K]
- * else [K][N];  z < batch with element strides sA, sB, sC;  tile: 0 auto, 1 = 64x64, 2 = 128x128, 3 = 128x128 in 16x16x4 MFMAs with 16-byte LDS fragment reads (interior shapes only: M, N multiples of 128, K of 32, 16-byte aligned rows; refused otherwise);
+ * else [K][N];  z < batch with element strides sA, sB, sC;  tile: 0 or 1 = 64x64 block tiles (the only body; other values are refused);
  * splits: 0 auto, 1 none, n = split K n ways through ws[ws_elems] (>= n*batch*M*N floats);
  * bias[N] optional, relu/accumulate flags. */
 int gcgcn_gemm(int M, int N, int K, const float* A, int64_t lda, int a_kc, const float* B, int64_t ldb, int b_kc,

@@ -78,6 +78,9 @@ def test_head_batched_ragged_matches_oracle(gpu_device, B, N, R, hop, head_gener
         torch.testing.assert_close(out[b, :n, :n].detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
         loss = loss + (ref * cot[b, :n, :n]).sum()
     loss.backward()
+    if 64 < R <= 97:      # served by the compacted rows (only pairs of existing entities are computed): every other slot is exactly zero
+        okm = torch.arange(N)[None, :] < nv[:, None]
+        assert float(out.detach().cpu()[~(okm[:, :, None] & okm[:, None, :])].abs().max()) == 0.0 if not bool(okm.all()) else True
     for a, b_ in zip(fg, fr):
         torch.testing.assert_close(a.grad.cpu(), b_.grad, rtol=1e-3, atol=1e-4 * max(1.0, b_.grad.abs().max().item()))
     grads = head.named_grads()
@@ -119,23 +122,32 @@ def test_head_generations_agree_at_bench_size(gpu_device):
         (out * dev(cot)).sum().backward()
         return [out.detach()] + [f.grad for f in fg] + [ner.grad, dis.grad, head.flat.grad.clone()]
 
+    # (head_compact = 0: every pair slot of the padded batch is computed, the path of a batch without n_valid; the compacted
+    # path -- only the pairs that exist, the default for a ragged batch -- is the last two variants)
     variants = {"gen1": dict(head_v1=1), "gen2": dict(head_v1=0), "gen2 bil2 forward": dict(head_v1=0, head_bil3=0),
                 "gen2 bil2 backward": dict(head_v1=0, head_bil3_bwd=0), "gen2 gemm dW": dict(head_v1=0, head_dw3=0),
-                "by size": dict()}
+                "by size": dict(), "compact": dict(head_compact=1), "compact bil2": dict(head_compact=1, head_bil3=0, head_bil3_bwd=0)}
+    dflt = {"head_v1": -1, "head_bil3": 1, "head_bil3_bwd": 1, "head_dw3": 1, "head_compact": 0}
     res = {}
     try:
         for name, opts in variants.items():
-            for k in ("head_v1", "head_bil3", "head_bil3_bwd", "head_dw3"):
-                _lib.call("gcgcn_set_option", k.encode(), opts.get(k, -1 if k == "head_v1" else 1))
+            for k, d in dflt.items():
+                _lib.call("gcgcn_set_option", k.encode(), opts.get(k, d))
             res[name] = run()
     finally:
-        for k in ("head_v1", "head_bil3", "head_bil3_bwd", "head_dw3"):
-            _lib.call("gcgcn_set_option", k.encode(), -1 if k == "head_v1" else 1)
+        for k, d in dflt.items():
+            _lib.call("gcgcn_set_option", k.encode(), 1 if k == "head_compact" else d)
     names = ["logits", "d f0", "d f1", "d f2", "d ner_emb", "d dis_embed", "d flat"]
+    ok = torch.arange(N)[None, :] < nv[:, None]
+    real = (ok[:, :, None] & ok[:, None, :]).to(gpu_device)                              # pairs of two existing entities
     for name, r in res.items():
         for what, a, b_ in zip(names, r, res["gen1"]):
+            if what == "logits" and name.startswith("compact"):
+                assert float(a[~real].abs().max()) == 0.0, f"{name}: logits of pairs with a padding entity must be exactly zero"
+                a, b_ = a[real], b_[real]
             torch.testing.assert_close(a, b_, rtol=1e-4, atol=1e-4 * max(1.0, b_.abs().max().item()), msg=lambda m: f"{name}, {what}: {m}")
     assert all(torch.equal(a, b_) for a, b_ in zip(res["by size"], res["gen2"]))      # 34 425 pairs: the size rule = generation 2
+    assert all(torch.equal(a, b_) for a, b_ in zip(run(), res["compact"]))            # the default for a ragged batch = compacted rows
     # one ragged document of the batch against the CPU oracle (logits + feature gradients; the sums over all documents are
     # tied to generation 1 above, which test_head_batched_ragged_matches_oracle ties to the oracle)
     b = 1

@@ -37,7 +37,7 @@ def check_param_grads(module, golden_grad_sd, prefix=""):
 # ------------------------------------------------------------------------------------------------------
 # raw MFMA GEMM
 # ------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile", [1, 2])
+@pytest.mark.parametrize("tile", [0, 1])
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 0), (1, 1), (0, 0), (0, 1)])
 @pytest.mark.parametrize("M,N,K,batch", [(64, 64, 16, 1), (100, 37, 53, 3), (256, 192, 256, 2), (5, 4, 8, 4),
                                           (130, 257, 18, 1)])
@@ -74,7 +74,7 @@ def test_gemm_a_identity_asymmetric_b(gpu_device):
     C = torch.empty(n, 40, device=gpu_device)
     Ad, Bd = A.to(gpu_device), B.to(gpu_device)      # keep the device copies alive across the call
     p = lambda t: ctypes.c_void_p(t.data_ptr())
-    for tile in (1, 2):
+    for tile in (0, 1):
         _lib.call("gcgcn_gemm", n, 40, n, p(Ad), n, 1, p(Bd), 40, 0, p(C), 40, 1, 0, 0, 0,
                   1.0, None, 0, 0, tile, 1, None, 0, None)
         assert torch.equal(C.cpu(), B)
@@ -106,49 +106,14 @@ def test_gemm_split_k(gpu_device, M, N, K, batch, splits, a_kc, b_kc):
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("a_kc,b_kc", [(1, 0), (1, 1), (0, 0), (0, 1)])
-@pytest.mark.parametrize("M,N,K,batch,splits", [(128, 128, 32, 1, 1), (256, 384, 96, 2, 1), (512, 256, 1024, 1, 2), (128, 256, 160, 3, 1),
-                                                 (128, 256, 128, 1, 1)])
-def test_gemm_big_tile_body(gpu_device, M, N, K, batch, splits, a_kc, b_kc):
-    """tile = 3: the 128 x 128 body of gemm_big.hpp (16x16x4 MFMAs, ds_read_b128 fragments, swizzled k-contiguous images) in all
-    four operand layouts, with the fused epilogue (bias + relu, accumulate), split-K slabs, odd and even k-tile counts; A = I
-    with an asymmetric B must come back bitwise (row / column maps of the permuted accumulator blocks)."""
-    g = torch.Generator().manual_seed(M * 5 + N * 3 + K + a_kc * 2 + b_kc)
-    A = torch.randn(batch, M, K, generator=g)
-    B = torch.randn(batch, K, N, generator=g)
-    bias = torch.randn(N, generator=g)
-    Ad = (A if a_kc else A.transpose(1, 2)).contiguous().to(gpu_device)
-    Bd = (B.transpose(1, 2) if b_kc else B).contiguous().to(gpu_device)
-    biasd = bias.to(gpu_device)
-    ws = torch.empty(max(1, splits * batch * M * N), device=gpu_device)
+def test_gemm_refuses_tile_bodies_that_no_longer_exist(gpu_device):
+    """Rounds 2-3 carried two 128 x 128 tile bodies (tile = 2, 3) that lost every A/B on this path's products; round 4 removed
+    them.  Asking for one is an error, not a silent fallback."""
+    A, B, C = (torch.zeros(128, 128, device=gpu_device) for _ in range(3))
     p = lambda t: ctypes.c_void_p(t.data_ptr())
-    lda, ldb = (K if a_kc else M), (K if b_kc else N)
-    C = torch.full((batch, M, N), float("nan"), device=gpu_device)
-    _lib.call("gcgcn_gemm", M, N, K, p(Ad), lda, a_kc, p(Bd), ldb, b_kc, p(C), N, batch, M * K, K * N, M * N,
-              0.5, p(biasd), 1, 0, 3, splits, p(ws), ws.numel(), None)
-    ref = torch.relu(0.5 * (A.double() @ B.double()) + bias.double()).float()
-    torch.testing.assert_close(C.cpu(), ref, rtol=1e-4, atol=2e-4 * math.sqrt(max(K, 256) / 256))
-    C2 = C.clone()
-    _lib.call("gcgcn_gemm", M, N, K, p(Ad), lda, a_kc, p(Bd), ldb, b_kc, p(C2), N, batch, M * K, K * N, M * N,
-              1.0, None, 0, 1, 3, splits, p(ws), ws.numel(), None)
-    torch.testing.assert_close(C2.cpu(), ref + (A.double() @ B.double()).float(), rtol=1e-4, atol=3e-4 * math.sqrt(max(K, 256) / 256))
-    if batch == 1 and splits == 1 and M == K:
-        eye = torch.eye(M)
-        Bi = torch.arange(K * N, dtype=torch.float32).view(K, N) % 1021.0
-        Ed = eye.to(gpu_device)                                      # symmetric: the same storage in both layouts
-        Bid = (Bi.t() if b_kc else Bi).contiguous().to(gpu_device)
-        Co = torch.empty(M, N, device=gpu_device)
-        _lib.call("gcgcn_gemm", M, N, K, p(Ed), K, a_kc, p(Bid), ldb, b_kc, p(Co), N, 1, 0, 0, 0, 1.0, None, 0, 0, 3, 1, None, 0, None)
-        assert torch.equal(Co.cpu(), Bi)
-
-
-def test_gemm_big_tile_body_refuses_ragged_shapes(gpu_device):
-    A = torch.randn(100, 64, device=gpu_device)
-    B = torch.randn(64, 128, device=gpu_device)
-    C = torch.empty(100, 128, device=gpu_device)
-    p = lambda t: ctypes.c_void_p(t.data_ptr())
-    with pytest.raises(RuntimeError, match="tile 3"):
-        _lib.call("gcgcn_gemm", 100, 128, 64, p(A), 64, 1, p(B), 128, 0, p(C), 128, 1, 0, 0, 0, 1.0, None, 0, 0, 3, 1, None, 0, None)
+    for tile in (2, 3):
+        with pytest.raises(RuntimeError, match="tile"):
+            _lib.call("gcgcn_gemm", 128, 128, 128, p(A), 128, 1, p(B), 128, 0, p(C), 128, 1, 0, 0, 0, 1.0, None, 0, 0, tile, 1, None, 0, None)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -448,6 +413,68 @@ def test_ragged_batch_matches_truncated_docs(gpu_device, B, N, D, L, H, nv):
             assert e1g.grad[b, n:].abs().max().item() == 0 and e1g.grad[b, :, n:].abs().max().item() == 0
             assert e2g.grad[b, n:].abs().max().item() == 0 and e2g.grad[b, :, n:].abs().max().item() == 0
     _check_stack_param_grads(hops, sdl)
+
+
+@pytest.mark.parametrize("B,N,D,L,H,train", [(8, 64, 256, 2, 8, False),    # cfg 2's document shape: 2048 rows, split-K, parked tiles
+                                             (8, 64, 256, 2, 8, True),     #   ... all six dropout sites on (same snapshots both ways)
+                                             (5, 48, 128, 4, 4, False),    # the BERT model's widths, N = 48: three row blocks per document
+                                             (32, 64, 256, 2, 8, True),    # the ragged bench itself (bench.py --ragged)
+                                             (3, 32, 768, 4, 4, False)])   # cfg 3's widths
+def test_row_block_launches_equal_the_dense_products(gpu_device, B, N, D, L, H, train):
+    """Ragged batches: the node-phase products run on the LIVE 16-row blocks only (gcgcn_row_blocks; GEMM rows gathered through
+    the block list, K = the live rows for weight gradients) against the same step with every row computed (the round-3 path,
+    functional.row_block_launches = False): every output and gradient agrees to summation-order slack, padding rows of
+    everything that leaves a block are EXACTLY zero, and all of it on NaN-poisoned recycled memory (conftest) -- a product that
+    read a row nobody wrote would show."""
+    g = torch.Generator().manual_seed(B * N + D)
+    nv = torch.clamp(torch.round(torch.randn(B, generator=g) * 6.0 + 19.5), 1, N).to(torch.int32)
+    nv[0], nv[-1] = N, 1                                      # a full document and a single entity
+    sd = O.init_stack_params(D, L, H, seed=3)
+    x, e1, e2, adj = O.synth_docs(B, N, D, seed=4)
+    x = x * (torch.arange(N)[None, :] < nv[:, None]).unsqueeze(-1).float()
+    cot = torch.randn(B, N, D, generator=g).to(gpu_device)
+    hops = gcgcn_amd.GraphHops(D, L, H).to(gpu_device).train(train)
+    hops.load_state_dict(sd, strict=True)
+    nvg = nv.to(gpu_device)
+    res = []
+    seen = []
+    orig_rb = F_.row_blocks
+
+    def spy(n_valid, B_, N_):
+        r = orig_rb(n_valid, B_, N_)
+        seen.append(r)
+        return r
+    try:
+        F_.row_blocks = spy
+        for on in (True, False):
+            F_.row_block_launches = on
+            gcgcn_amd.manual_seed(77, gpu_device)
+            xs = [dev_leaf(t, gpu_device) for t in (x, e1, e2)]
+            hops.zero_grad()
+            junk = torch.full((B * N * H * D * 4,), float("nan"), device=gpu_device)     # poisoned blocks for the workspaces to recycle
+            del junk
+            f = hops(xs[0], [xs[1], xs[2]], adj.to(gpu_device), n_valid=nvg)
+            torch.autograd.backward(f[-1], cot)
+            res.append([f[1].detach(), f[2].detach(), xs[0].grad, xs[1].grad, xs[2].grad] +
+                       [p.grad.clone() for p in hops.parameters() if p.grad is not None])
+    finally:
+        F_.row_block_launches = True
+        F_.row_blocks = orig_rb
+    assert seen[0] is not None and seen[0].numel() == 4 + B * N // 16 and seen[-1] is None          # the list was built once per hop loop, then not at all
+    live = int(seen[0][0].item())
+    assert live == int(((nv + 15) // 16).sum())
+    blocks = seen[0][4:].cpu().tolist()
+    assert sorted(blocks) == list(range(B * N // 16))                                             # a permutation: live first, then dead
+    assert all((blk % (N // 16)) * 16 < int(nv[blk // (N // 16)]) for blk in blocks[:live])
+    names = ["x1", "x2", "dX", "dE1", "dE2", "d gat", "d mha", "d caggc", "d maggc"]
+    assert len(res[0]) == len(res[1]) == 9
+    pad = (torch.arange(N)[None, :] >= nv[:, None]).to(gpu_device)
+    for nm, a, b_ in zip(names, *res):
+        assert torch.isfinite(a).all(), f"{nm}: non-finite values on the row-block path"
+        top = max(1.0, b_.abs().max().item())
+        torch.testing.assert_close(a, b_, rtol=2e-4, atol=2e-5 * top, msg=lambda m: f"{nm}: {m}")
+        if nm in ("x1", "x2", "dX"):
+            assert float(a[pad].abs().max()) == 0.0 if bool(pad.any()) else True, f"{nm}: padding rows must be exactly zero"
 
 
 @pytest.mark.parametrize("B,N,D,L,H", [(2, 16, 32, 2, 4),        # guarded (ragged-shape) kernel instantiations
@@ -881,6 +908,9 @@ def test_chain_and_per_product_paths_agree(gpu_device):
     (2, 64, 384, 2, 2, False, False),    # gh = 192, two sub-layers
     (2, 7, 256, 4, 2, False, True),      # gh = 64, four sub-layers, one row block
     (1, 1, 64, 1, 1, False, False),      # a single entity, a single sub-layer
+    (3, 42, 128, 4, 4, True, True),      # the BERT model's graph blocks: hidden 128 over four sub-layers -> gh = 32, two waves (bert:237,247-248)
+    (2, 64, 128, 4, 4, False, False),    #   ... every row block full
+    (2, 20, 64, 2, 2, True, False),      # gh = 32, two sub-layers
 ])
 def test_chain_t_matches_generic_chain(gpu_device, B, N, D, L, H, ragged, train):
     """chain_t.hip (column strips, chained products, pushed dense connections; N <= 64) against the generic chain kernels on

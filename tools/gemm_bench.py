@@ -28,7 +28,7 @@ def timeit(fn, iters=30, warm=5):
     return s.elapsed_time(e) / iters * 1e3  # us
 
 
-def bench(name, M, N, K, a_kc, b_kc, batch=1, tiles=(0, 1, 2), splits=(0, 1)):
+def bench(name, M, N, K, a_kc, b_kc, batch=1, tiles=(1,), splits=(0, 1)):
     A = torch.randn(batch, M, K, device=dev)
     B = torch.randn(batch, K, N, device=dev)
     Ad = (A if a_kc else A.transpose(1, 2)).contiguous()

@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """Throughput of the classifier head on MI355X: documents/second forward + backward through
-gcgcn_amd.ClassifierHead, and the MFMA roofline of the bilinear kernel (gc::head_gemm_kernel, fp32 MFMA, operands generated in
-registers).
+gcgcn_amd.ClassifierHead, and the MFMA roofline of the bilinear kernels (gc::head_bil3_kernel<1..3> / gc::head_dw_kernel at bench
+size, gc::head_gemm_kernel<1..4> below 32 768 pairs; fp32 MFMA, operands generated in registers).
 
-    python tools/head_bench.py [--B 32] [--N 64] [--steps 10] [--cpu]
+    python tools/head_bench.py [--B 32] [--N 64] [--steps 10] [--cpu] [--ragged [--dense]]
+
+--ragged: DocRED-like entity counts n_valid ~ clip(round(N(19.5, 6^2)), 2, min(42, N)) padded to N; the pair passes then run on
+the pairs that exist (compacted rows); --dense switches that off (every pair slot of the padded batch, the round-3 path).
 """
 import argparse
 import ctypes
@@ -26,6 +29,8 @@ def main():
     ap.add_argument("--R", type=int, default=97)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--cpu", action="store_true")
+    ap.add_argument("--ragged", action="store_true")
+    ap.add_argument("--dense", action="store_true", help="with --ragged: compute every pair slot (option head_compact = 0)")
     a = ap.parse_args()
     import gcgcn_amd
     from gcgcn_amd import _lib
@@ -39,11 +44,18 @@ def main():
     ntype = torch.randint(0, 7, (B, N), generator=g, device=dev)
     rel = torch.randint(-10, 11, (B, N, N), generator=g, device=dev)
     cot = torch.randn(B, N, N, R, generator=g, device=dev)
+    n_valid, real_pairs = None, B * N * N
+    if a.ragged:
+        gc_ = torch.Generator().manual_seed(4242)
+        n_valid = torch.clamp(torch.round(torch.randn(B, generator=gc_) * 6.0 + 19.5), 2, min(42, N)).to(torch.int32).to(dev)
+        real_pairs = int((n_valid.long() ** 2).sum().item())
+        if a.dense:
+            _lib.call("gcgcn_set_option", b"head_compact", 0)
 
     def step():
         for t in feats + [ner, dis, head.flat]:
             t.grad = None
-        out = head(feats, ntype, rel, ner, dis)
+        out = head(feats, ntype, rel, ner, dis, n_valid=n_valid)
         torch.autograd.backward(out, cot)
 
     for _ in range(2):
@@ -66,13 +78,19 @@ def main():
             shares[f] = {"ms_per_step": round(ms.value / 3, 4), "launches_per_step": round(n.value / 3, 1), "work": w.value / 3}
     hb = shares.get("head_bilinear")
     pairs = B * N * N
-    useful = 2.0 * pairs * 128 * 128 * R * 4 + 2.0 * pairs * 256 * R * 1     # four bilinear passes + the linear part, unpadded
+    computed = real_pairs if (a.ragged and not a.dense and 64 < R <= 97) else pairs
+    if hb and computed != pairs:          # the host-side counter assumes every pair slot; the compacted path runs the real ones
+        hb["work"] *= computed / pairs
+    useful = 2.0 * real_pairs * 128 * 128 * R * 4 + 2.0 * real_pairs * 256 * R * 1     # four bilinear passes + the linear part, unpadded, real pairs
     line = {"metric": "docs/sec fwd+bwd through the classifier head (SURVEY 8 f3)", "value": round(B / dt, 1), "unit": "docs/s",
             "ms_per_step": round(dt * 1e3, 3),
-            "config": {"workload": f"ClassifierHead fwd+bwd, B={B} N={N} ({pairs} pairs) hidden=128 R={R}, eager launches"},
+            "config": {"workload": f"ClassifierHead fwd+bwd, B={B} N={N} ({pairs} pair slots" +
+                                   (f", ragged: {real_pairs} real pairs, {'every slot computed' if a.dense else 'compacted rows'}" if a.ragged else "") +
+                                   f") hidden=128 R={R}, eager launches"},
             "time_shares_ms_per_step": {k: {kk: vv for kk, vv in v.items() if kk != "work"} for k, v in shares.items()},
             "roofline": None if not hb else {
-                "bound": "mfma", "kernel": "gc::head_gemm_kernel<1..4> (bilinear passes)", "launches": hb["launches_per_step"],
+                "bound": "mfma", "kernel": ("gc::head_bil3_kernel<1..3> + gc::head_dw_kernel" if (pairs >= 32768 or (a.ragged and not a.dense)) else
+                                             "gc::head_gemm_kernel<1..4>") + " (bilinear passes)", "launches": hb["launches_per_step"],
                 "achieved": round(hb["work"] / (hb["ms_per_step"] * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": round(hb["work"] / (hb["ms_per_step"] * 1e-3) / MFMA_F32_PEAK, 4),
                 "work": "executed fp32 flops (2MNK incl. the padding of R to 128 columns)",

@@ -2,7 +2,11 @@
 """The whole post-encoder model (gcgcn_amd.GraphModelTail: f1 producer -> CAGGC -> f1 -> MAGGC -> f3 head) + the trainer's loss
 (f2), forward + backward, on DocRED-shaped synthetic batches: documents/second and where the time goes.
 
-    python tools/tail_bench.py [--B 32] [--N 42] [--S 5] [--T 512] [--live 0.15] [--steps 10]
+    python tools/tail_bench.py [--B 32] [--N 42] [--S 5] [--T 512] [--live 0.15] [--steps 10] [--ragged] [--layers 2] [--heads 8]
+
+--ragged: DocRED-like entity counts n_valid ~ clip(round(N(19.5, 6^2)), 2, N) in a batch padded to N (what a real batch looks like;
+the default computes N entities in every document).  --layers / --heads: sub-layers and heads of the graph blocks (the GloVe model:
+2 / 8, glove:250-251; the BERT model: 4 / 4, bert:247-248 -- 32 features per sub-layer).
 """
 import argparse
 import ctypes
@@ -26,6 +30,9 @@ def main():
     ap.add_argument("--T", type=int, default=512)
     ap.add_argument("--live", type=float, default=0.15)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--ragged", action="store_true")
+    ap.add_argument("--layers", type=int, default=2)
+    ap.add_argument("--heads", type=int, default=8)
     ap.add_argument("--compact", action="store_true", help="the producers hand over compact rows: E / dE of the hops are never written")
     ap.add_argument("--skip-dead-hop", action="store_true", help="do not compute the hop whose output never reaches the classifier")
     a = ap.parse_args()
@@ -42,15 +49,21 @@ def main():
     ntype = torch.randint(0, 7, (B, N), generator=g, device=dev)
     rel = torch.randint(-10, 11, (B, N, N), generator=g, device=dev)
     labels = (torch.rand(B, N, N, R, generator=g, device=dev) < 0.03).float()
-    tail = gcgcn_amd.GraphModelTail().to(dev).train()
+    tail = gcgcn_amd.GraphModelTail(layer_num=a.layers, head_num=a.heads).to(dev).train()
+    n_valid = None
+    if a.ragged:
+        gr = torch.Generator().manual_seed(4242)
+        n_valid = torch.clamp(torch.round(torch.randn(B, generator=gr) * 6.0 + 19.5), 2, N).to(torch.int32).to(dev)
+        with torch.no_grad():                       # padding rows of the node features must be zero (include/gcgcn.h)
+            node.mul_((torch.arange(N, device=dev)[None, :] < n_valid[:, None]).unsqueeze(-1).float())
     tail.compact_edges, tail.skip_dead_hop = a.compact, a.skip_dead_hop
     gcgcn_amd.manual_seed(1337, dev)
 
     def step():
         for t in [ctx, node, table, ner] + list(tail.parameters()):
             t.grad = None
-        logits = tail(ctx, node, None, sen, ph, pt, ntype, rel, table, ner)
-        loss = gcgcn_amd.pair_bce_loss(logits, labels).sum() / B
+        logits = tail(ctx, node, None, sen, ph, pt, ntype, rel, table, ner, n_valid=n_valid)
+        loss = gcgcn_amd.pair_bce_loss(logits, labels, n_valid=n_valid).sum() / B
         loss.backward()
 
     for _ in range(3):
@@ -79,7 +92,8 @@ def main():
         shares[name] = round(tot, 3)
     print(json.dumps({"metric": "docs/sec fwd+bwd through the whole post-encoder model + loss", "value": round(B / dt, 1), "unit": "docs/s",
                       "ms_per_step": round(dt * 1e3, 3),
-                      "config": {"workload": f"GraphModelTail (2 hops, hidden 128, L=2, H=8, R=97) + pair_bce_loss, train mode, B={B} N={N} "
+                      "config": {"workload": f"GraphModelTail (2 hops, hidden 128, L={a.layers}, H={a.heads}, R=97) + pair_bce_loss, train mode, B={B} N={N} "
+                                             + (f"(ragged: mean n_valid {n_valid.float().mean().item():.1f}) " if a.ragged else "") +
                                              f"S={S} T={T}, {a.live:.0%} of the sentence slots start at token 0, uint8 position ids, eager launches"
                                              + (", compact edge rows (no E / dE tensors)" if a.compact else "") + (", dead last hop skipped" if a.skip_dead_hop else "")},
                       "gpu_ms_per_step_by_part": shares}))
