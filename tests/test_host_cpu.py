@@ -198,6 +198,19 @@ def test_deferral_is_switched_off_under_ddp():
     assert seen[0][0] is False and seen[1][0] is True
     assert any("DistributedDataParallel" in w for w in seen[1][1])
     assert F_._under_ddp() is False
+    # a torch build without the private marker: the test fails CLOSED (no parking) once several ranks exist, and stays off alone
+    saved = DDP._active_ddp_module
+    try:
+        del DDP._active_ddp_module
+        assert F_._under_ddp() is False                      # no process group: nothing to protect
+        real = (dist.is_initialized, dist.get_world_size)
+        dist.is_initialized, dist.get_world_size = (lambda: True), (lambda *a, **k: 2)
+        try:
+            assert F_._under_ddp() is True
+        finally:
+            dist.is_initialized, dist.get_world_size = real
+    finally:
+        DDP._active_ddp_module = saved
 
 
 def test_tail_keys_as_root_and_as_submodule():
