@@ -127,8 +127,13 @@ struct Bil2 {
   // compacted pair rows (ragged batches, head_fwd / head_bwd): the number of rows lives on the device (workgroups past it exit
   // at once), and output row r goes to row crow[r] of C (the pair's slot in the padded [B, N, N, .] tensor); NULL = dense
   const int* rows_dev; const int* crow;
-  int sel_lo, sel_hi;   // with rows_dev: this launch runs only when sel_lo <= *rows_dev < sel_hi (two tile sizes are launched for a
+  int sel_lo, sel_hi;   // with rows_dev: this launch runs only when sel_lo <= *rows_dev < sel_hi (two variants are launched for a
                         // device-side count; the one whose range does not hold the count leaves at once)
+  // K split over the four b-chunks (gridDim.y = 4; head_bil3_kernel): workgroup (tile, y) runs chunk y of the k sequence (y = 3
+  // also the Linear tail of MODE 1) and stores its RAW partial sums to part[y][row][128]; head_bil_combine_kernel sums the
+  // four in order, adds the bias and stores / scatters.  For row counts that leave most of the chip idle otherwise.
+  float* part;
+  int part_rows;        // rows of one partial slab
 };
 
 // position in the k-step sequence: for bc in 0..3: aa in 0..per_bc-1 (aa == nA: the Linear's et half, MODE 1), then tail steps
@@ -296,7 +301,11 @@ __global__ __launch_bounds__(256, 2) void head_bil3_kernel(const Bil2 a) {
   const long row = min(m0 + wave * 32 + l31, nrows - 1);   // this lane's A row (clamped: rows past the end are never stored)
   const float* __restrict__ prow = a.P + row * HW;
   const float* __restrict__ qrow = a.Q + row * HW;
-  const int per_bc = a.nA + (MODE == 1 ? 1 : 0), nsteps = 4 * per_bc + (MODE == 1 ? 4 : 0);
+  const int per_bc = a.nA + (MODE == 1 ? 1 : 0);
+  // the k sequence: four b-chunks of per_bc steps, then (MODE 1) four tail steps.  Unsplit: all of it; split (a.part): chunk
+  // blockIdx.y, the last one with the tail
+  const int ysp = a.part ? (int)blockIdx.y : 0;
+  const int nsteps = a.part ? per_bc + ((MODE == 1 && ysp == 3) ? 4 : 0) : 4 * per_bc + (MODE == 1 ? 4 : 0);
   // per-thread offsets of its four 16-byte pieces of a weight tile (32-bit: the weights are < 2^31 floats), the step adds
   // a uniform offset
   unsigned offW[4], offW2[4];
@@ -385,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void head_bil3_kernel(const Bil2 a) {
     }
   };
   float rb0[4][4], rb1[4][4];
-  BilPos pc = {0, 0}, pl = {0, 0};   // compute position, load position (two steps ahead)
+  BilPos pc = {ysp, 0}, pl = {ysp, 0};   // compute position, load position (two steps ahead)
   loadB(rb0, pl);
   storeB(rb0, lds);
   pl.next(per_bc);
@@ -395,12 +404,12 @@ __global__ __launch_bounds__(256, 2) void head_bil3_kernel(const Bil2 a) {
   float pa = pval(pp);
   pp.next(per_bc);
   float pn = pval(pp);
-  loadQ(0);
+  loadQ(ysp);
   __syncthreads();
   for (int s = 0; s < nsteps; s += 2) {
     loadB(rb1, pl);
     pl.next(per_bc);
-    if (pc.aa == 0 && pc.bc > 0 && pc.bc < 4) loadQ(pc.bc);
+    if (pc.aa == 0 && pc.bc > ysp && pc.bc < 4) loadQ(pc.bc);
     compute(bl0, pc, pa);
     pc.next(per_bc), pp.next(per_bc);
     pa = pn, pn = pval(pp);
@@ -409,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void head_bil3_kernel(const Bil2 a) {
     if (s + 1 >= nsteps) break;
     loadB(rb0, pl);
     pl.next(per_bc);
-    if (pc.aa == 0 && pc.bc > 0 && pc.bc < 4) loadQ(pc.bc);
+    if (pc.aa == 0 && pc.bc > ysp && pc.bc < 4) loadQ(pc.bc);
     compute(bl0 + SB, pc, pa);
     pc.next(per_bc), pp.next(per_bc);
     pa = pn, pn = pval(pp);
@@ -418,6 +427,23 @@ __global__ __launch_bounds__(256, 2) void head_bil3_kernel(const Bil2 a) {
   }
   // epilogue: lane holds columns {0, 32, 64} + l31 of rows m0 + wave*32 + (r & 3) + 8 (r >> 2) + 4 lh, and its k half of column 96
   a96 += __shfl_xor(a96, 32);
+  if (a.part) {   // K split: raw partial sums of this chunk, [y][row][128]; the combine kernel adds the bias and stores
+    float* __restrict__ wp = a.part + (long)ysp * a.part_rows * 128;
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) {
+      const int col = j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long rw = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (rw < nrows) wp[rw * 128 + col] = (j == 0 ? acc0[r] : j == 1 ? acc1[r] : j == 2 ? acc2[r] : acc3[r]);
+      }
+    }
+    if (MODE == 1 && lh == 0) {
+      const long rw = m0 + wave * 32 + l31;
+      if (rw < nrows) wp[rw * 128 + 96] = a96;
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < NACC; ++j) {
     const int col = j * 32 + l31;
@@ -545,13 +571,39 @@ static bool head_v1(long pairs) {
 // the forward pass's 128-pair tile with column 96 on the vector ALU (GCGCN_HEAD_BIL3=0 / set_option("head_bil3", 0): A/B knob)
 static bool head_bil3_ok(int ncol) { return option("head_bil3", 1) != 0 && ncol > 64 && ncol <= 97; }
 
+// out[row, col] = sum_y part[y][row][col] + bias[col] for the K-split passes above (y in order: deterministic), row < *rows_dev,
+// scattered through crow where the output is the padded logits tensor.
+__global__ __launch_bounds__(256) void head_bil_combine_kernel(const float* __restrict__ part, int part_rows, const int* __restrict__ rows_dev,
+                                                               int sel_lo, int sel_hi, const float* __restrict__ bias, const int* __restrict__ crow,
+                                                               float* __restrict__ C, int ncol, int ldc) {
+  const int nrows = *rows_dev;
+  if (nrows < sel_lo || nrows >= sel_hi) return;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  const long row = e >> 5;
+  const int c4 = (int)(e & 31) * 4;
+  if (row >= nrows) return;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int y = 0; y < 4; ++y) {
+    const float4 v = ld4(part + ((long)y * part_rows + row) * 128 + c4);
+    s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+  }
+  float* o = C + (crow ? (long)crow[row] : row) * ldc;
+  const float vs[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (c4 + u < ncol) o[c4 + u] = vs[u] + (bias ? bias[c4 + u] : 0.f);
+}
+
 constexpr int HEAD_TILE128_MIN_ROWS = 32768;   // one 128-pair tile per compute unit (the rule head_v1 applies to host-side counts)
 static int head_bil2(int mode, const float* P, const float* Q, const float* W, const float* W2, const float* bias, float* C, long rows,
-                     int nA, int ncol, int ldc, hipStream_t st, const int* rows_dev = nullptr, const int* crow = nullptr) {
+                     int nA, int ncol, int ldc, hipStream_t st, const int* rows_dev = nullptr, const int* crow = nullptr,
+                     float* part = nullptr, long part_rows = 0) {
   Bil2 a;
   a.P = P, a.Q = Q, a.W = W, a.W2 = W2, a.bias = bias, a.C = C, a.rows = (int)rows, a.nA = nA, a.ncol = ncol, a.ldc = ldc, a.accumulate_unused = 0;
   a.rows_dev = rows_dev, a.crow = crow;   // (rows = the capacity the grid is sized for)
   a.sel_lo = 0, a.sel_hi = 0x7fffffff;
+  a.part = nullptr, a.part_rows = 0;
   const dim3 grid((unsigned)cdiv(rows, 64)), grid128((unsigned)cdiv(rows, 128)), block(256);
   const double flops = 2.0 * rows * ncol * (double)(nA * HW + (mode == 1 ? 2 * HW : 0));
   const bool wide = option("head_bil3_bwd", 1) != 0;
@@ -567,14 +619,28 @@ static int head_bil2(int mode, const float* P, const float* Q, const float* W, c
     else GC_LAUNCH_TIMED("head_bilinear", flops, (head_bil2_kernel<3>), grid, block, 0, st, b);
   };
   if (rows_dev && tile128) {
-    // The count is on the device, the better tile depends on it: 128-pair tiles (each generated operand value feeds 3-4 MFMAs)
-    // once there is a tile per compute unit, 64-pair tiles below that (a DocRED batch of 32 documents: 14 k real pairs = 109
-    // big tiles on 256 compute units: 4.14 ms per step against 3.39 with the small ones).  Both are launched; the one whose range
-    // does not hold the count leaves at once (a few microseconds of a millisecond-sized pass).
+    // The count is on the device and the better launch shape depends on it; the host launches both, the one whose range does
+    // not hold the count leaves at once (a few microseconds of a millisecond-sized pass).  One 128-pair tile per compute unit
+    // and more (>= 32 768 pairs): the plain tiles.  Fewer (a DocRED batch of 32 documents: 14 k real pairs = 109 tiles on 256
+    // compute units, each streaming the whole 6.4 MB weight through its LDS): every tile split four ways over the b-chunks of
+    // the k sequence -- four times the workgroups, a quarter of the weight each -- plus a combine pass; without a partial-sum
+    // workspace, 64-pair tiles (4.14 -> 3.39 ms per step; the split: see DESIGN.md section 9).
     Bil2 big = a, small = a;
     big.sel_lo = HEAD_TILE128_MIN_ROWS, small.sel_hi = HEAD_TILE128_MIN_ROWS;
     launch128(big, 0.5 * flops);    // (the host-side work counter: one of the two runs, the timer sees both)
     if (int e = check_launch("head_bil3")) return e;
+    if (part && part_rows > 0) {
+      small.part = part, small.part_rows = (int)part_rows;
+      const long prow = rows < part_rows ? rows : part_rows;     // (counts below the threshold never exceed the slab)
+      const dim3 grid4((unsigned)cdiv(prow, 128), 4);
+      if (mode == 1) GC_LAUNCH_TIMED("head_bilinear", 0.5 * flops, head_bil3_kernel<1>, grid4, block, 0, st, small);
+      else if (mode == 2) GC_LAUNCH_TIMED("head_bilinear", 0.5 * flops, head_bil3_kernel<2>, grid4, block, 0, st, small);
+      else GC_LAUNCH_TIMED("head_bilinear", 0.5 * flops, head_bil3_kernel<3>, grid4, block, 0, st, small);
+      if (int e = check_launch("head_bil3 split")) return e;
+      hipLaunchKernelGGL(head_bil_combine_kernel, dim3((unsigned)cdiv(prow * 32, 256)), dim3(256), 0, st, part, (int)part_rows, rows_dev,
+                         small.sel_lo, small.sel_hi, bias, crow, C, ncol, ldc);
+      return check_launch("head_bil_combine");
+    }
     launch64(small, 0.5 * flops);
     return check_launch("head_bil2");
   }
@@ -833,6 +899,8 @@ struct HeadBufs {
   float *U, *Tt, *Rt, *UT, *bsum, *EH, *ET;                                  // forward (EH / ET saved for backward)
   float *doutp, *dEH, *dET, *dUT, *partR, *partT, *dRt, *dTt, *dW, *scratch;  // backward
   long scratch_elems;
+  float *partF, *partB;   // [4][part_rows][128] partial sums of the K-split bilinear passes (small compacted row counts)
+  long part_rows;
   int* idx;   // compacted pair rows of a ragged batch: [count | - | off[0..B] | prow[B N^2]] (head_index_kernel); NULL = dense
 };
 static long head_idx_ints(int B, int N) { return ((2 + (long)B + 1 + 3) & ~3L) + (long)B * N * N; }
@@ -887,7 +955,8 @@ int head_fwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int di
   }
   if (compact) {   // the pairs that exist, scattered into the padded tensor; every other slot is zero
     GC_REQUIRE(hipMemsetAsync(logits, 0, sizeof(float) * pairs * R, st) == hipSuccess, "head: memset failed");
-    return head_bil2(1, w.EH, w.ET, flat + y.Wb, flat + y.Wc, w.bsum, logits, pairs, HW, R, R, st, idx_cnt(w), idx_prow(w, B));
+    return head_bil2(1, w.EH, w.ET, flat + y.Wb, flat + y.Wc, w.bsum, logits, pairs, HW, R, R, st, idx_cnt(w), idx_prow(w, B), w.partF,
+                     w.part_rows);
   }
   GemmArgs g;   // logits = [eh (x) et | eh | et] [W_b ; W_c]^T + (b_b + b_c)                     (glove:358)
   g.A = w.EH, g.B = flat + y.Wb, g.C = logits, g.ldc = R;
@@ -940,7 +1009,8 @@ int head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int di
     GemmArgs g;
     g.A = w.doutp, g.B = flat + y.Wb, g.C = w.dEH, g.ldc = HW, g.M = (int)pairs, g.N = HW, g.K = R * HW;
     o.P = w.doutp, o.Q = w.ET;
-    if (compact || !head_v1(pairs)) GC_TRY(head_bil2(2, w.doutp, w.ET, flat + y.Wb, nullptr, nullptr, w.dEH, pairs, R, HW, HW, st, cnt));
+    if (compact || !head_v1(pairs))
+      GC_TRY(head_bil2(2, w.doutp, w.ET, flat + y.Wb, nullptr, nullptr, w.dEH, pairs, R, HW, HW, st, cnt, nullptr, compact ? w.partB : nullptr, w.part_rows));
     else GC_TRY(head_gemm(2, g, o, st));
     GC_TRY(rows_gemm(w.doutp, HW, 1, flat + y.Wc, 2 * HW, 0, w.dEH, HW, (int)pairs, HW, HW, 1, 1));
   }
@@ -948,7 +1018,8 @@ int head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int di
     GemmArgs g;
     g.A = w.doutp, g.B = flat + y.Wb, g.C = w.dET, g.ldc = HW, g.M = (int)pairs, g.N = HW, g.K = R * HW;
     o.P = w.doutp, o.Q = w.EH;
-    if (compact || !head_v1(pairs)) GC_TRY(head_bil2(3, w.doutp, w.EH, flat + y.Wb, nullptr, nullptr, w.dET, pairs, R, HW, HW, st, cnt));
+    if (compact || !head_v1(pairs))
+      GC_TRY(head_bil2(3, w.doutp, w.EH, flat + y.Wb, nullptr, nullptr, w.dET, pairs, R, HW, HW, st, cnt, nullptr, compact ? w.partB : nullptr, w.part_rows));
     else GC_TRY(head_gemm(3, g, o, st));
     GC_TRY(rows_gemm(w.doutp, HW, 1, flat + y.Wc + HW, 2 * HW, 0, w.dET, HW, (int)pairs, HW, HW, 1, 1));
   }
@@ -1023,6 +1094,8 @@ static HeadBufs head_bind(float* fwd, float* bwd, int B, int N, int R, int ND, l
   auto tf = [&](long n) { float* p = base ? base + at : nullptr; at += (n + 3) & ~3L; return p; };
   w.U = tf(BN * HW), w.Tt = tf(7 * HW), w.Rt = tf((long)ND * HW), w.UT = tf(BN * HW), w.bsum = tf(HW), w.EH = tf(pairs * HW);
   w.ET = tf(pairs * HW);
+  w.part_rows = pairs < HEAD_TILE128_MIN_ROWS ? pairs : HEAD_TILE128_MIN_ROWS;
+  w.partF = tf(4 * w.part_rows * 128);
   if (n_fwd) *n_fwd = at;
   base = bwd, at = 0;
   w.doutp = tf(pairs * HW), w.dEH = tf(pairs * HW), w.dET = tf(pairs * HW), w.dUT = tf(BN * HW), w.partR = tf((long)B * ND * HW);
@@ -1032,6 +1105,7 @@ static HeadBufs head_bind(float* fwd, float* bwd, int B, int N, int R, int ND, l
   const long cs = colsum_scratch_elems(pairs, HW, 1);
   if (w.scratch_elems < cs) w.scratch_elems = cs;
   w.scratch = tf(w.scratch_elems);
+  w.partB = tf(4 * w.part_rows * 128);
   if (n_bwd) *n_bwd = at;
   return w;
 }

@@ -162,6 +162,52 @@ def test_head_generations_agree_at_bench_size(gpu_device):
         torch.testing.assert_close(res["gen2"][1 + i][b, :n].cpu(), fr[i].grad, rtol=1e-3, atol=1e-4 * max(1.0, fr[i].grad.abs().max().item()))
 
 
+@pytest.mark.parametrize("B,N,full", [(20, 45, True),      # 38 k real pairs: above the one-tile-per-compute-unit threshold -> plain 128-pair tiles
+                                      (20, 45, False),     # ~13 k real pairs: every tile split four ways over the k sequence + combine
+                                      (3, 20, False)])     # a slab smaller than the threshold (capacity 1 200 pairs)
+def test_head_compacted_rows_at_both_launch_shapes(gpu_device, B, N, full):
+    """The compacted path picks its launch shape from a count that lives on the device (both shapes are launched, one leaves):
+    logits and every gradient against the path that computes every pair slot, on both sides of the threshold."""
+    R = 97
+    g = torch.Generator().manual_seed(B * 100 + N + int(full))
+    head = gcgcn_amd.ClassifierHead().to(gpu_device)
+    feats = [torch.rand(B, N, 128, generator=g) * 2 - 1 for _ in range(3)]
+    ntype, rel = torch.randint(0, 7, (B, N), generator=g), torch.randint(-10, 11, (B, N, N), generator=g)
+    nv = torch.full((B,), N, dtype=torch.int32) if full else torch.randint(2, N + 1, (B,), generator=g).to(torch.int32)
+    nv[-1] = max(2, N // 3)
+    cot = torch.randn(B, N, N, R, generator=g)
+    ner0, dis0 = torch.randn(7, 20, generator=g) * 0.3, torch.randn(21, 20, generator=g) * 0.3
+    dev = lambda t: t.to(gpu_device)
+    real = int((nv.long() ** 2).sum())
+    assert (real >= 32768) == full
+
+    def run():
+        head.zero_grad()
+        fg = [dev(f).requires_grad_() for f in feats]
+        ner, dis = dev(ner0).requires_grad_(), dev(dis0).requires_grad_()
+        out = head(fg, dev(ntype), dev(rel), ner, dis, n_valid=dev(nv))
+        (out * dev(cot)).sum().backward()
+        return [out.detach()] + [f.grad for f in fg] + [ner.grad, dis.grad, head.flat.grad.clone()]
+    try:
+        _lib.call("gcgcn_set_option", b"head_compact", 0)
+        _lib.call("gcgcn_set_option", b"head_v1", 0)
+        dense = run()
+        _lib.call("gcgcn_set_option", b"head_compact", 1)
+        comp, comp2 = run(), run()
+    finally:
+        _lib.call("gcgcn_set_option", b"head_compact", 1)
+        _lib.call("gcgcn_set_option", b"head_v1", -1)
+    ok = torch.arange(N)[None, :] < nv[:, None]
+    pairs_ok = (ok[:, :, None] & ok[:, None, :]).to(gpu_device)
+    assert float(comp[0][~pairs_ok].abs().max()) == 0.0
+    names = ["logits", "d f0", "d f1", "d f2", "d ner_emb", "d dis_embed", "d flat"]
+    for what, a, b_ in zip(names, comp, dense):
+        if what == "logits":
+            a, b_ = a[pairs_ok], b_[pairs_ok]
+        torch.testing.assert_close(a, b_, rtol=1e-4, atol=1e-4 * max(1.0, b_.abs().max().item()), msg=lambda m: f"{what}: {m}")
+    assert all(torch.equal(a, b_) for a, b_ in zip(comp, comp2))                     # deterministic
+
+
 def test_head_rejects_what_it_cannot_index(gpu_device):
     """ner_emb must have the 7 rows the kernels index (glove:241: nn.Embedding(7, ...)); ids out of range raise like the
     reference's embedding lookups (IndexError) when checking is on (the default outside graph capture)."""
