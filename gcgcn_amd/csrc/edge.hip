@@ -182,7 +182,6 @@ __global__ __launch_bounds__(64 * EW) void edge_bwd_carry_kernel(const float* __
                                                                  const Spread sp, const GatTail gt, const GemmGroup gg) {
   // one LDS image for both kinds of workgroup (the rows need N + EW * D floats of it): a fourth workgroup fits per CU
   __shared__ __attribute__((aligned(16))) float tile_lds[lds_floats<1, 1, true, true>()];
-  const int ntile = gg.tile_begin[gg.nprob];
   int r;
   if (spread_pick((int)blockIdx.x, sp, r)) {
     gemm_group_block<RB>(gg, r, tile_lds);
