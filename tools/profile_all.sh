@@ -10,6 +10,9 @@ for w in "$@"; do
     head42)      bash tools/profile_workload.sh ${round}_head_n42 tools/head_bench.py --N 42 --steps 5;;
     producer)    bash tools/profile_workload.sh ${round}_producer tools/producer_bench.py --steps 5;;
     tail)        bash tools/profile_workload.sh ${round}_tail tools/tail_bench.py --steps 5;;
+    tail_ragged) bash tools/profile_workload.sh ${round}_tail_ragged tools/tail_bench.py --ragged --steps 5;;
+    head_ragged) bash tools/profile_workload.sh ${round}_head_ragged tools/head_bench.py --ragged --steps 5;;
+    c2_ragged)   bash tools/profile_workload.sh ${round}_c2_ragged bench.py --config c2 --ragged --steps 20 --warmup 5 --no-cpu-baseline;;
   esac
   echo "== $w done"
 done
