@@ -212,6 +212,8 @@ def main():
     if args.ragged:
         g = torch.Generator().manual_seed(4242 + rank)
         n_valid = torch.clamp(torch.round(torch.randn(B, generator=g) * 6.0 + 19.5), 2, min(42, N)).to(torch.int32).to(dev)
+        if os.environ.get("GCGCN_BENCH_NVALID"):      # experiment switch: every document with the same number of real entities
+            n_valid = torch.full((B,), int(os.environ["GCGCN_BENCH_NVALID"]), dtype=torch.int32, device=dev)
     nsets = max(1, args.input_sets)
     sets = []                                     # resident batches, rotated: step i runs on sets[i % nsets]
     for k in range(nsets):

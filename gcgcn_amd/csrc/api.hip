@@ -114,7 +114,7 @@ static Opt g_opts[] = {{"head_v1", 0, false},   {"head_bil3", 0, false},  {"head
                        {"maggc_fuse", 0, false}, {"carry_spread", 0, false}, {"chain_spread", 0, false},
                        {"carry_cohort", 0, false}, {"chain_cohort", 0, false}, {"carry_spread_min", 0, false},
                        {"chain_spread_min", 0, false}, {"att_in_chain", 0, false}, {"fold_slices", 0, false}, {"head_sum_fold", 0, false},
-                       {"head_compact", 0, false}};
+                       {"head_compact", 0, false}, {"chain_big", 0, false}};
 int option(const char* name, int dflt) {
   for (Opt& o : g_opts) {
     if (strcmp(o.name, name) != 0) continue;
@@ -149,6 +149,16 @@ static bool use_chain() {
     g_chain = (e && e[0] == '1') ? 0 : 1;
   }
   return g_chain != 0;
+}
+
+// Graphs of more than 64 entities have no LDS-resident chain kernel: the generic chain kernels hand every product's tiles through
+// L2 inside one workgroup per (document, head) pair, and at that size each product is a full launch of its own anyway (cfg 5:
+// 4096 tiles).  Measured at cfg 5 (same session, profiles/r04_ab_chain_big.txt): per-product launches 7.67-7.74 ms, chain
+// kernels 7.86-7.90 ms per step; the one chain launch that pays is a FORWARD one with an edge mean riding in it (the chain hides
+// under the HBM-bound passenger: 698 us against 705 + 64).  Option chain_big = 1 restores the chain kernels everywhere (A/B, tests).
+static bool use_chain_for(int N, bool fwd_with_ride) {
+  if (!use_chain()) return false;
+  return N <= 64 || fwd_with_ride || option("chain_big", 0) != 0;
 }
 
 // GCGCN_NO_MHA_CORE=1 (or gcgcn_set_option("mha_core", 0)) sends small graphs through the generic batched-GEMM +
@@ -533,7 +543,7 @@ int gcgcn_gcn_fwd(int B, int N, int D, int L, int H, const float* X, const float
   // The per-(doc, head) context, with the passenger that will actually ride attached.  Ragged batch with a row-block list:
   // the products around the chain run on the rows that exist; what they leave on the dead row blocks is ZERO (rb_zero), so the
   // chain kernels -- whichever serves the shape -- see exactly what the dense products would have left there.
-  const bool chain = use_chain();
+  const bool chain = use_chain_for(N, er.kind && chain_can_carry(er));
   EdgeRide er_chain = er;
   if (er.kind && !(chain && chain_can_carry(er))) er_chain.kind = 0;
   GcnCtx c = make_ctx(B, N, D, L, H, y, X, A, flat, n_valid, drop);
@@ -659,13 +669,14 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
   c.Pn = const_cast<float*>(Pn), c.Y = const_cast<float*>(Y), c.rinv = const_cast<float*>(rinv);
   c.dYa = dYa, c.dM = dM, c.dP = dP, c.dA = dA, c.drow = drow, c.oWlin = y.oWlin;
   // ragged batch with a row-block list: the products around the chain run on the rows that exist (see gcgcn_gcn_fwd)
+  const bool chain = use_chain_for(N, false);
   {
     EdgeRide er_chain = er;
-    if (er.kind && !(use_chain() && chain_can_carry(er))) er_chain.kind = 0;
+    if (er.kind && !(chain && chain_can_carry(er))) er_chain.kind = 0;
     c.ride = er_chain;
   }
   const int* rows = (rowblk && n_valid && N % 16 == 0 && N >= 32) ? rowblk : nullptr;
-  const bool fuse = use_chain() && scratch && chain_bwd_fusable(c) && (((uintptr_t)dXres) & 15) == 0 &&
+  const bool fuse = chain && scratch && chain_bwd_fusable(c) && (((uintptr_t)dXres) & 15) == 0 &&
                     (((uintptr_t)dout) & 15) == 0 && (((uintptr_t)dout_m) & 15) == 0 && (long)M * HD >= (long)D * D;
   // sum_h Wlin_h: from the forward call if it left one, else summed here into dYa's buffer (free when the chain computes dHO)
   const float* wsum = (fuse && H > 1) ? (wsum_fwd ? wsum_fwd : dYa) : nullptr;
@@ -743,7 +754,6 @@ int gcgcn_gcn_bwd(int B, int N, int D, int L, int H, const float* X, const float
   }
 
   {  // the dependent per-(doc, head) sequence, last sub-layer first
-    const bool chain = use_chain();
     if (er.kind && !c.ride.kind) {
       GC_TRY(edge_bcast(er.in, er.n_valid, er.out, er.B, er.N, er.D, st));
       er.kind = 0;

@@ -20,6 +20,14 @@
 
 namespace gc {
 
+#ifdef GC_T_TRACE
+__device__ long long gc_trace_s[256];
+#define TS(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) gc_trace_s[(i) + (c.H == 1 ? 64 : 0)] = wall_clock64(); } while (0)
+extern "C" int gcgcn_debug_trace_s(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gc_trace_s), sizeof(long long) * 256); }
+#else
+#define TS(i)
+#endif
+
 __device__ __forceinline__ bool dev_al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // A chain workgroup is 512 threads = two 256-thread tile teams with an LDS image each.  The teams walk the
@@ -255,6 +263,7 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_fwd_kernel(const GcnCtx c
                                      blockIdx.x - c.B * c.H, lds);
     return;
   }
+  TS(0);
   float* const As = lds;
   float* const Ps = As + 64 * S_LA;
   float* const Ys = Ps + 64 * S_LP;
@@ -302,13 +311,14 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_fwd_kernel(const GcnCtx c
     gv[0][q] = Gg[row * HD + (unsigned)col];
     xv[0][q] = Xg[row * D + (unsigned)col];
   }
+  TS(1);
   if (own_att) {
     // MultiHeadAttention's core for this (document, head) pair (mha_body.hpp; scratch: the Y image, free until the first
     // product's epilogue): P / A to global memory for backward, the adjacency the chain uses into As; its rows again from
     // there for the normaliser
-    mha_core_fwd_body(Ys, z, c.mha.Q, c.n_valid, c.mha.P, c.mha.A, 64, c.D, c.H, c.mha.dh, c.mha.kchunk, c.mha.alpha, c.mha.drop, t,
-                      t < 256, As, S_LA, CW);
-    __syncthreads();
+    mha_core_fwd_body<true>(Ys, z, c.mha.Q, c.n_valid, c.mha.P, c.mha.A, 64, c.D, c.H, c.mha.dh, c.mha.kchunk, c.mha.alpha, c.mha.drop, t,
+                            t < 256, As, S_LA, CW);
+    lds_barrier();   // (LDS only: the adjacency image is complete; nobody waits for the P / A stores)
 #pragma unroll
     for (int u = 0; u < 8; ++u) s[u] = As[(wave * 8 + u) * S_LA + lane];
   } else {
@@ -318,6 +328,7 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_fwd_kernel(const GcnCtx c
       *reinterpret_cast<f32x4*>(As + (idx >> 4) * S_LA + (idx & 15) * 4) = a[u];
     }
   }
+  TS(2);
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int idx = t + 512 * u;
@@ -347,7 +358,9 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_fwd_kernel(const GcnCtx c
   }
 #pragma unroll
   for (int q = 0; q < 16; ++q) pv[q] = Pg[(unsigned)acc_row(r0, q) * HD + S_GH + (unsigned)col];
+  TS(3);
   lds_barrier();
+  TS(4);
 
 #pragma unroll
   for (int l = 0; l < 2; ++l) {
@@ -369,12 +382,15 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_fwd_kernel(const GcnCtx c
         c.Pn[zoff + (unsigned)row * HD + lo] = acc[q];
         Ps[row * S_LP + col] = acc[q];
       }
+      TS(8);
       lds_barrier();
+      TS(9);
     }
     // Y_l = relu((G_l + A_h Pn_l) rinv);  HO_l = dropout(Y_l) + X_l          (glove:42-50, 71-76)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
     mma_lds<64, true, false>(acc, As + (rb * 32 + r) * S_LA + 4 * hf, 0, Ps + (4 * hf) * S_LP + col, S_LP);
+    TS(5 + 5 * l);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int row = acc_row(r0, q);
@@ -386,7 +402,9 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_fwd_kernel(const GcnCtx c
       if (dd) w = (rng_u32(key, (uint64_t)(zoff + (long)o)) >= c.drop.thresh) ? v * c.drop.scale : 0.f;
       Hg[o] = w + xv[l][q];
     }
+    TS(6 + 5 * l);
     if (l == 0) lds_barrier();
+    TS(7 + 5 * l);
   }
 }
 
@@ -410,6 +428,7 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
     edge_bcast_row<4, CW>(r.in, r.n_valid, r.out, r.N, r.D, 0, pb);
     return;
   }
+  TS(20);
   float* const As = lds;
   float* const Ds = As + 64 * S_LA;     // dM_l; between the sub-layers the updated dY_0
   float* const Ps = Ds + 64 * S_LP;     // Pn_l
@@ -529,7 +548,9 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
 #pragma unroll
         for (int m = 0; m < 4; ++m) wsv[g][m] = Ws8[(8 * g + m) * 256];
     }
+    TS(21);
     lds_barrier();
+    TS(22);
     if (c.colpart && h == 0) {  // the output bias gradient's column sums of this document: rows 0-31 and 32-63
       const int cc = t & 255, half = t >> 8;
       float sacc = 0.f;
@@ -587,10 +608,12 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
 #pragma unroll
           for (int j = 0; j < 4; ++j) ho[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[m][j], ho[j], 0, 0, 0);
       };
+      TS(23);
       gload(0, br[0]);
       gload(1, br[1]);
       sstore(0, br[0]);
       lds_barrier();
+      TS(24);
       for (int ch = 0; ch < 16; ch += 2) {   // two chunks per trip: register sets and stages are compile-time constants
         if (ch + 2 < 16) gload(ch + 2, br[0]);
         compute(ch, 0);
@@ -602,6 +625,7 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
         lds_barrier();
       }
     }
+    TS(25);
     request_rows();   // for the row phase and the images of sub-layer 1: they land while the products below finish
     request_pn1();
     lds_barrier();  // everybody is done with the dout image: the K halves meet in its place, dXres's K quarters in Ds
@@ -655,11 +679,13 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
     lds_barrier();
 #pragma unroll
     for (int q = 0; q < 16; ++q) gv[q] = Qs[acc_row(r0, q) * S_LP + col];
+    TS(26);
   }
 
   auto sublayer = [&](auto lt) __attribute__((always_inline)) {   // l is a compile-time constant: the two passes differ in what they read and hand on
     constexpr int l = decltype(lt)::value;
     const unsigned lo = (unsigned)l * S_GH;
+    TS(30 + 10 * l);
     // through Y = relu(S), S = M rinv:  dS = dY [Y > 0];  dM = dS rinv;  drow -= rinv sum_c dS Y
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -691,7 +717,9 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
       }
       if (t < 64) Rs[t] = rs;
     }
+    TS(31 + 10 * l);
     lds_barrier();
+    TS(32 + 10 * l);
     // dPn_l = A_h^T dM_l   and   dA += dM_l Pn_l^T (this wave's K half): both wait only for dM_l
     f32x16 acc;
 #pragma unroll
@@ -708,10 +736,13 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
 #pragma unroll
       for (int u = 0; u < 8; ++u) wd[u] = *reinterpret_cast<const f32x4*>(W + (t + 512 * u) * 4);
     }
+    TS(33 + 10 * l);
     mma_lds<64, true, true>(dacc, Ds + ((ab & 1) * 32 + r) * S_LP + kh * 64 + 4 * hf, 0,
                             Ps + ((ab >> 1) * 32 + r) * S_LP + kh * 64 + 4 * hf, 0);
+    TS(34 + 10 * l);
     if constexpr (l == 1) {
       lds_barrier();  // dPn_1 complete in LDS; dM_1 and Pn_1 images free
+      TS(35 + 10 * l);
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int idx = t + 512 * u;
@@ -732,11 +763,14 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
         for (int q = 0; q < 16; ++q)  // dY_0 as it arrives (dropout_bwd(dHO_0))
           gv[q] = Gy[(unsigned)acc_row(r0, q) * HD + (unsigned)col];
       }
+      TS(36 + 10 * l);
       lds_barrier();
+      TS(37 + 10 * l);
       // dY_0 += dPn_1 Wd_1^T:  B[k][n] = Wd_1[n][k], this lane's column n is a row of the image
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[q] = 0.f;
       mma_lds<S_GH, true, true>(acc, Qs + (rb * 32 + r) * S_LP + 4 * hf, 0, Ws + col * S_LP + 4 * hf, 0);
+      TS(38 + 10 * l);
       lds_barrier();  // everybody is done with Wd_1's image
 #pragma unroll
       for (int q = 0; q < 16; ++q) Ds[acc_row(r0, q) * S_LP + col] = acc[q] + gv[q];
@@ -767,6 +801,7 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
   } else if (t >= 256 && t < 320) {
     c.drow[(long)z * 64 + (t - 256)] = Ts[t - 256];
   }
+  TS(55);
 }
 
 // the shape the LDS-resident kernels are written for

@@ -99,9 +99,9 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_fwd_kernel(const GcnCtx c)
       const int row = N + (idx >> 4), c4 = (idx & 15) * 4;
       *reinterpret_cast<t4*>(As + row * T_LA + c4) = t4{0.f, 0.f, 0.f, 0.f};
     }
-    mha_core_fwd_body(Ys, z, c.mha.Q, c.n_valid, c.mha.P, c.mha.A, N, c.D, c.H, c.mha.dh, c.mha.kchunk, c.mha.alpha, c.mha.drop, t,
-                      t < 256, As, T_LA, W);
-    __syncthreads();
+    mha_core_fwd_body<true>(Ys, z, c.mha.Q, c.n_valid, c.mha.P, c.mha.A, N, c.D, c.H, c.mha.dh, c.mha.kchunk, c.mha.alpha, c.mha.drop, t,
+                            t < 256, As, T_LA, W);
+    t_barrier();   // (LDS only: the adjacency image is complete; nobody waits for the P / A stores)
     for (int i = w; i < 64; i += W) {
       const float s = wave_sum(i < N ? As[i * T_LA + lane] : 0.f);
       if (lane == 0) {

@@ -52,6 +52,9 @@ __device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 
 // (mha_core.hip), the LDS-resident chain kernels run it in their prologue (chain.hip: a_lds != NULL receives the adjacency the
 // chain will use -- A, or P when there is no dropout -- as an image of row pitch a_pitch, so that the chain reads it from LDS
 // and the attention core needs no launch).  Same arithmetic in both uses, bit for bit.
+// LB: the barriers wait for this wave's LDS operations only (the chain kernels: __syncthreads() would also wait for every
+// outstanding prefetch of the chain to land and for the P / A stores below to be acknowledged -- nobody in the kernel reads those).
+template <bool LB = false>
 __device__ __forceinline__ void mha_core_fwd_body(float* __restrict__ sm, const int z, const float* __restrict__ Q,
                                                   const int* __restrict__ n_valid, float* __restrict__ P, float* __restrict__ A,
                                                   int N, int D, int H, int dh, int kchunk, float alpha, const Drop& drop,
@@ -59,6 +62,10 @@ __device__ __forceinline__ void mha_core_fwd_body(float* __restrict__ sm, const 
                                                   const int nwaves) {
   float* S = sm;             // [MT][MS]
   float* qs = sm + MT * MS;  // [MT][kchunk + 1]
+  auto barrier = [&]() __attribute__((always_inline)) {
+    if constexpr (LB) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();
+  };
   const int b = z / H, h = z - b * H;
   const int lane = t & 63, wave = t >> 6;
   const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
@@ -70,9 +77,9 @@ __device__ __forceinline__ void mha_core_fwd_body(float* __restrict__ sm, const 
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   for (int k0 = 0; k0 < dh; k0 += kchunk) {
     const int kc = min(kchunk, dh - k0);
-    if (k0) __syncthreads();
+    if (k0) barrier();
     if (on) load_q_chunk(qs, q, N, D, k0, kc, (kc + 3) & ~3, ld, t);
-    __syncthreads();
+    barrier();
     if (on) {
       const float* pa = qs + (32 * wr + (lane & 31)) * ld + (lane >> 5);
       const float* pb = qs + (32 * wc + (lane & 31)) * ld + (lane >> 5);
@@ -83,7 +90,7 @@ __device__ __forceinline__ void mha_core_fwd_body(float* __restrict__ sm, const 
 #pragma unroll
     for (int r = 0; r < 16; ++r) S[(32 * wr + mfma_row(r, lane)) * MS + 32 * wc + (lane & 31)] = acc[r] * alpha;
   }
-  __syncthreads();
+  barrier();
   // row softmax over the valid columns, dropout; lane = column; every wave of the workgroup takes rows
   const bool dd = A && drop.snap;
   const uint64_t key = dd ? drop_key(drop) : 0;

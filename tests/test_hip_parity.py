@@ -896,6 +896,35 @@ def test_chain_and_per_product_paths_agree(gpu_device):
         _lib.call("gcgcn_set_option", b"bogus", 1)
 
 
+@pytest.mark.parametrize("B,N,D,L,H,train", [(2, 128, 128, 2, 4, False), (1, 128, 128, 2, 4, True), (2, 80, 64, 2, 2, False)])
+def test_graphs_above_64_entities_chain_kernels_against_per_product_launches(gpu_device, B, N, D, L, H, train):
+    """More than 64 entities (what cfg 5 runs): by default only a FORWARD chain launch with an edge mean riding in it uses the
+    generic chain kernels, everything else one launch per product (round-4 A/B at cfg 5).  Option chain_big = 1 puts the chain
+    kernels back everywhere: same outputs and gradients, same dropout draws.  (N = 80: the unaligned instantiations.)"""
+    sd = O.init_stack_params(D, L, H, seed=31)
+    x, e1, e2, adj = O.synth_docs(B, N, D, seed=32)
+    hops = gcgcn_amd.GraphHops(D, L, H).to(gpu_device).train(train)
+    hops.load_state_dict(sd, strict=True)
+    cot = torch.randn(B, N, D, generator=torch.Generator().manual_seed(9)).to(gpu_device)
+    res = []
+    try:
+        for big in (0, 1):
+            _lib.call("gcgcn_set_option", b"chain_big", big)
+            gcgcn_amd.manual_seed(99, gpu_device)
+            xs = [dev_leaf(t, gpu_device) for t in (x, e1, e2)]
+            hops.zero_grad()
+            f = hops(xs[0], [xs[1], xs[2]], adj.to(gpu_device))
+            torch.autograd.backward(f[-1], cot)
+            res.append([f[1].detach(), f[2].detach(), xs[0].grad, xs[1].grad, xs[2].grad] +
+                       [p.grad.clone() for p in hops.parameters() if p.grad is not None])
+    finally:
+        _lib.call("gcgcn_set_option", b"chain_big", 0)
+    assert len(res[0]) == len(res[1]) == 9
+    for i, (a, b_) in enumerate(zip(*res)):
+        top = max(1.0, b_.abs().max().item())
+        torch.testing.assert_close(a, b_, rtol=2e-4, atol=2e-5 * top, msg=lambda m: f"tensor {i}: {m}")
+
+
 @pytest.mark.parametrize("B,N,D,L,H,ragged,train", [
     (3, 64, 768, 4, 4, False, False),    # cfg 3 (bert-sized): gh = 192, four sub-layers, 12 waves
     (2, 64, 768, 4, 4, True, True),      #   ... ragged, dropout on
