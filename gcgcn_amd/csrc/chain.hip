@@ -217,7 +217,8 @@ constexpr int S_LA = 68;    // row pitch of the 64x64 adjacency image (floats; 1
 constexpr int S_LP = 132;   // row pitch of a 64x128 operand image
 constexpr int S_GH = 128;
 constexpr int S_FWD_LDS = 64 * S_LA + 2 * 64 * S_LP + 64 + S_GH * S_LP;   // + the Wd_1 image [128][132]
-constexpr int S_BWD_LDS = 64 * S_LA + 3 * 64 * S_LP + 128;
+constexpr int S_BWD_XS = 6 * 16 * 64;   // dXres: the partial sums of three K quarters (FUSE, H > 1)
+constexpr int S_BWD_LDS = 64 * S_LA + 3 * 64 * S_LP + 128 + S_BWD_XS;
 static_assert(S_FWD_LDS >= CHAIN_LDS && S_BWD_LDS >= CHAIN_LDS + XCHG_LDS, "passengers use the chain kernels' LDS");
 static_assert(S_BWD_LDS * sizeof(float) <= 160 * 1024, "LDS of one compute unit");
 
@@ -436,6 +437,7 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
   float* const Qs = Ps + 64 * S_LP;     // dPn_1; at the end the K halves of dA meet here
   float* const Rs = Qs + 64 * S_LP;     // rinv
   float* const Ts = Rs + 64;            // gradient of the normaliser's row sums
+  float* const Es = Ts + 64;            // FUSE: dXres's K quarters meet here
   // Workgroups go to the eight XCDs round robin (blockIdx % 8).  With z = b H + h and H = 8 an XCD would run ONE head; give
   // each XCD all heads of a few documents instead: the heads of a document share dout_b (and X_b, A's neighbours) in its L2.
   int b, h;
@@ -558,13 +560,16 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
       for (int i = 0; i < 32; ++i) sacc += Xs[(half * 32 + i) * S_LX + cc];
       c.colpart[(long)(2 * b + half) * 256 + cc] = sacc;
     }
-    // dHO_b = dout_b Wlin[:, h]: wave = (rows rb, sub-layer l2 = its 128 columns, every other group of 8 k: k2).  Four
-    // accumulators whose columns interleave: lane r owns columns 4 r .. 4 r + 3, accumulator j the columns = j (mod 4), so one
-    // 16-byte B read feeds four MFMAs and the results leave as 16-byte stores.
-    const int l2 = (wave >> 1) & 1, k2 = wave >> 2;
-    f32x16 ho[4];
+    // dHO_b = dout_b Wlin[:, h]: wave = (rows rb, column quarter cq: 64 columns of the head's 256 = half a sub-layer), the whole
+    // K.  Two accumulators whose columns interleave: lane r owns columns 2 r, 2 r + 1, accumulator j the columns = j (mod 2), so
+    // one 8-byte B read feeds two MFMAs and the results leave as 8-byte stores.  (Round 3 split K over wave pairs instead, four
+    // accumulators of 128 columns each: the halves then met in LDS behind two more barriers -- 7.0 us between the product and the
+    // first sub-layer, profiles/r04_chain_phase_trace_before.txt.)
+    const int cq = wave >> 1, l2 = cq >> 1, cl = (cq & 1) * 64 + 2 * r;   // cl: first of this lane's two columns in its sub-layer
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x16 ho[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int q = 0; q < 16; ++q) ho[j][q] = 0.f;
     float* __restrict__ Xr = c.dXres + (long)b * 64 * 256;
@@ -578,6 +583,10 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
         const f32x4 av = *reinterpret_cast<const f32x4*>(pax + 8 * g);
 #pragma unroll
         for (int m = 0; m < 4; ++m) xs[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], wsv[g][m], xs[0], 0, 0, 0);
+      }
+      if (kq > 0) {  // the quarters meet in an area of their own: read back behind the product's last barrier
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Es[(((kq - 1) * 2 + rb2) * 16 + q) * 64 + lane] = xs[0][q];
       }
     }
     {  // Wlin's slice goes through LDS in chunks of 16 k (two stages in the dM image's place), loaded once per workgroup by all
@@ -596,17 +605,20 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
 #pragma unroll
         for (int u = 0; u < 2; ++u) *reinterpret_cast<f32x4*>(Bs + st * BST + ((t >> 6) + 8 * u) * S_LB + (t & 63) * 4) = d[u];
       };
-      const float* pa = Xs + (rb * 32 + r) * S_LX + k2 * 8 + 4 * hf;
-      const float* pb = Bs + (k2 * 8 + 4 * hf) * S_LB + l2 * S_GH + 4 * r;
+      const float* pa = Xs + (rb * 32 + r) * S_LX + 4 * hf;
+      const float* pb = Bs + (4 * hf) * S_LB + cq * 64 + 2 * r;
       auto compute = [&](const int ch, const int st) __attribute__((always_inline)) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(pa + 16 * ch);
-        f32x4 b[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) b[m] = *reinterpret_cast<const f32x4*>(pb + st * BST + m * S_LB);
+        for (int g2 = 0; g2 < 2; ++g2) {   // the two groups of 8 k of a chunk: the four k of a read go to four MFMAs, lanes 32-63 take the next four
+          const f32x4 a = *reinterpret_cast<const f32x4*>(pa + 16 * ch + 8 * g2);
+          f32x2 b[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+          for (int m = 0; m < 4; ++m) b[m] = *reinterpret_cast<const f32x2*>(pb + st * BST + (8 * g2 + m) * S_LB);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) ho[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[m][j], ho[j], 0, 0, 0);
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) ho[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[m][j], ho[j], 0, 0, 0);
+        }
       };
       TS(23);
       gload(0, br[0]);
@@ -622,58 +634,42 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
         if (ch + 3 < 16) gload(ch + 3, br[1]);
         compute(ch + 1, 1);
         if (ch + 2 < 16) sstore(0, br[0]);
+        if (ch == 12) {   // for the row phase and the images of sub-layer 1: they land while the last chunks run
+          request_rows();
+          request_pn1();
+        }
         lds_barrier();
       }
     }
     TS(25);
-    request_rows();   // for the row phase and the images of sub-layer 1: they land while the products below finish
-    request_pn1();
-    lds_barrier();  // everybody is done with the dout image: the K halves meet in its place, dXres's K quarters in Ds
-    if (k2 == 1) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) Xs[(((wave & 3) * 4 + j) * 16 + q) * 64 + lane] = ho[j][q];
-    }
-    if (c.H != 1 && kq > 0) {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) Ds[(((kq - 1) * 2 + rb2) * 16 + q) * 64 + lane] = xs[0][q];
-    }
-    lds_barrier();
-    if (k2 == 0) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) ho[j][q] += Xs[(((wave & 3) * 4 + j) * 16 + q) * 64 + lane];
-    }
+    // (the loop's last barrier: everybody is done with the dout image and the weight stages, and dXres's quarters are in Es)
     if (c.H != 1 && kq == 0) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         float v = xs[0][q];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) v += Ds[((k * 2 + rb2) * 16 + q) * 64 + lane];
+        for (int k = 0; k < 3; ++k) v += Es[((k * 2 + rb2) * 16 + q) * 64 + lane];
         Xr[acc_row(rb2 * 32 + hf * 4, q) * 256 + h * 32 + r] = v;
       }
     }
-    lds_barrier();  // the exchange areas are free
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int idx = t + 512 * u;
       *reinterpret_cast<f32x4*>(Ps + (idx >> 5) * S_LP + (idx & 31) * 4) = p1[u];
     }
-    if (k2 == 0) {  // dY = dropout_bwd(dHO): images for the row phase (sub-layer 1) and for dY_0's accumulator start
+    {  // dY = dropout_bwd(dHO): images for the row phase (sub-layer 1) and for dY_0's accumulator start
       float* const img = l2 ? Ds : Qs;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = acc_row(r0, q);
-        f32x4 g = {ho[0][q], ho[1][q], ho[2][q], ho[3][q]};
-        if (c.H == 1) *reinterpret_cast<f32x4*>(Xr + row * 256 + l2 * S_GH + 4 * r) = g;
+        f32x2 g = {ho[0][q], ho[1][q]};
+        if (c.H == 1) *reinterpret_cast<f32x2*>(Xr + row * 256 + l2 * S_GH + cl) = g;
         if (dd) {
-          const long o = zoff + (long)((unsigned)row * HD + (unsigned)(l2 * S_GH + 4 * r));
+          const long o = zoff + (long)((unsigned)row * HD + (unsigned)(l2 * S_GH + cl));
 #pragma unroll
-          for (int j = 0; j < 4; ++j) g[j] = (rng_u32(key, (uint64_t)(o + j)) >= c.drop.thresh) ? g[j] * c.drop.scale : 0.f;
+          for (int j = 0; j < 2; ++j) g[j] = (rng_u32(key, (uint64_t)(o + j)) >= c.drop.thresh) ? g[j] * c.drop.scale : 0.f;
         }
-        *reinterpret_cast<f32x4*>(img + row * S_LP + 4 * r) = g;
+        *reinterpret_cast<f32x2*>(img + row * S_LP + cl) = g;
       }
     }
     lds_barrier();
