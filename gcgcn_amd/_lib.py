@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GCGCN_LIB=<path> loads another build of the same ABI (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("GCGCN_LIB") or os.path.join(_HERE, "lib", "libgcgcn_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 SALT_GAT = 0x47415431
 SALT_MHA = 0x4D484131
@@ -57,6 +57,7 @@ SIGNATURES = {
     "gcgcn_edge_mean_bwd": (I, [I, I, I, P, P, P, P]),
     "gcgcn_mha_layout": (I, [I, P]),
     "gcgcn_mha_scratch": (L, [I, I, I]),
+    "gcgcn_row_blocks_ints": (L, [I, I]),
     "gcgcn_row_blocks": (I, [I, I, P, P, P]),
     "gcgcn_mha_fwd": (I, [I, I, I, I, P, P, P, P, F, P, P, P, P, P, P]),
     "gcgcn_mha_bwd": (I, [I, I, I, I, P, P, P, F, P, P, P, P, P, P, P, P, P, P, I, P, P]),

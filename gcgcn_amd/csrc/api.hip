@@ -185,9 +185,12 @@ static int make_ride(const char* who, const gcgcn_edge_ride* ride, int kind, Edg
 }
 
 // Row blocks of a ragged batch (gcgcn_row_blocks) on one GEMM problem: mode 1 = M is the document-row dimension, 2 = K is.
+// (mode 2 -- weight gradients -- walks the list of live 32-row k-tiles behind the block list: g.K = B N is set by then)
 static void use_rows(GemmArgs& g, const int* rowblk, int mode, int zero_dead = 0) {
   if (!rowblk) return;
-  g.rb = rowblk + ROWBLK_HDR, g.rb_n = rowblk, g.rb_mode = mode, g.rb_zero = zero_dead;
+  if (mode == 2) g.rb = rowblk + ROWBLK_HDR + g.K / 16, g.rb_n = rowblk + 1;
+  else g.rb = rowblk + ROWBLK_HDR, g.rb_n = rowblk;
+  g.rb_mode = mode, g.rb_zero = zero_dead;
 }
 
 static GcnCtx make_ctx(int B, int N, int D, int L, int H, const GcnLayout& y, const float* X, const float* A,
@@ -206,7 +209,7 @@ using namespace gc;
 
 extern "C" {
 
-int gcgcn_version(void) { return 5; }
+int gcgcn_version(void) { return 6; }
 const char* gcgcn_last_error(void) { return g_err; }
 
 int gcgcn_set_option(const char* name, int value) {
@@ -224,6 +227,7 @@ int gcgcn_set_option(const char* name, int value) {
   return 1;
 }
 
+int64_t gcgcn_row_blocks_ints(int B, int N) { return (B > 0 && N > 0 && N % 16 == 0) ? row_blocks_ints(B, N) : 0; }
 int gcgcn_row_blocks(int B, int N, const int32_t* n_valid, int32_t* out, void* stream) {
   return row_blocks(n_valid, B, N, out, (hipStream_t)stream);
 }

@@ -301,7 +301,7 @@ static int prepare(GemmArgs& g, int tile, int splits, long group_work) {
   g.ksplit = (splits > 1) ? g.K / splits : g.K;
   if (g.rb) {  // row blocks of a ragged batch: only what the gathering tile body serves, anything else runs dense (equally correct)
     const bool interior = g.vecA && g.vecB && g.M % 64 == 0 && g.N % 64 == 0 && g.K % BK == 0 && g.ksplit % BK == 0 && g.rb_n;
-    const bool ok = interior && ((g.rb_mode == 1 && g.a_kc && nb == 1) || (g.rb_mode == 2 && !g.a_kc && !g.b_kc && g.K % 64 == 0));
+    const bool ok = interior && ((g.rb_mode == 1 && g.a_kc && nb == 1) || (g.rb_mode == 2 && !g.a_kc && !g.b_kc && g.K % 64 == 0 && g.K / BK <= ROWBLK_KTILES_MAX));
     // M-side: a launch that does not fill the chip anyway gains nothing from skipping tiles and pays the list's lookups in
     // its latency-bound prologue (128-tile output projection: 21 vs 16 us measured) -- dense below one tile per compute unit
     // and slot (a problem inside a group launch shares the launch: group_work > 0 keeps it)

@@ -113,22 +113,6 @@ struct TilePtr {
     }
     kstep = 1;
   }
-  // rb_mode 2, operand [k][cols] with k the document rows: a k-tile is BMN / 32 blocks of 16 rows; the thread keeps its row
-  // INSIDE a block and its columns, the block comes with every request (id[q]; -1: past the live blocks, contributes zeros).
-  __device__ __forceinline__ void init_k(const float* __restrict__ src, long ld, int mn0, int t) {
-    static_assert(!KC && BMN == 64, "k-gathered operands are stored [k][cols], 64 columns per tile");
-#pragma unroll
-    for (int q = 0; q < BMN / 32; ++q) p[q] = src + (long)(t >> 4) * ld + mn0 + ((t & 15) << 2);
-    kstep = ld;
-  }
-  __device__ __forceinline__ void load_k(float (&r)[BMN / 32][4], const int (&id)[2]) const {
-#pragma unroll
-    for (int q = 0; q < BMN / 32; ++q) {
-      float4 v = *reinterpret_cast<const float4*>(p[q] + (long)max(id[q], 0) * 16 * kstep);
-      if (id[q] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      r[q][0] = v.x, r[q][1] = v.y, r[q][2] = v.z, r[q][3] = v.w;
-    }
-  }
 };
 
 // How a tile body obtains its operands.  PlainOperands reads g.A / g.B; other policies (head.hip: operands that are
@@ -375,17 +359,28 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
   constexpr bool FASTP = ALIGNED && std::is_same<OPS, PlainOperands>::value;
   // ragged batches (GemmArgs::rb): the live 16-row blocks of the document-row dimension
   const bool rbm = RB && FASTP && AKC && g.rb && g.rb_mode == 1;             // M = document rows: A rows gathered, C rows scattered
-  const bool rbk = RB && FASTP && !AKC && !BKC && g.rb && g.rb_mode == 2;    // K = document rows: both operands gathered
-  const int nl = (rbm || rbk) ? __builtin_amdgcn_readfirstlane(*g.rb_n) : 0;
+  const bool rbk = RB && FASTP && !AKC && !BKC && g.rb && g.rb_mode == 2;    // K = document rows: the live 32-row k-tiles only
+  const int nl = rbm ? __builtin_amdgcn_readfirstlane(*g.rb_n) : 0;
+  const int nkt = rbk ? __builtin_amdgcn_readfirstlane(*g.rb_n) : 0;
   int kbeg = sp * g.ksplit;
   int kend = min(g.K, kbeg + g.ksplit);
+  // rb_mode 2: the ascending list of live k-tiles (at most ROWBLK_KTILES_MAX = 256, gemm.hip prepare()) sits in four registers,
+  // entry e in lane e % 64 of register e / 64: the k-loop picks its tiles with v_readlane, no memory operation.  (Round 4 first
+  // gathered 16-row blocks through scalar loads inside the k-loop: twice the time per k-step of the dense loop, which made the
+  // skipped rows a wash -- cfg 2 ragged, edge_bwd_carry 81 us with the list against 83 us dense.)  Rows of a live k-tile that
+  // belong to a dead block hold zeros in one operand and finite values in the other, exactly as in the dense product.
+  int kl[4] = {-1, -1, -1, -1};
   if (rbk) {
-    // K = the live rows.  Every slice runs the SAME number of k-tiles (two tile teams of one workgroup share its barriers):
-    // ceil(k-tiles / splits), at least one; blocks past the live ones load zeros (ids() below), so a slice that reaches
-    // past the end -- or lies wholly behind it -- just adds zeros.
-    const int kt_all = (nl * 16 + BK - 1) / BK;
-    const int ks = max((kt_all + g.splits - 1) / g.splits, 1) * BK;
+    // Every slice runs the SAME number of k-tiles (two tile teams of one workgroup share its barriers): ceil(k-tiles / splits),
+    // at least one; list positions past the end contribute zeros, so a slice that reaches past it -- or lies wholly behind it --
+    // just adds zeros.
+    const int ks = max((nkt + g.splits - 1) / g.splits, 1) * BK;
     kbeg = sp * ks, kend = kbeg + ks;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = lane + 64 * j;
+      kl[j] = e < nkt ? g.rb[e] : -1;
+    }
   }
 
   const float* __restrict__ A = g.A + z1 * g.sA1 + z2 * g.sA2;
@@ -431,43 +426,47 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
       if (rbm) tpa.init_rows(A, g.lda, m0, t, g.rb, max(nl, 1));
       else tpa.init(A, g.lda, m0, t);
       tpb.init(B, g.ldb, n0, t);
-    } else if constexpr (!BKC && BM == 64 && BN == 64) {
-      if (rbk) tpa.init_k(A, g.lda, m0, t), tpb.init_k(B, g.ldb, n0, t);
-      else tpa.init(A, g.lda, m0, t), tpb.init(B, g.ldb, n0, t);
     } else {
       tpa.init(A, g.lda, m0, t), tpb.init(B, g.ldb, n0, t);
     }
   }
-  // rb_mode 2: the two 16-row blocks of a set's NEXT request, fetched one request ahead (scalar loads that have long
-  // landed when the request is issued: a request must not wait for its own addresses in the middle of a k-tile's MFMAs)
-  int id0[2] = {0, 0}, id1[2] = {0, 0};
-  auto ids = [&](int (&id)[2], int kt) {
-    // (wave-uniform by construction; readfirstlane makes the compiler see it, so these are scalar loads -- as vector loads
-    // their wait would also drain the operand requests in flight and take the two-tile prefetch apart)
-    const int bi = __builtin_amdgcn_readfirstlane(kof(kt) >> 4);
-    id[0] = bi < nl ? g.rb[bi] : -1;
-    id[1] = bi + 1 < nl ? g.rb[bi + 1] : -1;
+  // rb_mode 2: the k-tile of a register set's NEXT request (-1: past the list, the request's registers are zeroed); wave-uniform
+  int id0 = 0, id1 = 0;
+  auto ids = [&](int& id, int kt) {
+    const int e = __builtin_amdgcn_readfirstlane(kbeg / BK + min(kt, nk - 1));
+    const int v = e < 64 ? kl[0] : e < 128 ? kl[1] : e < 192 ? kl[2] : kl[3];
+    id = e < 4 * 64 ? __builtin_amdgcn_readlane(v, e & 63) : -1;
   };
-  auto load_a = [&](float (&r)[BM / 32][4], int k0, const int (&id)[2]) {
+  auto load_a = [&](float (&r)[BM / 32][4], int k0, const int id) {
     if constexpr (FASTP) {
-      if constexpr (!AKC && !BKC && BM == 64 && BN == 64) {
-        if (rbk) tpa.load_k(r, id);
-        else tpa.load(r, k0);
-      } else {
-        tpa.load(r, k0);
+      if constexpr (RB && !AKC && !BKC) {
+        if (rbk) {
+          tpa.load(r, max(id, 0) * BK);
+          if (id < 0) {
+#pragma unroll
+            for (int q = 0; q < BM / 32; ++q) r[q][0] = r[q][1] = r[q][2] = r[q][3] = 0.f;
+          }
+          return;
+        }
       }
+      tpa.load(r, k0);
     } else {
       ops.template load_a<BM, AKC, ALIGNED>(r, g, A, m0, k0, kend, t);
     }
   };
-  auto load_b = [&](float (&r)[BN / 32][4], int k0, const int (&id)[2]) {
+  auto load_b = [&](float (&r)[BN / 32][4], int k0, const int id) {
     if constexpr (FASTP) {
-      if constexpr (!AKC && !BKC && BM == 64 && BN == 64) {
-        if (rbk) tpb.load_k(r, id);
-        else tpb.load(r, k0);
-      } else {
-        tpb.load(r, k0);
+      if constexpr (RB && !AKC && !BKC) {
+        if (rbk) {
+          tpb.load(r, max(id, 0) * BK);
+          if (id < 0) {
+#pragma unroll
+            for (int q = 0; q < BN / 32; ++q) r[q][0] = r[q][1] = r[q][2] = r[q][3] = 0.f;
+          }
+          return;
+        }
       }
+      tpb.load(r, k0);
     } else {
       ops.template load_b<BN, BKC, ALIGNED>(r, g, B, n0, k0, kend, t);
     }

@@ -66,12 +66,12 @@ row_block_launches = os.environ.get("GCGCN_ROW_BLOCKS", "1") != "0"      # GCGCN
 
 
 def row_blocks(n_valid: Optional[Tensor], B: int, N: int) -> Optional[Tensor]:
-    """int32[4 + B N / 16] for gcgcn_gcn_fwd / _bwd / gcgcn_mha_fwd / _bwd (``rowblk``), or None (dense products)."""
+    """int32[gcgcn_row_blocks_ints(B, N)] for gcgcn_gcn_fwd / _bwd / gcgcn_mha_fwd / _bwd (``rowblk``), or None (dense products)."""
     # (N = 16 is one block per document: nothing to skip but whole empty documents, and the list's lookups cost cfg 1 10 %)
     if n_valid is None or not row_block_launches or N % 16 != 0 or N < 32 or not n_valid.is_cuda:
         return None
     nv = n_valid.to(dtype=torch.int32).contiguous()
-    out = torch.empty(4 + B * N // 16, dtype=torch.int32, device=nv.device)
+    out = torch.empty(int(_lib.lib().gcgcn_row_blocks_ints(B, N)), dtype=torch.int32, device=nv.device)
     call("gcgcn_row_blocks", B, N, _p(nv), _p(out), _stream())
     return out
 

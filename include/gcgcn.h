@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-int gcgcn_version(void);            /* ABI version, currently 5 */
+int gcgcn_version(void);            /* ABI version, currently 6 */
 const char* gcgcn_last_error(void); /* message of the last failing call on this thread */
 
 /* Run-time switches for A/B tests.  "chain": 1 (default) = the per-(doc, head) products of a conv run inside the
@@ -43,17 +43,21 @@ const char* gcgcn_last_error(void); /* message of the last failing call on this 
  * environment variable GCGCN_<NAME> once when nobody set it (DESIGN.md section 6 lists them). */
 int gcgcn_set_option(const char* name, int value);
 
-/* ---- ragged batches: the entity rows that exist (ABI v5) -------------------------------------------------------------- */
+/* ---- ragged batches: the entity rows that exist (ABI v5; v6: the k-tile list) ------------------------------------------ */
 /* The reference runs one UNPADDED document per call (config/Config.py:339-354): its products have n rows.  A padded batch
  * [B, N, .] with n_valid has sum_b n_b real rows of B N.  gcgcn_row_blocks lists the 16-row blocks of the [B N]-row tensors,
- * the LIVE ones first (block r of document b is live iff 16 r < n_valid[b]): out = int32[4 + B N / 16] = {live count, 0, 0, 0,
- * list}; N must be a multiple of 16.  Given as `rowblk` to gcgcn_gcn_fwd / _bwd and gcgcn_mha_fwd / _bwd (NULL = dense), the
- * node-phase products of the block -- X WnX, Ebar We, X Wq, the output projection, every data gradient and every weight
- * gradient (K = the live rows) -- run on the live blocks only; the tensors keep their padded layout, outputs that leave the
- * block (out, dX, dEbar, Q) are zero on padding rows as always.  Everything stays on the device (no host read; the list is
- * rebuilt by every replay of a captured step).  A block whose shape the column-strip chain kernels do not serve (N > 64, or
- * a width they are not instantiated for) ignores the list and computes every row, as does a forward / backward pair without
- * n_valid.  The SAME list must be given to a block's forward and backward. */
+ * the LIVE ones first (block r of document b is live iff 16 r < n_valid[b]), and behind them the live 32-row k-tiles of the
+ * same rows (tile kt = blocks 2 kt and 2 kt + 1, live iff one of them is), ascending:
+ *   out = int32[gcgcn_row_blocks_ints(B, N)] = {live blocks, live k-tiles, 0, 0 | B N / 16 blocks | the live k-tiles};
+ * N must be a multiple of 16.  Given as `rowblk` to gcgcn_gcn_fwd / _bwd and gcgcn_mha_fwd / _bwd (NULL = dense), the
+ * node-phase products of the block -- X WnX, Ebar We, X Wq, the output projection, every data gradient -- run on the live
+ * blocks only, and every weight gradient (K = the document rows) on the live k-tiles (up to 256 of them, B N <= 8192; longer
+ * lists run dense); the tensors keep their padded layout, outputs that leave the block (out, dX, dEbar, Q) are zero on
+ * padding rows as always.  Everything stays on the device (no host read; the list is rebuilt by every replay of a captured
+ * step).  A block whose shape the column-strip chain kernels do not serve (N > 64, or a width they are not instantiated for)
+ * ignores the list and computes every row, as does a forward / backward pair without n_valid.  The SAME list must be given
+ * to a block's forward and backward. */
+int64_t gcgcn_row_blocks_ints(int B, int N);
 int gcgcn_row_blocks(int B, int N, const int32_t* n_valid, int32_t* out, void* stream);
 
 /* ---- per-kernel timing for roofline reports (bench.py) ------------------------------------------- */

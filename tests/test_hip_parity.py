@@ -460,12 +460,18 @@ def test_row_block_launches_equal_the_dense_products(gpu_device, B, N, D, L, H, 
     finally:
         F_.row_block_launches = True
         F_.row_blocks = orig_rb
-    assert seen[0] is not None and seen[0].numel() == 4 + B * N // 16 and seen[-1] is None          # the list was built once per hop loop, then not at all
+    nblk = B * N // 16
+    assert seen[0] is not None and seen[0].numel() == 4 + nblk + (nblk + 1) // 2 and seen[-1] is None   # the list was built once per hop loop, then not at all
     live = int(seen[0][0].item())
     assert live == int(((nv + 15) // 16).sum())
-    blocks = seen[0][4:].cpu().tolist()
-    assert sorted(blocks) == list(range(B * N // 16))                                             # a permutation: live first, then dead
+    blocks = seen[0][4:4 + nblk].cpu().tolist()
+    assert sorted(blocks) == list(range(nblk))                                                    # a permutation: live first, then dead
     assert all((blk % (N // 16)) * 16 < int(nv[blk // (N // 16)]) for blk in blocks[:live])
+    # the live 32-row k-tiles (weight gradients walk these): tile kt = blocks 2 kt, 2 kt + 1, live iff one of them is; ascending
+    nkt = int(seen[0][1].item())
+    ktiles = seen[0][4 + nblk:4 + nblk + nkt].cpu().tolist()
+    want = sorted({blk // 2 for blk in blocks[:live]})
+    assert ktiles == want
     names = ["x1", "x2", "dX", "dE1", "dE2", "d gat", "d mha", "d caggc", "d maggc"]
     assert len(res[0]) == len(res[1]) == 9
     pad = (torch.arange(N)[None, :] >= nv[:, None]).to(gpu_device)
