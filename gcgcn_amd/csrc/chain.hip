@@ -20,6 +20,8 @@
 
 namespace gc {
 
+// Trace build (-DGC_T_TRACE, tools/trace_chain.py): workgroup 0 of the chain_s kernels stamps the 100 MHz wall clock at phase
+// boundaries (forward 0..19, backward 20..63; CAGGC's launches 64 slots further); compiled out of the product build.
 #ifdef GC_T_TRACE
 __device__ long long gc_trace_s[256];
 #define TS(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) gc_trace_s[(i) + (c.H == 1 ? 64 : 0)] = wall_clock64(); } while (0)

@@ -32,6 +32,18 @@
 
 namespace gc {
 
+// Trace build (-DGC_T_TRACE, tools/trace_chain.py): workgroup 0 stamps the 100 MHz wall clock at phase boundaries (forward:
+// slots 0..63, backward: 100.. for the MAGGC launch, 164.. for CAGGC's); compiled out of the product build.
+#ifdef GC_T_TRACE
+__device__ long long gc_trace_t[256];
+#define TR(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) gc_trace_t[i] = wall_clock64(); } while (0)
+#define TRB(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) gc_trace_t[(i) + (c.H == 1 ? 64 : 0)] = wall_clock64(); } while (0)
+extern "C" int gcgcn_debug_trace_t(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gc_trace_t), sizeof(long long) * 256); }
+#else
+#define TR(i)
+#define TRB(i)
+#endif
+
 typedef float t4 __attribute__((ext_vector_type(4)));
 
 constexpr int T_LA = 68;  // row pitch of the 64 x 64 adjacency image (16-byte rows, conflict-free 16-byte reads)
@@ -69,6 +81,7 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_fwd_kernel(const GcnCtx c)
                                     blockIdx.x - c.B * c.H, lds);
     return;
   }
+  TR(0);
   float* const As = lds;
   float* const Ys = As + 64 * T_LA;
   float* const Ws = Ys + 64 * P;                    // [2 stages][L - 1 pending sub-layers][16 k][P]
@@ -135,6 +148,7 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_fwd_kernel(const GcnCtx c)
       }
     }
   }
+  TR(1);
   // ---- Pn of every sub-layer: this wave's columns, all rows, in accumulator layout ---------------------------------------
   t4 Pa[L][4];
 #pragma unroll
@@ -148,10 +162,12 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_fwd_kernel(const GcnCtx c)
         Pa[l][rb][v] = (row < N && rb < nrb) ? Pg[(unsigned)row * HD + (unsigned)(l * GH + col)] : 0.f;
       }
   t_barrier();
+  TR(2);
 
   auto layer = [&](auto lt) __attribute__((always_inline)) {
     constexpr int l = decltype(lt)::value;
     constexpr int NP = L - 1 - l;                     // sub-layers still waiting for this one's output
+    TR(10 + 8 * l);
     // requests first: the epilogue's operands and the first two weight chunks land while the aggregation runs
     float gv[4][4], xv[4][4];
 #pragma unroll
@@ -196,6 +212,7 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_fwd_kernel(const GcnCtx c)
         }
       }
     }
+    TR(11 + 8 * l);
     // ---- Y_l = relu((G_l + A_h Pn_l) rinv);  HO_l = dropout(Y_l) + X_l          (glove:42-50, 71-76) ----------------------
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
@@ -214,8 +231,10 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_fwd_kernel(const GcnCtx c)
       }
     if constexpr (NP > 0) {
       // ---- push: Pn_l' += Y_l Wd_l'[l gh : (l + 1) gh, :] for every later sub-layer, 16 k per chunk --------------------
+      TR(12 + 8 * l);
       sstore(0, wr[0]);
       t_barrier();   // Y_l's image and the first weight chunk are complete
+      TR(13 + 8 * l);
       auto compute = [&](const int ch, const int st) __attribute__((always_inline)) {
         t4 a[4];
 #pragma unroll
@@ -244,6 +263,7 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_fwd_kernel(const GcnCtx c)
         if (ch + 2 < NC) sstore(0, wr[0]);
         t_barrier();
       }
+      TR(14 + 8 * l);
       // Pn_{l+1} is complete: saved for backward
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
@@ -259,6 +279,7 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_fwd_kernel(const GcnCtx c)
   if constexpr (L > 1) layer(std::integral_constant<int, 1>());
   if constexpr (L > 2) layer(std::integral_constant<int, 2>());
   if constexpr (L > 3) layer(std::integral_constant<int, 3>());
+  TR(50);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -321,6 +342,7 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_bwd_kernel(const GcnCtx c,
     edge_bcast_row<4, W>(r.in, r.n_valid, r.out, r.N, r.D, 0, pb);
     return;
   }
+  TRB(100);
   float* const ATs = lds;                  // A_h transposed: [k = column of A][row of A]
   float* const Ds = ATs + 64 * T_LA;       // dM_l, then dPn_l
   float* const Ps = Ds + 64 * P;           // Pn_l, then the weight stages
@@ -377,6 +399,7 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_bwd_kernel(const GcnCtx c,
 
   auto layer = [&](auto lt) __attribute__((always_inline)) {
     constexpr int l = decltype(lt)::value;
+    TRB(110 + 8 * l);
     // ---- requests: Y_l, dY_l (this wave's strip) and the Pn_l image ------------------------------------------------------
     float yv[4][4], dy[4][4];
 #pragma unroll
@@ -416,7 +439,9 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_bwd_kernel(const GcnCtx c,
       const int idx = t + NT * u, row = idx / (GH / 4), c4 = (idx - row * (GH / 4)) * 4;
       *reinterpret_cast<t4*>(Ps + row * P + c4) = pn[u];
     }
+    TRB(111 + 8 * l);
     t_barrier();   // dM_l, Pn_l images and the row-sum partials are complete
+    TRB(112 + 8 * l);
     if (t < 64) {
       float s = 0.f;
 #pragma unroll
@@ -444,6 +469,7 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_bwd_kernel(const GcnCtx c,
         if (row < N) Qg[(unsigned)row * HD + (unsigned)(l * GH + col)] = q[rb][v];
       }
     }
+    TRB(113 + 8 * l);
     // first weight chunks of the push below: requested now, they land while dA's share runs
     constexpr int NQ = l * NC;                         // 16-deep chunks of the push: (l', chunk) flattened
     t4 wr[2];
@@ -478,6 +504,7 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_bwd_kernel(const GcnCtx c,
         }
       }
     }
+    TRB(114 + 8 * l);
     if constexpr (l > 0) {
       t_barrier();   // everybody is done with the dM_l and Pn_l images
 #pragma unroll
@@ -486,6 +513,7 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_bwd_kernel(const GcnCtx c,
         for (int v = 0; v < 4; ++v) Ds[(16 * rb + 4 * g + v) * P + col] = q[rb][v];
       sstore(0, wr[0]);
       t_barrier();   // dPn_l's image and the first weight chunk are complete
+      TRB(115 + 8 * l);
       // ---- push: dY_l' += dPn_l Wd_l[l' gh + n', k]^T for l' < l ---------------------------------------------------------
       auto compute = [&](const int qi, const int st) __attribute__((always_inline)) {
         const int lp = qi / NC, ch = qi - lp * NC;
@@ -523,6 +551,7 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_bwd_kernel(const GcnCtx c,
   if constexpr (L > 2) layer(std::integral_constant<int, 2>());
   if constexpr (L > 1) layer(std::integral_constant<int, 1>());
   layer(std::integral_constant<int, 0>());
+  TRB(150);
   // ---- dA = sum over the k ranges + drow (every column of a row); drow itself ---------------------------------------------
   t_barrier();   // sub-layer 0 is done with the images; Ts is final
   if (ks > 0 && ob < nrb) {      // (only with more than four waves: OBW == 1)
@@ -560,6 +589,7 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_bwd_kernel(const GcnCtx c,
     }
   }
   if (t < N) c.drow[(long)z * N + t] = Ts[t];
+  TRB(151);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

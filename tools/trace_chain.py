@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""In-kernel phase timestamps of the chain kernels (workgroup 0, 100 MHz wall clock), from a trace build of the library:
+
+    cd gcgcn_amd/csrc && make                       # the product objects
+    for f in chain chain_t; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DGC_T_TRACE -c $f.hip -o /tmp/${f}_trace.o; done
+    hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/trace.so $(ls *.o | grep -v '^chain') /tmp/chain_trace.o /tmp/chain_t_trace.o
+    GCGCN_LIB=$PWD/../../build/trace.so python tools/trace_chain.py --config c2      (on the GPU box)
+
+Prints microseconds since the kernel's first stamp per slot (slot meanings: the TR / TRB / TS calls in chain_t.hip / chain.hip).
+profiles/r04_chain_phase_trace_before.txt was made this way."""
+import argparse
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+import gcgcn_amd  # noqa: E402
+from gcgcn_amd import _lib  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", default="c2", choices=sorted(bench.CONFIGS))
+ap.add_argument("--iters", type=int, default=3)
+args = ap.parse_args()
+cfg = bench.CONFIGS[args.config]
+dev = torch.device("cuda:0")
+torch.manual_seed(1)
+hops = gcgcn_amd.GraphHops(cfg["D"], cfg["L"], cfg["H"]).to(dev).train()
+gcgcn_amd.manual_seed(5, dev)
+x, e1, e2, adj = bench.synth(cfg, 3, dev)
+for t in (x, e1, e2):
+    t.requires_grad_()
+h = _lib.lib()
+if not hasattr(h, "gcgcn_debug_trace_s"):
+    sys.exit("not a trace build: set GCGCN_LIB to a library whose chain.hip / chain_t.hip were compiled with -DGC_T_TRACE")
+buf = (ctypes.c_longlong * 256)()
+
+
+def show(tag, v, lo, hi):
+    if v[lo]:
+        print(f"  {tag:28s}", " ".join(f"{i - lo}:{(v[i] - v[lo]) / 100.0:.1f}" for i in range(lo, hi) if v[i]))
+
+
+for it in range(args.iters):
+    hops(x, [e1, e2], adj)[-1].sum().backward()
+    torch.cuda.synchronize()
+    print("iteration", it)
+    h.gcgcn_debug_trace_s(buf)
+    v = list(buf)
+    show("chain_s fwd MAGGC", v, 0, 20), show("chain_s bwd MAGGC", v, 20, 64)
+    show("chain_s fwd CAGGC", v, 64, 84), show("chain_s bwd CAGGC", v, 84, 128)
+    h.gcgcn_debug_trace_t(buf)
+    v = list(buf)
+    show("chain_t fwd (last launch)", v, 0, 64), show("chain_t bwd MAGGC", v, 100, 164), show("chain_t bwd CAGGC", v, 164, 228)
