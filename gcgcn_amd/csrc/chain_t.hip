@@ -432,7 +432,12 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_bwd_kernel(const GcnCtx c,
         Ds[row * P + col] = m;
         if (row < N) Mg[(unsigned)row * HD + (unsigned)(l * GH + col)] = m;
         const float part = row16_sum(gsel * yv[rb][v]);
-        if (j == 0) Tp[w * 64 + row] = part;
+        // Ragged instantiations: every lane of the row holds the sum and stores it.  A store under `j == 0` is the one lane-divergent
+        // region of this kernel, and with it <192, 4, false> -- 190 spilled registers -- returned a different dA on every run for
+        // documents of three row blocks once a change elsewhere in the file had moved its register allocation (round 4; the
+        // instantiation spills more without the branch and is deterministic).  The FULL instantiations keep the branch (cfg 3:
+        // +2 % step time without it); tests/test_hip_parity.py::test_chain_t_is_deterministic scans every instantiation.
+        if (!FULL || j == 0) Tp[w * 64 + row] = part;
       }
 #pragma unroll
     for (int u = 0; u < PV; ++u) {
@@ -595,7 +600,13 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_bwd_kernel(const GcnCtx c,
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
-static bool chain_t_full(const GcnCtx& c) { return c.N > 48 && !c.n_valid; }
+// Ragged batches at the widest four-sub-layer shape (cfg 3's) run the FULL instantiation too: no row skipping, but 29 spilled
+// registers instead of 353 (cfg 3 ragged 1.437 -> 1.417 ms; option chain_t_wide_full = 0: the ragged instantiation, A/B and tests).
+// Padding rows hold zeros in every input, as for gcn_chain_s_*.
+static bool chain_t_full(const GcnCtx& c) {
+  if (c.N > 48 && !c.n_valid) return true;
+  return c.N > 48 && c.gh == 192 && c.L == 4 && option("chain_t_wide_full", 1) != 0;
+}
 template <int GH, int L>
 static void launch_fwd(const GcnCtx& c, dim3 grid, double fl, hipStream_t st) {
   if (chain_t_full(c)) GC_LAUNCH_TIMED("gcn_chain_fwd", fl, (gcn_chain_t_fwd_kernel<GH, L, true>), grid, dim3(4 * GH), 0, st, c);

@@ -902,6 +902,49 @@ def test_chain_and_per_product_paths_agree(gpu_device):
         _lib.call("gcgcn_set_option", b"bogus", 1)
 
 
+@pytest.mark.parametrize("gh,L", [(32, 2), (32, 4), (64, 1), (64, 2), (64, 3), (64, 4), (128, 1), (128, 2), (128, 3), (128, 4),
+                                  (192, 2), (192, 4), (256, 1), (256, 2)])
+def test_chain_t_is_deterministic(gpu_device, gh, L):
+    """Every instantiation of the column-strip chain kernels, documents of one to four row blocks, one and two heads: a block's
+    forward and backward run three times on the same inputs must agree BITWISE (out, dX, dEbar, dA, dflat).  Round 4: the
+    <192, 4, ragged> backward (190 spilled registers, one lane-divergent store) returned a different dA on every run for documents
+    of three row blocks -- after a change elsewhere in the file had moved its register allocation; the parity tests, which
+    compare against another kernel generation with a tolerance, passed or failed by luck."""
+    D, N = gh * L, 64
+    if (gh, L) == (192, 4):        # ragged batches of this shape run the FULL instantiation by default: scan the ragged one as well
+        _lib.call("gcgcn_set_option", b"chain_t_wide_full", 0)
+        try:
+            _scan_chain_t_determinism(gpu_device, gh, L, D, N)
+        finally:
+            _lib.call("gcgcn_set_option", b"chain_t_wide_full", 1)
+    _scan_chain_t_determinism(gpu_device, gh, L, D, N)
+
+
+def _scan_chain_t_determinism(gpu_device, gh, L, D, N):
+    for H in (1, 2):
+        for nvl in ([64, 39, 17, 5], [48, 33], None):
+            B = len(nvl) if nvl else 2
+            g = torch.Generator().manual_seed(gh + L)
+            flat = (torch.randn(_lib.layout("gcn", D, L, H)[5], generator=g) * 0.05).to(gpu_device)
+            nv = torch.tensor(nvl if nvl else [N] * B, dtype=torch.int32)
+            m = (torch.arange(N)[None, :] < nv[:, None]).float()
+            x = (torch.randn(B, N, D, generator=g) * m[..., None]).to(gpu_device)
+            ebar = (torch.randn(B, N, D, generator=g) * 0.3 * m[..., None]).to(gpu_device)
+            adj = (torch.rand(B, H, N, N, generator=g) * m[:, None, :, None] * m[:, None, None, :]).to(gpu_device)
+            cot = torch.randn(B, N, D, generator=g).to(gpu_device)
+            runs = []
+            for _ in range(3):
+                xs = [t.clone().requires_grad_() for t in (x, ebar, adj, flat)]
+                junk = torch.full((B * N * H * D * 4,), float("nan"), device=gpu_device)     # poisoned blocks for the workspaces to recycle
+                del junk
+                o = F_.gcn_stack(xs[0], xs[1], xs[2], xs[3], L, H, n_valid=nv.to(gpu_device) if nvl else None, training=False)
+                torch.autograd.backward(o, cot)
+                runs.append([o.detach()] + [t.grad.clone() for t in xs])
+            for r in runs[1:]:
+                for name, a, b_ in zip(("out", "dX", "dEbar", "dA", "dflat"), runs[0], r):
+                    assert torch.equal(a, b_), f"gh={gh} L={L} H={H} n_valid={nvl}: {name} differs between two runs by {float((a - b_).abs().max()):.3e}"
+
+
 @pytest.mark.parametrize("B,N,D,L,H,train", [(2, 128, 128, 2, 4, False), (1, 128, 128, 2, 4, True), (2, 80, 64, 2, 2, False)])
 def test_graphs_above_64_entities_chain_kernels_against_per_product_launches(gpu_device, B, N, D, L, H, train):
     """More than 64 entities (what cfg 5 runs): by default only a FORWARD chain launch with an edge mean riding in it uses the
