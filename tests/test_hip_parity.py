@@ -902,6 +902,50 @@ def test_chain_and_per_product_paths_agree(gpu_device):
         _lib.call("gcgcn_set_option", b"bogus", 1)
 
 
+@pytest.mark.parametrize("B,N,D,L,H,ragged,train", [
+    (4, 64, 256, 2, 8, False, True),     # cfg 2's shape: chain_s, fused MAGGC hop, parked tiles
+    (4, 64, 256, 2, 8, True, True),      #   ... ragged: row blocks, k-tile lists
+    (3, 64, 768, 4, 4, False, True),     # cfg 3's shape: chain_t <192, 4>
+    (3, 64, 768, 4, 4, True, False),
+    (4, 42, 128, 2, 8, True, True),      # the reference's own model
+    (3, 42, 128, 4, 4, True, True),      # the BERT model's graph blocks
+    (8, 16, 128, 2, 8, False, True),     # cfg 1
+    (1, 128, 128, 2, 4, False, True),    # more than 64 entities: per-product launches, softmax kernels
+    (2, 80, 64, 2, 2, True, False),      # unaligned shapes (the guarded instantiations, which spill the most)
+])
+def test_whole_step_is_deterministic(gpu_device, B, N, D, L, H, ragged, train):
+    """The library claims bitwise reproducibility (no atomics, fixed summation orders, counter-based dropout): the same hop loop
+    run three times from the same seeds returns identical outputs and gradients, on NaN-poisoned recycled memory."""
+    sd = O.init_stack_params(D, L, H, seed=11)
+    x, e1, e2, adj = O.synth_docs(B, N, D, seed=12)
+    n_valid = None
+    if ragged:
+        n_valid = torch.randint(1, N + 1, (B,), generator=torch.Generator().manual_seed(N + B)).to(torch.int32)
+        n_valid[0] = N
+        if B > 1:
+            n_valid[1] = min(N, 39)                    # three row blocks
+        x = x * (torch.arange(N)[None, :] < n_valid[:, None]).unsqueeze(-1).float()
+        n_valid = n_valid.to(gpu_device)
+    hops = gcgcn_amd.GraphHops(D, L, H).to(gpu_device).train(train)
+    hops.load_state_dict(sd, strict=True)
+    cot = torch.randn(B, N, D, generator=torch.Generator().manual_seed(5)).to(gpu_device)
+    runs = []
+    for _ in range(3):
+        gcgcn_amd.manual_seed(123, gpu_device)
+        xs = [dev_leaf(t, gpu_device) for t in (x, e1, e2)]
+        hops.zero_grad()
+        junk = torch.full((B * N * H * D * 4,), float("nan"), device=gpu_device)
+        del junk
+        f = hops(xs[0], [xs[1], xs[2]], adj.to(gpu_device), n_valid=n_valid)
+        torch.autograd.backward(f[-1], cot)
+        runs.append([f[1].detach(), f[2].detach(), xs[0].grad, xs[1].grad, xs[2].grad] +
+                    [p.grad.clone() for p in hops.parameters() if p.grad is not None])
+    names = ["x1", "x2", "dX", "dE1", "dE2", "d gat", "d mha", "d caggc", "d maggc"]
+    for r in runs[1:]:
+        for nm, a, b_ in zip(names, runs[0], r):
+            assert torch.equal(a, b_), f"{nm} differs between two runs by {float((a - b_).abs().max()):.3e}"
+
+
 @pytest.mark.parametrize("gh,L", [(32, 2), (32, 4), (64, 1), (64, 2), (64, 3), (64, 4), (128, 1), (128, 2), (128, 3), (128, 4),
                                   (192, 2), (192, 4), (256, 1), (256, 2)])
 def test_chain_t_is_deterministic(gpu_device, gh, L):
