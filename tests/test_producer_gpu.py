@@ -126,6 +126,17 @@ def test_producer_matches_oracle(gpu_device, B, N, S, T, Hd, P, dtype, ranges):
     for k, want in dsd.items():
         torch.testing.assert_close(grads[k].cpu(), want, rtol=1e-3, atol=1e-4 * max(1.0, want.abs().max().item()),
                                    msg=lambda m: f"grad {k}: {m}")
+    # reproducible: the same call again -- the forward bitwise; the gradients up to the order of the fp32 atomics that the node-term
+    # gradient and a few parameter-sized partials still use (producer.hip header)
+    first = [e.detach().clone(), cg.grad.clone(), ng.grad.clone(), tg.grad.clone()] + [v.clone() for v in grads.values()]
+    prod.zero_grad()
+    cg2, ng2, tg2 = (dev(t).requires_grad_() for t in (ctx, node, table))
+    e2 = prod(cg2, dev(sen), dev(ph), dev(pt), ng2, tg2)
+    (e2 * dev(cot)).sum().backward()
+    second = [e2.detach(), cg2.grad, ng2.grad, tg2.grad] + list(prod.named_grads().values())
+    assert torch.equal(first[0], second[0]), "producer forward differs between two runs"
+    for i, (a, b_) in enumerate(zip(first[1:], second[1:])):
+        torch.testing.assert_close(a, b_, rtol=1e-5, atol=1e-6 * max(1.0, float(a.abs().max())), msg=lambda m: f"producer gradient {i}: {m}")
 
 
 def test_producer_ragged_capacities_and_empty(gpu_device):
