@@ -419,7 +419,8 @@ def test_ragged_batch_matches_truncated_docs(gpu_device, B, N, D, L, H, nv):
                                              (8, 64, 256, 2, 8, True),     #   ... all six dropout sites on (same snapshots both ways)
                                              (5, 48, 128, 4, 4, False),    # the BERT model's widths, N = 48: three row blocks per document
                                              (32, 64, 256, 2, 8, True),    # the ragged bench itself (bench.py --ragged)
-                                             (3, 32, 768, 4, 4, False)])   # cfg 3's widths
+                                             (3, 32, 768, 4, 4, False),    # cfg 3's widths
+                                             (136, 64, 64, 2, 2, False)])  # B N = 8704 rows: 272 k-tiles, past what a tile body keeps in its lanes -> weight gradients dense, the rest on row blocks
 def test_row_block_launches_equal_the_dense_products(gpu_device, B, N, D, L, H, train):
     """Ragged batches: the node-phase products run on the LIVE 16-row blocks only (gcgcn_row_blocks; GEMM rows gathered through
     the block list, K = the live rows for weight gradients) against the same step with every row computed (the round-3 path,
