@@ -903,6 +903,40 @@ def test_chain_and_per_product_paths_agree(gpu_device):
         _lib.call("gcgcn_set_option", b"bogus", 1)
 
 
+@pytest.mark.parametrize("N,D,L,H", [(64, 256, 2, 8), (42, 128, 2, 8), (16, 128, 2, 8), (64, 768, 4, 4), (128, 128, 2, 4)])
+@pytest.mark.parametrize("train", [False, True])
+def test_empty_document_in_a_batch(gpu_device, N, D, L, H, train):
+    """n_valid = 0 (a batch padded with an empty document): every output and gradient of that document is exactly zero, nothing
+    is NaN, and the other documents come out as they do in a batch without it."""
+    sd = O.init_stack_params(D, L, H, seed=3)
+    x, e1, e2, adj = O.synth_docs(3, N, D, seed=4)
+    nv = torch.tensor([N, 0, 5], dtype=torch.int32)
+    x = x * (torch.arange(N)[None, :] < nv[:, None]).unsqueeze(-1).float()
+    hops = gcgcn_amd.GraphHops(D, L, H).to(gpu_device).train(False)   # (dropout draws depend on the position in the batch)
+    hops.load_state_dict(sd, strict=True)
+
+    def run(sel):
+        xs = [dev_leaf(t[sel], gpu_device) for t in (x, e1, e2)]
+        hops.zero_grad()
+        hops.train(train and len(sel) == 3)
+        f = hops(xs[0], [xs[1], xs[2]], adj[sel].to(gpu_device), n_valid=nv[sel].to(gpu_device))
+        f[-1].sum().backward()
+        return [f[1].detach(), f[2].detach(), xs[0].grad, xs[1].grad, xs[2].grad], [p.grad.clone() for p in hops.parameters() if p.grad is not None]
+    full, pfull = run([0, 1, 2])
+    for t in full + pfull:
+        assert torch.isfinite(t).all()
+    for t in full:
+        assert float(t[1].abs().max()) == 0.0
+    if not train:
+        part, ppart = run([0, 2])
+        for a, b_ in zip(full, part):
+            top = max(1.0, float(b_.abs().max()))
+            torch.testing.assert_close(a[[0, 2]], b_, rtol=2e-4, atol=2e-5 * top)
+        for a, b_ in zip(pfull, ppart):
+            top = max(1.0, float(b_.abs().max()))
+            torch.testing.assert_close(a, b_, rtol=2e-4, atol=2e-5 * top)
+
+
 @pytest.mark.parametrize("B,N,D,L,H,ragged,train", [
     (4, 64, 256, 2, 8, False, True),     # cfg 2's shape: chain_s, fused MAGGC hop, parked tiles
     (4, 64, 256, 2, 8, True, True),      #   ... ragged: row blocks, k-tile lists
