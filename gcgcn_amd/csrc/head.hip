@@ -872,6 +872,42 @@ __global__ __launch_bounds__(256) void head_table_bwd_kernel(const long long* __
   __syncthreads();
   if (half == 0) part[((long)b * nk + k) * HW + c] = red[0][c] + red[1][c];
 }
+// The relative-position table's partial gradient in ONE pass over a document's pairs (the kernel above scans them once per table
+// row: 21 workgroups read the same ids to keep 1 / 21 of the rows each).  Workgroup (b, s) takes slice s of document b's items in
+// order; a thread owns one column of one side and adds into its own cell of an LDS table [side][id][column] -- no two threads
+// share a cell, the order inside a slice is the items' order, the slices meet in head_table_fin_kernel in fixed order: deterministic.
+constexpr int HT_SLICES = 8, HT_IDS = 32;
+__global__ __launch_bounds__(256) void head_table_rel_bwd_kernel(const long long* __restrict__ ids, const float* __restrict__ X1,
+                                                                 const float* __restrict__ X2, float* __restrict__ part, long per_doc,
+                                                                 int dis_plus, int nk, const int* __restrict__ off,
+                                                                 const int* __restrict__ prow) {
+  __shared__ float acc[2][HT_IDS][HW];
+  const int b = blockIdx.x, sl = blockIdx.y;
+  const int c = threadIdx.x & (HW - 1), half = threadIdx.x >> 7;
+  const float* __restrict__ X = half ? X2 : X1;
+  for (int k = 0; k < nk; ++k) acc[half][k][c] = 0.f;
+  const long lo = off ? off[b] : (long)b * per_doc, hi = off ? off[b + 1] : lo + per_doc, len = hi - lo;
+  const long q0 = lo + len * sl / HT_SLICES, q1 = lo + len * (sl + 1) / HT_SLICES;
+  long q = q0;
+  for (; q + 4 <= q1; q += 4) {   // four items requested together; the adds stay in item order
+    int id[4];
+    float x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int d = (int)ids[prow ? prow[q + u] : q + u];
+      id[u] = min(max(half ? dis_plus - d : dis_plus + d, 0), nk - 1);
+      x[u] = X[(q + u) * HW + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[half][id[u]][c] += x[u];
+  }
+  for (; q < q1; ++q) {
+    const int d = (int)ids[prow ? prow[q] : q];
+    acc[half][min(max(half ? dis_plus - d : dis_plus + d, 0), nk - 1)][c] += X[q * HW + c];
+  }
+  __syncthreads();
+  for (int k = half; k < nk; k += 2) part[(((long)b * HT_SLICES + sl) * nk + k) * HW + c] = acc[0][k][c] + acc[1][k][c];
+}
 __global__ __launch_bounds__(256) void head_table_fin_kernel(const float* __restrict__ part, float* __restrict__ out, int B, int n) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
@@ -1058,10 +1094,10 @@ int head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int di
     hipLaunchKernelGGL(head_node_bwd_kernel, dim3((unsigned)BN), dim3(256), 0, st, w.dEH, w.dET, w.dUT, N, compact ? idx_off(w) : nullptr,
                        n_valid);
     GC_TRY(check_launch("head_node_bwd"));
-    hipLaunchKernelGGL(head_table_bwd_kernel, dim3(B, ND), dim3(256), 0, st, rel, w.dEH, w.dET, w.partR, (long)N * N, dis_plus, ND,
-                       compact ? idx_off(w) : nullptr, prow);
+    hipLaunchKernelGGL(head_table_rel_bwd_kernel, dim3(B, HT_SLICES), dim3(256), 0, st, rel, w.dEH, w.dET, w.partR, (long)N * N, dis_plus,
+                       ND, compact ? idx_off(w) : nullptr, prow);
     GC_TRY(check_launch("head_table_bwd/rel"));
-    hipLaunchKernelGGL(head_table_fin_kernel, dim3(cdiv((long)ND * HW, 256)), dim3(256), 0, st, w.partR, w.dRt, B, ND * HW);
+    hipLaunchKernelGGL(head_table_fin_kernel, dim3(cdiv((long)ND * HW, 256)), dim3(256), 0, st, w.partR, w.dRt, B * HT_SLICES, ND * HW);
     GC_TRY(check_launch("head_table_fin/rel"));
     hipLaunchKernelGGL(head_table_bwd_kernel, dim3(B, 7), dim3(256), 0, st, type, w.dUT, (const float*)nullptr, w.partT, (long)N, 0, 7,
                        (const int*)nullptr, (const int*)nullptr);
@@ -1098,7 +1134,7 @@ static HeadBufs head_bind(float* fwd, float* bwd, int B, int N, int R, int ND, l
   w.partF = tf(4 * w.part_rows * 128);
   if (n_fwd) *n_fwd = at;
   base = bwd, at = 0;
-  w.doutp = tf(pairs * HW), w.dEH = tf(pairs * HW), w.dET = tf(pairs * HW), w.dUT = tf(BN * HW), w.partR = tf((long)B * ND * HW);
+  w.doutp = tf(pairs * HW), w.dEH = tf(pairs * HW), w.dET = tf(pairs * HW), w.dUT = tf(BN * HW), w.partR = tf((long)B * HT_SLICES * ND * HW);
   w.partT = tf((long)B * 7 * HW), w.dRt = tf((long)ND * HW), w.dTt = tf(7 * HW), w.dW = tf((long)HW * 2 * HW);
   // split-K partials: up to 8 slabs of the [R, 16384] bilinear weight gradient
   w.scratch_elems = 8L * R * HW * HW;
@@ -1149,7 +1185,7 @@ int gcgcn_head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, 
                    const int64_t* node_type, const int64_t* node_relative_pos, const float* ner_emb, const float* dis_table,
                    const int32_t* n_valid, const float* flat, float* fbuf, int32_t* ibuf, float* bbuf, const float* dlogits,
                    float* const* dfeats, float* dner_emb, float* ddis_table, float* dflat, void* stream) {
-  GC_REQUIRE(B > 0 && N > 0 && Hd > 0 && nf > 0 && nf <= 8 && Pt > 0 && Pr > 0 && R > 0 && ND > 0, "head_bwd: bad shape");
+  GC_REQUIRE(B > 0 && N > 0 && Hd > 0 && nf > 0 && nf <= 8 && Pt > 0 && Pr > 0 && R > 0 && ND > 0 && ND <= HT_IDS, "head_bwd: bad shape");
   GC_REQUIRE(feats && node_type && node_relative_pos && ner_emb && dis_table && flat && fbuf && bbuf && dlogits && dfeats && dner_emb &&
                  ddis_table && dflat,
              "head_bwd: null pointer");
