@@ -151,6 +151,9 @@ bool chain_t_ok(const GcnCtx& c, bool bwd);
 bool chain_t_fwd_att_ok(const GcnCtx& c);
 int gcn_chain_t_fwd(const GcnCtx& c, dim3 grid, double flops, hipStream_t st);
 int gcn_chain_t_bwd(const GcnCtx& c, double flops, hipStream_t st, DeferQueue* carry);
+// the full-size instantiation: every document fills all four 16-row blocks exactly (N == 64, no n_valid) -- one body, no
+// switch, no bounds test; everything else runs the instantiation that picks a body per document (chain_t.hpp)
+inline bool chain_t_full(const GcnCtx& c) { return c.N == 64 && !c.n_valid; }
 
 // chain.hip
 bool chain_fwd_computes_attention(const GcnCtx& c);   // the forward chain kernel of this shape takes c.mha

@@ -254,32 +254,34 @@ def analyse(body):
 
 def main():
   ap = argparse.ArgumentParser()
-  ap.add_argument('asm')
+  ap.add_argument('asm', nargs='+')
   ap.add_argument('--kernel', default='.', help='regex on the demangled kernel name')
   ap.add_argument('--list', action='store_true', help='print every masked access and hazard')
   ap.add_argument('--fail-on', choices=['hazard', 'masked', 'spill', 'never'], default='hazard')
+  ap.add_argument('--quiet', action='store_true', help='print only the kernels that fail the chosen criterion')
   args = ap.parse_args()
-  ks = list(kernels(args.asm))
-  names = demangle([k for k, _ in ks])
   bad = 0
-  for name, body in ks:
-    dn = names.get(name, name)
-    if not re.search(args.kernel, dn):
-      continue
-    r = analyse(body)
-    print('%-110s slots %4d  accesses %4d  masked %4d  hazards %3d  exec-regions %4d' % (dn[:110], r['spill_dwords'], r['n_acc'], r['masked'], len(r['hazards']), r['regions']))
-    if args.list:
-      for a in r['acc']:
-        if a[3]:
-          print('    masked %-5s slots %s  exec %s  | %s' % (a[1], a[2], '/'.join(a[3]), r['ins'][a[0]].text))
-      for h in r['hazards']:
-        print('    HAZARD load @%d slot %d under exec %s; written on every path only under: %s  | %s' % (h[0], h[1], '/'.join(h[2]) or 'full', ['/'.join(c) or 'full' for c in h[3]] or 'NOTHING', r['ins'][h[0]].text))
-    if args.fail_on == 'spill' and r['spill_dwords']:
-      bad += 1
-    elif args.fail_on == 'masked' and r['masked']:
-      bad += 1
-    elif args.fail_on == 'hazard' and r['hazards']:
-      bad += 1
+  for path in args.asm:
+    ks = list(kernels(path))
+    names = demangle([k for k, _ in ks])
+    for name, body in ks:
+      dn = names.get(name, name)
+      if not re.search(args.kernel, dn):
+        continue
+      r = analyse(body)
+      fails = (args.fail_on == 'spill' and r['spill_dwords']) or (args.fail_on == 'masked' and r['masked']) or (args.fail_on == 'hazard' and r['hazards'])
+      if fails or not args.quiet:
+        print('%s%-110s slots %4d  accesses %4d  masked %4d  hazards %3d  exec-regions %4d' % ('FAIL ' if fails else '', dn[:110], r['spill_dwords'], r['n_acc'], r['masked'], len(r['hazards']), r['regions']))
+      if args.list:
+        for a in r['acc']:
+          if a[3]:
+            print('    masked %-5s slots %s  exec %s  | %s' % (a[1], a[2], '/'.join(a[3]), r['ins'][a[0]].text))
+      if args.list or fails:
+        for h in r['hazards']:
+          print('    HAZARD load @%d slot %d under exec %s; written on every path only under: %s  | %s' % (h[0], h[1], '/'.join(h[2]) or 'full', ['/'.join(c) or 'full' for c in h[3]] or 'NOTHING', r['ins'][h[0]].text))
+      bad += 1 if fails else 0
+  if not bad and args.quiet:
+    print('spill check (%s): ok' % args.fail_on)
   return 1 if bad else 0
 
 
