@@ -177,3 +177,72 @@ def test_tail_with_compact_edges(gpu_device):
         torch.testing.assert_close(a, b_, rtol=1e-4, atol=1e-6 * max(1.0, b_.abs().max().item() * 10))
     for di in range(len(docs)):
         torch.testing.assert_close(res[True][0][di].cpu(), torch.from_numpy(r[f"doc{di}.logits"]), rtol=1e-4, atol=1e-4)
+
+
+def test_tail_graph_replay_matches_eager(gpu_device):
+    """tools/tail_bench.py --mode graph times replays of ONE hipGraph holding the whole post-encoder step (producer -> CAGGC ->
+    producer -> MAGGC -> head -> loss, forward + backward).  Under capture nothing may be read back to the host (the live-slot /
+    live-pair / pair-row counts stay on the device) and every replay has to rewrite every result.  Ragged batch, eval mode: the
+    replayed logits and loss are BITWISE those of an eager step on the same inputs, on the first and on the third replay; the
+    gradients agree to the summation order of the producers' documented fp32 atomics (and bitwise where no atomic is involved:
+    the head's and the graph blocks' parameters behind the loss)."""
+    ctx, node, table, sen, ph, pt, nv = _compact_case(gpu_device, B=3, N=13, S=3, T=48, seed=23)
+    nv = torch.tensor([13, 5, 12], dtype=torch.int32, device=gpu_device)
+    node = node * (torch.arange(13, device=gpu_device)[None, :] < nv[:, None]).unsqueeze(-1).float()
+    B, N, _ = node.shape
+    g = torch.Generator().manual_seed(5)
+    ner = (torch.randn(7, 20, generator=g) * 0.3).to(gpu_device).requires_grad_()
+    ntype = torch.randint(0, 7, (B, N), generator=g).to(gpu_device)
+    rel = torch.randint(-10, 11, (B, N, N), generator=g).to(gpu_device)
+    labels = (torch.rand(B, N, N, 97, generator=g) < 0.05).float().to(gpu_device)
+    tail = gcgcn_amd.GraphModelTail().to(gpu_device).eval()
+    leaves = [ctx.requires_grad_(), node.requires_grad_(), table.requires_grad_(), ner]
+    from gcgcn_amd import functional as F_
+    rows, pairs = F_.producer_live_counts(sen.view(torch.uint8), nv)      # capacities up front: no host read inside the step
+    out = {}
+
+    def step():
+        for t in leaves + list(tail.parameters()):
+            t.grad = None
+        logits = tail(ctx, node, None, sen, ph, pt, ntype, rel, table, ner, n_valid=nv, max_live_slots=rows, max_live_pairs=pairs)
+        loss = gcgcn_amd.pair_bce_loss(logits, labels, n_valid=nv).sum() / B
+        loss.backward()
+        out["logits"], out["loss"] = logits, loss
+
+    def grad_refs():
+        refs = {f"leaf{i}": t.grad for i, t in enumerate(leaves)}
+        refs.update({n: p.grad for n, p in tail.named_parameters() if p.grad is not None})
+        return refs
+
+    # capture first (warm-up on a side stream, as bench.py and tools/_graph_mode.py do), then the eager reference step
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()
+        step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    torch.cuda.synchronize()
+    g_logits, g_loss, g_grads = out["logits"], out["loss"], grad_refs()     # the tensors every replay rewrites
+    step()                                                                  # eager, same inputs
+    torch.cuda.synchronize()
+    want = dict(logits=out["logits"].detach().clone(), loss=out["loss"].detach().clone(), grads={k: v.clone() for k, v in grad_refs().items()})
+    assert len(want["grads"]) >= 6 and all(torch.isfinite(v).all() for v in want["grads"].values())
+    assert want["grads"].keys() == g_grads.keys()
+    for rep in range(3):
+        g_logits.detach().fill_(float("nan"))                               # poison: the replay has to rewrite everything
+        for v in g_grads.values():
+            v.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(g_logits.detach(), want["logits"]), f"replay {rep}: logits differ from the eager step"
+        assert torch.equal(g_loss.detach(), want["loss"]), f"replay {rep}: loss differs from the eager step"
+        for k, w_ in want["grads"].items():
+            torch.testing.assert_close(g_grads[k], w_, rtol=1e-4, atol=1e-5 * max(1.0, w_.abs().max().item()),
+                                       msg=lambda m: f"replay {rep}, gradient {k}: {m}")
+        for k in ("head.flat", "graphcnn.0.flat", "get_weighted_adj_matrix.flat"):
+            if k in want["grads"]:
+                assert torch.equal(g_grads[k], want["grads"][k]), f"replay {rep}: gradient {k} is not bitwise the eager step's"

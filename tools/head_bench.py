@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--cpu", action="store_true")
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--dense", action="store_true", help="with --ragged: compute every pair slot (option head_compact = 0)")
+    ap.add_argument("--mode", default="both", choices=["eager", "graph", "both"],
+                    help="graph: the step captured in one hipGraph and replayed (how bench.py times the hot path); eager: launches from Python")
     a = ap.parse_args()
     import gcgcn_amd
     from gcgcn_amd import _lib
@@ -58,14 +60,11 @@ def main():
         out = head(feats, ntype, rel, ner, dis, n_valid=n_valid)
         torch.autograd.backward(out, cot)
 
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / a.steps
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import _graph_mode
+    graph = _graph_mode.capture(step) if a.mode != "eager" else None
+    ms_mode = _graph_mode.timed(step, graph, a.steps, a.mode)
+    dt = ms_mode.get("graph", ms_mode.get("eager")) / 1e3      # the headline is the graph-mode figure when there is one
     shares = {}
     for f in ("head_bilinear", "head_gemm", "head_feat", "gemm_splitk_reduce", "colsum"):
         _lib.call("gcgcn_prof_start", f.encode(), 256)
@@ -83,10 +82,10 @@ def main():
         hb["work"] *= computed / pairs
     useful = 2.0 * real_pairs * 128 * 128 * R * 4 + 2.0 * real_pairs * 256 * R * 1     # four bilinear passes + the linear part, unpadded, real pairs
     line = {"metric": "docs/sec fwd+bwd through the classifier head (SURVEY 8 f3)", "value": round(B / dt, 1), "unit": "docs/s",
-            "ms_per_step": round(dt * 1e3, 3),
+            "ms_per_step": round(dt * 1e3, 3), "ms_per_step_by_mode": {k: round(v, 3) for k, v in ms_mode.items()},
             "config": {"workload": f"ClassifierHead fwd+bwd, B={B} N={N} ({pairs} pair slots" +
                                    (f", ragged: {real_pairs} real pairs, {'every slot computed' if a.dense else 'compacted rows'}" if a.ragged else "") +
-                                   f") hidden=128 R={R}, eager launches"},
+                                   f") hidden=128 R={R}, " + ("one hipGraph per step (replays)" if "graph" in ms_mode else "eager launches")},
             "time_shares_ms_per_step": {k: {kk: vv for kk, vv in v.items() if kk != "work"} for k, v in shares.items()},
             "roofline": None if not hb else {
                 "bound": "mfma", "kernel": ("gc::head_bil3_kernel<1..3> + gc::head_dw_kernel" if (pairs >= 32768 or (a.ragged and not a.dense)) else

@@ -23,6 +23,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 class Cfg:
@@ -84,6 +85,9 @@ def main():
     ap.add_argument("--vocab", type=int, default=20000)
     ap.add_argument("--skip-dead-hop", action="store_true", help="do not compute the hop whose output never reaches the classifier")
     ap.add_argument("--torch-adam", action="store_true", help="A/B: torch.optim.Adam instead of FusedAdam")
+    ap.add_argument("--mode", default="both", choices=["eager", "graph", "both"],
+                    help="graph: additionally, forward -> loss -> backward -> optimiser step of each resident batch captured in one hipGraph "
+                         "(collate stays on the host, outside the graph) and the replays timed; eager: launches from Python only")
     a = ap.parse_args()
     import gcgcn_amd
     from gcgcn_amd import _lib, functional as F_
@@ -133,6 +137,28 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     split = {n: round(sum(e0.elapsed_time(e1) for e0, e1 in evs) / a.steps, 3) for n, evs in parts.items()}
+    ms_mode = {"eager": round(dt * 1e3, 3)}
+    if a.mode != "eager":                    # the device side of the step as one hipGraph per resident batch
+        import _graph_mode
+        resident = [collate(b, dev) for b in batches]
+
+        def model_step(bt):
+            logits = model(*[bt[n] for n in order], n_valid=bt["n_valid"])
+            loss = gcgcn_amd.pair_bce_loss(logits, bt["label_matrix"], n_valid=bt["n_valid"]).sum() / a.B
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+
+        graphs = [_graph_mode.capture(lambda bt=bt: model_step(bt)) for bt in resident]
+        if all(g is not None for g in graphs):
+            cnt = [0]
+
+            def replay():
+                graphs[cnt[0] % len(graphs)].replay()
+                cnt[0] += 1
+            for _ in range(3):
+                replay()
+            ms_mode["graph (collate outside)"] = round(_graph_mode.wall_ms(replay, a.steps), 3)
     # GPU time of the model's parts inside forward + backward (HIP events around the library's own launches)
     groups = {"encoder (PyTorch: embeddings, BiLSTM, linear_re) + everything outside the library": None,
               "edge-feature producers (f1)": ["prod_", "gemm_dyn"], "classifier head (f3)": ["head_"],
@@ -155,7 +181,7 @@ def main():
     nv = np.mean([d.n for b in batches for d in b])
     print(json.dumps({
         "metric": "docs/sec, full training step of GCGCN_glove (collate -> forward -> loss -> backward -> Adam)", "value": round(a.B / dt, 1),
-        "unit": "docs/s", "ms_per_step": round(dt * 1e3, 3), "dtype": "f32", "data": "synthetic",
+        "unit": "docs/s", "ms_per_step": round(dt * 1e3, 3), "ms_per_step_by_mode": ms_mode, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"B={a.B} DocRED-shaped documents (T=512, mean {nv:.1f} entities, padded per batch), vocabulary {a.vocab}, "
                                f"train mode, {'FusedAdam (one launch)' if not a.torch_adam else 'torch.optim.Adam'}, eager launches, "
                                f"{a.batches} resident packed batches rotated" + (", dead last hop skipped" if a.skip_dead_hop else "")},
