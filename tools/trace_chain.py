@@ -1,12 +1,10 @@
 #!/usr/bin/env python3
 """In-kernel phase timestamps of the chain kernels (workgroup 0, 100 MHz wall clock), from a trace build of the library:
 
-    cd gcgcn_amd/csrc && make                       # the product objects
-    for f in chain chain_t; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DGC_T_TRACE -c $f.hip -o /tmp/${f}_trace.o; done
-    hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/trace.so $(ls *.o | grep -v '^chain') /tmp/chain_trace.o /tmp/chain_t_trace.o
-    GCGCN_LIB=$PWD/../../build/trace.so python tools/trace_chain.py --config c2      (on the GPU box)
+    make -C gcgcn_amd/csrc -j8 trace                # build/trace.so: chain.hip and the chain_t units with -DGC_T_TRACE
+    GCGCN_LIB=$PWD/build/trace.so python tools/trace_chain.py --config c2      (on the GPU box)
 
-Prints microseconds since the kernel's first stamp per slot (slot meanings: the TR / TRB / TS calls in chain_t.hip / chain.hip).
+Prints microseconds since the kernel's first stamp per slot (slot meanings: the TR / TRB / TS calls in chain_t.hpp / chain.hip).
 profiles/r04_chain_phase_trace_before.txt was made this way."""
 import argparse
 import ctypes
@@ -51,6 +49,10 @@ for it in range(args.iters):
     v = list(buf)
     show("chain_s fwd MAGGC", v, 0, 20), show("chain_s bwd MAGGC", v, 20, 64)
     show("chain_s fwd CAGGC", v, 64, 84), show("chain_s bwd CAGGC", v, 84, 128)
-    h.gcgcn_debug_trace_t(buf)
-    v = list(buf)
-    show("chain_t fwd (last launch)", v, 0, 64), show("chain_t bwd MAGGC", v, 100, 164), show("chain_t bwd CAGGC", v, 164, 228)
+    for u in range(4):      # one trace buffer per translation unit of the column-strip kernels (chain_t_u<u>.hip)
+        fn = getattr(h, f"gcgcn_debug_trace_t_{u}", None)
+        if fn is None:
+            continue
+        fn(buf)
+        v = list(buf)
+        show(f"chain_t[u{u}] fwd (last launch)", v, 0, 64), show(f"chain_t[u{u}] bwd MAGGC", v, 100, 164), show(f"chain_t[u{u}] bwd CAGGC", v, 164, 228)
