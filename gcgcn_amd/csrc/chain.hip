@@ -811,13 +811,21 @@ static bool chain_small_ok(const GcnCtx& c, bool bwd) {
 
 static bool chain_aligned(const GcnCtx& c, bool bwd);
 // the dispatch rule of gcn_chain_fwd / _bwd: chain_t.hip takes the shape instead of the default shape's own kernels
+// (option chain_t: 0 never; 1 (default) wherever the default shape's own kernels do not apply, and at that shape too for RAGGED
+// batches -- the column-strip kernels skip 16-row blocks per document, gcn_chain_s_* own 32 rows per wave and do not: cfg 2
+// ragged 71.2 k -> 72.5 k docs/s at B = 32; dense batches stay on gcn_chain_s_* (0.522 vs 0.542 ms); 2: everywhere)
+static bool chain_s_preferred(const GcnCtx& c, bool s_ok) {
+  const int mode = option("chain_t", 1);
+  return s_ok && (mode < 2) && !(mode == 1 && c.n_valid != nullptr);
+}
 static bool chain_t_takes(const GcnCtx& c, bool bwd) {
   const bool s_ok = chain_aligned(c, bwd) && chain_small_ok(c, bwd);
-  return chain_t_ok(c, bwd) && !(s_ok && option("chain_t", 1) < 2);
+  return chain_t_ok(c, bwd) && !chain_s_preferred(c, s_ok);
 }
-bool chain_bwd_fusable(const GcnCtx& c) {
+bool chain_bwd_fusable(const GcnCtx& c) {   // asked before c.dout is set
   const bool on = option("chain_fuse", 1) != 0;
   auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+  if (on && chain_t_takes(c, true)) return chain_t_bwd_fusable(c);
   return on && chain_small_ok(c, true) && c.N == 64 && (c.H == 1 || c.H == 8) && al(c.A) && al(c.Pn) && al(c.Y) && al(c.dM) &&
          al(c.dP) && al(c.dA) && al(c.flat + c.oWd) && al(c.flat + c.oWlin) && c.HD % 4 == 0;
 }
@@ -868,7 +876,7 @@ int gcn_chain_fwd(const GcnCtx& c, hipStream_t st) {
   // option chain_t: 1 (default) = the column-strip kernels (chain_t.hip) wherever the default shape's own kernels do not
   // apply, 2 = also there (A/B), 0 = never
   const bool s_ok = chain_aligned(c, false) && chain_small_ok(c, false);
-  if (chain_t_ok(c, false) && !(s_ok && option("chain_t", 1) < 2)) return gcn_chain_t_fwd(c, grid, fl * c.B * c.H, st);
+  if (chain_t_ok(c, false) && !chain_s_preferred(c, s_ok)) return gcn_chain_t_fwd(c, grid, fl * c.B * c.H, st);
   // only the LDS-resident kernels run the attention core in their prologue: a caller that left it to the chain (c.mha) and ends
   // up here would get a convolution over adjacencies nobody computed
   GC_REQUIRE(!c.mha.Q || s_ok, "gcn_chain_fwd: the attention core was left to a chain kernel that does not run it");
@@ -894,7 +902,7 @@ int gcn_chain_bwd(const GcnCtx& c, hipStream_t st, DeferQueue* carry) {
   // beside the chain's own duration (~8 us per dependent product and tile pass, measured at cfg 2 / cfg 3); a problem is
   // split at the budget, the rest of its tiles rides in GATAttention's edge pass.  K % 64 == 0 for equal halves.
   const bool s_ok = chain_aligned(c, true) && chain_small_ok(c, true);
-  const bool use_t = !c.dout && chain_t_ok(c, true) && !(s_ok && option("chain_t", 1) < 2);
+  const bool use_t = chain_t_ok(c, true) && !chain_s_preferred(c, s_ok);
   if (use_t) return gcn_chain_t_bwd(c, fl, st, chain_passengers() ? carry : nullptr);
   int ng = 0;
   if (carry && carry->n > 0 && (long)c.B * c.H <= 64 && ((long)c.B * c.N) % 64 == 0 && chain_passengers()) {

@@ -32,13 +32,35 @@ bool chain_t_ok(const GcnCtx& c, bool bwd) {
   if (!shape) return false;
   auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
   bool ok = al(c.A) && al(c.flat + c.oWd) && c.wd_head % 4 == 0 && c.HD % 4 == 0 && al(c.Pn) && al(c.Y);
-  if (bwd) ok = ok && !c.dout && al(c.dYa) && al(c.dM) && al(c.dP);
+  if (bwd) ok = ok && (c.dout ? chain_t_bwd_fusable(c) && al(c.dout) && al(c.dXres) && (!c.dout_m || al(c.dout_m)) : al(c.dYa)) && al(c.dM) && al(c.dP);
   else ok = ok && al(c.G) && al(c.HO) && al(c.X);
   if (c.ride.kind) {   // the passenger bodies use 16-byte accesses and (forward) waves x D floats of the kernel's LDS
     const int lds_fwd = 64 * T_LA + 64 * (c.gh + 4) + 2 * (c.L - 1) * 16 * (c.gh + 4) + 64;
     ok = ok && c.ride.D % 4 == 0 && al(c.ride.in) && al(c.ride.out) && (bwd || (long)chain_t_waves(c.gh) * c.ride.D <= lds_fwd);
   }
   return ok;
+}
+
+// The backward kernel can compute the output projection's input gradient itself (chain_t.hpp FUSE): blocks of at most 256
+// features whose residual-gradient share divides over the waves (one head: no such product); option chain_fuse = 0: never
+bool chain_t_bwd_fusable(const GcnCtx& c) {
+  if (option("chain_fuse", 1) == 0 || option("chain_t_fuse", 1) == 0 || c.N > 64 || c.D != c.L * c.gh || c.D > 256 || c.D % 32 != 0 || c.gh > 128 || 16 % c.L != 0) return false;
+  bool shape = false;
+#define X(gh_, l_) shape = shape || (c.gh == gh_ && c.L == l_);
+  GC_CHAIN_T_HOST_SHAPES(X)
+#undef X
+  if (!shape) return false;
+  auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+  if (!al(c.flat + c.oWlin) || c.HD % 4 != 0) return false;
+  if (c.H == 1) return true;
+  const int W = c.gh / 16;
+  if (c.D % c.H != 0) return false;
+  const int DH = c.D / c.H;
+  if (DH % 16 != 0) return false;
+  const int ncg = DH / 16;
+  if (ncg > W || W % ncg != 0) return false;
+  const int kw = W / ncg;
+  return c.D % kw == 0 && (c.D / kw) % 16 == 0;
 }
 
 // the forward kernel can run the attention core in its prologue: the core's scratch (score tile + one Q chunk) fits the Y image

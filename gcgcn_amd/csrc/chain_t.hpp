@@ -87,6 +87,10 @@ __device__ __forceinline__ t4 t_ld4(t_desc d, unsigned voff, unsigned soff) {
 __device__ __forceinline__ void t_st(t_desc d, unsigned voff, unsigned soff, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), d, (int)voff, (int)soff, 0);
 }
+typedef unsigned t_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void t_st4(t_desc d, unsigned voff, unsigned soff, t4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(t_u4, v), d, (int)voff, (int)soff, 0);
+}
 
 // "this value exists now": an empty volatile statement that reads and writes an accumulator, so that the instructions producing
 // it can be neither sunk past this point nor hoisted above it
@@ -96,6 +100,16 @@ template <int GH, int L>
 constexpr int t_fwd_lds() { return 64 * T_LA + 64 * (GH + 4) + 2 * (L - 1) * 16 * (GH + 4) + 64; }
 template <int GH>
 constexpr int t_bwd_lds() { return 64 * T_LA + 2 * 64 * (GH + 4) + (GH / 16) * 64 + 128; }
+// FUSE (the output projection's input gradient computed by the backward kernel itself): the dout image [64][D + 4] and two
+// 16-deep stages of Wlin's slice lie over the dM / Pn images (used only afterwards); behind the row-sum areas the K slices of
+// the residual gradient meet
+constexpr int t_max(int a, int b) { return a > b ? a : b; }
+template <int GH, int L>
+constexpr int t_bwd_region() { return t_max(2 * 64 * (GH + 4), 96 * (L * GH + 4)); }
+template <int GH, int L>
+constexpr int t_bwd_fuse_lds() { return 64 * T_LA + t_bwd_region<GH, L>() + (GH / 16) * 64 + 128 + (GH / 16) * 1024; }
+template <int GH, int L>
+constexpr bool t_fuse_shape() { return L * GH <= 256 && GH <= 128 && 16 % L == 0; }   // wider blocks: the images do not fit (and the product is a launch's worth); L = 3: the image pieces do not divide over the threads
 
 // ---------------------------------------------------------------------------------------------------------------------
 // forward:  rinv = 1 / rowsum(A_h);  for l:  Y_l = relu((G_l + A_h Pn_l) rinv),  HO_l = dropout(Y_l) + X_l,
@@ -371,8 +385,15 @@ __device__ __forceinline__ void t_parked_tiles(const GemmGroup4& cg, int pb, flo
   }
 }
 
-template <int GH, int L, int NRB>
-__device__ __forceinline__ void chain_t_bwd_body(const GcnCtx& c, float* __restrict__ lds, const int z, const int b, const int h) {
+// FUSE: the gradient of the block's output-projection input is computed here instead of arriving in dYa (what
+// gcn_chain_s_bwd<true> does at its one shape, chain.hip):  dHO_{b,h} = dout_b Wlin[:, h]  (N x D x D per pair, Wlin's slice
+// streamed through LDS), dY = dropout_bwd(dHO), dXres_b = sum_h dHO_{b,h} = dout_b (sum_h Wlin[:, h]): this workgroup's D / H
+// columns of it (one head: dHO itself); dout is masked / un-dropped while it is staged (and written back as dout_m for dWlin),
+// its column sums (the output bias gradient, stage 1) leave from the image.  Removes the dHO launch, the mask launch and the
+// head-sum / dropout kernel (glove:74-78 / 111-118): five launches of a ragged cfg-2 step's 27, four of cfg 1's 24.
+template <int GH, int L, int NRB, bool FUSE>
+__device__ __forceinline__ void chain_t_bwd_body(const GcnCtx& c, float* __restrict__ lds, const int z, const int b, const int h, const int nv) {
+  constexpr int REG = FUSE ? t_bwd_region<GH, L>() : 2 * 64 * (GH + 4);       // floats of the image region
   constexpr int W = GH / 16, NT = 4 * GH, P = GH + 4, NC = GH / 16, SP = 20;   // SP: row pitch of a [gh][16 k] weight stage
   static_assert(2 * GH * SP <= 64 * P, "weight stages live in the Pn image");
   static_assert(W <= 4 || (W / 4 - 1) * 4096 <= 64 * P, "dA exchange lives in the dM image");
@@ -382,7 +403,7 @@ __device__ __forceinline__ void chain_t_bwd_body(const GcnCtx& c, float* __restr
   float* const ATs = lds;                  // A_h transposed: [k = column of A][row of A]
   float* const Ds = ATs + 64 * T_LA;       // dM_l, then dPn_l
   float* const Ps = Ds + 64 * P;           // Pn_l, then the weight stages
-  float* const Tp = Ps + 64 * P;           // [W][64] per-wave partial row sums
+  float* const Tp = Ds + REG;              // [W][64] per-wave partial row sums
   float* const Ts = Tp + W * 64;           // gradient of the normaliser's row sums
   float* const Rs = Ts + 64;               // rinv
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 15, g = lane >> 4;
@@ -436,6 +457,7 @@ __device__ __forceinline__ void chain_t_bwd_body(const GcnCtx& c, float* __restr
   t4 dacc[OBW][4];
   constexpr int PV = (64 * (GH / 4)) / NT;  // 16-byte pieces of a 64 x gh image per thread (= 4)
   static_assert(PV * NT == 64 * (GH / 4) && NT == 16 * (GH / 4), "image load mapping");
+  t4 dyf[FUSE ? L : 1][4];                  // FUSE: dY_l of every sub-layer (this wave's strip), computed in front of the sub-layers
   const int prow = t / (GH / 4), pc4 = (t - prow * (GH / 4)) * 4;          // a thread's first piece of the Pn image
   const unsigned pvoff = ((unsigned)prow * HD + (unsigned)pc4) * 4u;
   float* const Psp = Ps + prow * P + pc4;
@@ -451,7 +473,8 @@ __device__ __forceinline__ void chain_t_bwd_body(const GcnCtx& c, float* __restr
       for (int v = 0; v < 4; ++v) {
         // (dYa's rows past the real entities' blocks may never have been written)
         yv[rb][v] = rb < NRB ? t_ld(Yd, tHD, rowHD(rb, v, l)) : 0.f;
-        dy[rb][v] = rb < NRB ? t_ld(Gd, tHD, rowHD(rb, v, l)) : 0.f;
+        if constexpr (FUSE) dy[rb][v] = dyf[l][rb][v];
+        else dy[rb][v] = rb < NRB ? t_ld(Gd, tHD, rowHD(rb, v, l)) : 0.f;
       }
     t4 pn[PV];   // piece u of a thread: 16 u rows below its first one (NT threads cover 16 rows), same columns
 #pragma unroll
@@ -596,6 +619,160 @@ __device__ __forceinline__ void chain_t_bwd_body(const GcnCtx& c, float* __restr
       if constexpr (l > 2) target(std::integral_constant<int, 2>());
     }
   };
+  if constexpr (FUSE) {
+    constexpr int D = L * GH, PX = D + 4, DV = (64 * (D / 4)) / NT;   // DV: 16-byte pieces of the dout image per thread (= 4 L)
+    static_assert(DV * NT == 64 * (D / 4) && NT % (D / 4) == 0, "dout image load mapping");
+    constexpr int DRS = NT / (D / 4);  // rows of the image between a thread's pieces
+    float* const Xs = Ds;             // [64][PX]   dout_b, masked / un-dropped
+    float* const Bs = Xs + 64 * PX;   // [2][16][PX] Wlin[16 k, this head's D columns]
+    float* const Es = Rs + 64;        // [W][64 lanes][16] K slices of this head's share of dXres
+    const t_desc Xrd = t_buffer(c.dXres + (long)b * N * D, N, D, D);
+    {  // ---- stage dout_b (padding rows get no gradient; back through the hop's output dropout, glove:341) ------------------
+      const t_desc Dgd = t_buffer(c.dout + (long)b * N * D, N, D, D);
+      const t_desc Dmd = t_buffer(c.dout_m ? c.dout_m + (long)b * N * D : c.dout, c.dout_m ? N : 0, D, D);
+      const bool od = c.dout_m && c.odrop.snap != nullptr;
+      const uint64_t okey = od ? drop_key(c.odrop) : 0;
+      const int drow = t / (D / 4), dc4 = (t - drow * (D / 4)) * 4;
+      const unsigned dvoff = ((unsigned)drow * D + (unsigned)dc4) * 4u;
+      t4 dv[DV];
+#pragma unroll
+      for (int u = 0; u < DV; ++u) dv[u] = t_ld4(Dgd, dvoff, (unsigned)(DRS * u) * D * 4u);
+#pragma unroll
+      for (int u = 0; u < DV; ++u) {
+        const int row = drow + DRS * u;
+        if (c.dout_m) {
+          const bool keep = row < nv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x = keep ? dv[u][e] : 0.f;
+            if (od) x = (rng_u32(okey, (uint64_t)(((long)b * N + row) * D + dc4 + e)) >= c.odrop.thresh) ? x * c.odrop.scale : 0.f;
+            dv[u][e] = x;
+          }
+          if (h == 0) t_st4(Dmd, dvoff, (unsigned)(DRS * u) * D * 4u, dv[u]);
+        }
+        *reinterpret_cast<t4*>(Xs + row * PX + dc4) = dv[u];
+      }
+    }
+    // ---- dHO_b = dout_b Wlin[:, h D .. h D + D): every sub-layer's strip of this wave, 16 k per chunk ----------------------
+    const t_desc Wld = t_buffer(c.flat + c.oWlin + (long)h * D, D, HD, D);     // Wlin's rows k, this head's D columns
+    const int wkr = t / (D / 4), wc4 = (t - wkr * (D / 4)) * 4;                // a thread's piece of a 16 x D chunk
+    constexpr int WV = (16 * (D / 4) + NT - 1) / NT;                            // pieces per thread and chunk
+    const unsigned wvoff = ((unsigned)wkr * HD + (unsigned)wc4) * 4u;
+    t4 wr[2][WV];
+    auto gload = [&](const int ch, t4 (&d)[WV]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int p = 0; p < WV; ++p) d[p] = t_ld4(Wld, wvoff, (unsigned)(16 * ch + DRS * p) * HD * 4u);
+    };
+    auto sstore = [&](const int st, const t4 (&d)[WV]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int p = 0; p < WV; ++p)
+        if (wkr + DRS * p < 16) *reinterpret_cast<t4*>(Bs + (st * 16 + wkr + DRS * p) * PX + wc4) = d[p];
+    };
+    gload(0, wr[0]);
+    gload(1, wr[1]);
+    t_barrier();   // the dout image (and A^T, rinv) are complete
+    if (c.colpart && h == 0) {  // the output bias gradient's column sums of this document: rows 0-31 and 32-63
+      for (int idx = t; idx < 2 * D; idx += NT) {
+        const int half = idx / D, cc = idx - half * D;
+        float sacc = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) sacc += Xs[(half * 32 + i) * PX + cc];
+        c.colpart[(long)(2 * b + half) * D + cc] = sacc;
+      }
+    }
+    // this head's D / H columns of dXres_b = dout_b Wsum (H > 1): DH / 16 column groups, each K-split over W / (DH / 16) waves
+    // (the host only fuses shapes where these divide: chain_t_bwd_fusable); the slices meet in Es behind the product's barriers
+    const int DH = D / c.H, ncg = max(DH >> 4, 1), kw = max(W / ncg, 1), cgi = w % ncg, ksl = w / ncg, klen = D / kw;
+    t4 xa[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) xa[rb] = t4{0.f, 0.f, 0.f, 0.f};
+    if (c.H != 1) {
+      const float* __restrict__ Wsp = c.Wsum + (unsigned)(ksl * klen + 4 * g) * (unsigned)D + (unsigned)(h * DH + cgi * 16 + j);
+      for (int k0 = 0; k0 < klen; k0 += 16) {
+        float bw[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) bw[v] = Wsp[(unsigned)(k0 + v) * (unsigned)D];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+          const t4 a = *reinterpret_cast<const t4*>(Xs + (16 * rb + j) * PX + ksl * klen + k0 + 4 * g);
+#pragma unroll
+          for (int v = 0; v < 4; ++v) xa[rb] = mfma16(a[v], bw[v], xa[rb]);
+        }
+      }
+      if (ksl > 0) {
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) Es[w * 1024 + (rb * 4 + v) * 64 + lane] = xa[rb][v];
+      }
+    }
+    t4 acc[L][4];
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[l][rb] = t4{0.f, 0.f, 0.f, 0.f};
+    const float* const Xsj = Xs + j * PX + 4 * g;
+    auto compute = [&](const int ch, const int st) __attribute__((always_inline)) {
+      t4 a[NRB > 0 ? NRB : 1];
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) a[rb] = *reinterpret_cast<const t4*>(Xsj + 16 * rb * PX + 16 * ch);
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        const float* wb = Bs + (st * 16 + 4 * g) * PX + l * GH + col;
+        float bv[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) bv[v] = wb[v * PX];
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+          for (int rb = 0; rb < NRB; ++rb) acc[l][rb] = mfma16(a[rb][v], bv[v], acc[l][rb]);
+      }
+    };
+    constexpr int NCH = D / 16;
+    static_assert(NCH % 2 == 0, "chunks are taken in pairs");
+    sstore(0, wr[0]);
+    t_barrier();
+#pragma nounroll
+    for (int ch = 0; ch < NCH; ch += 2) {   // two chunks per trip: register sets and stages are compile-time constants
+      if (ch + 2 < NCH) gload(ch + 2, wr[0]);
+      compute(ch, 0);
+      sstore(1, wr[1]);
+      t_barrier();
+      if (ch + 3 < NCH) gload(ch + 3, wr[1]);
+      compute(ch + 1, 1);
+      if (ch + 2 < NCH) sstore(0, wr[0]);
+      t_barrier();
+    }
+    if (c.H != 1 && ksl == 0) {   // (the slices were written before the product's first barrier)
+      const unsigned xvoff = ((unsigned)(4 * g) * D + (unsigned)(h * DH + cgi * 16 + j)) * 4u;
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          float x = xa[rb][v];
+          for (int s2 = 1; s2 < kw; ++s2) x += Es[(s2 * ncg + cgi) * 1024 + (rb * 4 + v) * 64 + lane];
+          t_st(Xrd, xvoff, (unsigned)(16 * rb + v) * D * 4u, x);
+        }
+    }
+    // dY_l = dropout_bwd(dHO_l) (the forward mask: same site, same element offsets); one head: dXres = dHO itself
+    const bool dd = c.drop.snap != nullptr;
+    const uint64_t key = dd ? drop_key(c.drop) : 0;
+    const unsigned xv1 = ((unsigned)(4 * g) * D + (unsigned)col) * 4u;
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        t_pin(acc[l][rb]);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int row = 16 * rb + 4 * g + v;
+          float x = acc[l][rb][v];
+          if (c.H == 1) t_st(Xrd, xv1, ((unsigned)(16 * rb + v) * D + (unsigned)(l * GH)) * 4u, x);
+          if (dd) x = (rng_u32(key, (uint64_t)(zoff + (long)((unsigned)row * HD + (unsigned)(l * GH + col)))) >= c.drop.thresh) ? x * c.drop.scale : 0.f;
+          dyf[l][rb][v] = x;
+        }
+      }
+  }
   t_barrier();
   static_assert(L >= 1 && L <= 4, "sub-layers are unrolled by hand");
   if constexpr (L > 3) layer(std::integral_constant<int, 3>());
@@ -636,11 +813,13 @@ __device__ __forceinline__ void chain_t_bwd_body(const GcnCtx& c, float* __restr
   TRB(151);
 }
 
-template <int GH, int L, bool FULL>
+template <int GH, int L, bool FULL, bool FUSE>
 __global__ __launch_bounds__(4 * GH) void gcn_chain_t_bwd_kernel(const GcnCtx c, const GemmGroup4 cg, const int npw) {
   constexpr int W = GH / 16;
-  __shared__ __attribute__((aligned(16))) float lds[t_bwd_lds<GH>()];
-  static_assert((GH / 64) * T_TEAM_LDS <= t_bwd_lds<GH>(), "parked tiles use the chain kernel's LDS");
+  constexpr int LDSF = FUSE ? t_bwd_fuse_lds<GH, L>() : t_bwd_lds<GH>();
+  static_assert(LDSF * sizeof(float) <= 160 * 1024, "LDS of one compute unit");
+  __shared__ __attribute__((aligned(16))) float lds[LDSF];
+  static_assert((GH / 64) * T_TEAM_LDS <= LDSF, "parked tiles use the chain kernel's LDS");
   if (blockIdx.x >= c.B * c.H) {
     int pb;
     if (spread_pick((int)blockIdx.x - c.B * c.H, c.carry, pb)) {  // passenger workgroup: GH / 64 tiles of a parked weight-gradient product
@@ -653,17 +832,17 @@ __global__ __launch_bounds__(4 * GH) void gcn_chain_t_bwd_kernel(const GcnCtx c,
     return;
   }
   const int z = blockIdx.x, b = z / c.H, h = z - b * c.H;
+  const int nv = c.n_valid ? min(max(c.n_valid[b], 0), c.N) : c.N;
   if constexpr (FULL) {
-    chain_t_bwd_body<GH, L, 4>(c, lds, z, b, h);
+    chain_t_bwd_body<GH, L, 4, FUSE>(c, lds, z, b, h, nv);
   } else {
-    const int nv = c.n_valid ? min(max(c.n_valid[b], 0), c.N) : c.N;
     const int nrb = (nv + 15) >> 4;
     switch (nrb) {
-      case 0: chain_t_bwd_body<GH, L, 0>(c, lds, z, b, h); break;
-      case 1: chain_t_bwd_body<GH, L, 1>(c, lds, z, b, h); break;
-      case 2: chain_t_bwd_body<GH, L, 2>(c, lds, z, b, h); break;
-      case 3: chain_t_bwd_body<GH, L, 3>(c, lds, z, b, h); break;
-      default: chain_t_bwd_body<GH, L, 4>(c, lds, z, b, h); break;
+      case 0: chain_t_bwd_body<GH, L, 0, FUSE>(c, lds, z, b, h, nv); break;
+      case 1: chain_t_bwd_body<GH, L, 1, FUSE>(c, lds, z, b, h, nv); break;
+      case 2: chain_t_bwd_body<GH, L, 2, FUSE>(c, lds, z, b, h, nv); break;
+      case 3: chain_t_bwd_body<GH, L, 3, FUSE>(c, lds, z, b, h, nv); break;
+      default: chain_t_bwd_body<GH, L, 4, FUSE>(c, lds, z, b, h, nv); break;
     }
   }
 }
@@ -676,8 +855,15 @@ static int chain_t_run_fwd(const GcnCtx& c, dim3 grid, double fl, hipStream_t st
 }
 template <int GH, int L>
 static int chain_t_run_bwd(const GcnCtx& c, const GemmGroup4& cg, int npw, dim3 grid, double fl, hipStream_t st) {
-  if (chain_t_full(c)) GC_LAUNCH_TIMED("gcn_chain_bwd", fl, (gcn_chain_t_bwd_kernel<GH, L, true>), grid, dim3(4 * GH), 0, st, c, cg, npw);
-  else GC_LAUNCH_TIMED("gcn_chain_bwd", fl, (gcn_chain_t_bwd_kernel<GH, L, false>), grid, dim3(4 * GH), 0, st, c, cg, npw);
+  if constexpr (t_fuse_shape<GH, L>()) {
+    if (c.dout) {   // the fused output-projection gradient (chain_t_bwd_fusable said yes)
+      if (chain_t_full(c)) GC_LAUNCH_TIMED("gcn_chain_bwd", fl, (gcn_chain_t_bwd_kernel<GH, L, true, true>), grid, dim3(4 * GH), 0, st, c, cg, npw);
+      else GC_LAUNCH_TIMED("gcn_chain_bwd", fl, (gcn_chain_t_bwd_kernel<GH, L, false, true>), grid, dim3(4 * GH), 0, st, c, cg, npw);
+      return check_launch("gcn_chain_t_bwd");
+    }
+  }
+  if (chain_t_full(c)) GC_LAUNCH_TIMED("gcn_chain_bwd", fl, (gcn_chain_t_bwd_kernel<GH, L, true, false>), grid, dim3(4 * GH), 0, st, c, cg, npw);
+  else GC_LAUNCH_TIMED("gcn_chain_bwd", fl, (gcn_chain_t_bwd_kernel<GH, L, false, false>), grid, dim3(4 * GH), 0, st, c, cg, npw);
   return check_launch("gcn_chain_t_bwd");
 }
 

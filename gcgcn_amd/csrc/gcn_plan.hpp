@@ -148,6 +148,7 @@ __host__ __device__ inline GemmArgs plan_bwd_dY(const GcnCtx& c, int l) {
 
 // chain_t.hip: LDS-resident chain kernels for N <= 64 and the instantiated (gh, L) pairs
 bool chain_t_ok(const GcnCtx& c, bool bwd);
+bool chain_t_bwd_fusable(const GcnCtx& c);   // the column-strip backward computes dHO / dXres itself (c.dout) at this shape
 bool chain_t_fwd_att_ok(const GcnCtx& c);
 int gcn_chain_t_fwd(const GcnCtx& c, dim3 grid, double flops, hipStream_t st);
 int gcn_chain_t_bwd(const GcnCtx& c, double flops, hipStream_t st, DeferQueue* carry);
