@@ -107,14 +107,12 @@ struct Opt {
   int value;
   bool resolved;
 };
-static Opt g_opts[] = {{"head_v1", 0, false},   {"head_bil3", 0, false},  {"head_bil3_bwd", 0, false}, {"head_dw3", 0, false},
-                       {"chain_s", 0, false},   {"chain_fuse", 0, false}, {"chain_carry", 0, false},   {"gat_ride", 0, false},
-                       {"chain_t", 0, false},   {"mha_ride", 0, false},
-                       {"chain_carry_pct", 0, false}, {"chain_carry_rounds", 0, false},
-                       {"maggc_fuse", 0, false}, {"carry_spread", 0, false}, {"chain_spread", 0, false},
+static Opt g_opts[] = {{"head_v1", 0, false},      {"head_bil3", 0, false},    {"head_bil3_bwd", 0, false}, {"head_dw3", 0, false},
+                       {"chain_fuse", 0, false},   {"chain_carry", 0, false},  {"gat_ride", 0, false},      {"chain_t", 0, false},
+                       {"mha_ride", 0, false},     {"maggc_fuse", 0, false},   {"carry_spread", 0, false},  {"chain_spread", 0, false},
                        {"carry_cohort", 0, false}, {"chain_cohort", 0, false}, {"carry_spread_min", 0, false},
                        {"chain_spread_min", 0, false}, {"att_in_chain", 0, false}, {"fold_slices", 0, false}, {"head_sum_fold", 0, false},
-                       {"head_compact", 0, false}, {"chain_big", 0, false}, {"chain_t_fuse", 0, false}};
+                       {"head_compact", 0, false}, {"chain_big", 0, false}};
 int option(const char* name, int dflt) {
   for (Opt& o : g_opts) {
     if (strcmp(o.name, name) != 0) continue;

@@ -804,8 +804,7 @@ __global__ __launch_bounds__(64 * CW) void gcn_chain_s_bwd_kernel(const GcnCtx c
 
 // the shape the LDS-resident kernels are written for
 static bool chain_small_ok(const GcnCtx& c, bool bwd) {
-  const bool on = option("chain_s", 1) != 0;
-  return on && c.N == 64 && c.L == 2 && c.gh == S_GH && c.D == 2 * S_GH && (c.flat + c.oWd) && c.wd_head % 4 == 0 &&
+  return c.N == 64 && c.L == 2 && c.gh == S_GH && c.D == 2 * S_GH && (c.flat + c.oWd) && c.wd_head % 4 == 0 &&
          (c.wd_off(1) % 4) == 0;
 }
 

@@ -44,7 +44,7 @@ bool chain_t_ok(const GcnCtx& c, bool bwd) {
 // The backward kernel can compute the output projection's input gradient itself (chain_t.hpp FUSE): blocks of at most 256
 // features whose residual-gradient share divides over the waves (one head: no such product); option chain_fuse = 0: never
 bool chain_t_bwd_fusable(const GcnCtx& c) {
-  if (option("chain_fuse", 1) == 0 || option("chain_t_fuse", 1) == 0 || c.N > 64 || c.D != c.L * c.gh || c.D > 256 || c.D % 32 != 0 || c.gh > 128 || 16 % c.L != 0) return false;
+  if (option("chain_fuse", 1) == 0 || c.N > 64 || c.D != c.L * c.gh || c.D > 256 || c.D % 32 != 0 || c.gh > 128 || 16 % c.L != 0) return false;
   bool shape = false;
 #define X(gh_, l_) shape = shape || (c.gh == gh_ && c.L == l_);
   GC_CHAIN_T_HOST_SHAPES(X)
@@ -106,8 +106,7 @@ int gcn_chain_t_bwd(const GcnCtx& c, double fl, hipStream_t st, DeferQueue* carr
     if (c.ride.kind == 2) t_chain += 4.0 * c.ride.B * c.ride.N * (double)c.ride.N * c.ride.D / 5.0e6;
     const double t_tile = 1.1 * (kmax / 32.0) * (1.0 + 0.3 * (nteam - 1));
     ok = ok && t_tile <= 1.25 * t_chain;
-    long wgs = idle * option("chain_carry_rounds", 1);
-    if (c.ride.kind == 2) wgs = wgs * option("chain_carry_pct", 100) / 100;
+    const long wgs = idle;
     if (ok && wgs > 0) {
       gemm_take_deferred_pairs(carry, cg, &fl, wgs * nteam, true);   // whole small problems first
       for (int i = 0; i < cg.nprob; ++i) npw += (cg.tile_take[i] + nteam - 1) / nteam;
