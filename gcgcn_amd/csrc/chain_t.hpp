@@ -670,7 +670,9 @@ __device__ __forceinline__ void chain_t_bwd_body(const GcnCtx& c, float* __restr
     };
     gload(0, wr[0]);
     gload(1, wr[1]);
+    TRB(101);
     t_barrier();   // the dout image (and A^T, rinv) are complete
+    TRB(102);
     if (c.colpart && h == 0) {  // the output bias gradient's column sums of this document: rows 0-31 and 32-63
       for (int idx = t; idx < 2 * D; idx += NT) {
         const int half = idx / D, cc = idx - half * D;
@@ -730,8 +732,10 @@ __device__ __forceinline__ void chain_t_bwd_body(const GcnCtx& c, float* __restr
     };
     constexpr int NCH = D / 16;
     static_assert(NCH % 2 == 0, "chunks are taken in pairs");
+    TRB(103);
     sstore(0, wr[0]);
     t_barrier();
+    TRB(104);
 #pragma nounroll
     for (int ch = 0; ch < NCH; ch += 2) {   // two chunks per trip: register sets and stages are compile-time constants
       if (ch + 2 < NCH) gload(ch + 2, wr[0]);
@@ -743,6 +747,7 @@ __device__ __forceinline__ void chain_t_bwd_body(const GcnCtx& c, float* __restr
       if (ch + 2 < NCH) sstore(0, wr[0]);
       t_barrier();
     }
+    TRB(105);
     if (c.H != 1 && ksl == 0) {   // (the slices were written before the product's first barrier)
       const unsigned xvoff = ((unsigned)(4 * g) * D + (unsigned)(h * DH + cgi * 16 + j)) * 4u;
 #pragma unroll
@@ -773,6 +778,7 @@ __device__ __forceinline__ void chain_t_bwd_body(const GcnCtx& c, float* __restr
         }
       }
   }
+  TRB(106);
   t_barrier();
   static_assert(L >= 1 && L <= 4, "sub-layers are unrolled by hand");
   if constexpr (L > 3) layer(std::integral_constant<int, 3>());

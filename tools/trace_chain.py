@@ -21,6 +21,7 @@ from gcgcn_amd import _lib  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="c2", choices=sorted(bench.CONFIGS))
 ap.add_argument("--iters", type=int, default=3)
+ap.add_argument("--ragged", action="store_true", help="DocRED-like n_valid (bench.py --ragged); workgroup 0 is document 0")
 args = ap.parse_args()
 cfg = bench.CONFIGS[args.config]
 dev = torch.device("cuda:0")
@@ -28,6 +29,14 @@ torch.manual_seed(1)
 hops = gcgcn_amd.GraphHops(cfg["D"], cfg["L"], cfg["H"]).to(dev).train()
 gcgcn_amd.manual_seed(5, dev)
 x, e1, e2, adj = bench.synth(cfg, 3, dev)
+n_valid = None
+if args.ragged:
+    g = torch.Generator().manual_seed(4242)
+    B, N = x.shape[0], x.shape[1]
+    n_valid = torch.clamp(torch.round(torch.randn(B, generator=g) * 6.0 + 19.5), 2, min(42, N)).to(torch.int32).to(dev)
+    with torch.no_grad():
+        x.mul_((torch.arange(N, device=dev)[None, :] < n_valid[:, None]).unsqueeze(-1).float())
+    print("n_valid[0] =", int(n_valid[0]))
 for t in (x, e1, e2):
     t.requires_grad_()
 h = _lib.lib()
@@ -42,7 +51,7 @@ def show(tag, v, lo, hi):
 
 
 for it in range(args.iters):
-    hops(x, [e1, e2], adj)[-1].sum().backward()
+    hops(x, [e1, e2], adj, n_valid=n_valid)[-1].sum().backward()
     torch.cuda.synchronize()
     print("iteration", it)
     h.gcgcn_debug_trace_s(buf)
