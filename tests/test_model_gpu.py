@@ -237,7 +237,12 @@ def test_model_trains_with_fused_adam(gpu_device):
         moved += int(not same)
         still += int(same)
     want_none = set(str(k) for k in r["names.grad_none"])
-    unmoved = sorted(k for k in a if torch.equal(a[k].cpu(), sd[k]) and k not in want_none)
+    # Biases in front of a softmax (GATAttention's wt.bias, the word attention's attention_all.bias): a softmax ignores a shift, their
+    # gradient is the rounding residue of an exact zero (1e-12 .. 1e-14 in the reference's own backward, the fixture's grad_sd) and
+    # whether that residue is +-1e-12 or exactly 0.0 depends on the ulps of the step before (PyTorch's LSTM / embedding backward use
+    # atomics).  Adam moves the parameter by ~lr in the first case and not at all in the second: both are right, neither is asserted.
+    residue = set(k for k, v in g["grad_sd"].items() if float(v.abs().max()) < 1e-9)
+    unmoved = sorted(k for k in a if torch.equal(a[k].cpu(), sd[k]) and k not in want_none and k not in residue)
     assert not unmoved, f"parameters with a gradient that did not move: {unmoved}"
     assert still >= len(want_none)                                               # the dead hop and linears_k stay where they were
 
