@@ -1113,6 +1113,45 @@ def test_chain_t_matches_generic_chain(gpu_device, B, N, D, L, H, ragged, train)
     assert not bad, "; ".join(bad)
 
 
+@pytest.mark.parametrize("N", [3, 15, 16, 17, 31, 33, 47, 48, 49, 63])
+@pytest.mark.parametrize("H", [1, 2])
+def test_chain_t_bounds_by_descriptor_at_every_row_count(gpu_device, N, H):
+    """Round 5: the column-strip kernels bound their strip accesses by buffer descriptors (rows past N read zero, their stores are
+    dropped by the hardware's range check) instead of comparing rows with N.  Graphs of N entities on either side of every 16-row
+    block boundary, three documents back to back in memory (a store past a document's last row would land in its neighbour), ragged
+    n_valid, one head (the fused backward's dXres = dHO path) and two: everything against the generic chain kernels, which test
+    rows the old way."""
+    B, D, L = 3, 128, 2
+    sd = O.init_stack_params(D, L, H, seed=31 * N + H)
+    x, e1, e2, adj = O.synth_docs(B, N, D, seed=N + 7 * H)
+    n_valid = torch.tensor([N, max(1, N - 5), max(1, (N + 1) // 2)], dtype=torch.int32)
+    x = x * (torch.arange(N)[None, :] < n_valid[:, None]).unsqueeze(-1).float()
+    hops = gcgcn_amd.GraphHops(D, L, H).to(gpu_device).eval()
+    hops.load_state_dict(sd, strict=True)
+    cot = torch.randn(B, N, D, generator=torch.Generator().manual_seed(5)).to(gpu_device)
+    res = []
+    try:
+        for mode in (2, 0):
+            _lib.call("gcgcn_set_option", b"chain_t", mode)
+            xs = [dev_leaf(t, gpu_device) for t in (x, e1, e2)]
+            hops.zero_grad()
+            f = hops(xs[0], [xs[1], xs[2]], n_valid=n_valid.to(gpu_device))
+            torch.autograd.backward(f[-1], cot)
+            res.append([f[1].detach(), f[2].detach(), xs[0].grad, xs[1].grad, xs[2].grad] +
+                       [p.grad.clone() for p in hops.parameters() if p.grad is not None])
+    finally:
+        _lib.call("gcgcn_set_option", b"chain_t", 1)
+    names = ["x1", "x2", "dX", "dE1", "dE2", "d gat", "d mha", "d caggc", "d maggc"]
+    assert len(res[0]) == len(res[1]) == 9
+    for nm, a, b_ in zip(names, *res):
+        assert torch.isfinite(a).all(), f"{nm}: not finite"
+        top = max(1.0, b_.abs().max().item())
+        err = (a - b_).abs()
+        assert bool((err <= 2e-5 * top + 2e-4 * b_.abs()).all()), f"{nm}: max |diff| {err.max().item():.3e} (largest entry {top:.3e})"
+    for b in range(B):   # padding rows of the outputs are exact zeros
+        assert float(res[0][1][b, int(n_valid[b]):].abs().max() if int(n_valid[b]) < N else 0.0) == 0.0
+
+
 def test_relu_decision_within_an_ulp_of_zero_is_what_separates_the_kernel_generations(gpu_device):
     """The seed on which test_chain_t_matches_generic_chain[2-64-384-2-2] once failed with a whole gradient column apart
     (round 3; answered then by moving the seed).  The claim -- ONE relu pre-activation lands within rounding of zero and the
