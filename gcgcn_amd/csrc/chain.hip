@@ -809,7 +809,7 @@ static bool chain_small_ok(const GcnCtx& c, bool bwd) {
 }
 
 static bool chain_aligned(const GcnCtx& c, bool bwd);
-// the dispatch rule of gcn_chain_fwd / _bwd: chain_t.hip takes the shape instead of the default shape's own kernels
+// the dispatch rule of gcn_chain_fwd / _bwd: the column-strip kernels (chain_t.hpp) take the shape instead of the default shape's own kernels
 // (option chain_t: 0 never; 1 (default) wherever the default shape's own kernels do not apply, and at that shape too for RAGGED
 // batches -- the column-strip kernels skip 16-row blocks per document, gcn_chain_s_* own 32 rows per wave and do not: cfg 2
 // ragged 71.2 k -> 72.5 k docs/s at B = 32; dense batches stay on gcn_chain_s_* (0.522 vs 0.542 ms); 2: everywhere)
@@ -872,8 +872,7 @@ int gcn_chain_fwd(const GcnCtx& c, hipStream_t st) {
   dim3 grid(chain_grid(c, 1)), block(64 * CW);
   double fl = 0;
   for (int l = 0; l < c.L; ++l) fl += 2.0 * c.N * c.gh * (c.N + (double)l * c.gh);
-  // option chain_t: 1 (default) = the column-strip kernels (chain_t.hip) wherever the default shape's own kernels do not
-  // apply, 2 = also there (A/B), 0 = never
+  // (which kernel generation serves the shape: chain_s_preferred above)
   const bool s_ok = chain_aligned(c, false) && chain_small_ok(c, false);
   if (chain_t_ok(c, false) && !chain_s_preferred(c, s_ok)) return gcn_chain_t_fwd(c, grid, fl * c.B * c.H, st);
   // only the LDS-resident kernels run the attention core in their prologue: a caller that left it to the chain (c.mha) and ends

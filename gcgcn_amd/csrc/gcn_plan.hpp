@@ -146,7 +146,7 @@ __host__ __device__ inline GemmArgs plan_bwd_dY(const GcnCtx& c, int l) {
   return g;
 }
 
-// chain_t.hip: LDS-resident chain kernels for N <= 64 and the instantiated (gh, L) pairs
+// chain_t.hip (host side) + chain_t.hpp / chain_t_u0..3.hip (kernels): LDS-resident chain kernels for N <= 64 and the instantiated (gh, L) pairs
 bool chain_t_ok(const GcnCtx& c, bool bwd);
 bool chain_t_bwd_fusable(const GcnCtx& c);   // the column-strip backward computes dHO / dXres itself (c.dout) at this shape
 bool chain_t_fwd_att_ok(const GcnCtx& c);

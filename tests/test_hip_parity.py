@@ -1067,7 +1067,7 @@ def test_graphs_above_64_entities_chain_kernels_against_per_product_launches(gpu
     (2, 20, 64, 2, 2, True, False),      # gh = 32, two sub-layers
 ])
 def test_chain_t_matches_generic_chain(gpu_device, B, N, D, L, H, ragged, train):
-    """chain_t.hip (column strips, chained products, pushed dense connections; N <= 64) against the generic chain kernels on
+    """chain_t.hpp (column strips, chained products, pushed dense connections; N <= 64) against the generic chain kernels on
     the same inputs, same dropout snapshots: outputs, dX, dE and every parameter gradient.  (The generic kernels are tied to
     the oracle by every other test in this file; at cfg 3 / the reference's shape those tests now run chain_t themselves.)"""
     # (seed of the (2, 64, 384, 2, 2) case: with 7 N + L one pre-activation of document 0 lands within an ulp of zero, the two

@@ -41,7 +41,7 @@ for t in (x, e1, e2):
     t.requires_grad_()
 h = _lib.lib()
 if not hasattr(h, "gcgcn_debug_trace_s"):
-    sys.exit("not a trace build: set GCGCN_LIB to a library whose chain.hip / chain_t.hip were compiled with -DGC_T_TRACE")
+    sys.exit("not a trace build: set GCGCN_LIB to a library built by `make -C gcgcn_amd/csrc trace` (chain.hip and the chain_t units compiled with -DGC_T_TRACE)")
 buf = (ctypes.c_longlong * 256)()
 
 
