@@ -103,6 +103,21 @@ def test_partial_srcc_overlap_needs_the_passes():
     assert H.analyse(_lines(src.format(gap="s_nop 7")), 0)[0] == []
 
 
+def test_accumulation_registers_are_tracked_like_vector_registers():
+    """A product whose destination is an a-register tuple, read back by v_accvgpr_read one wait state short; the v-register of
+    the same number is a different register."""
+    src = """
+        v_mfma_f32_16x16x4_f32 a[0:3], v8, v9, a[0:3]
+        s_nop {n}
+        v_accvgpr_read_b32 v20, a1
+        v_add_f32_e32 v21, v1, v2
+        s_endpgm
+    """
+    f = H.analyse(_lines(src.format(n=8)), 0)[0]
+    assert len(f) == 1 and f[0][2] == 1001 and f[0][3] == 9 and f[0][4] == 10
+    assert H.analyse(_lines(src.format(n=9)), 0)[0] == []
+
+
 def test_spill_reloaded_under_a_wider_mask_than_its_store_is_found():
     bad = """
         v_mov_b32_e32 v1, 0

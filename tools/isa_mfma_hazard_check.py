@@ -40,7 +40,7 @@ from collections import defaultdict
 
 LABEL = re.compile(r'^(\.LBB\d+_\d+):')
 KSTART = re.compile(r'^(_Z\w+):\s')
-VREG = re.compile(r'\bv(\d+)\b|\bv\[(\d+):(\d+)\]')
+VREG = re.compile(r'\b([va])(\d+)\b|\b([va])\[(\d+):(\d+)\]')   # vector and accumulation registers (a-registers: number + 1000)
 
 PASSES = [
     (re.compile(r'v_mfma_f32_32x32x2_?f32'), 16), (re.compile(r'v_mfma_f32_32x32x1_?(2b_)?f32'), 16),
@@ -61,9 +61,10 @@ def regs(tok):
   out = []
   for m in VREG.finditer(tok):
     if m.group(1) is not None:
-      out.append(int(m.group(1)))
+      out.append(int(m.group(2)) + (1000 if m.group(1) == 'a' else 0))
     else:
-      out.extend(range(int(m.group(2)), int(m.group(3)) + 1))
+      base = 1000 if m.group(3) == 'a' else 0
+      out.extend(range(base + int(m.group(4)), base + int(m.group(5)) + 1))
   return out
 
 
@@ -239,7 +240,7 @@ def main():
       if f or args.list:
         print('%s: %-100s mfma %5d  hazards %d' % (path.split('/')[-1], dn[:100], nm, len(f)))
       for x, y, r, have, need in f:
-        print('    v%d: line %d `%s`  <- %d wait states (need %d) <-  line %d `%s`' % (r, y.line, y.text, have, need, x.line, x.text))
+        print('    %s%d: line %d `%s`  <- %d wait states (need %d) <-  line %d `%s`' % ('a' if r >= 1000 else 'v', r % 1000, y.line, y.text, have, need, x.line, x.text))
       bad += 1 if f else 0
   if not bad:
     print('no MFMA result is read too early on any path')
