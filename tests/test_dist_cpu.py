@@ -85,6 +85,50 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
+def _worker_c4(rank, world, port, out):
+    """Config c4's partitioning (BASELINE.json configs[3]): 256 documents over 8 ranks = 32 per rank, one coalesced all-reduce of
+    the four flat gradients, every rank ends with sum over ranks / global batch."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(1337)
+        hops = gcgcn_amd.GraphHops(16, 2, 4)
+        bucket = FlatGradBucket(hops)
+        docs = torch.arange(256.0).view(256, 1)
+        n_valid = torch.arange(256, dtype=torch.int32)
+        xs, ns = shard_batch([docs, n_valid], rank, world)
+        assert xs.shape[0] == 32 and xs.flatten().tolist() == [32.0 * rank + k for k in range(32)]
+        assert ns.tolist() == list(range(32 * rank, 32 * rank + 32))
+        bucket.zero_grad()
+        # a rank's gradient = the sum over ITS documents; the reduced gradient must be the mean over all 256
+        loss = sum((p * xs.sum() * float(i + 1)).sum() for i, p in enumerate(bucket.params))
+        loss.backward()
+        bucket.all_reduce(global_docs=256)
+        for i, p in enumerate(bucket.params):
+            want = float(i + 1) * (255.0 * 256.0 / 2.0) / 256.0
+            assert torch.allclose(p.grad, torch.full_like(p, want)), (i, p.grad.flatten()[:3], want)
+        out.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        out.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+def test_c4_partitioning_gloo_world8():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_c4, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=200) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert sorted(res) == [(r, "ok") for r in range(8)], res
+
+
 @pytest.mark.timeout(120)
 @pytest.mark.parametrize("target", [_worker, _worker_overlap], ids=["single_allreduce", "overlapped_slices"])
 def test_flat_bucket_allreduce_gloo_world2(target):
