@@ -183,11 +183,10 @@ static int make_ride(const char* who, const gcgcn_edge_ride* ride, int kind, Edg
 }
 
 // Row blocks of a ragged batch (gcgcn_row_blocks) on one GEMM problem: mode 1 = M is the document-row dimension, 2 = K is.
-// (mode 2 -- weight gradients -- walks the list of live 32-row k-tiles behind the block list: g.K = B N is set by then)
+// (both walk the same list of live 16-row blocks: mode 1 four at a time as a 64-row tile, mode 2 two at a time as a k-tile)
 static void use_rows(GemmArgs& g, const int* rowblk, int mode, int zero_dead = 0) {
   if (!rowblk) return;
-  if (mode == 2) g.rb = rowblk + ROWBLK_HDR + g.K / 16, g.rb_n = rowblk + 1;
-  else g.rb = rowblk + ROWBLK_HDR, g.rb_n = rowblk;
+  g.rb = rowblk + ROWBLK_HDR, g.rb_n = rowblk;
   g.rb_mode = mode, g.rb_zero = zero_dead;
 }
 

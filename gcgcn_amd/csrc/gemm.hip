@@ -301,7 +301,7 @@ static int prepare(GemmArgs& g, int tile, int splits, long group_work) {
   g.ksplit = (splits > 1) ? g.K / splits : g.K;
   if (g.rb) {  // row blocks of a ragged batch: only what the gathering tile body serves, anything else runs dense (equally correct)
     const bool interior = g.vecA && g.vecB && g.M % 64 == 0 && g.N % 64 == 0 && g.K % BK == 0 && g.ksplit % BK == 0 && g.rb_n;
-    const bool ok = interior && ((g.rb_mode == 1 && g.a_kc && nb == 1) || (g.rb_mode == 2 && !g.a_kc && !g.b_kc && g.K % 64 == 0 && g.K / BK <= ROWBLK_KTILES_MAX));
+    const bool ok = interior && ((g.rb_mode == 1 && g.a_kc && nb == 1) || (g.rb_mode == 2 && !g.a_kc && !g.b_kc && g.K % 64 == 0 && g.K / 16 <= ROWBLK_LIST_MAX));
     // M-side: a launch that does not fill the chip anyway gains nothing from skipping tiles and pays the list's lookups in
     // its latency-bound prologue (128-tile output projection: 21 vs 16 us measured) -- dense below one tile per compute unit
     // and slot (a problem inside a group launch shares the launch: group_work > 0 keeps it)
@@ -417,6 +417,15 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* 
     if (g.splits > 1) reds += (int)(nb * cdiv((long)g.M * g.N / 4, 256));
     flops += 2.0 * g.M * g.N * g.K * nb;
     gg.p[gg.nprob++] = g;
+  }
+  static const bool dump = getenv("GCGCN_GROUP_DUMP") != nullptr;   // diagnosis: what each group launch is made of
+  if (dump) {
+    fprintf(stderr, "gemm_group: %d problems, %d tile workgroups, mha pairs %d\n", gg.nprob, tiles, mha ? mha->count : 0);
+    for (int i = 0; i < gg.nprob; ++i) {
+      const GemmArgs& g = gg.p[i];
+      fprintf(stderr, "  %-12s M %5d N %5d K %5d batch %3d splits %2d a_kc %d b_kc %d rb_mode %d tiles %5d\n", g.tag, g.M, g.N, g.K,
+              g.batch1 * g.batch2, g.splits, g.a_kc, g.b_kc, g.rb ? g.rb_mode : 0, gg.tile_count[i]);
+    }
   }
   const bool ride3 = col && col->ready_slices < 0 && col->C > 0;   // head sum: no partials, no second stage
   const bool ride2 = col && col->ready_slices > 0 && col->C > 0;

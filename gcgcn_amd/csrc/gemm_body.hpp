@@ -99,6 +99,26 @@ struct TilePtr {
       r[q][0] = v.x, r[q][1] = v.y, r[q][2] = v.z, r[q][3] = v.w;
     }
   }
+  // rb_mode 2, [k][.] operand of a 64-wide tile: this thread's piece q lies in rows 16 q .. 16 q + 15 of the k-tile, so a k-tile
+  // made of two 16-row blocks ia, ib of the source (any two: the live blocks of a ragged batch, in list order) is two loads
+  // at wave-uniform offsets.  A block id < 0 (past the end of the list) gives zeros.
+  __device__ __forceinline__ void load_blocks(float (&r)[BMN / 32][4], const int ia, const int ib) const {
+    static_assert(!KC && BMN == 64, "row-block k-tiles: [k][64]-wide operands");
+    const float4 v0 = *reinterpret_cast<const float4*>(p[0] + (long)(max(ia, 0) * 16) * kstep);
+    const float4 v1 = *reinterpret_cast<const float4*>(p[1] + (long)(max(ib, 0) * 16 - 16) * kstep);
+    r[0][0] = v0.x, r[0][1] = v0.y, r[0][2] = v0.z, r[0][3] = v0.w;
+    r[1][0] = v1.x, r[1][1] = v1.y, r[1][2] = v1.z, r[1][3] = v1.w;
+    // (real branches, which the empty asm statements keep: if-converted into selects on the loaded registers, the zeroing made
+    // every k-tile wait for its own request at once -- s_waitcnt vmcnt(1) straight behind the loads, edge_bwd_carry 64 -> 75 us)
+    if (ia < 0) {
+      asm volatile("");
+      r[0][0] = r[0][1] = r[0][2] = r[0][3] = 0.f;
+    }
+    if (ib < 0) {
+      asm volatile("");
+      r[1][0] = r[1][1] = r[1][2] = r[1][3] = 0.f;
+    }
+  }
   // ---- ragged batches (GemmArgs::rb): the document rows that exist, through the list of live 16-row blocks -------------
   // rb_mode 1, KC operand [rows][k]: this thread's rows are fixed for the whole k-loop, so the list is read once, here.
   // Blocks of the tile past the live ones (only the last live tile has any) read a live block instead: their results are
@@ -359,16 +379,19 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
   constexpr bool FASTP = ALIGNED && std::is_same<OPS, PlainOperands>::value;
   // ragged batches (GemmArgs::rb): the live 16-row blocks of the document-row dimension
   const bool rbm = RB && FASTP && AKC && g.rb && g.rb_mode == 1;             // M = document rows: A rows gathered, C rows scattered
-  const bool rbk = RB && FASTP && !AKC && !BKC && g.rb && g.rb_mode == 2;    // K = document rows: the live 32-row k-tiles only
+  const bool rbk = RB && FASTP && !AKC && !BKC && g.rb && g.rb_mode == 2;    // K = document rows: the live 16-row blocks only
   const int nl = rbm ? __builtin_amdgcn_readfirstlane(*g.rb_n) : 0;
-  const int nkt = rbk ? __builtin_amdgcn_readfirstlane(*g.rb_n) : 0;
+  const int nlk = rbk ? __builtin_amdgcn_readfirstlane(*g.rb_n) : 0;
+  const int nkt = (nlk + 1) >> 1;   // k-tiles of two live blocks each (the last one may be half empty)
   int kbeg = sp * g.ksplit;
   int kend = min(g.K, kbeg + g.ksplit);
-  // rb_mode 2: the ascending list of live k-tiles (at most ROWBLK_KTILES_MAX = 256, gemm.hip prepare()) sits in four registers,
-  // entry e in lane e % 64 of register e / 64: the k-loop picks its tiles with v_readlane, no memory operation.  (Round 4 first
-  // gathered 16-row blocks through scalar loads inside the k-loop: twice the time per k-step of the dense loop, which made the
-  // skipped rows a wash -- cfg 2 ragged, edge_bwd_carry 81 us with the list against 83 us dense.)  Rows of a live k-tile that
-  // belong to a dead block hold zeros in one operand and finite values in the other, exactly as in the dense product.
+  // rb_mode 2: the ascending list of live 16-row blocks (at most ROWBLK_LIST_MAX = 512, gemm.hip prepare()) sits in four
+  // registers, two 16-bit entries to a lane: k-tile e = list entries 2 e and 2 e + 1 in lane e % 64 of register e / 64.  The
+  // k-loop picks the two blocks of its next k-tile with one v_readlane, no memory operation, and fetches each operand's two
+  // halves at wave-uniform offsets (TilePtr::load_blocks).  (Round 4 first gathered blocks through scalar loads inside the
+  // k-loop: twice the time per k-step of the dense loop; then walked live 32-row k-TILES -- tile kt = blocks 2 kt, 2 kt + 1 of
+  // the padded tensor, live iff one of them is -- which keeps a document of 1-16 entities, or of 33-48, at a whole extra half
+  // tile: 62 % of the dense k-steps at DocRED's entity counts where the blocks are 43 %.)
   int kl[4] = {-1, -1, -1, -1};
   if (rbk) {
     // Every slice runs the SAME number of k-tiles (two tile teams of one workgroup share its barriers): ceil(k-tiles / splits),
@@ -376,10 +399,15 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
     // just adds zeros.
     const int ks = max((nkt + g.splits - 1) / g.splits, 1) * BK;
     kbeg = sp * ks, kend = kbeg + ks;
+    // four unconditional 8-byte loads in flight together (entry nlk of an odd-length list exists: the dead blocks follow the
+    // live ones and K / 16 is even), the conditions applied afterwards: a tile's prologue waits for ONE round trip
+    int2 pr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pr[j] = *reinterpret_cast<const int2*>(g.rb + 2 * min(lane + 64 * j, max(nkt - 1, 0)));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int e = lane + 64 * j;
-      kl[j] = e < nkt ? g.rb[e] : -1;
+      kl[j] = e < nkt ? (pr[j].x | ((2 * e + 1 < nlk ? pr[j].y : 0xffff) << 16)) : -1;
     }
   }
 
@@ -430,22 +458,21 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
       tpa.init(A, g.lda, m0, t), tpb.init(B, g.ldb, n0, t);
     }
   }
-  // rb_mode 2: the k-tile of a register set's NEXT request (-1: past the list, the request's registers are zeroed); wave-uniform
-  int id0 = 0, id1 = 0;
-  auto ids = [&](int& id, int kt) {
+  // rb_mode 2: the two blocks of a register set's NEXT request (-1: past the list, that half of the registers is zeroed); wave-uniform
+  struct BlkPair { int a, b; };
+  BlkPair id0 = {0, 0}, id1 = {0, 0};
+  auto ids = [&](BlkPair& id, int kt) {
     const int e = __builtin_amdgcn_readfirstlane(kbeg / BK + min(kt, nk - 1));
     const int v = e < 64 ? kl[0] : e < 128 ? kl[1] : e < 192 ? kl[2] : kl[3];
-    id = e < 4 * 64 ? __builtin_amdgcn_readlane(v, e & 63) : -1;
+    const int pr = e < 4 * 64 ? __builtin_amdgcn_readlane(v, e & 63) : -1;
+    id.a = pr == -1 ? -1 : (pr & 0xffff);                                   // (a live block id is < 0xffff: -1 is "no k-tile" only)
+    id.b = ((unsigned)pr >> 16) == 0xffffu ? -1 : (int)((unsigned)pr >> 16);
   };
-  auto load_a = [&](float (&r)[BM / 32][4], int k0, const int id) {
+  auto load_a = [&](float (&r)[BM / 32][4], int k0, const BlkPair id) {
     if constexpr (FASTP) {
-      if constexpr (RB && !AKC && !BKC) {
+      if constexpr (RB && !AKC && !BKC && TM == 1) {
         if (rbk) {
-          tpa.load(r, max(id, 0) * BK);
-          if (id < 0) {
-#pragma unroll
-            for (int q = 0; q < BM / 32; ++q) r[q][0] = r[q][1] = r[q][2] = r[q][3] = 0.f;
-          }
+          tpa.load_blocks(r, id.a, id.b);
           return;
         }
       }
@@ -454,15 +481,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
       ops.template load_a<BM, AKC, ALIGNED>(r, g, A, m0, k0, kend, t);
     }
   };
-  auto load_b = [&](float (&r)[BN / 32][4], int k0, const int id) {
+  auto load_b = [&](float (&r)[BN / 32][4], int k0, const BlkPair id) {
     if constexpr (FASTP) {
-      if constexpr (RB && !AKC && !BKC) {
+      if constexpr (RB && !AKC && !BKC && TN == 1) {
         if (rbk) {
-          tpb.load(r, max(id, 0) * BK);
-          if (id < 0) {
-#pragma unroll
-            for (int q = 0; q < BN / 32; ++q) r[q][0] = r[q][1] = r[q][2] = r[q][3] = 0.f;
-          }
+          tpb.load_blocks(r, id.a, id.b);
           return;
         }
       }

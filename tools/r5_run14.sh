@@ -1,0 +1,12 @@
+R=$GRAFT_REPO_ROOT; cd $R
+timeout -k 10 600 python -m pytest tests/test_hip_parity.py tests/test_model_gpu.py -m gpu -x -q -k "row_block or ragged or empty_document or determin" > gpurun_out/r5_run14_tests.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r5_run14_tests.log
+GCGCN_GROUP_DUMP=1 timeout -k 10 200 python bench.py --config c2 --ragged --mode eager --steps 1 --warmup 0 --no-cpu-baseline 2> gpurun_out/r5_group_dump_c2_ragged.txt | tail -1 | cut -c1-100
+for c in c2; do
+  for rep in 1 2; do
+    for w in old new; do
+      if [ $w = old ]; then export GCGCN_LIB=$R/build/ab_old.so; else unset GCGCN_LIB; fi
+      r=$(timeout -k 10 200 python bench.py --config $c --ragged --steps 40 --warmup 10 --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])")
+      echo "$c ragged $w rep$rep: $r" | tee -a gpurun_out/ab_rowblk16.log
+    done
+  done
+done
