@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GCGCN_LIB=<path> loads another build of the same ABI (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("GCGCN_LIB") or os.path.join(_HERE, "lib", "libgcgcn_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 SALT_GAT = 0x47415431
 SALT_MHA = 0x4D484131

@@ -112,7 +112,7 @@ static Opt g_opts[] = {{"head_v1", 0, false},      {"head_bil3", 0, false},    {
                        {"mha_ride", 0, false},     {"maggc_fuse", 0, false},   {"carry_spread", 0, false},  {"chain_spread", 0, false},
                        {"carry_cohort", 0, false}, {"chain_cohort", 0, false}, {"carry_spread_min", 0, false},
                        {"chain_spread_min", 0, false}, {"att_in_chain", 0, false}, {"fold_slices", 0, false}, {"head_sum_fold", 0, false},
-                       {"head_compact", 0, false}, {"chain_big", 0, false}};
+                       {"head_compact", 0, false}, {"chain_big", 0, false},   {"split_widen", 0, false}};
 int option(const char* name, int dflt) {
   for (Opt& o : g_opts) {
     if (strcmp(o.name, name) != 0) continue;
@@ -206,7 +206,7 @@ using namespace gc;
 
 extern "C" {
 
-int gcgcn_version(void) { return 6; }
+int gcgcn_version(void) { return 7; }
 const char* gcgcn_last_error(void) { return g_err; }
 
 int gcgcn_set_option(const char* name, int value) {

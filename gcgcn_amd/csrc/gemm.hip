@@ -37,9 +37,9 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 2 : 1)) void gemm_kernel(const
   const int nwg = gx * gy * gridDim.z;
   const int q = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
   if (RB && g.rb && g.rb_mode == 1) {   // ragged batch: the live tile rows in XCD-balanced order, then the dead ones (gemm_body.hpp)
-    int bx, by, zs;
-    if (!tile_of_rows(g, q, gx, gy, bx, by, zs)) return;
-    gemm_body<TM, TN, AKC, BKC, ALIGNED, GC_GEMM_EG, 0, EPI_ALL, PlainOperands, RB>(g, lds, bx, by, zs);
+    int bx, by, zs, wide;
+    if (!tile_of_rows(g, q, gx, gy, bx, by, zs, wide)) return;
+    gemm_body<TM, TN, AKC, BKC, ALIGNED, GC_GEMM_EG, 0, EPI_ALL, PlainOperands, RB>(g, lds, bx, by, zs, threadIdx.x, true, PlainOperands(), nullptr, 0, wide);
     return;
   }
   const int b = xcd_remap(q, nwg);
@@ -154,9 +154,12 @@ __device__ __forceinline__ void reduce4(const GemmArgs& g, int z, long idx4) {
   int row = (int)(idx / g.N);
   const int col = (int)(idx - (long)row * g.N);
   const int z1 = z / g.batch2, z2 = z - z1 * g.batch2;
+  int nsplit = g.splits;
   if (g.rb && g.rb_mode == 1) {  // ragged batch: virtual row -> its place in the padded tensors; rows past the live blocks
     const int bi = row >> 4;     // are zero-stored (outputs that leave the block) or left alone
     const int prow = g.rb[bi] * 16 + (row & 15);
+    const int tm = (g.M + 63) >> 6;
+    nsplit *= split_width(g, min((*g.rb_n + 3) >> 2, tm), tm);   // the tile workgroups cut K this much finer (gemm_body.hpp)
     if (bi >= *g.rb_n) {
       if (g.rb_zero) {
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -174,7 +177,7 @@ __device__ __forceinline__ void reduce4(const GemmArgs& g, int z, long idx4) {
   const float4* w = reinterpret_cast<const float4*>(g.ws + (long)z * mn + idx);
   const long stride4 = nb * mn / 4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int s = 0; s < g.splits; ++s) {
+  for (int s = 0; s < nsplit; ++s) {
     const float4 v = w[(long)s * stride4];
     acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
   }
@@ -308,6 +311,10 @@ static int prepare(GemmArgs& g, int tile, int splits, long group_work) {
     const bool small = g.rb_mode == 1 && group_work <= 0 && (long)cdiv(g.M, 64) * cdiv(g.N, 64) * splits <= 256;
     if (!ok || small) g.rb = nullptr, g.rb_n = nullptr, g.rb_mode = 0, g.rb_zero = 0;
   }
+  // a split row-block problem may cut K finer on the device (split_width): as far as the workspace holds the slabs
+  g.widen = 1;
+  if (g.rb && g.rb_mode == 1 && g.splits > 1 && option("split_widen", 1))
+    while (g.widen < 4 && (long)g.splits * 2 * g.widen * nb * g.M * g.N <= g.ws_elems) g.widen *= 2;
   return tile;
 }
 
@@ -400,9 +407,10 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* 
     const long own = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * nb;
     // the group shares one workspace: give each split problem its own slice
     if (g.splits > 1) {
-      const long need = (long)g.splits * nb * g.M * g.N;
+      while (g.widen > 1 && ws_used + (long)g.splits * g.widen * nb * g.M * g.N > g.ws_elems) g.widen /= 2;
+      const long need = (long)g.splits * g.widen * nb * g.M * g.N;
       if (ws_used + need > g.ws_elems) {  // no room left: this problem goes unsplit
-        g.splits = 1, g.ksplit = g.K;
+        g.splits = 1, g.ksplit = g.K, g.widen = 1;
       } else {
         g.ws = g.ws + ws_used;
         ws_used += need, any_split = true;
@@ -423,8 +431,8 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* 
     fprintf(stderr, "gemm_group: %d problems, %d tile workgroups, mha pairs %d\n", gg.nprob, tiles, mha ? mha->count : 0);
     for (int i = 0; i < gg.nprob; ++i) {
       const GemmArgs& g = gg.p[i];
-      fprintf(stderr, "  %-12s M %5d N %5d K %5d batch %3d splits %2d a_kc %d b_kc %d rb_mode %d tiles %5d\n", g.tag, g.M, g.N, g.K,
-              g.batch1 * g.batch2, g.splits, g.a_kc, g.b_kc, g.rb ? g.rb_mode : 0, gg.tile_count[i]);
+      fprintf(stderr, "  %-12s M %5d N %5d K %5d batch %3d splits %2d (widen %d) a_kc %d b_kc %d rb_mode %d tiles %5d\n", g.tag, g.M, g.N, g.K,
+              g.batch1 * g.batch2, g.splits, g.widen, g.a_kc, g.b_kc, g.rb ? g.rb_mode : 0, gg.tile_count[i]);
     }
   }
   const bool ride3 = col && col->ready_slices < 0 && col->C > 0;   // head sum: no partials, no second stage

@@ -67,8 +67,10 @@ struct GemmArgs {
   float* ws = nullptr;
   long ws_elems = 0;
   // filled by the launcher
-  int vecA = 0, vecB = 0;
+  short vecA = 0, vecB = 0;
   int splits = 1, ksplit = 0;
+  int widen = 1;   // rb_mode 1, splits > 1: a launch of a ragged batch may cut K up to `widen` times finer ON THE DEVICE, with the tile
+                   // workgroups its dead rows leave idle (split_width, gemm_body.hpp); the workspace holds splits * widen slabs
 };
 
 // Enqueue on `stream`.  tile: 0 or 1 = the 64x64 block body (the only one; the two 128x128 bodies of earlier rounds lost every

@@ -354,11 +354,27 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, const Epi& e, const 
 
 // RB: the row-block paths of a ragged batch (GemmArgs::rb) are compiled in.  A separate instantiation, chosen by the launcher:
 // with them in every body the DENSE launches lost 3-9 % (cfg 2 / cfg 1: more registers, a longer prologue) -- A/B of round 4.
+// A split problem of a ragged batch whose M is the document-row dimension (rb_mode 1) is launched with the DENSE number of tile
+// workgroups (the host never reads n_valid); the tile rows past the live blocks exit at once and leave their compute units idle --
+// at DocRED's entity counts 14 of 32 tile rows are live, a launch of 512 workgroups runs 224, one per compute unit, each walking
+// its k-tiles at a lone workgroup's latency-bound pace (cfg 2: 46 us for what two resident workgroups per unit do in half that).
+// So the device cuts K finer instead: `w` times (a power of two, at most g.widen) as long as the live tiles times w still fit the
+// launched tile rows and a slice keeps at least four whole k-tiles.  The same function of the live-block count gives the tile
+// workgroups and the reduce pass their slice count: splits * w partial slabs, summed in slice order as always.
+__device__ __forceinline__ int split_width(const GemmArgs& g, const int tml, const int tm) {
+  int w = 1;
+  if (g.splits > 1)
+    while (2 * w <= g.widen && 2 * w * tml <= tm && (g.ksplit / (2 * w)) % BK == 0 && g.ksplit / (2 * w) >= 4 * BK) w *= 2;
+  return w;
+}
+
+// wide: this launch's extra K cut (split_width; 1 everywhere but the split row-block problems of a ragged batch)
 template <int TM, int TN, bool AKC, bool BKC, bool ALIGNED, int EG = GC_GEMM_EG, int MASK = 0, int RT = EPI_ALL, class OPS = PlainOperands,
           bool RB = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__ lds, const int bx, const int by,
                                           const int zs, const int t = threadIdx.x, const bool do_store = true,
-                                          const OPS& ops = OPS(), float* __restrict__ xchg = nullptr, const int role = 0) {
+                                          const OPS& ops = OPS(), float* __restrict__ xchg = nullptr, const int role = 0,
+                                          const int wide = 1) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int PF = GC_GEMM_PF;
   constexpr int LDA = AKC ? BM + 1 : BM;
@@ -373,7 +389,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
   const int wr = wave >> 1, wc = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  const int z = zs / g.splits, sp = zs - z * g.splits;
+  const int nsplit = RB ? g.splits * wide : g.splits, ksplit = RB ? g.ksplit / wide : g.ksplit;
+  const int z = zs / nsplit, sp = zs - z * nsplit;
   const int z1 = z / g.batch2, z2 = z - z1 * g.batch2;
   const int m0 = by * BM, n0 = bx * BN;
   constexpr bool FASTP = ALIGNED && std::is_same<OPS, PlainOperands>::value;
@@ -383,8 +400,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
   const int nl = rbm ? __builtin_amdgcn_readfirstlane(*g.rb_n) : 0;
   const int nlk = rbk ? __builtin_amdgcn_readfirstlane(*g.rb_n) : 0;
   const int nkt = (nlk + 1) >> 1;   // k-tiles of two live blocks each (the last one may be half empty)
-  int kbeg = sp * g.ksplit;
-  int kend = min(g.K, kbeg + g.ksplit);
+  int kbeg = sp * ksplit;
+  int kend = min(g.K, kbeg + ksplit);
   // rb_mode 2: the ascending list of live 16-row blocks (at most ROWBLK_LIST_MAX = 512, gemm.hip prepare()) sits in four
   // registers, two 16-bit entries to a lane: k-tile e = list entries 2 e and 2 e + 1 in lane e % 64 of register e / 64.  The
   // k-loop picks the two blocks of its next k-tile with one v_readlane, no memory operation, and fetches each operand's two
@@ -397,7 +414,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
     // Every slice runs the SAME number of k-tiles (two tile teams of one workgroup share its barriers): ceil(k-tiles / splits),
     // at least one; list positions past the end contribute zeros, so a slice that reaches past it -- or lies wholly behind it --
     // just adds zeros.
-    const int ks = max((nkt + g.splits - 1) / g.splits, 1) * BK;
+    const int ks = max((nkt + nsplit - 1) / nsplit, 1) * BK;
     kbeg = sp * ks, kend = kbeg + ks;
     // four unconditional 8-byte loads in flight together (entry nlk of an odd-length list exists: the dead blocks follow the
     // live ones and K / 16 is even), the conditions applied afterwards: a tile's prologue waits for ONE round trip
@@ -434,7 +451,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
   // rb_mode 1: a tile whose rows all lie past the live blocks does no arithmetic: it stores zeros where the output leaves
   // the block (rb_zero), nothing otherwise.  (Split problems: the reduce pass does the same per row, gemm.hip.)
   if (rbm && (m0 >> 4) >= nl && !xchg) {
-    if (g.rb_zero && do_store && g.splits <= 1) {
+    if (g.rb_zero && do_store && nsplit <= 1) {
       const Epi e = make_epi(g, z1, z2);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -596,7 +613,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
   }
   // ---- store ------------------------------------------------------------------------------
   if (!do_store) return;
-  if (g.splits > 1 && !xchg) {  // raw partial sums -> workspace [split][batch][M][N]
+  if (nsplit > 1 && !xchg) {  // raw partial sums -> workspace [split][batch][M][N]
     float* __restrict__ W = g.ws + ((long)sp * g.batch1 * g.batch2 + z) * g.M * g.N;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -673,9 +690,12 @@ __device__ __forceinline__ void tile_of(int q, const int count, const int tn, co
 // re-cut on the device: positions [0, live tiles) are the live tiles in the usual XCD-balanced order (leaving them where
 // they are would hand the XCDs that own the front of the list all the work), the positions behind them are the dead tile
 // rows -- zero-stored where the output leaves the block, left at once otherwise.  False: nothing to do for this position.
-__device__ __forceinline__ bool tile_of_rows(const GemmArgs& g, const int q, const int tn, const int tm, int& bx, int& by, int& zs) {
+__device__ __forceinline__ bool tile_of_rows(const GemmArgs& g, const int q, const int tn, const int tm, int& bx, int& by, int& zs,
+                                             int& wide) {
   const int nl = __builtin_amdgcn_readfirstlane(*g.rb_n);
-  const int tml = min((nl + 3) >> 2, tm), live = tml * tn * g.splits;
+  const int tml = min((nl + 3) >> 2, tm);
+  wide = split_width(g, tml, tm);
+  const int live = tml * tn * g.splits * wide;
   if (q < live) {
     tile_of(q, live, tn, tml, bx, by, zs);
     return true;
@@ -694,18 +714,20 @@ __device__ __forceinline__ void gemm_group_block(const G& gg, int hb, float* __r
   if (b >= gg.tile_take[i]) return;
   const GemmArgs& g = gg.p[i];
   const int tn = g.N >> 6, tm = g.M >> 6;
-  int bx, by, zs;
+  int bx, by, zs, wide = 1;
   if (RB && g.rb && g.rb_mode == 1) {
-    if (!tile_of_rows(g, b + gg.tile_first[i], tn, tm, bx, by, zs)) return;
+    if (!tile_of_rows(g, b + gg.tile_first[i], tn, tm, bx, by, zs, wide)) return;
   } else {
     tile_of(b + gg.tile_first[i], gg.tile_count[i], tn, tm, bx, by, zs);
   }
+  const int t = threadIdx.x;
+  const PlainOperands po;
   if (g.a_kc) {
-    if (g.b_kc) gemm_body<1, 1, true, true, true, GC_GEMM_EG, 0, EPI_ALL, PlainOperands, RB>(g, lds, bx, by, zs);
-    else gemm_body<1, 1, true, false, true, GC_GEMM_EG, 0, EPI_ALL, PlainOperands, RB>(g, lds, bx, by, zs);
+    if (g.b_kc) gemm_body<1, 1, true, true, true, GC_GEMM_EG, 0, EPI_ALL, PlainOperands, RB>(g, lds, bx, by, zs, t, true, po, nullptr, 0, wide);
+    else gemm_body<1, 1, true, false, true, GC_GEMM_EG, 0, EPI_ALL, PlainOperands, RB>(g, lds, bx, by, zs, t, true, po, nullptr, 0, wide);
   } else {
-    if (g.b_kc) gemm_body<1, 1, false, true, true, GC_GEMM_EG, 0, EPI_ALL, PlainOperands, RB>(g, lds, bx, by, zs);
-    else gemm_body<1, 1, false, false, true, GC_GEMM_EG, 0, EPI_ALL, PlainOperands, RB>(g, lds, bx, by, zs);
+    if (g.b_kc) gemm_body<1, 1, false, true, true, GC_GEMM_EG, 0, EPI_ALL, PlainOperands, RB>(g, lds, bx, by, zs, t, true, po, nullptr, 0, wide);
+    else gemm_body<1, 1, false, false, true, GC_GEMM_EG, 0, EPI_ALL, PlainOperands, RB>(g, lds, bx, by, zs, t, true, po, nullptr, 0, wide);
   }
 }
 

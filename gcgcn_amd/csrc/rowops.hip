@@ -543,11 +543,10 @@ __global__ __launch_bounds__(256) void mask_rows_kernel(const float* __restrict_
 // launchers
 // =============================================================================================
 // ---- row blocks of a ragged batch ----------------------------------------------------------------------------------------
-// One workgroup: per-document live-block counts, exclusive scans over the documents (live and dead lists), then every
-// document writes its blocks; then the same for the 32-row K TILES of the [B N]-row tensors (tile kt = blocks 2 kt, 2 kt + 1,
-// live iff one of them is): weight-gradient products walk those (gemm_body.hpp, rb_mode 2).  B N / 16 is a few hundred
-// entries; this is launch latency, nothing else.
-//   out = { live blocks, live k-tiles, 0, 0 | blocks: live ascending, then dead ascending | live k-tiles ascending }
+// One workgroup: per-document live-block counts, exclusive scan over the documents, then every document writes its blocks
+// (live list and dead list, each ascending).  B N / 16 is a few hundred entries; this is launch latency, nothing else.
+//   out = { live blocks, 0, 0, 0 | blocks: live ascending, then dead ascending }
+// Row-dimension products take the live list four blocks at a time (a 64-row tile), weight gradients two at a time (a k-tile).
 __global__ __launch_bounds__(256) void row_blocks_kernel(const int* __restrict__ n_valid, int B, int N, int* __restrict__ out) {
   __shared__ int part[256];
   __shared__ int total;
@@ -564,7 +563,7 @@ __global__ __launch_bounds__(256) void row_blocks_kernel(const int* __restrict__
       run += v;
     }
     total = run;
-    out[0] = run, out[2] = 0, out[3] = 0;
+    out[0] = run, out[1] = 0, out[2] = 0, out[3] = 0;
   }
   __syncthreads();
   const int total_live = total;
@@ -577,28 +576,6 @@ __global__ __launch_bounds__(256) void row_blocks_kernel(const int* __restrict__
       else out[ROWBLK_HDR + dead_at++] = b * per + r;
     }
   }
-  // ---- live k-tiles --------------------------------------------------------------------------------------------------
-  const int nblk = B * per, ntile = (nblk + 1) >> 1, tchunk = (ntile + 255) / 256;
-  auto blk_live = [&](int gb) { return gb < nblk && (gb % per) * 16 < min(max(n_valid[gb / per], 0), N); };
-  __syncthreads();   // part[] is free
-  int c = 0;
-  for (int kt = t * tchunk; kt < min(ntile, (t + 1) * tchunk); ++kt) c += (blk_live(2 * kt) || blk_live(2 * kt + 1)) ? 1 : 0;
-  part[t] = c;
-  __syncthreads();
-  if (t == 0) {
-    int run = 0;
-    for (int k = 0; k < 256; ++k) {
-      const int v = part[k];
-      part[k] = run;
-      run += v;
-    }
-    out[1] = run;
-  }
-  __syncthreads();
-  int at = part[t];
-  int* __restrict__ kl = out + ROWBLK_HDR + nblk;
-  for (int kt = t * tchunk; kt < min(ntile, (t + 1) * tchunk); ++kt)
-    if (blk_live(2 * kt) || blk_live(2 * kt + 1)) kl[at++] = kt;
 }
 int row_blocks(const int* n_valid, int B, int N, int* out, hipStream_t st) {
   GC_REQUIRE(n_valid && out && B > 0 && N > 0 && N % 16 == 0, "row_blocks: needs n_valid and N a multiple of 16 (N = %d)", N);

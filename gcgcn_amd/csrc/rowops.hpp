@@ -49,7 +49,7 @@ int edge_bcast(const float* dEbar, const int* n_valid, float* dE, int B, int N, 
 int row_blocks(const int* n_valid, int B, int N, int* out, hipStream_t st);
 constexpr int ROWBLK_HDR = 4;
 constexpr int ROWBLK_LIST_MAX = 512;   // live-block lists a tile body keeps in its lanes (eight registers): longer ones run dense
-static inline long row_blocks_ints(int B, int N) { return ROWBLK_HDR + (long)B * N / 16 + ((long)B * N / 16 + 1) / 2; }
+static inline long row_blocks_ints(int B, int N) { return ROWBLK_HDR + (long)B * N / 16; }
 
 // mha_core.hip: fused attention core of MultiHeadAttention for N <= 64
 bool mha_core_ok(int N, int D, int H, const void* Q, const void* dQ);

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-int gcgcn_version(void);            /* ABI version, currently 6 */
+int gcgcn_version(void);            /* ABI version, currently 7 */
 const char* gcgcn_last_error(void); /* message of the last failing call on this thread */
 
 /* Run-time switches for A/B tests.  "chain": 1 (default) = the per-(doc, head) products of a conv run inside the
@@ -43,16 +43,16 @@ const char* gcgcn_last_error(void); /* message of the last failing call on this 
  * environment variable GCGCN_<NAME> once when nobody set it (DESIGN.md section 6 lists them). */
 int gcgcn_set_option(const char* name, int value);
 
-/* ---- ragged batches: the entity rows that exist (ABI v5; v6: the k-tile list) ------------------------------------------ */
+/* ---- ragged batches: the entity rows that exist (ABI v5; v7: one list serves every product) ------------------------------- */
 /* The reference runs one UNPADDED document per call (config/Config.py:339-354): its products have n rows.  A padded batch
  * [B, N, .] with n_valid has sum_b n_b real rows of B N.  gcgcn_row_blocks lists the 16-row blocks of the [B N]-row tensors,
- * the LIVE ones first (block r of document b is live iff 16 r < n_valid[b]), and behind them the live 32-row k-tiles of the
- * same rows (tile kt = blocks 2 kt and 2 kt + 1, live iff one of them is), ascending:
- *   out = int32[gcgcn_row_blocks_ints(B, N)] = {live blocks, live k-tiles, 0, 0 | B N / 16 blocks | the live k-tiles};
+ * the LIVE ones first (block r of document b is live iff 16 r < n_valid[b]; ascending), the dead ones behind them:
+ *   out = int32[gcgcn_row_blocks_ints(B, N)] = {live blocks, 0, 0, 0 | B N / 16 blocks};
  * N must be a multiple of 16.  Given as `rowblk` to gcgcn_gcn_fwd / _bwd and gcgcn_mha_fwd / _bwd (NULL = dense), the
  * node-phase products of the block -- X WnX, Ebar We, X Wq, the output projection, every data gradient -- run on the live
- * blocks only, and every weight gradient (K = the document rows) on the live k-tiles (up to 256 of them, B N <= 8192; longer
- * lists run dense); the tensors keep their padded layout, outputs that leave the block (out, dX, dEbar, Q) are zero on
+ * blocks only (four to a 64-row tile), and every weight gradient (K = the document rows) sums over the live blocks only (two
+ * to a k-tile; lists of up to 512 blocks, B N <= 8192 -- longer ones run dense); the tensors keep their padded layout,
+ * outputs that leave the block (out, dX, dEbar, Q) are zero on
  * padding rows as always.  Everything stays on the device (no host read; the list is rebuilt by every replay of a captured
  * step).  A block whose shape the column-strip chain kernels do not serve (N > 64, or a width they are not instantiated for)
  * ignores the list and computes every row, as does a forward / backward pair without n_valid.  The SAME list must be given

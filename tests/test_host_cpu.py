@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in gcgcn.h but missing from libgcgcn_hip.so"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.gcgcn_version() == _lib.ABI_VERSION == 6
+    assert lib.gcgcn_version() == _lib.ABI_VERSION == 7
 
 
 @pytest.mark.parametrize("D,L,H", [(8, 2, 2), (128, 2, 8), (768, 4, 4), (512, 2, 8), (12, 4, 4)])
