@@ -296,7 +296,15 @@ static int prepare(GemmArgs& g, int tile, int splits, long group_work) {
   const long t64 = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * nb;
   (void)t64;
   tile = 1;  // measured: 64x64 tiles beat both 128x128 bodies on every product of this path (dropped experiments)
-  if (splits == 0) splits = pick_splits(g.K, group_work > 0 ? group_work : t64 * cdiv(g.K, BK));
+  if (splits == 0) {
+    splits = pick_splits(g.K, group_work > 0 ? group_work : t64 * cdiv(g.K, BK));
+    // The host never reads n_valid: a long-K problem on the row blocks of a ragged batch that "fills the chip" by its dense tile
+    // count (cfg 3's K = 3072 data gradients: 768 tiles, three per compute unit, unsplit) runs with fewer than half of them live,
+    // one to a compute unit, at a lone workgroup's pace (336 live tiles of 96 k-tiles: 109 us).  Split it once here; what the launch
+    // really finds is dealt with on the device (split_width cuts finer with the workgroups of the dead rows).  Counting every
+    // row-block problem at half its dense work instead split the short ones too: cfg 2 ragged 78.0k -> 71.9k docs/s.
+    if (splits == 1 && g.rb && g.rb_mode == 1 && cdiv(g.K, BK) >= 48 && t64 <= 1024 && g.K % (2 * BK) == 0 && option("split_widen", 1)) splits = 2;
+  }
   if (splits > 1 && (!g.ws || (long)splits * nb * g.M * g.N > g.ws_elems || g.K % (splits * BK) != 0 || g.N % 4 != 0 ||
                      (((uintptr_t)g.ws) & 15) != 0))
     splits = 1;

@@ -172,7 +172,7 @@ int gemm_dyn(const GemmArgs& g, const int* cnt, int dyn, long cap, hipStream_t s
 // Floats of split-K workspace that lets every GEMM of a [rows x cols]-sized problem split freely.
 inline long gemm_ws_elems(long rows, long cols) {
   long need = 16 * rows * cols;
-  const long cap = 8L << 20;
+  const long cap = 16L << 20;   // 64 MB (r5: two split + device-widened K = 3072 data gradients of cfg 3 need 12.6 M floats)
   return need < cap ? need : cap;
 }
 
