@@ -374,36 +374,24 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* 
     }
   // pass 1: fix every problem's split factor and count its workgroups
   GemmArgs prep[64];
-  long blocks[64];
   bool groupable[64];
-  long total_blocks = 0;
   int ng = 0;
   for (int oi = 0; oi < n; ++oi) {
     GemmArgs& g = prep[oi];
     g = probs[order[oi]];
-    blocks[oi] = 0, groupable[oi] = false;
+    groupable[oi] = false;
     if (g.M == 0 || g.N == 0) continue;
     if (prepare(g, 1, 0, work) < 0) return 1;
     const bool al = g.vecA && g.vecB && g.M % 64 == 0 && g.N % 64 == 0 && g.ksplit % BK == 0;
     groupable[oi] = al && ng < GemmGroup::MAXP;
-    if (groupable[oi]) {
-      ++ng;
-      blocks[oi] = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * g.batch1 * g.batch2 * g.splits;
-      total_blocks += blocks[oi];
-    }
+    if (groupable[oi]) ++ng;
   }
-  // Wave quantisation: the kernel is resident 4 workgroups per CU (1024 slots).  A launch that overflows the
-  // slots by a few workgroups runs a whole extra round for them; the smallest problem is then peeled into its
-  // own launch (it re-picks its split factor for a launch of its own).
-  constexpr long SLOTS = 256 * 4;
-  const long over = total_blocks % SLOTS;
-  if (total_blocks > SLOTS && over > 0 && over <= SLOTS / 8 && ng > 1) {
-    int best = -1;
-    for (int oi = 0; oi < n; ++oi)
-      if (groupable[oi] && blocks[oi] >= over && blocks[oi] <= 4 * over && (best < 0 || blocks[oi] < blocks[best])) best = oi;
-    if (best >= 0) groupable[best] = false;
-  }
-  // pass 2: peeled / ungroupable problems first (own launches), then the group
+  // (Until round 5 a launch that overflowed the 1024 resident slots by <= 128 workgroups had its smallest problem peeled into a
+  // launch of its own -- "a whole extra round for a few workgroups".  With the tile order and the kernels of this round the
+  // separate launch costs more than the tail: cfg 2's Q projection, 128 tiles, was an 11 us launch in front of a 2048-tile
+  // group; inside it the step is 0.5066 against 0.5124 ms, ragged 0.4085 against 0.4142, cfg 3 / cfg 5 -0.2 / -0.4 %, cfg 1 a
+  // tie.  The rule is gone.)
+  // pass 2: ungroupable problems first (own launches), then the group
   for (int oi = 0; oi < n; ++oi) {
     if (groupable[oi] || probs[order[oi]].M == 0 || probs[order[oi]].N == 0) continue;
     if (int e = gemm(probs[order[oi]], stream)) return e;
