@@ -478,7 +478,15 @@ int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat,
     if (scratch) {  // dbq = column sums of dQ ride in the same two launches
       ColRide cr;
       cr.X = dQ, cr.out = dflat + (long)D * D, cr.part = scratch + wse, cr.R = M, cr.ld = D, cr.C = D;
-      GC_TRY(gemm_group(gs, ng, st, &cr));
+      // with dWq parked the launch has nothing to reduce: the sums' second stage (one workgroup) would be a launch of its own --
+      // it is parked too (nobody reads dbq before the end of backward; `scratch` must then outlive the call like dQ and X)
+      bool later = false;
+      GC_TRY(gemm_group(gs, ng, st, &cr, (ng == 1 && defer_queue) ? &later : nullptr));
+      if (later) {
+        cr.ready_slices = COL_RIDE_SLICES;
+        if (!gemm_defer_col2((DeferQueue*)defer_queue, cr))
+          GC_TRY(colsum(cr.part, nullptr, cr.out, cr.ready_slices, cr.C, cr.C, 1, 0, 0, 0, 0, nullptr, st));
+      }
     } else {
       GC_TRY(gemm_group(gs, ng, st));
       GC_TRY(colsum(dQ, nullptr, dflat + (long)D * D, M, D, D, 1, 0, 0, 0, 0, scratch, st));
@@ -489,7 +497,7 @@ int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat,
 
 void* gcgcn_defer_create(void) { return new (std::nothrow) DeferQueue(); }
 void gcgcn_defer_destroy(void* queue) { delete (DeferQueue*)queue; }
-int gcgcn_defer_count(const void* queue) { return queue ? ((const DeferQueue*)queue)->n : 0; }
+int gcgcn_defer_count(const void* queue) { return queue ? ((const DeferQueue*)queue)->n + ((const DeferQueue*)queue)->ncol2 : 0; }
 int gcgcn_defer_flush(void* queue, void* stream) { return gemm_flush_deferred((DeferQueue*)queue, (hipStream_t)stream); }
 
 // ---------------------------------------------------------------------------------------------

@@ -179,10 +179,15 @@ __global__ __launch_bounds__(64 * EW) void edge_bwd_carry_kernel(const float* __
                                                                  const float* __restrict__ dlogit,
                                                                  const float* __restrict__ dEbar, float* __restrict__ dE,
                                                                  float* __restrict__ dvpart, int N, int D, int nt,
-                                                                 const Spread sp, const GatTail gt, const GemmGroup gg) {
+                                                                 const Spread sp, const GatTail gt, const GemmGroup gg,
+                                                                 const int col_base) {
   // one LDS image for both kinds of workgroup (the rows need N + EW * D floats of it): a fourth workgroup fits per CU
   __shared__ __attribute__((aligned(16))) float tile_lds[lds_floats<1, 1, true, true>()];
   int r;
+  if (col_base > 0 && (int)blockIdx.x >= col_base) {   // behind everything else: the second stage of a parked column sum (gg.col)
+    col_ride_stage2_block(gg.col, (int)blockIdx.x - col_base);
+    return;
+  }
   if (spread_pick((int)blockIdx.x, sp, r)) {
     gemm_group_block<RB>(gg, r, tile_lds);
     return;
@@ -276,7 +281,10 @@ int edge_bwd(const float* E, const float* v, const int* n_valid, const float* dl
                         ? gemm_take_deferred(carry, gg, &gflops)
                         : 0;
   if (ntile > 0) {  // parked weight-gradient products ride along
-    dim3 grid((unsigned)((long)B * N + ngat + ntile));
+    // ... and one parked second stage of a column sum (a bias gradient's 64 partial rows -> its C columns), in trailing workgroups
+    const int col_base = gemm_take_deferred_col2(carry, gg.col) ? (int)((long)B * N + ngat + ntile) : 0;
+    const int ncolwg = col_base ? cdiv(gg.col.C, 256) : 0;
+    dim3 grid((unsigned)((long)B * N + ngat + ntile + ncolwg));
     // options carry_spread: percentage of the launch the tile cohorts are spread over (0: all tiles first, the order until
     // round 3), carry_cohort: tiles per cohort; launches of fewer than carry_spread_min tiles keep them in front
     const Spread sp = make_spread(ntile, (long)B * N + ngat, option("carry_cohort", 256),
@@ -286,7 +294,7 @@ int edge_bwd(const float* E, const float* v, const int* n_valid, const float* dl
     for (int i = 0; i < gg.nprob; ++i) any_rb = any_rb || gg.p[i].rb != nullptr;
 #define GC_EDGE_CARRY(NT, RBV)                                                                                                  \
   GC_LAUNCH_TIMED("edge_bwd", bytes, (edge_bwd_carry_kernel<4, NT, RBV>), grid, block, 0, st, E, v, n_valid, dlogit, dEbar, dE, \
-                  dvpart, N, D, nt_store(), sp, gt, gg)
+                  dvpart, N, D, nt_store(), sp, gt, gg, col_base)
     if (nt_e1()) { if (any_rb) GC_EDGE_CARRY(true, true); else GC_EDGE_CARRY(true, false); }
     else { if (any_rb) GC_EDGE_CARRY(false, true); else GC_EDGE_CARRY(false, false); }
 #undef GC_EDGE_CARRY

@@ -97,18 +97,7 @@ __device__ __forceinline__ void group_tail(const GemmGroup& gg, const int idx, f
     return;
   }
   if (cr.ready_slices > 0) {  // partial sums from an earlier launch: out[c] = their sum, slices in order
-    const int c = idx * 256 + threadIdx.x;
-    if (c < cr.C) {  // 16 independent loads in flight, summed in slice order
-      float s = 0.f;
-      for (int q0 = 0; q0 < cr.ready_slices; q0 += 16) {
-        float v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = cr.part[(long)min(q0 + u, cr.ready_slices - 1) * cr.C + c];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) s += (q0 + u < cr.ready_slices) ? v[u] : 0.f;
-      }
-      cr.out[c] = s;
-    }
+    col_ride_stage2_block(cr, idx);
     return;
   }
   col_ride_stage1(cr, idx, lds);
@@ -588,6 +577,17 @@ bool gemm_defer(DeferQueue* q, const GemmArgs& g_in) {
   return true;
 }
 
+bool gemm_defer_col2(DeferQueue* q, const ColRide& c) {
+  if (!q || q->ncol2 >= DeferQueue::COLCAP || c.ready_slices <= 0 || !c.part || !c.out || c.C <= 0) return false;
+  q->col2[q->ncol2++] = c;
+  return true;
+}
+bool gemm_take_deferred_col2(DeferQueue* q, ColRide& out) {
+  if (!q || q->ncol2 == 0) return false;
+  out = q->col2[--q->ncol2];
+  return true;
+}
+
 static int tiles_of(const GemmArgs& g);
 // longest K first (they run the longest: start them first); small_first: among equal K the problems with the fewest tiles
 // lead -- a carrier with a tile budget then completes whole small problems instead of a slice of a big one, which keeps the
@@ -678,6 +678,9 @@ int gemm_flush_deferred(DeferQueue* q, hipStream_t stream) {
     q->n -= n;
     if (int e = gemm_group(probs, n, stream)) return e;
   }
+  ColRide c2;
+  while (gemm_take_deferred_col2(q, c2))   // second stages of column sums that met no carrier
+    if (int e = colsum(c2.part, nullptr, c2.out, c2.ready_slices, c2.C, c2.C, 1, 0, 0, 0, 0, nullptr, stream)) return e;
   return 0;
 }
 

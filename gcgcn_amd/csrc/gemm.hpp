@@ -141,8 +141,15 @@ struct DeferQueue {
   GemmArgs p[CAP];
   int done[CAP] = {};  // tiles of p[i] already carried by an earlier launch
   int n = 0;
+  // second stages of riding column sums (bias gradients: ColRide::ready_slices > 0, the partials are in memory) that nobody
+  // needs before the end of backward either: the next carrying edge pass sums them in a trailing workgroup, or the flush does
+  static constexpr int COLCAP = 4;
+  ColRide col2[COLCAP];
+  int ncol2 = 0;
 };
 bool gemm_defer(DeferQueue* q, const GemmArgs& g);  // q == nullptr: never parks
+bool gemm_defer_col2(DeferQueue* q, const ColRide& c);          // c.ready_slices > 0; false: run it now
+bool gemm_take_deferred_col2(DeferQueue* q, ColRide& out);      // pops one parked second stage
 // Move up to MAXP parked problems into gg (longest K first, per-problem XCD-aligned tile ranges); returns the number
 // of workgroups (0: nothing parked).  flops (optional) accumulates 2MNK of the taken problems.
 int gemm_take_deferred(DeferQueue* q, GemmGroup& gg, double* flops);

@@ -665,6 +665,23 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* __restrict__
   }
 }
 
+// Stage 2 of a riding column sum whose partials are in memory (ColRide::ready_slices > 0): out[c] = their sum, slices in
+// order, 16 independent loads in flight; workgroup idx of 256 threads serves columns [256 idx, 256 idx + 256).
+__device__ __forceinline__ void col_ride_stage2_block(const ColRide& cr, const int idx) {
+  const int c = idx * 256 + (int)(threadIdx.x & 255);
+  if (c < cr.C && threadIdx.x < 256) {
+    float s = 0.f;
+    for (int q0 = 0; q0 < cr.ready_slices; q0 += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = cr.part[(long)min(q0 + u, cr.ready_slices - 1) * cr.C + c];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += (q0 + u < cr.ready_slices) ? v[u] : 0.f;
+    }
+    cr.out[c] = s;
+  }
+}
+
 // Workgroups are dealt round-robin over the 8 XCDs (ids b and b + 8 share an XCD and its 4 MiB L2).
 // Give each XCD one CONTIGUOUS run of the row-major tile list instead of every 8th tile, so that the
 // tiles resident on an XCD share A row panels / B column panels in its L2 (speed only; any placement

@@ -299,6 +299,7 @@ class MhaFn(torch.autograd.Function):
 # and leaves nothing behind; passes of other models, devices or threads never share a queue.
 defer_weight_grads = os.environ.get("GCGCN_DEFER", "1") != "0"      # GCGCN_DEFER=0: A/B knob
 defer_mha_weight_grads = False
+defer_fused_mha_weight_grads = os.environ.get("GCGCN_DEFER_MHA", "1") != "0"   # the fused MAGGC hop's dWq + dbq second stage (A/B knob)
 _warned_ddp = [False]
 
 
@@ -372,11 +373,12 @@ def _current_pass() -> Optional[_BackwardPass]:
     return None if ref is None else ref()
 
 
-def _pass_for_parking(ctx, idx: int) -> Optional[_BackwardPass]:
-    """The running backward pass if input ``idx`` of this function (a flat parameter) may be parked, else None."""
+def _pass_for_parking(ctx, idx: int, leaf=None) -> Optional[_BackwardPass]:
+    """The running backward pass if input ``idx`` of this function (a flat parameter: ``leaf``, default ``ctx.flat_leaf``) may be
+    parked, else None."""
     if not (defer_weight_grads and ctx.needs_input_grad[idx]):
         return None
-    leaf = ctx.flat_leaf
+    leaf = ctx.flat_leaf if leaf is None else leaf
     if leaf is None or leaf._post_accumulate_grad_hooks or leaf._backward_hooks:
         return None
     tid = torch._C._current_graph_task_id()
@@ -521,6 +523,7 @@ class MaggcFn(torch.autograd.Function):
         ctx.p_mha, ctx.snap_mha = float(p_mha), snap_mha
         ctx.out_p, ctx.out_snap = float(out_p), out_snap
         ctx.flat_leaf = flat if (flat.is_leaf and not _under_ddp()) else None
+        ctx.flat_mha_leaf = flat_mha if (flat_mha.is_leaf and not _under_ddp()) else None
         ctx.next_shape = None if e_next is None else tuple(e_next.shape)
         return out, ebar_next
 
@@ -555,13 +558,19 @@ class MaggcFn(torch.autograd.Function):
         if bp is not None:
             bp.park(ctx.flat_leaf, dflat, (x, ebar, Y, HO, dout, dout_m, W2, W3, ctx.rowblk))
             dflat = None
-        # the rest of the attention's backward: dX = dQ Wq + dXc, dWq = dQ^T X, dbq (the core already ran, as passengers)
+        # the rest of the attention's backward: dX = dQ Wq + dXc, dWq = dQ^T X, dbq (the core already ran, as passengers).
+        # dWq and the second stage of dbq's column sums are needed by nobody before the end of backward: parked like the
+        # convolution's weight gradients (round 5: the launch then has nothing to reduce -- one launch less, a shorter group)
         dX = torch.empty_like(x)
         dflat_mha = torch.empty_like(flat_mha)
         dS = torch.empty(1, device=dev)
         scratch2 = torch.empty(max(_lib.lib().gcgcn_mha_scratch(B, N, D), 1), device=dev)
+        bq = _pass_for_parking(ctx, 2, ctx.flat_mha_leaf) if (defer_fused_mha_weight_grads and ctx.flat_mha_leaf is not None) else None
         call("gcgcn_mha_bwd", B, N, D, H, _p(x), _p(flat_mha), _p(ctx.snap_mha), ctx.p_mha, _p(Q), _p(P), _p(dA), _p(dXc), _p(dX),
-             _p(dflat_mha), _p(dS), _p(dQ), _p(scratch2), None, 1, _p(ctx.rowblk), _stream())
+             _p(dflat_mha), _p(dS), _p(dQ), _p(scratch2), None if bq is None else bq.queue, 1, _p(ctx.rowblk), _stream())
+        if bq is not None:
+            bq.park(ctx.flat_mha_leaf, dflat_mha, (x, dQ, scratch2, ctx.rowblk))
+            dflat_mha = None
         return dX, dEbar, dflat_mha, dflat, None, None, None, None, None, None, None, dE_next, None, None, None
 
 
