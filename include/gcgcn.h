@@ -141,8 +141,9 @@ int64_t gcgcn_mha_scratch(int B, int N, int D);
 int gcgcn_mha_fwd(int B, int N, int D, int H, const float* X, const int32_t* n_valid, const float* flat,
                   const void* rng_snap, float p, float* Q, float* P, float* A, float* scratch, const int32_t* rowblk, void* stream);
 /* backward.  dX_in[B,N,D] (NULL = zero) as in gcgcn_gat_bwd.  Workspace: dS[B,H,N,N], dQ[B,N,D],
- * scratch[gcgcn_mha_scratch].  defer_queue (may be NULL): dWq is parked as described at gcgcn_gcn_bwd (keep X, dQ and
- * dflat alive until the flush). */
+ * scratch[gcgcn_mha_scratch].  defer_queue (may be NULL): dWq is parked as described at gcgcn_gcn_bwd, and so is the second
+ * stage of dbq's column sums (its 64 partial rows live in `scratch`: a later gcgcn_gat_bwd given the same queue sums them in a
+ * trailing workgroup of its edge pass, or the flush does) -- keep X, dQ, scratch and dflat alive until the flush. */
 int gcgcn_mha_bwd(int B, int N, int D, int H, const float* X, const float* flat, const void* rng_snap, float p,
                   const float* Q, const float* P, const float* dA, const float* dX_in, float* dX, float* dflat,
                   float* dS, float* dQ, float* scratch, void* defer_queue, int core_done, const int32_t* rowblk, void* stream);
