@@ -96,7 +96,12 @@ int gcn_chain_t_bwd(const GcnCtx& c, double fl, hipStream_t st, DeferQueue* carr
     for (int i = 0; i < carry->n; ++i) {
       ok = ok && carry->p[i].K % BK == 0 && carry->p[i].splits <= 1;
       ok = ok && !(carry->p[i].rb && (chain_t_full(c) || carry->p[i].rb_mode != 2));   // row-block products: the ragged instantiations only
-      kmax = carry->p[i].K > kmax ? carry->p[i].K : kmax;
+      // (a row-block product walks the live blocks only -- 43 % of K at DocRED's entity counts; the host never reads n_valid and
+      // prices it at half its K.  At full price no tile fitted beside cfg 2's ragged CAGGC chain, whose 224 idle compute units then
+      // waited out the launch while the last edge pass ran all 740 tiles: chain 43.6 -> 51.2 us with 304 of them aboard, edge pass
+      // 62.4 -> 48.8; ragged cfg 2 79.4 k -> 80.8 k docs/s, `profiles/r05_ab_chain_t_rb_pct.txt`.)
+      const int keff = carry->p[i].rb ? carry->p[i].K / 2 : carry->p[i].K;
+      kmax = keff > kmax ? keff : kmax;
     }
     // A tile runs its whole K inside one workgroup (~1.1 us per 32-deep k-step, slower with several teams on the unit): it
     // only pays where the chain itself runs that long.  Chain: MFMAs per wave x 32 cycles x waves per SIMD at ~0.55 of the
