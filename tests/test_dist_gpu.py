@@ -58,7 +58,7 @@ def _worker(rank, world, port, out):
 
             grads(plain, x, e1, e2, cot)                                        # one process, the global batch
             whole = [p.grad.clone() for p in plain.params]
-            assert len(parked) == 2                                             # both convolutions parked their products
+            assert len(parked) == 3                                             # both convolutions and the fused hop's attention projection parked their products
             bucket = FlatGradBucket(hops, overlap=overlap)
             del parked[:]
             xs, a, b, c = shard_batch([x, e1, e2, cot], rank, world)            # this rank's documents
@@ -67,7 +67,7 @@ def _worker(rank, world, port, out):
                 assert not parked, "hooked parameters must not be parked"       # _pass_for_parking refuses: hooks present
                 assert len(bucket._pending) == len(bucket.params)
             else:
-                assert len(parked) == 2
+                assert len(parked) == 3
             bucket.all_reduce()                                                 # the collective itself, on device tensors
             F_._BackwardPass.park = orig
             err = max(((p.grad - w).abs().max() / w.abs().max().clamp_min(1e-12)).item()
