@@ -1105,12 +1105,34 @@ int head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int di
     hipLaunchKernelGGL(head_table_fin_kernel, dim3(cdiv(7L * HW, 256)), dim3(256), 0, st, w.partT, w.dTt, B, 7 * HW);
     GC_TRY(check_launch("head_table_fin/type"));
   }
-  // dense layer: entity part, type part, relative-position part
-  for (int k = 0; k < nf; ++k) {
-    GC_TRY(small_gemm(w.dUT, HW, 1, flat + y.Wd + (long)k * Hd, y.Fin, 0, dfeats[k], Hd, (int)BN, Hd, HW, nullptr, 0, ws, wse, st));
-    GC_TRY(small_gemm(w.dUT, HW, 0, feats[k], Hd, 0, dflat + y.Wd + (long)k * Hd, y.Fin, HW, Hd, (int)BN, nullptr, 0, ws, wse, st));
+  // dense layer: entity part, type part, relative-position part.  The entity part's 2 nf products (data and weight gradient of
+  // every feature group) are independent of each other: ONE group launch (+ one reduce for the split weight gradients) with
+  // the bias gradient's column sums riding in both, where round 4 issued 3 nf + 2 launches of 5-8 us each.
+  if (nf >= 1 && 2 * nf <= 8 && ws && wse > (long)COL_RIDE_SLICES * HW + 4) {
+    GemmArgs gs[8];
+    const long col_elems = ((long)COL_RIDE_SLICES * HW + 3) & ~3L;    // the riding column sum's partials: the workspace's tail
+    for (int k = 0; k < nf; ++k) {
+      GemmArgs& gx = gs[2 * k];
+      gx = GemmArgs();
+      gx.A = w.dUT, gx.lda = HW, gx.a_kc = 1, gx.B = flat + y.Wd + (long)k * Hd, gx.ldb = y.Fin, gx.b_kc = 0;
+      gx.C = dfeats[k], gx.ldc = Hd, gx.M = (int)BN, gx.N = Hd, gx.K = HW;
+      GemmArgs& gw = gs[2 * k + 1];
+      gw = GemmArgs();
+      gw.A = w.dUT, gw.lda = HW, gw.a_kc = 0, gw.B = feats[k], gw.ldb = Hd, gw.b_kc = 0;
+      gw.C = dflat + y.Wd + (long)k * Hd, gw.ldc = y.Fin, gw.M = HW, gw.N = Hd, gw.K = (int)BN;
+      gx.ws = gw.ws = ws, gx.ws_elems = gw.ws_elems = wse - col_elems;
+      gx.tag = gw.tag = "head_gemm";
+    }
+    ColRide cr;
+    cr.X = w.dUT, cr.out = dflat + y.bd, cr.part = ws + (wse - col_elems), cr.R = BN, cr.ld = HW, cr.C = HW;
+    GC_TRY(gemm_group(gs, 2 * nf, st, &cr));
+  } else {
+    for (int k = 0; k < nf; ++k) {
+      GC_TRY(small_gemm(w.dUT, HW, 1, flat + y.Wd + (long)k * Hd, y.Fin, 0, dfeats[k], Hd, (int)BN, Hd, HW, nullptr, 0, ws, wse, st));
+      GC_TRY(small_gemm(w.dUT, HW, 0, feats[k], Hd, 0, dflat + y.Wd + (long)k * Hd, y.Fin, HW, Hd, (int)BN, nullptr, 0, ws, wse, st));
+    }
+    GC_TRY(colsum(w.dUT, nullptr, dflat + y.bd, BN, HW, HW, 1, 0, 0, 0, 0, ws, st));
   }
-  GC_TRY(colsum(w.dUT, nullptr, dflat + y.bd, BN, HW, HW, 1, 0, 0, 0, 0, ws, st));
   GC_TRY(small_gemm(w.dTt, HW, 0, ner_emb, Pt, 0, dflat + y.Wd + (long)nf * Hd, y.Fin, HW, Pt, 7, nullptr, 0, nullptr, 0, st));
   GC_TRY(small_gemm(w.dTt, HW, 1, flat + y.Wd + (long)nf * Hd, y.Fin, 0, dner_emb, Pt, 7, Pt, HW, nullptr, 0, nullptr, 0, st));
   // ner_emb = nn.Embedding(7, 20, padding_idx=0) (glove:241): the padding row never receives a gradient
