@@ -911,8 +911,16 @@ __global__ __launch_bounds__(256) void head_table_rel_bwd_kernel(const long long
 __global__ __launch_bounds__(256) void head_table_fin_kernel(const float* __restrict__ part, float* __restrict__ out, int B, int n) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
+  // the slices in order, 16 requests in flight at a time (one at a time, the loop was B dependent round trips: 256 slices of the
+  // relative-position table took 61 us on 11 workgroups)
   float s = 0.f;
-  for (int b = 0; b < B; ++b) s += part[(long)b * n + e];
+  for (int b0 = 0; b0 < B; b0 += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = part[(long)min(b0 + u, B - 1) * n + e];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += (b0 + u < B) ? v[u] : 0.f;
+  }
   out[e] = s;
 }
 
