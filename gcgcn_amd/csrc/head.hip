@@ -924,6 +924,58 @@ __global__ __launch_bounds__(256) void head_table_fin_kernel(const float* __rest
   out[e] = s;
 }
 
+// The dense layer's products with the two embedding tables (7 entity types x Pt, ND distance buckets x Pr; glove:241-242, 354):
+// a few thousand outputs of 7 .. 128 terms each.  As GEMM launches they were one 5-10 us launch per product (2 forward, 4 +
+// a memset backward); here one launch each way, a role per blockIdx.y, plain fp32 dot products in k order.
+//   forward   role 0: Tt[r, c] = sum_p ner[r, p] Wt[c, p]          role 1: Rt[r, c] = sum_p dis[r, p] Wr[c, p]
+//   backward  role 0: dWt[c, p] = sum_r dTt[r, c] ner[r, p]         role 1: dner[r, p] = sum_c dTt[r, c] Wt[c, p]  (row 0 = padding_idx: 0)
+//             role 2: dWr[c, p] = sum_r dRt[r, c] dis[r, p]         role 3: ddis[r, p] = sum_c dRt[r, c] Wr[c, p]
+// Wt / Wr: columns [nf Hd, nf Hd + Pt) and [nf Hd + Pt, Fin) of the dense weight W[HW][Fin] (row stride Fin).
+__global__ __launch_bounds__(256) void head_tables_fwd_kernel(const float* __restrict__ ner, const float* __restrict__ dis,
+                                                              const float* __restrict__ Wt, const float* __restrict__ Wr, long Fin,
+                                                              float* __restrict__ Tt, float* __restrict__ Rt, int Pt, int Pr, int ND) {
+  const int role = blockIdx.y;
+  const float* __restrict__ tab = role ? dis : ner;
+  const float* __restrict__ W = role ? Wr : Wt;
+  float* __restrict__ out = role ? Rt : Tt;
+  const int rows = role ? ND : 7, P = role ? Pr : Pt;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < rows * HW; e += gridDim.x * 256) {
+    const int r = e / HW, c = e - r * HW;
+    float s = 0.f;
+    for (int p_ = 0; p_ < P; ++p_) s = fmaf(tab[r * P + p_], W[(long)c * Fin + p_], s);
+    out[e] = s;
+  }
+}
+__global__ __launch_bounds__(256) void head_tables_bwd_kernel(const float* __restrict__ dTt, const float* __restrict__ dRt,
+                                                              const float* __restrict__ ner, const float* __restrict__ dis,
+                                                              const float* __restrict__ Wt, const float* __restrict__ Wr, long Fin,
+                                                              float* __restrict__ dWt, float* __restrict__ dWr, float* __restrict__ dner,
+                                                              float* __restrict__ ddis, int Pt, int Pr, int ND) {
+  const int role = blockIdx.y, side = role >> 1;          // side 0: the type table, 1: the distance table
+  const float* __restrict__ dT = side ? dRt : dTt;
+  const float* __restrict__ tab = side ? dis : ner;
+  const float* __restrict__ W = side ? Wr : Wt;
+  const int rows = side ? ND : 7, P = side ? Pr : Pt;
+  if ((role & 1) == 0) {   // weight gradient [HW][P] (row stride Fin)
+    float* __restrict__ dW = side ? dWr : dWt;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < HW * P; e += gridDim.x * 256) {
+      const int c = e / P, p_ = e - c * P;
+      float s = 0.f;
+      for (int r = 0; r < rows; ++r) s = fmaf(dT[r * HW + c], tab[r * P + p_], s);
+      dW[(long)c * Fin + p_] = s;
+    }
+  } else {                 // table gradient [rows][P]
+    float* __restrict__ dtab = side ? ddis : dner;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < rows * P; e += gridDim.x * 256) {
+      const int r = e / P, p_ = e - r * P;
+      float s = 0.f;
+      if (side || r > 0)   // ner_emb = nn.Embedding(7, 20, padding_idx=0) (glove:241): the padding row never receives a gradient
+        for (int c = 0; c < HW; ++c) s = fmaf(dT[r * HW + c], W[(long)c * Fin + p_], s);
+      dtab[e] = s;
+    }
+  }
+}
+
 // =====================================================================================================================
 struct HeadLayout { long Wd, bd, Wc, bc, bb, Wb, total; int Fin; };
 // flat = [dense_layer W [128, Fin] | b | classification_layer_01 W [R, 256] | b | bili b [R] | bili W [R, 128, 128]]
@@ -979,8 +1031,12 @@ int head_fwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int di
   for (int k = 0; k < nf; ++k)  // U = sum_k feats_k W_k^T + b           (glove:354-355, the entity part of the dense layer)
     GC_TRY(small_gemm(feats[k], Hd, 1, flat + y.Wd + (long)k * Hd, y.Fin, 1, w.U, HW, (int)BN, HW, Hd, k == 0 ? flat + y.bd : nullptr,
                       k > 0, nullptr, 0, st));
-  GC_TRY(small_gemm(ner_emb, Pt, 1, flat + y.Wd + (long)nf * Hd, y.Fin, 1, w.Tt, HW, 7, HW, Pt, nullptr, 0, nullptr, 0, st));
-  GC_TRY(small_gemm(dis_table, Pr, 1, flat + y.Wd + (long)nf * Hd + Pt, y.Fin, 1, w.Rt, HW, ND, HW, Pr, nullptr, 0, nullptr, 0, st));
+  {
+    ProfScope ps("head_gemm", st);
+    hipLaunchKernelGGL(head_tables_fwd_kernel, dim3(cdiv((long)(ND > 7 ? ND : 7) * HW, 256), 2), dim3(256), 0, st, ner_emb, dis_table,
+                       flat + y.Wd + (long)nf * Hd, flat + y.Wd + (long)nf * Hd + Pt, (long)y.Fin, w.Tt, w.Rt, Pt, Pr, ND);
+    GC_TRY(check_launch("head_tables_fwd"));
+  }
   {
     ProfScope ps("head_feat", st);
     hipLaunchKernelGGL(head_node_kernel, dim3(cdiv(BN * HW, 256)), dim3(256), 0, st, w.U, w.Tt, type, w.UT, BN, flat + y.bb, flat + y.bc,
@@ -1141,12 +1197,14 @@ int head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int di
     }
     GC_TRY(colsum(w.dUT, nullptr, dflat + y.bd, BN, HW, HW, 1, 0, 0, 0, 0, ws, st));
   }
-  GC_TRY(small_gemm(w.dTt, HW, 0, ner_emb, Pt, 0, dflat + y.Wd + (long)nf * Hd, y.Fin, HW, Pt, 7, nullptr, 0, nullptr, 0, st));
-  GC_TRY(small_gemm(w.dTt, HW, 1, flat + y.Wd + (long)nf * Hd, y.Fin, 0, dner_emb, Pt, 7, Pt, HW, nullptr, 0, nullptr, 0, st));
-  // ner_emb = nn.Embedding(7, 20, padding_idx=0) (glove:241): the padding row never receives a gradient
-  GC_REQUIRE(hipMemsetAsync(dner_emb, 0, sizeof(float) * Pt, st) == hipSuccess, "head: memset failed");
-  GC_TRY(small_gemm(w.dRt, HW, 0, dis_table, Pr, 0, dflat + y.Wd + (long)nf * Hd + Pt, y.Fin, HW, Pr, ND, nullptr, 0, nullptr, 0, st));
-  GC_TRY(small_gemm(w.dRt, HW, 1, flat + y.Wd + (long)nf * Hd + Pt, y.Fin, 0, ddis_table, Pr, ND, Pr, HW, nullptr, 0, nullptr, 0, st));
+  {
+    ProfScope ps("head_gemm", st);
+    const int widest = Pt > Pr ? Pt : Pr;
+    hipLaunchKernelGGL(head_tables_bwd_kernel, dim3(cdiv((long)HW * widest, 256), 4), dim3(256), 0, st, w.dTt, w.dRt, ner_emb, dis_table,
+                       flat + y.Wd + (long)nf * Hd, flat + y.Wd + (long)nf * Hd + Pt, (long)y.Fin, dflat + y.Wd + (long)nf * Hd,
+                       dflat + y.Wd + (long)nf * Hd + Pt, dner_emb, ddis_table, Pt, Pr, ND);
+    GC_TRY(check_launch("head_tables_bwd"));
+  }
   return 0;
 }
 
