@@ -817,24 +817,26 @@ __global__ __launch_bounds__(256) void head_node_bwd_kernel(const float* __restr
   const long b = bn / N;
   const int n = (int)(bn - b * N);
   const int c = threadIdx.x & (HW - 1), half = threadIdx.x >> 7;   // 2 x 128 threads: half 0 sums the head side, half 1 the tail side
+  // one side's len rows of this entity, `step` pair rows apart, in order; eight requests in flight at a time
+  auto side_sum = [&](const float* __restrict__ X, const long first, const long step, const int len) {
+    float s = 0.f;
+    for (int i0 = 0; i0 < len; i0 += 8) {
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = X[(first + (long)min(i0 + u, len - 1) * step) * HW + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (i0 + u < len) ? x[u] : 0.f;
+    }
+    return s;
+  };
   float a = 0.f;
   if (off) {
     const int nv = min(max(n_valid[b], 0), N);
     const long base = off[b];
-    if (n < nv) {
-      if (half == 0) {
-        for (int i = 0; i < nv; ++i) a += dEH[(base + (long)i * nv + n) * HW + c];
-      } else {
-        for (int j = 0; j < nv; ++j) a += dET[(base + (long)n * nv + j) * HW + c];
-      }
-    }
+    if (n < nv) a = half == 0 ? side_sum(dEH, base + n, nv, nv) : side_sum(dET, base + (long)n * nv, 1, nv);
   } else {
     const long base = b * N * N;
-    if (half == 0) {
-      for (int i = 0; i < N; ++i) a += dEH[(base + (long)i * N + n) * HW + c];
-    } else {
-      for (int j = 0; j < N; ++j) a += dET[(base + (long)n * N + j) * HW + c];
-    }
+    a = half == 0 ? side_sum(dEH, base + n, N, N) : side_sum(dET, base + (long)n * N, 1, N);
   }
   red[half][c] = a;
   __syncthreads();

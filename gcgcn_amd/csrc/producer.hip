@@ -792,10 +792,17 @@ __global__ __launch_bounds__(256) void prod_table_fin_kernel(const float* __rest
                                                              float* __restrict__ dwab) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= rec) return;
+  // documents and chunks in order, eight requests in flight at a time (one dependent round trip per record before: 36 us)
   float v = 0.f;
   for (int b = 0; b < B; ++b) {
     const int live = (min(tmax[b], T) + TCH - 1) / TCH;
-    for (int c = 0; c < live; ++c) v += part[((long)b * nchunk + c) * rec + e];
+    for (int c0 = 0; c0 < live; c0 += 8) {
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = part[((long)b * nchunk + min(c0 + u, live - 1)) * rec + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += (c0 + u < live) ? x[u] : 0.f;
+    }
   }
   if (e < nd_hd) ddisF[e] = v;
   else dwab[e - nd_hd] = v;
@@ -811,8 +818,16 @@ __global__ __launch_bounds__(256) void prod_colsum_dyn_kernel(const float* __res
   const long R = *cnt, rps = (R + DCS - 1) / DCS;
   const long r0 = sp * rps, r1 = min(R, r0 + rps);
   float acc = 0.f;
-  if (c < C)
-    for (long r = r0 + wave; r < r1; r += 4) acc += X[r * C + c];
+  if (c < C && r0 + wave < r1) {   // this wave's rows in order, eight requests in flight at a time
+    const long last = r0 + wave + ((r1 - 1 - r0 - wave) / 4) * 4;
+    for (long r = r0 + wave; r < r1; r += 32) {
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = X[min(r + 4 * u, last) * C + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (r + 4 * u < r1) ? x[u] : 0.f;
+    }
+  }
   red[wave][lane] = acc;
   __syncthreads();
   if (wave == 0 && c < C) part[(long)sp * C + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
