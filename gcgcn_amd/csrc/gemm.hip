@@ -337,6 +337,10 @@ int gemm(const GemmArgs& g_in, hipStream_t stream, int tile, int splits) {
   GC_REQUIRE(nb * g.splits <= 65535, "gemm: batch %ld x splits %d exceeds grid.z", nb, g.splits);
   GC_REQUIRE(cdiv(g.M, 64) <= 65535, "gemm: M %d exceeds grid.y", g.M);
   const bool al = g.vecA && g.vecB && g.M % 64 == 0 && g.N % 64 == 0 && g.ksplit % BK == 0;
+  static const bool dump = getenv("GCGCN_GROUP_DUMP") != nullptr;   // diagnosis (with the group launches' dump)
+  if (dump)
+    fprintf(stderr, "gemm: %-12s M %5d N %5d K %5d batch %3ld splits %2d a_kc %d b_kc %d rb_mode %d %s\n", g.tag, g.M, g.N, g.K, nb, g.splits,
+            g.a_kc, g.b_kc, g.rb ? g.rb_mode : 0, al ? "interior" : "guarded");
   return al ? launch<1, 1, true>(g, stream) : launch<1, 1, false>(g, stream);
 }
 

@@ -924,6 +924,29 @@ static int linear_bwd_w(const float* dY, const float* X, long M, int Nout, int K
   return cnt ? gemm_dyn(g, cnt, 2, cap, st) : gemm(g, st);
 }
 
+// The three gradients of one Linear layer on a static row count -- dW = dY^T X, db = column sums of dY, dX (+)= dY W -- in ONE
+// group launch (+ its reduce): the two products are independent, the column sums ride in both launches (gemm.hpp, ColRide).
+// Separately they were a weight-gradient launch, its reduce, one or two column-sum launches and the data-gradient launch.
+static int linear_bwd_all(const float* dY, const float* X, long M, int Nout, int K, const float* W, float* dW, float* db, float* dX,
+                          int accumulate_x, float* ws, long wse, hipStream_t st) {
+  const long col_elems = ((long)COL_RIDE_SLICES * Nout + 3) & ~3L;
+  if (!ws || wse <= col_elems + 4) {
+    GC_TRY(linear_bwd_w(dY, X, M, Nout, K, dW, ws, wse, st));
+    GC_TRY(colsum(dY, nullptr, db, M, Nout, Nout, 1, 0, 0, 0, 0, ws, st));
+    return linear_bwd_x(dY, M, Nout, W, K, dX, accumulate_x, ws, wse, st);
+  }
+  GemmArgs gs[2];
+  gs[0].A = dY, gs[0].lda = Nout, gs[0].a_kc = 0, gs[0].B = X, gs[0].ldb = K, gs[0].b_kc = 0;
+  gs[0].C = dW, gs[0].ldc = K, gs[0].M = Nout, gs[0].N = K, gs[0].K = (int)M;
+  gs[1].A = dY, gs[1].lda = Nout, gs[1].a_kc = 1, gs[1].B = W, gs[1].ldb = K, gs[1].b_kc = 0;
+  gs[1].C = dX, gs[1].ldc = K, gs[1].M = (int)M, gs[1].N = K, gs[1].K = Nout, gs[1].accumulate = accumulate_x;
+  gs[0].ws = gs[1].ws = ws, gs[0].ws_elems = gs[1].ws_elems = wse - col_elems;
+  gs[0].tag = gs[1].tag = "prod_gemm";
+  ColRide cr;
+  cr.X = dY, cr.out = db, cr.part = ws + (wse - col_elems), cr.R = M, cr.ld = Nout, cr.C = Nout;
+  return gemm_group(gs, 2, st, &cr);
+}
+
 struct ProdBufs {  // caller-owned device memory (include/gcgcn.h lists the sizes)
   float *sentF, *disF, *table, *CW, *stats, *cwa, *sfeat, *nterm, *score, *CS, *Ec;
 };
@@ -1030,9 +1053,7 @@ int prod_bwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx
   GC_TRY(linear_bwd_w(g.dsfeat, w.cwa, 0, Hd, Hd, dflat + y.Wss, ws, wse, st, nrows, cap_rows));
   GC_TRY(colsum_dyn(g.dsfeat, nrows, Hd, g.part, dflat + y.bss, st));
   GC_TRY(linear_bwd_x(g.dsfeat, 0, Hd, flat + y.Wss, Hd, g.dcwa, 1, ws, wse, st, nrows, cap_rows));   // dcwa += dsfeat W_ss
-  GC_TRY(linear_bwd_w(g.dnterm, node, BN, Hd, Hd, dflat + y.Wsp, ws, wse, st));
-  GC_TRY(colsum(g.dnterm, nullptr, dflat + y.bsp, BN, Hd, Hd, 1, 0, 0, 0, 0, ws, st));
-  GC_TRY(linear_bwd_x(g.dnterm, BN, Hd, flat + y.Wsp, Hd, dnode, 0, ws, wse, st));
+  GC_TRY(linear_bwd_all(g.dnterm, node, BN, Hd, Hd, flat + y.Wsp, dflat + y.Wsp, dflat + y.bsp, dnode, 0, ws, wse, st));
   // linear_word_att
   GC_TRY(linear_bwd_w(g.dcwa, w.CW, 0, Hd, 2 * Hd, dflat + y.Wlw, ws, wse, st, nrows, cap_rows));
   GC_TRY(colsum_dyn(g.dcwa, nrows, Hd, g.part, dflat + y.blw, st));
@@ -1061,9 +1082,7 @@ int prod_bwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx
                  hipMemcpyAsync(dflat + y.ba, g.dwb + 2 * Hd + 1, sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess,
              "producer: copy failed");
   // word_attention.attention_sent / attention_pos
-  GC_TRY(linear_bwd_w(g.dsentF, ctx, BT, Hd, Hd, dflat + y.Ws, ws, wse, st));
-  GC_TRY(colsum(g.dsentF, nullptr, dflat + y.bs, BT, Hd, Hd, 1, 0, 0, 0, 0, ws, st));
-  GC_TRY(linear_bwd_x(g.dsentF, BT, Hd, flat + y.Ws, Hd, dctx, 1, ws, wse, st));                     // dctx += dsentF W_s
+  GC_TRY(linear_bwd_all(g.dsentF, ctx, BT, Hd, Hd, flat + y.Ws, dflat + y.Ws, dflat + y.bs, dctx, 1, ws, wse, st));   // dctx += dsentF W_s
   GC_TRY(linear_bwd_w(g.ddisF, dis_table, ND, Hd, P, dflat + y.Wp, ws, wse, st));
   GC_TRY(colsum(g.ddisF, nullptr, dflat + y.bp, ND, Hd, Hd, 1, 0, 0, 0, 0, ws, st));
   GC_TRY(linear_bwd_x(g.ddisF, ND, Hd, flat + y.Wp, P, ddis_table, 0, ws, wse, st));
