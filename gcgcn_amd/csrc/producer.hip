@@ -959,7 +959,21 @@ int prod_fwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx
   GC_REQUIRE((size_t)PW * 2 * T * sizeof(float) <= 64 * 1024, "producer: T=%d tokens exceed the LDS budget", T);
   const ProdLayout y = prod_layout(Hd, P);
   const long BT = (long)B * T;
-  GC_TRY(linear_fwd(ctx, BT, Hd, flat + y.Ws, flat + y.bs, Hd, w.sentF, ws, wse, st));          // glove:178
+  {  // two Linear layers on static inputs in one launch: the token states (glove:178) and the per-entity term of the sentence
+     // attention (glove:202), which nothing needs before prod_sent_fwd below
+    GemmArgs gs[2];
+    for (int q = 0; q < 2; ++q) {
+      GemmArgs& g = gs[q];
+      g.A = q ? node : ctx, g.lda = Hd, g.a_kc = 1;
+      g.B = flat + (q ? y.Wsp : y.Ws), g.ldb = Hd, g.b_kc = 1;
+      g.C = q ? w.nterm : w.sentF, g.ldc = Hd;
+      g.M = q ? (int)((long)B * N) : (int)BT, g.N = Hd, g.K = Hd;
+      g.bias = flat + (q ? y.bsp : y.bs);
+      g.ws = ws, g.ws_elems = wse;
+      g.tag = "prod_gemm";
+    }
+    GC_TRY(gemm_group(gs, 2, st));
+  }
   GC_TRY(linear_fwd(dis_table, ND, P, flat + y.Wp, flat + y.bp, Hd, w.disF, ws, wse, st));      // glove:179 on the 21 ids
   {
     ProfScope ps("prod_table", st);
@@ -978,7 +992,6 @@ int prod_fwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx
   }
   GC_TRY(linear_fwd(w.CW, 0, 2 * Hd, flat + y.Wlw, flat + y.blw, Hd, w.cwa, ws, wse, st, ix.counts, cap_rows));       // :320-321
   GC_TRY(linear_fwd(w.cwa, 0, Hd, flat + y.Wss, flat + y.bss, Hd, w.sfeat, ws, wse, st, ix.counts, cap_rows));        // :201
-  GC_TRY(linear_fwd(node, (long)B * N, Hd, flat + y.Wsp, flat + y.bsp, Hd, w.nterm, ws, wse, st));                    // :202 per entity
   {
     ProfScope ps("prod_sent", st);
     PROD_LAUNCH(prod_sent_fwd_kernel, Hd, dim3(PGRID), dim3(64 * PW), 0, st, w.sfeat, w.cwa, w.nterm, flat + y.wsa, flat + y.bsa,
