@@ -1101,9 +1101,8 @@ int head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int di
     return gemm_dyn(g, cnt, dyn, pairs, st);
   };
   // bias gradients: both biases see the column sums of dlogits
-  GC_TRY(colsum(w.doutp, nullptr, w.dW, pairs, R, HW, 1, 0, 0, 0, 0, ws, st));
-  GC_REQUIRE(hipMemcpyAsync(dflat + y.bb, w.dW, sizeof(float) * R, hipMemcpyDeviceToDevice, st) == hipSuccess, "head: copy failed");
-  GC_REQUIRE(hipMemcpyAsync(dflat + y.bc, w.dW, sizeof(float) * R, hipMemcpyDeviceToDevice, st) == hipSuccess, "head: copy failed");
+  GC_TRY(colsum(w.doutp, nullptr, dflat + y.bb, pairs, R, HW, 1, 0, 0, 0, 0, ws, st));
+  GC_REQUIRE(hipMemcpyAsync(dflat + y.bc, dflat + y.bb, sizeof(float) * R, hipMemcpyDeviceToDevice, st) == hipSuccess, "head: copy failed");
   HeadOps o;
   memset(&o, 0, sizeof(o));
   o.ldp = o.ldq = HW, o.KB = R * HW, o.nmax = R, o.rows = (int)pairs;

@@ -1035,7 +1035,12 @@ int prod_bwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx
   GC_REQUIRE(sizeof(float) * PW * ((size_t)ND * Hd + Hd + 1) <= 150 * 1024, "producer_bwd: hidden width %d exceeds the LDS budget of the table backward", Hd);
   // zero the atomics' targets
   GC_REQUIRE(hipMemsetAsync(g.dnterm, 0, sizeof(float) * BN * Hd, st) == hipSuccess, "producer: memset failed");
-  GC_REQUIRE(hipMemsetAsync(g.dwb, 0, sizeof(float) * 2 * (Hd + 1), st) == hipSuccess, "producer: memset failed");
+  // the two attention vectors' gradients (d w | d b, Hd + 1 floats each) are accumulated / written straight into dflat where the
+  // layout keeps each pair adjacent (Hd a multiple of 4: always, for the reference's 128); through g.dwb + four copies otherwise
+  const bool adj = y.ba == y.wa + Hd && y.bsa == y.wsa + Hd;
+  float* const dws = adj ? dflat + y.wsa : g.dwb;             // sentence attention: accumulated by prod_sent_bwd (zeroed here)
+  float* const dww = adj ? dflat + y.wa : g.dwb + Hd + 1;     // word attention: written by prod_table_fin
+  GC_REQUIRE(hipMemsetAsync(dws, 0, sizeof(float) * (Hd + 1), st) == hipSuccess, "producer: memset failed");
   // linear_sentence_att: E = CS W_ls^T + b_ls on live pairs, b_ls on every other real pair
   if (dE) {
     {
@@ -1056,12 +1061,13 @@ int prod_bwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx
   {
     ProfScope ps("prod_sent", st);
     PROD_LAUNCH(prod_sent_bwd_kernel, Hd, dim3(PGRID), dim3(64 * PW), sizeof(float) * (Hd + 1), st, w.sfeat, w.cwa, w.nterm,
-                       flat + y.wsa, w.score, g.dCS, ix, g.dcwa, g.dsfeat, g.dnterm, g.dwb, N, Hd);
+                       flat + y.wsa, w.score, g.dCS, ix, g.dcwa, g.dsfeat, g.dnterm, dws, N, Hd);
     GC_TRY(check_launch("prod_sent_bwd"));
   }
-  GC_REQUIRE(hipMemcpyAsync(dflat + y.wsa, g.dwb, sizeof(float) * Hd, hipMemcpyDeviceToDevice, st) == hipSuccess &&
-                 hipMemcpyAsync(dflat + y.bsa, g.dwb + Hd, sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess,
-             "producer: copy failed");
+  if (!adj)
+    GC_REQUIRE(hipMemcpyAsync(dflat + y.wsa, g.dwb, sizeof(float) * Hd, hipMemcpyDeviceToDevice, st) == hipSuccess &&
+                   hipMemcpyAsync(dflat + y.bsa, g.dwb + Hd, sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess,
+               "producer: copy failed");
   // sentence_attention.attention_sent / attention_pos
   GC_TRY(linear_bwd_w(g.dsfeat, w.cwa, 0, Hd, Hd, dflat + y.Wss, ws, wse, st, nrows, cap_rows));
   GC_TRY(colsum_dyn(g.dsfeat, nrows, Hd, g.part, dflat + y.bss, st));
@@ -1088,12 +1094,13 @@ int prod_bwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx
                 flat + y.wa, g.dtable, ix.tmax, g.dsentF, g.tpart, T, Hd, ND);
     GC_TRY(check_launch("prod_table_bwd"));
     hipLaunchKernelGGL(prod_table_fin_kernel, dim3(cdiv(rec, 256)), dim3(256), 0, st, g.tpart, ix.tmax, B, T, nchunk, rec, ND * Hd, g.ddisF,
-                       g.dwb + Hd + 1);
+                       dww);
     GC_TRY(check_launch("prod_table_fin"));
   }
-  GC_REQUIRE(hipMemcpyAsync(dflat + y.wa, g.dwb + Hd + 1, sizeof(float) * Hd, hipMemcpyDeviceToDevice, st) == hipSuccess &&
-                 hipMemcpyAsync(dflat + y.ba, g.dwb + 2 * Hd + 1, sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess,
-             "producer: copy failed");
+  if (!adj)
+    GC_REQUIRE(hipMemcpyAsync(dflat + y.wa, g.dwb + Hd + 1, sizeof(float) * Hd, hipMemcpyDeviceToDevice, st) == hipSuccess &&
+                   hipMemcpyAsync(dflat + y.ba, g.dwb + 2 * Hd + 1, sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess,
+               "producer: copy failed");
   // word_attention.attention_sent / attention_pos
   GC_TRY(linear_bwd_all(g.dsentF, ctx, BT, Hd, Hd, flat + y.Ws, dflat + y.Ws, dflat + y.bs, dctx, 1, ws, wse, st));   // dctx += dsentF W_s
   GC_TRY(linear_bwd_w(g.ddisF, dis_table, ND, Hd, P, dflat + y.Wp, ws, wse, st));
