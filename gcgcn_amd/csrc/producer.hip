@@ -49,41 +49,73 @@ __device__ __forceinline__ int pos_at(const void* pos, int pos_bytes, long idx) 
 }
 
 // ---- index: pass A, one workgroup per document -------------------------------------------------------------------
+// (Round 5: one workgroup per document is 32 workgroups of pure latency -- per 256 pairs it ran S dependent byte loads and a
+// 16-barrier Hillis-Steele scan, 28 us per call and two calls per step of the model.  Now the liveness bytes of eight chunks of
+// pairs are requested together, and the scan is a wave prefix (shuffles) plus one hand-over between the four waves: two
+// barriers per chunk.  Same integers out.)
 __global__ __launch_bounds__(256) void prod_index_a_kernel(const unsigned char* __restrict__ sen, const int* __restrict__ n_valid,
                                                            ProdIdx ix, int N, int S, int T) {
-  __shared__ int sc[256], sp[256];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ int wsum[2][4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
   const int NN = N * N;
+  auto wave_incl = [&](int v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(v, d, 64);
+      if (lane >= d) v += t;
+    }
+    return v;
+  };
   int run_s = 0, run_p = 0;
-  for (int base = 0; base < NN; base += 256) {
-    const int p = base + tid;
-    int bits = 0;
-    if (p < NN) {
-      const int i = p / N, j = p - i * N;
-      if (i < nv && j < nv) {
-        const long s0 = ((long)b * NN + p) * S;
-        for (int s = 0; s < S; ++s)
-          if (sen[(s0 + s) * T] != 0) bits |= 1 << s;
+  constexpr int CH = 8;   // chunks of 256 pairs whose loads are in flight together
+  for (int base0 = 0; base0 < NN; base0 += CH * 256) {
+    int bitsv[CH];
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+      const int p = base0 + ch * 256 + tid;
+      int bits = 0;
+      if (p < NN) {
+        const int i = p / N, j = p - i * N;
+        if (i < nv && j < nv) {
+          const long s0 = ((long)b * NN + p) * S;
+          for (int sb = 0; sb < S; sb += 8) {
+            unsigned char v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = sen[(s0 + min(sb + u, S - 1)) * T];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (sb + u < S && v[u] != 0) bits |= 1 << (sb + u);
+          }
+        }
       }
+      bitsv[ch] = bits;
     }
-    const int c = __popc(bits), live = c > 0;
-    sc[tid] = c, sp[tid] = live;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {  // inclusive Hillis-Steele scan of both counters
-      const int a = tid >= d ? sc[tid - d] : 0, q = tid >= d ? sp[tid - d] : 0;
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+      const int base = base0 + ch * 256;
+      if (base >= NN) break;                       // (uniform)
+      const int p = base + tid, bits = bitsv[ch];
+      const int c = __popc(bits), live = c > 0;
+      const int ic = wave_incl(c), il = wave_incl(live);
+      if (lane == 63) wsum[0][wave] = ic, wsum[1][wave] = il;
       __syncthreads();
-      sc[tid] += a, sp[tid] += q;
+      int offc = 0, offl = 0, totc = 0, totl = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int a_ = wsum[0][w], q_ = wsum[1][w];
+        if (w < wave) offc += a_, offl += q_;
+        totc += a_, totl += q_;
+      }
+      if (p < NN) {
+        const long pp = (long)b * NN + p;
+        ix.pair_bits[pp] = bits;
+        ix.pair_row0[pp] = run_s + offc + ic - c;          // local to the document; pass B adds the document's offset
+        ix.pair_prow[pp] = live ? run_p + offl + il - 1 : -1;
+      }
+      run_s += totc, run_p += totl;
       __syncthreads();
     }
-    if (p < NN) {
-      const long pp = (long)b * NN + p;
-      ix.pair_bits[pp] = bits;
-      ix.pair_row0[pp] = run_s + sc[tid] - c;         // local to the document; pass B adds the document's offset
-      ix.pair_prow[pp] = live ? run_p + sp[tid] - 1 : -1;
-    }
-    run_s += sc[255], run_p += sp[255];
-    __syncthreads();
   }
   if (tid == 0) ix.doc_counts[2 * b] = run_s, ix.doc_counts[2 * b + 1] = run_p;
 }
