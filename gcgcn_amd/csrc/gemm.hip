@@ -483,15 +483,17 @@ int gemm_group(const GemmArgs* probs, int n, hipStream_t stream, const ColRide* 
 }
 
 // ---- one dimension known only on the device (gemm.hpp) --------------------------------------------------------
+// vb / vgrid: this workgroup's index and the number of workgroups walking the problem's tile list (the whole grid, or one
+// problem's share of a pair launch)
 template <bool AKC, bool BKC, bool ALIGNED>
-__global__ __launch_bounds__(256, 4) void gemm_dyn_kernel(GemmArgs g, const int* __restrict__ cnt, int dyn, int splits) {
-  __shared__ __attribute__((aligned(16))) float lds[lds_floats<1, 1, AKC, BKC>()];
+__device__ __forceinline__ void gemm_dyn_walk(GemmArgs& g, float* __restrict__ lds, const int* __restrict__ cnt, const int dyn,
+                                              const int splits, const int vb, const int vgrid) {
   const int c = *cnt;
   const int cr = ALIGNED ? (c + 63) & ~63 : c;
   if (dyn == 1) {
     g.M = cr, g.splits = 1, g.ksplit = g.K;
     const int tn = (g.N + 63) >> 6, tiles = ((cr + 63) >> 6) * tn;
-    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    for (int tile = vb; tile < tiles; tile += vgrid) {
       gemm_body<1, 1, AKC, BKC, ALIGNED>(g, lds, tile % tn, tile / tn, 0);
       __syncthreads();  // the next tile restages LDS
     }
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(256, 4) void gemm_dyn_kernel(GemmArgs g, const int*
   g.ksplit = ((((cr + splits - 1) / splits) + BK - 1) / BK) * BK;
   if (g.ksplit < BK) g.ksplit = BK;
   const int tn = (g.N + 63) >> 6, tm = (g.M + 63) >> 6, tiles = tm * tn * splits;
-  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+  for (int tile = vb; tile < tiles; tile += vgrid) {
     const int sp = tile % splits, r = tile / splits;
     const int bx = r % tn, by = r / tn;
     if (sp * g.ksplit >= cr) {  // this K slice is empty
@@ -511,13 +513,28 @@ __global__ __launch_bounds__(256, 4) void gemm_dyn_kernel(GemmArgs g, const int*
           const int row = by * 64 + (e >> 6), col = bx * 64 + (e & 63);
           if (row < g.M && col < g.N) W[(long)row * g.N + col] = 0.f;
         }
-      } else if (cr == 0) {  // no rows at all: C = epilogue(0) is produced by the body over zero k-steps -- not reachable
-      }                      // (ksplit >= BK, sp == 0, cr == 0 handled below)
+      }                      // (cr == 0 with one slice: gemm_dyn_zero_kernel defines C)
       continue;
     }
     gemm_body<1, 1, AKC, BKC, ALIGNED>(g, lds, bx, by, sp);
     __syncthreads();
   }
+}
+
+template <bool AKC, bool BKC, bool ALIGNED>
+__global__ __launch_bounds__(256, 4) void gemm_dyn_kernel(GemmArgs g, const int* __restrict__ cnt, int dyn, int splits) {
+  __shared__ __attribute__((aligned(16))) float lds[lds_floats<1, 1, AKC, BKC>()];
+  gemm_dyn_walk<AKC, BKC, ALIGNED>(g, lds, cnt, dyn, splits, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The two gradients of one Linear layer on a device-side row count in ONE launch: the weight gradient (K = *cnt: operands
+// [K][.], split over `splits` slices) on the first gridW workgroups, the data gradient (M = *cnt: dY [M][K] times W [K][N]) on
+// the rest.  Interior shapes only (gemm_dyn_pair below checks).
+__global__ __launch_bounds__(256, 4) void gemm_dyn_pair_kernel(GemmArgs gw, GemmArgs gx, const int* __restrict__ cnt, int splits,
+                                                               int gridW) {
+  __shared__ __attribute__((aligned(16))) float lds[lds_floats<1, 1, true, false>()];
+  if ((int)blockIdx.x < gridW) gemm_dyn_walk<false, false, true>(gw, lds, cnt, 2, splits, (int)blockIdx.x, gridW);
+  else gemm_dyn_walk<true, false, true>(gx, lds, cnt, 1, 1, (int)blockIdx.x - gridW, (int)gridDim.x - gridW);
 }
 
 // *cnt == 0 with dyn == 2: every slice is empty; C must still be defined (zeros).
@@ -576,6 +593,41 @@ int gemm_dyn(const GemmArgs& g_in, const int* cnt, int dyn, long cap, hipStream_
     return check_launch("gemm_dyn_reduce");
   }
   return 0;
+}
+
+// dW = dY^T X (dyn = 2) and dX (+)= dY W (dyn = 1) of one Linear layer whose row count lives on the device: one launch + the
+// weight gradient's reduce instead of two launches + the reduce.  Falls back to two gemm_dyn calls for shapes the pair kernel
+// does not serve (guarded tiles, an unsplittable weight gradient).
+int gemm_dyn_pair(const GemmArgs& gw_in, const GemmArgs& gx_in, const int* cnt, long cap, hipStream_t st) {
+  GemmArgs gw = gw_in, gx = gx_in;
+  GC_REQUIRE(cnt && cap >= 0, "gemm_dyn_pair: bad arguments");
+  if (cap == 0) cap = 1;
+  gw.K = (int)((cap + 63) & ~63L), gx.M = (int)((cap + 63) & ~63L);
+  bool ok = gw.batch1 == 1 && gw.batch2 == 1 && gx.batch1 == 1 && gx.batch2 == 1 && !gw.a_kc && !gw.b_kc && gx.a_kc && !gx.b_kc;
+  ok = ok && prepare(gw, 1, 1, 0) >= 0 && prepare(gx, 1, 1, 0) >= 0;
+  ok = ok && gw.vecA && gw.vecB && gw.N % 64 == 0 && gw.M % 64 == 0 && gx.vecA && gx.vecB && gx.N % 64 == 0 && gx.K % BK == 0;
+  int splits = 1;
+  if (ok) {   // the split factor of gemm_dyn (dyn = 2)
+    const long tiles = (long)cdiv(gw.M, 64) * cdiv(gw.N, 64);
+    long want = (1024 + tiles - 1) / tiles, most = cap / (8 * BK);
+    if (most < 1) most = 1;
+    splits = (int)(want < most ? want : most);
+    if (splits > 64) splits = 64;
+    ok = splits > 1 && gw.ws && (long)splits * gw.M * gw.N <= gw.ws_elems && gw.N % 4 == 0 && (((uintptr_t)gw.ws) & 15) == 0;
+  }
+  if (!ok) {
+    if (int e = gemm_dyn(gw_in, cnt, 2, cap, st)) return e;
+    return gemm_dyn(gx_in, cnt, 1, cap, st);
+  }
+  gw.splits = splits;
+  const long tw = (long)cdiv(gw.M, 64) * cdiv(gw.N, 64) * splits, tx = (long)cdiv(cap, 64) * cdiv(gx.N, 64);
+  const int gridW = (int)(tw < 1024 ? tw : 1024), gridX = (int)(tx < 1024 ? (tx > 0 ? tx : 1) : 1024);
+  GC_LAUNCH_TIMED("gemm_dyn", 0.0, gemm_dyn_pair_kernel, dim3(gridW + gridX), dim3(256), 0, st, gw, gx, cnt, splits, gridW);
+  if (int e = check_launch("gemm_dyn_pair")) return e;
+  ProfScope ps("gemm_splitk_reduce", st);
+  dim3 rgrid(cdiv((long)gw.M * gw.N / 4, 256), 1);
+  hipLaunchKernelGGL(splitk_reduce_kernel, rgrid, dim3(256), 0, st, gw);
+  return check_launch("gemm_dyn_reduce");
 }
 
 // ---- deferred problems ------------------------------------------------------------------------------------------

@@ -175,6 +175,9 @@ int splitk_reduce(const GemmArgs& g, hipStream_t st);
 // dyn = 2 at least one operand's rows in [*cnt, roundup64(*cnt)) must be zero.  Other shapes take the guarded body
 // with the exact count.
 int gemm_dyn(const GemmArgs& g, const int* cnt, int dyn, long cap, hipStream_t st);
+// The weight gradient (dyn = 2: gw) and the data gradient (dyn = 1: gx) of one Linear layer on the same device-side row count, in one
+// launch (+ the weight gradient's reduce).
+int gemm_dyn_pair(const GemmArgs& gw, const GemmArgs& gx, const int* cnt, long cap, hipStream_t st);
 
 // Floats of split-K workspace that lets every GEMM of a [rows x cols]-sized problem split freely.
 inline long gemm_ws_elems(long rows, long cols) {

@@ -956,6 +956,18 @@ static int linear_bwd_w(const float* dY, const float* X, long M, int Nout, int K
   return cnt ? gemm_dyn(g, cnt, 2, cap, st) : gemm(g, st);
 }
 
+// dW = dY^T X and dX (+)= dY W of one Linear layer whose row count lives on the device: one launch (+ dW's reduce), gemm_dyn_pair
+static int linear_bwd_wx_dyn(const float* dY, const float* X, int Nout, int K, const float* W, float* dW, float* dX, int accumulate_x,
+                             float* ws, long wse, hipStream_t st, const int* cnt, long cap) {
+  GemmArgs gw, gx;
+  gw.A = dY, gw.lda = Nout, gw.a_kc = 0, gw.B = X, gw.ldb = K, gw.b_kc = 0, gw.C = dW, gw.ldc = K, gw.M = Nout, gw.N = K, gw.K = 0;
+  gx.A = dY, gx.lda = Nout, gx.a_kc = 1, gx.B = W, gx.ldb = K, gx.b_kc = 0, gx.C = dX, gx.ldc = K, gx.M = 0, gx.N = K, gx.K = Nout;
+  gx.accumulate = accumulate_x;
+  gw.ws = gx.ws = ws, gw.ws_elems = gx.ws_elems = wse;
+  gw.tag = gx.tag = "prod_gemm";
+  return gemm_dyn_pair(gw, gx, cnt, cap, st);
+}
+
 // The three gradients of one Linear layer on a static row count -- dW = dY^T X, db = column sums of dY, dX (+)= dY W -- in ONE
 // group launch (+ its reduce): the two products are independent, the column sums ride in both launches (gemm.hpp, ColRide).
 // Separately they were a weight-gradient launch, its reduce, one or two column-sum launches and the data-gradient launch.
@@ -1088,8 +1100,7 @@ int prod_bwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx
     // reached the caller through the consumers (compact.hip) and is added by autograd
     GC_TRY(colsum(dEc_in, nullptr, dflat + y.bls, up64(cap_pairs), Hd, Hd, 1, 0, 0, 0, 0, ws, st));
   }
-  GC_TRY(linear_bwd_w(g.dEc, w.CS, 0, Hd, 2 * Hd, dflat + y.Wls, ws, wse, st, npairs, cap_pairs));
-  GC_TRY(linear_bwd_x(g.dEc, 0, Hd, flat + y.Wls, 2 * Hd, g.dCS, 0, ws, wse, st, npairs, cap_pairs));
+  GC_TRY(linear_bwd_wx_dyn(g.dEc, w.CS, Hd, 2 * Hd, flat + y.Wls, dflat + y.Wls, g.dCS, 0, ws, wse, st, npairs, cap_pairs));
   {
     ProfScope ps("prod_sent", st);
     PROD_LAUNCH(prod_sent_bwd_kernel, Hd, dim3(PGRID), dim3(64 * PW), sizeof(float) * (Hd + 1), st, w.sfeat, w.cwa, w.nterm,
@@ -1101,14 +1112,12 @@ int prod_bwd(int B, int N, int S, int T, int Hd, int P, int ND, const float* ctx
                    hipMemcpyAsync(dflat + y.bsa, g.dwb + Hd, sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess,
                "producer: copy failed");
   // sentence_attention.attention_sent / attention_pos
-  GC_TRY(linear_bwd_w(g.dsfeat, w.cwa, 0, Hd, Hd, dflat + y.Wss, ws, wse, st, nrows, cap_rows));
   GC_TRY(colsum_dyn(g.dsfeat, nrows, Hd, g.part, dflat + y.bss, st));
-  GC_TRY(linear_bwd_x(g.dsfeat, 0, Hd, flat + y.Wss, Hd, g.dcwa, 1, ws, wse, st, nrows, cap_rows));   // dcwa += dsfeat W_ss
+  GC_TRY(linear_bwd_wx_dyn(g.dsfeat, w.cwa, Hd, Hd, flat + y.Wss, dflat + y.Wss, g.dcwa, 1, ws, wse, st, nrows, cap_rows));   // dcwa += dsfeat W_ss
   GC_TRY(linear_bwd_all(g.dnterm, node, BN, Hd, Hd, flat + y.Wsp, dflat + y.Wsp, dflat + y.bsp, dnode, 0, ws, wse, st));
   // linear_word_att
-  GC_TRY(linear_bwd_w(g.dcwa, w.CW, 0, Hd, 2 * Hd, dflat + y.Wlw, ws, wse, st, nrows, cap_rows));
   GC_TRY(colsum_dyn(g.dcwa, nrows, Hd, g.part, dflat + y.blw, st));
-  GC_TRY(linear_bwd_x(g.dcwa, 0, Hd, flat + y.Wlw, 2 * Hd, g.dCW, 0, ws, wse, st, nrows, cap_rows));
+  GC_TRY(linear_bwd_wx_dyn(g.dcwa, w.CW, Hd, 2 * Hd, flat + y.Wlw, dflat + y.Wlw, g.dCW, 0, ws, wse, st, nrows, cap_rows));
   // word attention -> score table and token states
   {
     ProfScope ps("prod_word", st);
