@@ -178,6 +178,8 @@ int gemm_dyn(const GemmArgs& g, const int* cnt, int dyn, long cap, hipStream_t s
 // The weight gradient (dyn = 2: gw) and the data gradient (dyn = 1: gx) of one Linear layer on the same device-side row count, in one
 // launch (+ the weight gradient's reduce).
 int gemm_dyn_pair(const GemmArgs& gw, const GemmArgs& gx, const int* cnt, long cap, hipStream_t st);
+// ... and two weight gradients of the same shape over the same rows (dyn = 2 both; one reduce launch for both)
+int gemm_dyn_pair_ww(const GemmArgs& ga, const GemmArgs& gb, const int* cnt, long cap, hipStream_t st);
 
 // Floats of split-K workspace that lets every GEMM of a [rows x cols]-sized problem split freely.
 inline long gemm_ws_elems(long rows, long cols) {

@@ -1149,8 +1149,20 @@ int head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int di
     }
   }
   // d W_c = dout^T [eh | et]    (computed 128 rows deep into a workspace, the R real rows copied out)
-  GC_TRY(rows_gemm(w.doutp, HW, 0, w.EH, HW, 0, w.dW, 2 * HW, HW, HW, (int)pairs, 0, 2));
-  GC_TRY(rows_gemm(w.doutp, HW, 0, w.ET, HW, 0, w.dW + HW, 2 * HW, HW, HW, (int)pairs, 0, 2));
+  if (compact) {   // the two halves over the same device-side pair count: one launch, one reduce
+    GemmArgs gh[2];
+    for (int q = 0; q < 2; ++q) {
+      GemmArgs& g = gh[q];
+      g.A = w.doutp, g.lda = HW, g.a_kc = 0, g.B = q ? w.ET : w.EH, g.ldb = HW, g.b_kc = 0;
+      g.C = w.dW + q * HW, g.ldc = 2 * HW, g.M = HW, g.N = HW, g.K = (int)pairs;
+      g.ws = ws, g.ws_elems = wse;
+      g.tag = "head_gemm";
+    }
+    GC_TRY(gemm_dyn_pair_ww(gh[0], gh[1], cnt, pairs, st));
+  } else {
+    GC_TRY(rows_gemm(w.doutp, HW, 0, w.EH, HW, 0, w.dW, 2 * HW, HW, HW, (int)pairs, 0, 2));
+    GC_TRY(rows_gemm(w.doutp, HW, 0, w.ET, HW, 0, w.dW + HW, 2 * HW, HW, HW, (int)pairs, 0, 2));
+  }
   GC_REQUIRE(hipMemcpyAsync(dflat + y.Wc, w.dW, sizeof(float) * R * 2 * HW, hipMemcpyDeviceToDevice, st) == hipSuccess, "head: copy failed");
   {
     ProfScope ps("head_feat", st);
