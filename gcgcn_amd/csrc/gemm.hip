@@ -530,14 +530,18 @@ __global__ __launch_bounds__(256, 4) void gemm_dyn_kernel(GemmArgs g, const int*
 // The two gradients of one Linear layer on a device-side row count in ONE launch: the weight gradient (K = *cnt: operands
 // [K][.], split over `splits` slices) on the first gridW workgroups, the data gradient (M = *cnt: dY [M][K] times W [K][N]) on
 // the rest.  Interior shapes only (gemm_dyn_pair below checks).
-// WW: the second problem is another weight gradient over the same rows (the classifier head's dW_c halves) instead of the data gradient.
-template <bool WW>
+// KIND 0: weight gradient + data gradient of one layer; 1: two weight gradients over the same rows (the classifier head's dW_c
+// halves); 2: two data-gradient-shaped products over the same rows (M = *cnt both: the head's dout W_c halves).
+template <int KIND>
 __global__ __launch_bounds__(256, 4) void gemm_dyn_pair_kernel(GemmArgs gw, GemmArgs gx, const int* __restrict__ cnt, int splits,
                                                                int gridW) {
   __shared__ __attribute__((aligned(16))) float lds[lds_floats<1, 1, true, false>()];
-  if ((int)blockIdx.x < gridW) gemm_dyn_walk<false, false, true>(gw, lds, cnt, 2, splits, (int)blockIdx.x, gridW);
-  else if (WW) gemm_dyn_walk<false, false, true>(gx, lds, cnt, 2, splits, (int)blockIdx.x - gridW, (int)gridDim.x - gridW);
-  else gemm_dyn_walk<true, false, true>(gx, lds, cnt, 1, 1, (int)blockIdx.x - gridW, (int)gridDim.x - gridW);
+  const int vb2 = (int)blockIdx.x - gridW, vg2 = (int)gridDim.x - gridW;
+  if ((int)blockIdx.x < gridW) {
+    if (KIND == 2) gemm_dyn_walk<true, false, true>(gw, lds, cnt, 1, 1, (int)blockIdx.x, gridW);
+    else gemm_dyn_walk<false, false, true>(gw, lds, cnt, 2, splits, (int)blockIdx.x, gridW);
+  } else if (KIND == 1) gemm_dyn_walk<false, false, true>(gx, lds, cnt, 2, splits, vb2, vg2);
+  else gemm_dyn_walk<true, false, true>(gx, lds, cnt, 1, 1, vb2, vg2);
 }
 // the two weight gradients' reduces in one launch (blockIdx.y picks the problem)
 __global__ __launch_bounds__(256) void splitk_reduce_pair_kernel(const GemmArgs ga, const GemmArgs gb) {
@@ -629,7 +633,7 @@ int gemm_dyn_pair(const GemmArgs& gw_in, const GemmArgs& gx_in, const int* cnt, 
   gw.splits = splits;
   const long tw = (long)cdiv(gw.M, 64) * cdiv(gw.N, 64) * splits, tx = (long)cdiv(cap, 64) * cdiv(gx.N, 64);
   const int gridW = (int)(tw < 1024 ? tw : 1024), gridX = (int)(tx < 1024 ? (tx > 0 ? tx : 1) : 1024);
-  GC_LAUNCH_TIMED("gemm_dyn", 0.0, gemm_dyn_pair_kernel<false>, dim3(gridW + gridX), dim3(256), 0, st, gw, gx, cnt, splits, gridW);
+  GC_LAUNCH_TIMED("gemm_dyn", 0.0, gemm_dyn_pair_kernel<0>, dim3(gridW + gridX), dim3(256), 0, st, gw, gx, cnt, splits, gridW);
   if (int e = check_launch("gemm_dyn_pair")) return e;
   ProfScope ps("gemm_splitk_reduce", st);
   dim3 rgrid(cdiv((long)gw.M * gw.N / 4, 256), 1);
@@ -665,12 +669,31 @@ int gemm_dyn_pair_ww(const GemmArgs& ga_in, const GemmArgs& gb_in, const int* cn
   ga.splits = gb.splits = splits;
   const long tw = (long)cdiv(ga.M, 64) * cdiv(ga.N, 64) * splits;
   const int gridW = (int)(tw < 1024 ? tw : 1024);
-  GC_LAUNCH_TIMED("gemm_dyn", 0.0, gemm_dyn_pair_kernel<true>, dim3(2 * gridW), dim3(256), 0, st, ga, gb, cnt, splits, gridW);
+  GC_LAUNCH_TIMED("gemm_dyn", 0.0, gemm_dyn_pair_kernel<1>, dim3(2 * gridW), dim3(256), 0, st, ga, gb, cnt, splits, gridW);
   if (int e = check_launch("gemm_dyn_pair_ww")) return e;
   ProfScope ps("gemm_splitk_reduce", st);
   dim3 rgrid(cdiv((long)ga.M * ga.N / 4, 256), 2);
   hipLaunchKernelGGL(splitk_reduce_pair_kernel, rgrid, dim3(256), 0, st, ga, gb);
   return check_launch("gemm_dyn_reduce");
+}
+
+// Two products whose M is the same device-side row count (dyn = 1 both, A [M][K] row-major, B [K][N]): one launch.
+int gemm_dyn_pair_xx(const GemmArgs& ga_in, const GemmArgs& gb_in, const int* cnt, long cap, hipStream_t st) {
+  GemmArgs ga = ga_in, gb = gb_in;
+  GC_REQUIRE(cnt && cap >= 0, "gemm_dyn_pair_xx: bad arguments");
+  if (cap == 0) cap = 1;
+  ga.M = gb.M = (int)((cap + 63) & ~63L);
+  bool ok = ga.batch1 == 1 && ga.batch2 == 1 && gb.batch1 == 1 && gb.batch2 == 1 && ga.a_kc && !ga.b_kc && gb.a_kc && !gb.b_kc;
+  ok = ok && prepare(ga, 1, 1, 0) >= 0 && prepare(gb, 1, 1, 0) >= 0;
+  ok = ok && ga.vecA && ga.vecB && gb.vecA && gb.vecB && ga.N % 64 == 0 && gb.N % 64 == 0 && ga.K % BK == 0 && gb.K % BK == 0;
+  if (!ok) {
+    if (int e = gemm_dyn(ga_in, cnt, 1, cap, st)) return e;
+    return gemm_dyn(gb_in, cnt, 1, cap, st);
+  }
+  const long ta = (long)cdiv(cap, 64) * cdiv(ga.N, 64), tb = (long)cdiv(cap, 64) * cdiv(gb.N, 64);
+  const int gridA = (int)(ta < 1024 ? (ta > 0 ? ta : 1) : 1024), gridB = (int)(tb < 1024 ? (tb > 0 ? tb : 1) : 1024);
+  GC_LAUNCH_TIMED("gemm_dyn", 0.0, gemm_dyn_pair_kernel<2>, dim3(gridA + gridB), dim3(256), 0, st, ga, gb, cnt, 1, gridA);
+  return check_launch("gemm_dyn_pair_xx");
 }
 
 // ---- deferred problems ------------------------------------------------------------------------------------------

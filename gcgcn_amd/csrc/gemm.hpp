@@ -180,6 +180,8 @@ int gemm_dyn(const GemmArgs& g, const int* cnt, int dyn, long cap, hipStream_t s
 int gemm_dyn_pair(const GemmArgs& gw, const GemmArgs& gx, const int* cnt, long cap, hipStream_t st);
 // ... and two weight gradients of the same shape over the same rows (dyn = 2 both; one reduce launch for both)
 int gemm_dyn_pair_ww(const GemmArgs& ga, const GemmArgs& gb, const int* cnt, long cap, hipStream_t st);
+// ... and two products whose M is the same device-side row count (dyn = 1 both)
+int gemm_dyn_pair_xx(const GemmArgs& ga, const GemmArgs& gb, const int* cnt, long cap, hipStream_t st);
 
 // Floats of split-K workspace that lets every GEMM of a [rows x cols]-sized problem split freely.
 inline long gemm_ws_elems(long rows, long cols) {

@@ -1113,7 +1113,7 @@ int head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int di
     if (compact || !head_v1(pairs))
       GC_TRY(head_bil2(2, w.doutp, w.ET, flat + y.Wb, nullptr, nullptr, w.dEH, pairs, R, HW, HW, st, cnt, nullptr, compact ? w.partB : nullptr, w.part_rows));
     else GC_TRY(head_gemm(2, g, o, st));
-    GC_TRY(rows_gemm(w.doutp, HW, 1, flat + y.Wc, 2 * HW, 0, w.dEH, HW, (int)pairs, HW, HW, 1, 1));
+    if (!compact) GC_TRY(rows_gemm(w.doutp, HW, 1, flat + y.Wc, 2 * HW, 0, w.dEH, HW, (int)pairs, HW, HW, 1, 1));   // (compacted: with d et's, below)
   }
   {  // d et = sum_(r,a) dout[p,r] eh[p,a] W_b[r,a,b]  + dout W_c[:, 128:]
     GemmArgs g;
@@ -1122,7 +1122,19 @@ int head_bwd(int B, int N, int Hd, int nf, int Pt, int Pr, int R, int ND, int di
     if (compact || !head_v1(pairs))
       GC_TRY(head_bil2(3, w.doutp, w.EH, flat + y.Wb, nullptr, nullptr, w.dET, pairs, R, HW, HW, st, cnt, nullptr, compact ? w.partB : nullptr, w.part_rows));
     else GC_TRY(head_gemm(3, g, o, st));
-    GC_TRY(rows_gemm(w.doutp, HW, 1, flat + y.Wc + HW, 2 * HW, 0, w.dET, HW, (int)pairs, HW, HW, 1, 1));
+    if (compact) {   // + dout W_c on both sides, over the device-side pair count: one launch for the two halves
+      GemmArgs gh[2];
+      for (int q = 0; q < 2; ++q) {
+        GemmArgs& g2 = gh[q];
+        g2.A = w.doutp, g2.lda = HW, g2.a_kc = 1, g2.B = flat + y.Wc + q * HW, g2.ldb = 2 * HW, g2.b_kc = 0;
+        g2.C = q ? w.dET : w.dEH, g2.ldc = HW, g2.M = (int)pairs, g2.N = HW, g2.K = HW, g2.accumulate = 1;
+        g2.ws = ws, g2.ws_elems = wse;
+        g2.tag = "head_gemm";
+      }
+      GC_TRY(gemm_dyn_pair_xx(gh[0], gh[1], cnt, pairs, st));
+    } else {
+      GC_TRY(rows_gemm(w.doutp, HW, 1, flat + y.Wc + HW, 2 * HW, 0, w.dET, HW, (int)pairs, HW, HW, 1, 1));
+    }
   }
   {  // d W_b[r, (a, b)] = sum_p dout[p, r] eh[p, a] et[p, b]
     GemmArgs g;
