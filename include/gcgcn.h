@@ -268,8 +268,9 @@ int gcgcn_pair_bce_bwd(int B, int N, int R, const float* logits, const float* la
  * beyond a capacity is NOT computed: ibuf[sizes[3] + 2] becomes 1 and every real pair of E is written as NaN, so an
  * undersized capacity is loud even inside a captured hipGraph).  Buffers (caller-owned): ibuf int32[sizes[0]], fbuf
  * float[sizes[1]] (written by forward, read by backward), bbuf float[sizes[2]] (backward workspace) from
- * gcgcn_producer_sizes.  Gradients w.r.t. ctx, the score table and the per-entity node terms are scatter-added with
- * fp32 atomics (reproducible up to summation order). */
+ * gcgcn_producer_sizes.  Two small sums of the backward -- the gradient of the per-entity node terms and of the sentence
+ * attention's vector / bias -- are scatter-added with fp32 atomics (reproducible up to summation order); every other sum
+ * (ctx, the score table, the weight gradients) is computed by its owner in a fixed order. */
 int gcgcn_producer_layout(int Hd, int P, int64_t* out17);
 int gcgcn_producer_count(int B, int N, int S, int T, const uint8_t* sen, const int32_t* n_valid, int32_t* counts2, void* stream);
 int gcgcn_producer_sizes(int B, int N, int S, int T, int Hd, int P, int ND, int64_t cap_rows, int64_t cap_pairs, int64_t* out7);
