@@ -415,6 +415,51 @@ def test_ragged_batch_matches_truncated_docs(gpu_device, B, N, D, L, H, nv):
     _check_stack_param_grads(hops, sdl)
 
 
+@pytest.mark.parametrize("B,N,D,L,H", [(32, 64, 256, 2, 8),      # the ragged bench: the split data gradients behind MAGGC's chain widen on the device
+                                       (8, 64, 768, 4, 4)])      # cfg 3's widths: K = 3072 row-block products get their one host split
+def test_ragged_launcher_switches_agree(gpu_device, B, N, D, L, H):
+    """Round 5's launcher changes for ragged batches, each against its switch: split row-block products cut finer on the device
+    (option split_widen) and the fused hop's attention projection parked (functional.defer_fused_mha_weight_grads).  Same
+    snapshots, train mode, NaN-poisoned recycled memory: outputs and every gradient agree to summation-order slack."""
+    g = torch.Generator().manual_seed(B + D)
+    nv = torch.clamp(torch.round(torch.randn(B, generator=g) * 6.0 + 19.5), 1, N).to(torch.int32)
+    nv[0], nv[-1] = N, 1
+    sd = O.init_stack_params(D, L, H, seed=5)
+    x, e1, e2, adj = O.synth_docs(B, N, D, seed=6)
+    x = x * (torch.arange(N)[None, :] < nv[:, None]).unsqueeze(-1).float()
+    cot = torch.randn(B, N, D, generator=g).to(gpu_device)
+    hops = gcgcn_amd.GraphHops(D, L, H).to(gpu_device).train(True)
+    hops.load_state_dict(sd, strict=True)
+    nvg = nv.to(gpu_device)
+
+    def run():
+        gcgcn_amd.manual_seed(99, gpu_device)
+        xs = [dev_leaf(t, gpu_device) for t in (x, e1, e2)]
+        hops.zero_grad()
+        junk = torch.full((B * N * H * D * 4,), float("nan"), device=gpu_device)
+        del junk
+        f = hops(xs[0], [xs[1], xs[2]], adj.to(gpu_device), n_valid=nvg)
+        torch.autograd.backward(f[-1], cot)
+        return [f[-1].detach(), xs[0].grad, xs[1].grad, xs[2].grad] + [p.grad.clone() for p in hops.parameters() if p.grad is not None]
+
+    try:
+        base = run()
+        _lib.call("gcgcn_set_option", b"split_widen", 0)
+        no_widen = run()
+        _lib.call("gcgcn_set_option", b"split_widen", 1)
+        F_.defer_fused_mha_weight_grads = False
+        no_park = run()
+    finally:
+        _lib.call("gcgcn_set_option", b"split_widen", 1)
+        F_.defer_fused_mha_weight_grads = True
+    for name, other in (("split_widen=0", no_widen), ("dWq not parked", no_park)):
+        assert len(other) == len(base)
+        for k, (a, b_) in enumerate(zip(base, other)):
+            assert torch.isfinite(a).all() and torch.isfinite(b_).all(), f"{name}: tensor {k} has non-finite values"
+            top = max(a.abs().max().item(), 1e-6)
+            torch.testing.assert_close(a, b_, rtol=2e-4, atol=2e-5 * top, msg=lambda m: f"{name}, tensor {k}: {m}")
+
+
 @pytest.mark.parametrize("B,N,D,L,H,train", [(8, 64, 256, 2, 8, False),    # cfg 2's document shape: 2048 rows, split-K, parked tiles
                                              (8, 64, 256, 2, 8, True),     #   ... all six dropout sites on (same snapshots both ways)
                                              (5, 48, 128, 4, 4, False),    # the BERT model's widths, N = 48: three row blocks per document
